@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build librefinenet_hip.so (gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../hipvsr/librefinenet_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+mkdir -p "$(dirname "$OUT")"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$ROOT/include" -I"$HERE" \
+    "$HERE/conv_igemm.hip" "$HERE/conv_wgrad.hip" "$HERE/small_kernels.hip" -o "$OUT" "$@"
+echo "built $OUT"

@@ -1,0 +1,319 @@
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   out[m][n] = sum_k A[m][k] * Wp[k][n],  m = (image, y, x) linearised,  k = (source, 16-channel chunk, tap)
+//
+// * A is never materialised: every K step gathers a [BM pixels][16 channels] slab straight from the NHWC
+//   source tensors (tap-shifted, zero outside the image).  Several sources concatenate along K, which is how
+//   torch.cat([x, h]) of the ConvLSTM cell, the 5-frame window of the refine block and the pixel-unshuffle of
+//   the upsampler backward disappear.
+// * Both slabs are staged through LDS as rows of 16 floats (4 x 16-B slots, slot XOR ((row>>2)&3) => the
+//   ds_read_b128 fragment reads are bank-conflict free) with register double buffering: the global loads of
+//   step k+1 are in flight while the MFMAs of step k run; one barrier per step.
+// * Inside a 16-channel chunk lane-half kh of the wave reads channels 8kh..8kh+7 with two 16-byte LDS reads;
+//   MFMA step s contracts channel s (kh = 0) and 8+s (kh = 1).  A and B use the same permutation, so the sum
+//   over K is unchanged.
+// * Epilogues: bias + store/accumulate into up to 4 channel segments; PixelShuffle fused into the store;
+//   ConvLSTM gate math (the 4 gates of a hidden channel sit in the same lane of the 4 column tiles of a wave).
+#include "rnh_common.h"
+
+namespace {
+
+template <int WM, int WN, int MI, int NI, int EPI>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P, const int MT, const int NT) {
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr int AIT = BM / 64;
+    constexpr int BIT = (BN * 4 + 255) / 256;
+    constexpr int STAGE = (BM + BN) * 4;          // float4 per stage
+    __shared__ float4 lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int wg = rnh_xcd_remap(blockIdx.x, MT * NT);
+    const int mt = wg / NT, nt = wg - mt * NT;
+    const int H = P.H, W = P.W, HW = H * W;
+    const int Mtot = P.B * HW;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- rows this thread stages ------------------------------------------------------------------
+    int rb[AIT], ry[AIT], rx[AIT];
+    bool rok[AIT];
+    const int c4 = tid & 3;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+        const int m = m0 + (tid >> 2) + 64 * it;
+        rok[it] = m < Mtot;
+        const int mm = rok[it] ? m : 0;
+        const int b = mm / HW, rem = mm - b * HW;
+        rb[it] = b;
+        ry[it] = rem / W;
+        rx[it] = rem - ry[it] * W;
+    }
+
+    // ---- K-step state: source s, chunk ch, tap t -----------------------------------------------------
+    int s = 0, ch = 0, t = 0;
+    int spix[AIT];                                   // pixel index of (b + img_off, y*scale+sy, x*scale+sx)
+    auto setup_src = [&](int si) {
+        const rnh_src_t &S = P.src[si];
+        const int Hs = H * S.scale, Ws = W * S.scale;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it)
+            spix[it] = ((rb[it] + S.img_off) * Hs + ry[it] * S.scale + S.sub_y) * Ws + rx[it] * S.scale + S.sub_x;
+    };
+    setup_src(0);
+
+    float4 ra[AIT], rw[BIT];
+    auto load_stage = [&](int ks) {
+        const rnh_src_t &S = P.src[s];
+        int dy = 0, dx = 0;
+        if (P.ntaps == 9) {
+            dy = t / 3 - 1;
+            dx = t - (dy + 1) * 3 - 1;
+        }
+        const int cc = ch * 16 + c4 * 4;
+        const bool cok = cc < S.nch;
+        const int tapoff = (dy * W * S.scale + dx) * S.scale;
+        const float *p1 = S.ptr + S.c0 + cc;
+        const float *p2 = S.ptr2 ? S.ptr2 + S.c0 + cc : nullptr;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const bool v = rok[it] && cok && (unsigned)(ry[it] + dy) < (unsigned)H && (unsigned)(rx[it] + dx) < (unsigned)W;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v) {
+                const long off = (long)(spix[it] + tapoff) * S.C;
+                val = rnh_ld4(p1 + off);
+                if (p2) val = val + rnh_ld4(p2 + off);
+            }
+            ra[it] = val;
+        }
+        const float *wb = P.wp + ((long)ks * P.Npad + n0) * 16;
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (BN * 4 % 256 == 0 || idx < BN * 4) rw[it] = rnh_ld4(wb + idx * 4);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float4 *As = lds + buf * STAGE;
+        float4 *Bs = As + BM * 4;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int r = (tid >> 2) + 64 * it;
+            As[r * 4 + (c4 ^ ((r >> 2) & 3))] = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (BN * 4 % 256 == 0 || idx < BN * 4) {
+                const int n = idx >> 2, q = idx & 3;
+                Bs[n * 4 + (q ^ ((n >> 2) & 3))] = rw[it];
+            }
+        }
+    };
+    auto advance = [&]() {
+        if (++t == P.ntaps) {
+            t = 0;
+            if (++ch * 16 >= P.src[s].nch) {
+                ch = 0;
+                if (++s < P.nsrc) setup_src(s);
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float4 *As = lds + buf * STAGE;
+        const float4 *Bs = As + BM * 4;
+        float a[MI][8], b[NI][8];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = (wm * MI + i) * 32 + l31, sw = (row >> 2) & 3;
+            const float4 v0 = As[row * 4 + ((2 * kh) ^ sw)], v1 = As[row * 4 + ((2 * kh + 1) ^ sw)];
+            a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
+            a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = (wn * NI + j) * 32 + l31, sw = (row >> 2) & 3;
+            const float4 v0 = Bs[row * 4 + ((2 * kh) ^ sw)], v1 = Bs[row * 4 + ((2 * kh + 1) ^ sw)];
+            b[j][0] = v0.x; b[j][1] = v0.y; b[j][2] = v0.z; b[j][3] = v0.w;
+            b[j][4] = v1.x; b[j][5] = v1.y; b[j][6] = v1.z; b[j][7] = v1.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- main loop --------------------------------------------------------------------------------------
+    const int nk = P.nk;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) {
+            advance();
+            load_stage(ks + 1);
+        }
+        compute(ks & 1);
+        if (more) store_stage((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------------
+    // accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        static_assert(EPI != RNH_EPI_LSTM || (WN == 1 && NI == 4), "LSTM epilogue wants the 4 gates in one wave");
+        const int hc = nt * 32 + l31;
+        if (hc >= P.hd) return;
+        const float bi = P.bias[n0 + l31], bf = P.bias[n0 + 32 + l31], bo = P.bias[n0 + 64 + l31],
+                    bg = P.bias[n0 + 96 + l31];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m >= Mtot) continue;
+                const float gi = 1.f / (1.f + expf(-(acc[i][0][r] + bi)));
+                const float gf = 1.f / (1.f + expf(-(acc[i][1][r] + bf)));
+                const float go = 1.f / (1.f + expf(-(acc[i][2][r] + bo)));
+                const float gg = tanhf(acc[i][3][r] + bg);
+                const long o = (long)m * P.hd + hc;
+                const float cp = P.c_prev ? P.c_prev[o] : 0.f;
+                const float cn = gf * cp + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * tanhf(cn);
+                if (P.gates_out) {
+                    float *gp = P.gates_out + (long)m * 4 * P.hd + hc;
+                    gp[0] = gi;
+                    gp[P.hd] = gf;
+                    gp[2 * P.hd] = go;
+                    gp[3 * P.hd] = gg;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + (wn * NI + j) * 32 + l31;
+            const float bv = P.bias ? P.bias[col] : 0.f;
+            if constexpr (EPI == RNH_EPI_PS) {
+                const int ncols = P.ps_cq * P.ps_r * P.ps_r;
+                if (col >= ncols) continue;
+                const int ij = col / P.ps_cq, c = col - ij * P.ps_cq;
+                const int pi = ij / P.ps_r, pj = ij - pi * P.ps_r;
+                const rnh_dst_t &D = P.dst[0];
+                const int Ho = H * P.ps_r, Wo = W * P.ps_r;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (m >= Mtot) continue;
+                        const int b = m / HW, rem = m - b * HW, y = rem / W, x = rem - y * W;
+                        const long o = ((long)((b + D.img_off) * Ho + y * P.ps_r + pi) * Wo + x * P.ps_r + pj) * D.C + D.c0 + c;
+                        const float v = acc[i][j][r] + bv;
+                        D.ptr[o] = D.accumulate ? D.ptr[o] + v : v;
+                    }
+            } else {
+                // destination segment of this column
+                int seg = -1, cbase = 0;
+#pragma unroll
+                for (int d = 0; d < RNH_MAX_DST; ++d) {
+                    if (d < P.ndst && seg < 0) {
+                        if (col < cbase + P.dst[d].ncols) seg = d;
+                        else cbase += P.dst[d].ncols;
+                    }
+                }
+                if (seg < 0) continue;
+                const rnh_dst_t &D = P.dst[seg];
+                float *dp = D.ptr + (long)D.img_off * HW * D.C + D.c0 + (col - cbase);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (m >= Mtot) continue;
+                        const long o = (long)m * D.C;
+                        const float v = acc[i][j][r] + bv;
+                        dp[o] = D.accumulate ? dp[o] + v : v;
+                    }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MI, int NI>
+int launch_tile(const rnh_conv_args_t &a, hipStream_t st) {
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    if (a.Npad % BN) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: Npad %d not a multiple of the tile's %d columns", a.Npad, BN);
+    const long M = (long)a.B * a.H * a.W;
+    const int MT = (int)((M + BM - 1) / BM), NT = a.Npad / BN;
+    const dim3 grid((unsigned)(MT * NT)), block(256);
+    switch (a.epilogue) {
+        case RNH_EPI_STORE:
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT);
+            break;
+        case RNH_EPI_PS:
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_PS>), grid, block, 0, st, a, MT, NT);
+            break;
+        case RNH_EPI_LSTM:
+            if constexpr (WN == 1 && NI == 4) {
+                hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT);
+            } else {
+                RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: the LSTM epilogue needs RNH_TILE_128x128_G");
+            }
+            break;
+        default:
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: unknown epilogue %d", a.epilogue);
+    }
+    RNH_CHECK_LAUNCH("rnh_conv_igemm");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int rnh_conv_igemm(const rnh_conv_args_t *args, void *stream) {
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: null args");
+    const rnh_conv_args_t &a = *args;
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: nsrc %d", a.nsrc);
+    if (a.B < 1 || a.H < 1 || a.W < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: bad geometry");
+    if ((long)a.B * a.H * a.W >= (1L << 31) / 16) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: too many output pixels");
+    if (a.ntaps != 9 && a.ntaps != 1) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: ntaps %d", a.ntaps);
+    if (!a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: null weights");
+    int nk = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (int e = rnh_check_src(a.src[i], "rnh_conv_igemm")) return e;
+        nk += (a.src[i].nch + 15) / 16 * a.ntaps;
+    }
+    if (nk != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: nk %d does not match the sources (%d)", a.nk, nk);
+    if (a.epilogue == RNH_EPI_LSTM) {
+        if (!a.h_out || !a.c_out || !a.bias || a.hd < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM epilogue args");
+        if (a.Npad != (a.hd + 31) / 32 * 128) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM Npad");
+    } else {
+        if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: ndst %d", a.ndst);
+        for (int i = 0; i < a.ndst; ++i)
+            if (!a.dst[i].ptr || a.dst[i].ncols < 1 || a.dst[i].C < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: bad destination");
+        if (a.epilogue == RNH_EPI_PS && (a.ps_r < 2 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad))
+            RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: pixel-shuffle args");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.tile) {
+        case RNH_TILE_128x128:   return launch_tile<2, 2, 2, 2>(a, st);
+        case RNH_TILE_128x128_G: return launch_tile<4, 1, 1, 4>(a, st);
+        case RNH_TILE_256x64:    return launch_tile<4, 1, 2, 2>(a, st);
+        case RNH_TILE_128x160:   return launch_tile<4, 1, 1, 5>(a, st);
+        default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: unknown tile %d", a.tile);
+    }
+}

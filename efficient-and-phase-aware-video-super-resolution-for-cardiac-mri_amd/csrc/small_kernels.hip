@@ -1,0 +1,630 @@
+// HBM-bound kernels of the RefineNet hot path (gfx950): the 1->C input convolution + PReLU and its backward,
+// the C->out_channels last convolution of the upsampler (forward, data gradient, weight gradient), the
+// ConvLSTM gate backward, the fused loss + gradient, element-wise sums, weight packing, phase-code plane.
+// All of them move 16 bytes per lane along the channel (NHWC) axis; reductions are two-pass
+// (per-block partials in a workspace, then one fixed-order sum) so results are bitwise reproducible.
+#include <stdarg.h>
+#include "rnh_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "no error";
+void rnh_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *rnh_last_error(void) { return g_err; }
+extern "C" int rnh_abi_version(void) { return RNH_ABI_VERSION; }
+extern "C" void rnh_struct_sizes(int32_t out[4]) {
+    out[0] = (int32_t)sizeof(rnh_src_t);
+    out[1] = (int32_t)sizeof(rnh_dst_t);
+    out[2] = (int32_t)sizeof(rnh_conv_args_t);
+    out[3] = (int32_t)sizeof(rnh_wgrad_args_t);
+}
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    // wave reduction (64 lanes) then across the waves of the block through LDS; result valid in thread 0
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kbase,
+                                    const int *knv, const int *ktap, const int *kcoff, const int *colmap, int nk, int Npad,
+                                    int Cout, int Cin, int ntaps, int kstride, int transposed) {
+    const long total = (long)nk * Npad * 16;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(e & 15);
+        const long r = e >> 4;
+        const int n = (int)(r % Npad), ks = (int)(r / Npad);
+        const int cm = colmap[n];
+        float v = 0.f;
+        if (cm >= 0 && kk < knv[ks]) {
+            const int kidx = kbase[ks] + kk * kstride;
+            const int cme = cm + (kcoff ? kcoff[ks] : 0);
+            const int o = transposed ? kidx : cme, i = transposed ? cme : kidx;
+            const int tp = transposed ? ntaps - 1 - ktap[ks] : ktap[ks];
+            v = w[((long)o * Cin + i) * ntaps + tp];
+        }
+        wp[e] = v;
+    }
+    if (biasp) {
+        for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < Npad; n += (long)gridDim.x * blockDim.x) {
+            const int cm = colmap[n];
+            biasp[n] = (bias && cm >= 0 && !transposed) ? bias[cm] : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// input block: y = PReLU(conv3x3(x) + b), x [B][H][W][Cin] -> y [B][H][W][Cout]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) inconv_fwd_kernel(const float *x, const float *w, const float *bias, const float *slope,
+                                                         float *y, int B, int H, int W, int Cin, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];      // [tap][ci][co]
+    const int nw = 9 * Cin * Cout;
+    for (int e = threadIdx.x; e < nw; e += blockDim.x) {
+        const int co = e % Cout, r = e / Cout, ci = r % Cin, tap = r / Cin;
+        sw[e] = w[(co * Cin + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const float a = slope[0];
+    const int G = Cout >> 2;
+    const long total = (long)B * H * W * G;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e % G);
+        const long p = e / G;
+        const int xx = (int)(p % W);
+        const long q = p / W;
+        const int yy = (int)(q % H);
+        float4 acc = rnh_ld4(bias + g * 4);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if ((unsigned)(yy + dy) >= (unsigned)H || (unsigned)(xx + dx) >= (unsigned)W) continue;
+            const float *xp = x + (p + dy * W + dx) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float xv = xp[ci];
+                const float4 wv = rnh_ld4(sw + (tap * Cin + ci) * Cout + g * 4);
+                acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+            }
+        }
+        acc.x = acc.x > 0.f ? acc.x : a * acc.x;
+        acc.y = acc.y > 0.f ? acc.y : a * acc.y;
+        acc.z = acc.z > 0.f ? acc.z : a * acc.z;
+        acc.w = acc.w > 0.f ? acc.w : a * acc.w;
+        rnh_st4(y + p * Cout + g * 4, acc);
+    }
+}
+
+constexpr int INB_BLOCKS = 512;
+constexpr int INB_MAXK = 36;     // 9 * Cin, Cin <= 4
+
+// thread = (co, sub); partial[block][co][9*Cin + 2] = {dW taps..., db, dslope}
+__global__ void __launch_bounds__(256) inconv_bwd_kernel(const float *x, const float *w, const float *bias, const float *slope,
+                                                         const float *dy, float *ws, int B, int H, int W, int Cin, int Cout) {
+    __shared__ float red[256];
+    const int K = 9 * Cin;
+    const int co = threadIdx.x % Cout, sub = threadIdx.x / Cout, nsub = blockDim.x / Cout;
+    float wr[INB_MAXK], acc[INB_MAXK];
+#pragma unroll
+    for (int k = 0; k < INB_MAXK; ++k) {
+        acc[k] = 0.f;
+        wr[k] = 0.f;
+        if (k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            wr[k] = w[(co * Cin + ci) * 9 + tap];
+        }
+    }
+    float db = 0.f, ds = 0.f;
+    const float a = slope[0], bv = bias[co];
+    const long M = (long)B * H * W;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per;
+    long p1 = p0 + per;
+    if (p1 > M) p1 = M;
+    for (long p = p0 + sub; p < p1; p += nsub) {
+        const int xx = (int)(p % W);
+        const int yy = (int)((p / W) % H);
+        float xv[INB_MAXK];
+        float z = bv;
+#pragma unroll
+        for (int k = 0; k < INB_MAXK; ++k) {
+            xv[k] = 0.f;
+            if (k < K) {
+                const int tap = k / Cin, ci = k - tap * Cin;
+                const int dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
+                if ((unsigned)(yy + dy_) < (unsigned)H && (unsigned)(xx + dx_) < (unsigned)W)
+                    xv[k] = x[(p + dy_ * W + dx_) * Cin + ci];
+                z += xv[k] * wr[k];
+            }
+        }
+        const float g = dy[p * Cout + co];
+        const float dz = z > 0.f ? g : a * g;
+        ds += z > 0.f ? 0.f : g * z;
+        db += dz;
+#pragma unroll
+        for (int k = 0; k < INB_MAXK; ++k)
+            if (k < K) acc[k] += dz * xv[k];
+    }
+    // reduce over sub through LDS, one quantity at a time (nsub is small)
+    float *out = ws + ((long)blockIdx.x * Cout + co) * (K + 2);
+    for (int k = 0; k < K + 2; ++k) {
+        float v = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < INB_MAXK; ++kk)
+            if (kk == k) v = acc[kk];
+        if (k == K) v = db;
+        if (k == K + 1) v = ds;
+        __syncthreads();
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (sub == 0) {
+            float s = 0.f;
+            for (int q = 0; q < nsub; ++q) s += red[q * Cout + co];
+            out[k] = s;
+        }
+    }
+}
+
+__global__ void inconv_bwd_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, float *dslope, int Cin, int Cout,
+                                         int accumulate) {
+    __shared__ float red[4];
+    const int K = 9 * Cin;
+    const int total = Cout * (K + 1);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int co = e / (K + 1), k = e - co * (K + 1);
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += ws[((long)b * Cout + co) * (K + 2) + k];
+        if (k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            float *o = dw + (co * Cin + ci) * 9 + tap;
+            *o = accumulate ? *o + s : s;
+        } else {
+            db[co] = accumulate ? db[co] + s : s;
+        }
+    }
+    if (blockIdx.x == 0) {
+        float v = 0.f;
+        for (int e = threadIdx.x; e < nblocks * Cout; e += blockDim.x) v += ws[(long)e * (K + 2) + K + 1];
+        const float s = block_sum(v, red);
+        if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// last conv of the upsampler: Cin -> Cout (Cout <= 4), HBM-bound
+// ---------------------------------------------------------------------------------------------------------
+constexpr int OC_MAX = 4;
+constexpr int OT = 16;                  // 16x16 output pixels per block
+constexpr int OROW = 20;                // 16 channels + 4 pad floats per halo pixel (conflict-free ds_read_b128)
+
+__global__ void __launch_bounds__(256) outconv_fwd_kernel(const float *x, const float *w, const float *bias, float *y, int B,
+                                                          int H, int W, int Cin, int Cout, int TX, int TY) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *halo = sm;                                   // [(OT+2)*(OT+2)][OROW]
+    float *swt = sm + (OT + 2) * (OT + 2) * OROW;       // [co][tap][Cin16] (Cin padded to 16)
+    const int Cp = (Cin + 15) & ~15;
+    for (int e = threadIdx.x; e < Cout * 9 * Cp; e += blockDim.x) {
+        const int ci = e % Cp, r = e / Cp, tap = r % 9, co = r / 9;
+        swt[e] = ci < Cin ? w[(co * Cin + ci) * 9 + tap] : 0.f;
+    }
+    const int tile = blockIdx.x;
+    const int b = tile / (TX * TY), tr = tile - b * TX * TY, ty = tr / TX, tx = tr - ty * TX;
+    const int y0 = ty * OT, x0 = tx * OT;
+    const int ly = threadIdx.x / OT, lx = threadIdx.x % OT;
+    float acc[OC_MAX];
+#pragma unroll
+    for (int co = 0; co < OC_MAX; ++co) acc[co] = co < Cout ? bias[co] : 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += 16) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < (OT + 2) * (OT + 2) * 4; e += blockDim.x) {
+            const int q = e & 3, hp = e >> 2, hy = hp / (OT + 2), hx = hp - hy * (OT + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + q * 4 < Cin)
+                v = rnh_ld4(x + (((long)b * H + gy) * W + gx) * Cin + c0 + q * 4);
+            rnh_st4(halo + hp * OROW + q * 4, v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int hp = (ly + tap / 3) * (OT + 2) + lx + tap % 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = rnh_ld4(halo + hp * OROW + q * 4);
+#pragma unroll
+                for (int co = 0; co < OC_MAX; ++co) {
+                    if (co < Cout) {
+                        const float4 wv = rnh_ld4(swt + (co * 9 + tap) * Cp + c0 + q * 4);
+                        acc[co] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+                    }
+                }
+            }
+        }
+    }
+    const int gy = y0 + ly, gx = x0 + lx;
+    if (gy < H && gx < W) {
+        float *o = y + (((long)b * H + gy) * W + gx) * Cout;
+#pragma unroll
+        for (int co = 0; co < OC_MAX; ++co)
+            if (co < Cout) o[co] = acc[co];
+    }
+}
+
+// dx[p][ci] = sum_{t,co} dy[p - t][co] * w[co][ci][t]; thread = (pixel, 4 input channels)
+__global__ void __launch_bounds__(256) outconv_dgrad_kernel(const float *dy, const float *w, float *dx, int B, int H, int W,
+                                                            int Cin, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [co][tap][ci]
+    for (int e = threadIdx.x; e < Cout * 9 * Cin; e += blockDim.x) {
+        const int ci = e % Cin, r = e / Cin, tap = r % 9, co = r / 9;
+        sw[e] = w[(co * Cin + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const int G = Cin >> 2;
+    const long total = (long)B * H * W * G;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e % G);
+        const long p = e / G;
+        const int xx = (int)(p % W);
+        const int yy = (int)((p / W) % H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
+            // contribution of output pixel p - t
+            if ((unsigned)(yy - dy_) >= (unsigned)H || (unsigned)(xx - dx_) >= (unsigned)W) continue;
+            const float *gp = dy + (p - dy_ * W - dx_) * Cout;
+            for (int co = 0; co < Cout; ++co) {
+                const float gv = gp[co];
+                const float4 wv = rnh_ld4(sw + (co * 9 + tap) * Cin + g * 4);
+                acc.x += gv * wv.x; acc.y += gv * wv.y; acc.z += gv * wv.z; acc.w += gv * wv.w;
+            }
+        }
+        rnh_st4(dx + p * Cin + g * 4, acc);
+    }
+}
+
+constexpr int OW_BLOCKS = 1024;
+// thread = (ci, sub): acc[co][t] += x[q][ci] * dy[q - t][co]; partial[block][co][ci][9] and db partial[block][co]
+__global__ void __launch_bounds__(256) outconv_wgrad_kernel(const float *x, const float *dy, float *ws, int B, int H, int W,
+                                                            int Cin, int Cout) {
+    __shared__ float red[256];
+    const int ci = threadIdx.x % Cin, sub = threadIdx.x / Cin, nsub = blockDim.x / Cin;
+    float acc[OC_MAX][9];
+    float dbp[OC_MAX];
+#pragma unroll
+    for (int co = 0; co < OC_MAX; ++co) {
+        dbp[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[co][t] = 0.f;
+    }
+    const long M = (long)B * H * W;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long q0 = (long)blockIdx.x * per;
+    long q1 = q0 + per;
+    if (q1 > M) q1 = M;
+    if (sub < nsub) {
+        for (long q = q0 + sub; q < q1; q += nsub) {
+            const int xx = (int)(q % W);
+            const int yy = (int)((q / W) % H);
+            const float xv = x[q * Cin + ci];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
+                if ((unsigned)(yy - dy_) >= (unsigned)H || (unsigned)(xx - dx_) >= (unsigned)W) continue;
+                const float *gp = dy + (q - dy_ * W - dx_) * Cout;
+#pragma unroll
+                for (int co = 0; co < OC_MAX; ++co)
+                    if (co < Cout) acc[co][t] += xv * gp[co];
+            }
+            if (ci == 0) {
+#pragma unroll
+                for (int co = 0; co < OC_MAX; ++co)
+                    if (co < Cout) dbp[co] += dy[q * Cout + co];
+            }
+        }
+    }
+    float *out = ws + (long)blockIdx.x * (Cout * Cin * 9 + Cout);
+    for (int co = 0; co < Cout; ++co) {
+        for (int t = 0; t < 10; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int c2 = 0; c2 < OC_MAX; ++c2)
+#pragma unroll
+                for (int t2 = 0; t2 < 9; ++t2)
+                    if (c2 == co && t2 == t) v = acc[c2][t2];
+            if (t == 9) {
+#pragma unroll
+                for (int c2 = 0; c2 < OC_MAX; ++c2)
+                    if (c2 == co) v = dbp[c2];
+            }
+            __syncthreads();
+            red[threadIdx.x] = (sub < nsub) ? v : 0.f;
+            __syncthreads();
+            if (sub == 0) {
+                float s = 0.f;
+                for (int k = 0; k < nsub; ++k) s += red[k * Cin + ci];
+                if (t < 9) out[(co * Cin + ci) * 9 + t] = s;
+                else if (ci == 0) out[Cout * Cin * 9 + co] = s;
+            }
+        }
+    }
+}
+
+__global__ void outconv_wgrad_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, int Cin, int Cout, int accumulate) {
+    const int nw = Cout * Cin * 9, total = nw + Cout;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += ws[(long)b * total + e];
+        float *o = e < nw ? dw + e : db + (e - nw);
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ConvLSTM gate backward
+// ---------------------------------------------------------------------------------------------------------
+__global__ void lstm_gates_bwd_kernel(const float *dh, const float *dcn, const float *gates, const float *cprev,
+                                      const float *cnext, float *dgates, float *dcprev, long npix, int hd) {
+    const int G = hd >> 2;
+    const long total = npix * G;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e % G);
+        const long p = e / G;
+        const long o = p * hd + g * 4, og = p * 4 * hd + g * 4;
+        const float4 vdh = rnh_ld4(dh + o);
+        const float4 vdc = dcn ? rnh_ld4(dcn + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vcp = cprev ? rnh_ld4(cprev + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vcn = rnh_ld4(cnext + o);
+        const float4 gi = rnh_ld4(gates + og), gf = rnh_ld4(gates + og + hd), go = rnh_ld4(gates + og + 2 * hd),
+                     gg = rnh_ld4(gates + og + 3 * hd);
+        float4 di, df, dgo, dg, dcp;
+#define RNH_GATE(c)                                               \
+    {                                                             \
+        const float th = tanhf(vcn.c);                            \
+        const float d_o = vdh.c * th;                             \
+        const float dct = vdc.c + vdh.c * go.c * (1.f - th * th); \
+        di.c = dct * gg.c * gi.c * (1.f - gi.c);                  \
+        df.c = dct * vcp.c * gf.c * (1.f - gf.c);                 \
+        dgo.c = d_o * go.c * (1.f - go.c);                         \
+        dg.c = dct * gi.c * (1.f - gg.c * gg.c);                  \
+        dcp.c = dct * gf.c;                                       \
+    }
+        RNH_GATE(x) RNH_GATE(y) RNH_GATE(z) RNH_GATE(w)
+#undef RNH_GATE
+        rnh_st4(dgates + og, di);
+        rnh_st4(dgates + og + hd, df);
+        rnh_st4(dgates + og + 2 * hd, dgo);
+        rnh_st4(dgates + og + 3 * hd, dg);
+        if (dcprev) rnh_st4(dcprev + o, dcp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// loss + gradient
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) loss_kernel(const float *o, const float *y, float *d_o, const float *gscale, float *ws,
+                                                   int T, long per, int kind, float eps) {
+    __shared__ float red[4];
+    const int gi = blockIdx.y, g = gi / T, i = gi - g * T;
+    const float *op = o + (long)gi * per, *yp = y + (long)i * per;
+    float *dp = d_o ? d_o + (long)gi * per : nullptr;
+    const float sc = (d_o && gscale) ? gscale[gi] / (float)per : 0.f;
+    float part = 0.f;
+    const long n4 = per >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const float4 a = rnh_ld4(op + e * 4), b = rnh_ld4(yp + e * 4);
+        float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}, gr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (kind == RNH_LOSS_L1) {
+                part += fabsf(d[k]);
+                gr[k] = d[k] > 0.f ? sc : (d[k] < 0.f ? -sc : 0.f);
+            } else {
+                const float r = sqrtf(d[k] * d[k] + eps);
+                part += r;
+                gr[k] = sc * d[k] / r;
+            }
+        }
+        if (dp) rnh_st4(dp + e * 4, make_float4(gr[0], gr[1], gr[2], gr[3]));
+    }
+    // tail (per not a multiple of 4)
+    for (long e = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x) {
+        const float d = op[e] - yp[e];
+        float gr;
+        if (kind == RNH_LOSS_L1) {
+            part += fabsf(d);
+            gr = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
+        } else {
+            const float r = sqrtf(d * d + eps);
+            part += r;
+            gr = sc * d / r;
+        }
+        if (dp) dp[e] = gr;
+    }
+    const float s = block_sum(part, red);
+    if (threadIdx.x == 0) ws[(long)gi * RNH_LOSS_BLOCKS + blockIdx.x] = s;
+}
+
+__global__ void loss_finalize_kernel(const float *ws, float *loss, int GT, long per) {
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= GT) return;
+    float s = 0.f;
+    for (int b = 0; b < RNH_LOSS_BLOCKS; ++b) s += ws[(long)gi * RNH_LOSS_BLOCKS + b];
+    loss[gi] = s / (float)per;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// element-wise
+// ---------------------------------------------------------------------------------------------------------
+__global__ void ew_add_kernel(float *out, const float *a, const float *b, const float *c, long n4, int accumulate) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        float4 v = rnh_ld4(a + e * 4);
+        if (b) v = v + rnh_ld4(b + e * 4);
+        if (c) v = v + rnh_ld4(c + e * 4);
+        if (accumulate) v = v + rnh_ld4(out + e * 4);
+        rnh_st4(out + e * 4, v);
+    }
+}
+
+__global__ void phase_plane_kernel(const float *pos, float *out, int N, int F, long HW) {
+    const long total = (long)N * F * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / HW;
+        const int f = (int)(img / N), n = (int)(img - (long)f * N);
+        rnh_st4(out + e * 4, make_float4(pos[n * F + f], 0.f, 0.f, 0.f));
+    }
+}
+
+inline int grid_for(long work_items, int block = 256, int cap = 8192) {
+    long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kbase,
+                                const int32_t *knv, const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk,
+                                int Npad, int Cout, int Cin, int ntaps, int kstride, int transposed, void *stream) {
+    if (!w || !wp || !kbase || !knv || !ktap || !colmap || nk < 1 || Npad < 1 || Cout < 1 || Cin < 1 || kstride < 1)
+        RNH_FAIL(RNH_E_ARG, "rnh_pack_weights: bad arguments");
+    if (ntaps != 9 && ntaps != 1) RNH_FAIL(RNH_E_RANGE, "rnh_pack_weights: ntaps %d", ntaps);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((long)nk * Npad * 16)), dim3(256), 0, (hipStream_t)stream, w, bias, wp,
+                       biasp, kbase, knv, ktap, kcoff, colmap, nk, Npad, Cout, Cin, ntaps, kstride, transposed);
+    RNH_CHECK_LAUNCH("rnh_pack_weights");
+    return 0;
+}
+
+extern "C" int rnh_inconv_prelu_fwd(const float *x, const float *w, const float *bias, const float *slope, float *y, int B, int H,
+                                    int W, int Cin, int Cout, void *stream) {
+    if (!x || !w || !bias || !slope || !y || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1)
+        RNH_FAIL(RNH_E_ARG, "rnh_inconv_prelu_fwd: bad arguments");
+    if (Cout & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_inconv_prelu_fwd: Cout must be a multiple of 4");
+    const size_t shm = (size_t)9 * Cin * Cout * sizeof(float);
+    if (shm > 60000) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_fwd: 9*Cin*Cout too large for LDS");
+    hipLaunchKernelGGL(inconv_fwd_kernel, dim3(grid_for((long)B * H * W * (Cout / 4))), dim3(256), shm, (hipStream_t)stream, x, w,
+                       bias, slope, y, B, H, W, Cin, Cout);
+    RNH_CHECK_LAUNCH("rnh_inconv_prelu_fwd");
+    return 0;
+}
+
+extern "C" int64_t rnh_inconv_bwd_ws_floats(int Cin, int Cout) { return (int64_t)INB_BLOCKS * Cout * (9 * Cin + 2); }
+
+extern "C" int rnh_inconv_prelu_bwd(const float *x, const float *w, const float *bias, const float *slope, const float *dy,
+                                    float *dw, float *db, float *dslope, float *ws, int B, int H, int W, int Cin, int Cout,
+                                    int accumulate, void *stream) {
+    if (!x || !w || !bias || !slope || !dy || !dw || !db || !dslope || !ws || B < 1 || H < 1 || W < 1)
+        RNH_FAIL(RNH_E_ARG, "rnh_inconv_prelu_bwd: bad arguments");
+    if (9 * Cin > INB_MAXK) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_bwd: Cin > 4 not supported");
+    if (Cout < 1 || Cout > 256 || 256 % Cout) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_bwd: Cout must divide 256");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(inconv_bwd_kernel, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
+    RNH_CHECK_LAUNCH("rnh_inconv_prelu_bwd");
+    hipLaunchKernelGGL(inconv_bwd_reduce_kernel, dim3(grid_for(Cout * (9 * Cin + 1))), dim3(256), 0, st, ws, INB_BLOCKS, dw, db,
+                       dslope, Cin, Cout, accumulate);
+    RNH_CHECK_LAUNCH("rnh_inconv_prelu_bwd(reduce)");
+    return 0;
+}
+
+extern "C" int rnh_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
+                               void *stream) {
+    if (!x || !w || !bias || !y || B < 1 || H < 1 || W < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "rnh_outconv_fwd: bad arguments");
+    if (Cin & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_outconv_fwd: Cin must be a multiple of 4");
+    if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_fwd: Cout must be 1..%d", OC_MAX);
+    const int Cp = (Cin + 15) & ~15;
+    const size_t shm = ((size_t)(OT + 2) * (OT + 2) * OROW + (size_t)Cout * 9 * Cp) * sizeof(float);
+    if (shm > 64000) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_fwd: Cin too large");
+    const int TX = (W + OT - 1) / OT, TY = (H + OT - 1) / OT;
+    hipLaunchKernelGGL(outconv_fwd_kernel, dim3((unsigned)(B * TX * TY)), dim3(256), shm, (hipStream_t)stream, x, w, bias, y, B, H,
+                       W, Cin, Cout, TX, TY);
+    RNH_CHECK_LAUNCH("rnh_outconv_fwd");
+    return 0;
+}
+
+extern "C" int rnh_outconv_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout, void *stream) {
+    if (!dy || !w || !dx || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) RNH_FAIL(RNH_E_ARG, "rnh_outconv_dgrad: bad arguments");
+    if (Cin & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_outconv_dgrad: Cin must be a multiple of 4");
+    const size_t shm = (size_t)Cout * 9 * Cin * sizeof(float);
+    if (shm > 60000) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_dgrad: Cout*Cin too large");
+    hipLaunchKernelGGL(outconv_dgrad_kernel, dim3(grid_for((long)B * H * W * (Cin / 4), 256, 16384)), dim3(256), shm,
+                       (hipStream_t)stream, dy, w, dx, B, H, W, Cin, Cout);
+    RNH_CHECK_LAUNCH("rnh_outconv_dgrad");
+    return 0;
+}
+
+extern "C" int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout) { return (int64_t)OW_BLOCKS * (Cout * Cin * 9 + Cout); }
+
+extern "C" int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, float *db, float *ws, int B, int H, int W, int Cin,
+                                 int Cout, int accumulate, void *stream) {
+    if (!x || !dy || !dw || !db || !ws || B < 1 || H < 1 || W < 1) RNH_FAIL(RNH_E_ARG, "rnh_outconv_wgrad: bad arguments");
+    if (Cin < 1 || Cin > 256) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_wgrad: Cin must be 1..256");
+    if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_wgrad: Cout must be 1..%d", OC_MAX);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(outconv_wgrad_kernel, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin, Cout);
+    RNH_CHECK_LAUNCH("rnh_outconv_wgrad");
+    hipLaunchKernelGGL(outconv_wgrad_reduce_kernel, dim3(grid_for(Cout * Cin * 9 + Cout)), dim3(256), 0, st, ws, OW_BLOCKS, dw, db,
+                       Cin, Cout, accumulate);
+    RNH_CHECK_LAUNCH("rnh_outconv_wgrad(reduce)");
+    return 0;
+}
+
+extern "C" int rnh_lstm_gates_bwd(const float *dh, const float *dc_next, const float *gates, const float *c_prev,
+                                  const float *c_next, float *dgates, float *dc_prev, int64_t npix, int hd, void *stream) {
+    if (!dh || !gates || !c_next || !dgates || npix < 1 || hd < 1) RNH_FAIL(RNH_E_ARG, "rnh_lstm_gates_bwd: bad arguments");
+    if (hd & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_lstm_gates_bwd: hd must be a multiple of 4");
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for(npix * (hd / 4))), dim3(256), 0, (hipStream_t)stream, dh, dc_next,
+                       gates, c_prev, c_next, dgates, dc_prev, (long)npix, hd);
+    RNH_CHECK_LAUNCH("rnh_lstm_gates_bwd");
+    return 0;
+}
+
+extern "C" int rnh_loss_fwd_bwd(const float *o, const float *y, float *loss, float *d_o, const float *gscale, float *ws, int G,
+                                int T, int64_t per, int kind, float eps, void *stream) {
+    if (!o || !y || !loss || !ws || G < 1 || T < 1 || per < 1) RNH_FAIL(RNH_E_ARG, "rnh_loss_fwd_bwd: bad arguments");
+    if (d_o && !gscale) RNH_FAIL(RNH_E_ARG, "rnh_loss_fwd_bwd: gradient requested without gscale");
+    if (kind != RNH_LOSS_L1 && kind != RNH_LOSS_CHARBONNIER) RNH_FAIL(RNH_E_RANGE, "rnh_loss_fwd_bwd: kind %d", kind);
+    if (per & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_loss_fwd_bwd: per-image element count must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_kernel, dim3(RNH_LOSS_BLOCKS, G * T), dim3(256), 0, st, o, y, d_o, gscale, ws, T, (long)per, kind, eps);
+    RNH_CHECK_LAUNCH("rnh_loss_fwd_bwd");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3((G * T + 63) / 64), dim3(64), 0, st, ws, loss, G * T, (long)per);
+    RNH_CHECK_LAUNCH("rnh_loss_fwd_bwd(finalize)");
+    return 0;
+}
+
+extern "C" int rnh_ew_add(float *out, const float *a, const float *b, const float *c, int64_t n, int accumulate, void *stream) {
+    if (!out || !a || n < 1) RNH_FAIL(RNH_E_ARG, "rnh_ew_add: bad arguments");
+    if (n & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_ew_add: n must be a multiple of 4");
+    hipLaunchKernelGGL(ew_add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, out, a, b, c, (long)(n / 4),
+                       accumulate);
+    RNH_CHECK_LAUNCH("rnh_ew_add");
+    return 0;
+}
+
+extern "C" int rnh_phase_plane(const float *pos, float *out, int N, int F, int H, int W, void *stream) {
+    if (!pos || !out || N < 1 || F < 1 || H < 1 || W < 1) RNH_FAIL(RNH_E_ARG, "rnh_phase_plane: bad arguments");
+    hipLaunchKernelGGL(phase_plane_kernel, dim3(grid_for((long)N * F * H * W)), dim3(256), 0, (hipStream_t)stream, pos, out, N, F,
+                       (long)H * W);
+    RNH_CHECK_LAUNCH("rnh_phase_plane");
+    return 0;
+}

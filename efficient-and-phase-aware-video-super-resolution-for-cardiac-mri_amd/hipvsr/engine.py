@@ -1,0 +1,310 @@
+"""RefineNet forward and hand-written backward, scheduled over an ``ops`` backend.
+
+Forward follows reference src/model/nets/refine_net.py:61-135 (frame loop, stage loop, grad / no-grad
+frames, three output groups per stage, in-place feature update); backward is what ``loss.backward()``
+(reference src/runner/trainers/acdc_vsr_refinenet_trainer.py:46) makes autograd do for that graph, written
+out by hand so that every step is one of the kernels of include/refinenet_hip.h:
+
+* frames are stored frame-major, image index b = frame * N + n, NHWC;
+* everything without a temporal dependence is batched over frames: the input block over all F frames, the
+  refine block over all F-4 windows, the upsampler over 3 branches x T frames, the LSTM weight gradients
+  over the T supervised frames;
+* no-grad ("update") frames (refine_net.py:74-93, :179-183) simply do not appear in the backward: their
+  hidden states enter as constants;
+* ``refine_block.prelu.weight`` never receives a gradient (quirk Q1, refine_net.py:150-155).
+
+The ``ops`` object is ``hipvsr.hip_ops.HipOps`` in the product.  tests/ substitutes a torch implementation of
+the same interface to check this scheduling logic against the oracle on machines without a GPU.
+"""
+from collections import OrderedDict
+
+from . import lib as L
+from .plans import Dst, NetPlans, Src
+
+
+class Context:
+    """What the forward keeps for the backward."""
+    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad')
+
+    def __init__(self):
+        self.stages = []
+        self.packed_dgrad = False
+
+
+class RefineNetEngine:
+    def __init__(self, cfg, ops):
+        self.cfg, self.ops = cfg, ops
+        self.plans = NetPlans(cfg)
+        self.hw = cfg.refine_window_size // 2
+        if (3 if self.plans.pos else 2) * cfg.refine_window_size > L.MAX_SRC:
+            raise ValueError(f'refine_window_size {cfg.refine_window_size} needs more than {L.MAX_SRC} conv sources')
+        if cfg.num_features[0] != cfg.num_features[-1]:
+            raise ValueError('num_features[0] must equal num_features[-1] (residual add, refine_net.py:102)')
+
+    # ------------------------------------------------------------------------------------------------
+    def param_order(self):
+        from .spec import state_dict_spec
+        return list(state_dict_spec(self.cfg).keys())
+
+    def _pack(self, params, which):
+        P = self.plans
+        for pl in P.conv_plans():
+            is_dgrad = pl.transposed
+            if (which == 'fwd') == (not is_dgrad):
+                self.ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, params, inputs, pos_codes, need_grad):
+        """inputs: list[F] of (N, Cin, H, W) tensors; pos_codes: (N, F, 1).
+        Returns (O_all, ctx): O_all is (S, 3, T*N, sH, sW, Cout) with image index i*N + n."""
+        ops, cfg, P = self.ops, self.cfg, self.plans
+        U, S, hw, w = cfg.num_updated_frames, cfg.num_stages, self.hw, cfg.refine_window_size
+        F = len(inputs)
+        T = F - 2 * U
+        if U == 0 or T <= 0 or U < hw:
+            # reference: inputs[U:-U] is empty for U == 0 and refine_maps is over-run for U < w//2
+            # (refine_net.py:66, :112) -> IndexError('list index out of range')
+            raise IndexError('list index out of range')
+        N, Cin, H, W = inputs[0].shape
+        nf, Lr, C, Cl = P.nf, P.L, P.C, P.Cl
+        s_up = cfg.upscale_factor
+        TN = T * N
+
+        ctx = Context()
+        ctx.N, ctx.H, ctx.W, ctx.F, ctx.T = N, H, W, F, T
+        x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
+        ctx.x_all = x_all
+        self._pack(params, 'fwd')
+        feat = ops.inconv_fwd(x_all, params['in_block.conv.weight'], params['in_block.conv.bias'],
+                              params['in_block.prelu.weight'])
+        P4 = ops.phase_plane(pos_codes, N, F, H, W) if P.pos else None
+        ctx.P4 = P4
+        O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
+
+        for s in range(S):
+            st = dict(feat=feat)
+            # ---- bidirectional ConvLSTM over the frames (refine_net.py:82-93) ----------------------------
+            for d in ('forward', 'backward'):
+                Hb = [ops.empty(F * N, H, W, hd) for hd in nf]
+                Cb = [ops.empty(F * N, H, W, hd) for hd in nf]
+                Gb = [ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None
+                order = range(F) if d == 'forward' else range(F - 1, -1, -1)
+                prev = None
+                for k in order:
+                    grad_frame = need_grad and U <= k < U + T
+                    for l in range(Lr):
+                        pl = P.lstm[(d, l)]
+                        xin = feat if l == 0 else Hb[l - 1]
+                        srcs = [Src(xin, img_off=k * N)]
+                        if cfg.memory:
+                            if prev is not None:
+                                srcs.append(Src(Hb[l], img_off=prev * N))
+                                plan = pl['full']
+                            else:
+                                plan = pl['first']
+                        else:
+                            srcs.append(Src(xin, img_off=k * N))
+                            plan = pl['full']
+                        ops.conv(plan, srcs, N, H, W, lstm=dict(
+                            hd=pl['hd'], c_prev=Cb[l][prev * N:(prev + 1) * N] if prev is not None else None,
+                            h_out=Hb[l][k * N:(k + 1) * N], c_out=Cb[l][k * N:(k + 1) * N],
+                            gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
+                    prev = k
+                st[d] = dict(H=Hb, C=Cb, G=Gb)
+            Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
+
+            # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
+            nwin = F - 2 * hw
+            srcs = []
+            for j in range(w):
+                srcs += [Src(Hf, img_off=j * N), Src(Hbk, img_off=j * N)]
+                if P.pos:
+                    srcs.append(Src(P4, img_off=j * N))
+            R = ops.empty(nwin * N, H, W, Cl)
+            if P.pos:
+                R1 = ops.empty(nwin * N, H, W, P.C1p)
+                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p)])
+                ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
+                st['R1'] = R1 if need_grad else None
+            else:
+                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R, Cl)])
+
+            # ---- three output groups through the upsampler (refine_net.py:100-113, :194-205) --------------
+            Sb = ops.empty(3 * TN, H, W, C)
+            fc = feat[U * N:(U + T) * N]
+            ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
+            ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
+            ops.add(Sb[2 * TN:], fc, R[(U - hw) * N:(U - hw + T) * N])
+            cur, h, wd, Ys = Sb, H, W, []
+            for u in P.up:
+                r = u['r']
+                Y = ops.empty(3 * TN, h * r, wd * r, C)
+                ops.conv(u['fwd'], [Src(cur)], 3 * TN, h, wd, ps=(Y, r))
+                Ys.append(Y)
+                cur, h, wd = Y, h * r, wd * r
+            ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=O_all[s].view(3 * TN, h, wd, cfg.out_channels))
+            if need_grad:
+                st['Sb'], st['Ys'] = Sb, Ys
+                ctx.stages.append(st)
+
+            # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
+            if S > 1 and s < S - 1:
+                nfeat = ops.empty(F * N, H, W, C)
+                ops.add(nfeat[0:hw * N], feat[0:hw * N], Hf[0:hw * N])
+                ops.add(nfeat[hw * N:(F - hw) * N], feat[hw * N:(F - hw) * N], R)
+                ops.add(nfeat[(F - hw) * N:], feat[(F - hw) * N:], Hbk[(F - hw) * N:])
+                feat = nfeat
+        return O_all, (ctx if need_grad else None)
+
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, params, ctx, dO_all, flat=None):
+        """dO_all: gradient of the loss w.r.t. O_all (same shape).  Returns an OrderedDict name -> gradient in
+        state-dict order (None for parameters that take no part, quirk Q1).  If ``flat`` (a 1-D buffer with
+        room for every parameter) is given the gradients are views into it (for a single all-reduce)."""
+        ops, cfg, P = self.ops, self.cfg, self.plans
+        U, S, hw, w = cfg.num_updated_frames, cfg.num_stages, self.hw, cfg.refine_window_size
+        N, H, W, F, T = ctx.N, ctx.H, ctx.W, ctx.F, ctx.T
+        nf, Lr, C, Cl = P.nf, P.L, P.C, P.Cl
+        TN = T * N
+        self._pack(params, 'bwd')
+
+        grads, touched = OrderedDict(), set()
+        off = 0
+        for name in self.param_order():
+            p = params[name]
+            if name == 'refine_block.prelu.weight':
+                grads[name] = None
+                if flat is not None:
+                    off += p.numel()
+                continue
+            if flat is not None:
+                grads[name] = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            else:
+                grads[name] = ops.empty(*p.shape)
+
+        def acc(name):
+            a = name in touched
+            touched.add(name)
+            return a
+
+        dfeat_next = None
+        for s in range(S - 1, -1, -1):
+            st = ctx.stages[s]
+            feat, Sb, Ys = st['feat'], st['Sb'], st['Ys']
+            Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
+            # ---- upsampler backward (3 branches x T frames at once) -----------------------------------------
+            sH, sW = dO_all.shape[3], dO_all.shape[4]
+            dO = dO_all[s].view(3 * TN, sH, sW, cfg.out_channels)
+            a = acc(P.last_w)
+            acc(P.last_b)
+            ops.outconv_wgrad(Ys[-1], dO, grads[P.last_w], grads[P.last_b], accumulate=a)
+            dcur = ops.outconv_dgrad(dO, params[P.last_w])
+            for ui in range(len(P.up) - 1, -1, -1):
+                u = P.up[ui]
+                r = u['r']
+                xin = Ys[ui - 1] if ui > 0 else Sb
+                h_in, w_in = xin.shape[1], xin.shape[2]
+                ysrcs = [Src(dcur, scale=r, sub=(ij // r, ij % r)) for ij in range(r * r)]
+                a = acc(u['wgrad'].wkey)
+                acc(u['wgrad'].bkey)
+                ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
+                          accumulate=a)
+                dnext = ops.empty(3 * TN, h_in, w_in, C)
+                ops.conv(u['dgrad'], ysrcs, 3 * TN, h_in, w_in, dsts=[Dst(dnext, C)])
+                dcur = dnext
+            dS = dcur
+            dHf, dHb, dR = dS[0:TN], dS[TN:2 * TN], dS[2 * TN:3 * TN]
+            dfeat = ops.empty(TN, H, W, C)
+            ops.add(dfeat, dHf, dHb, dR)
+            if dfeat_next is not None:                # feat[s+1] = feat[s] + R[s] on the supervised frames
+                ops.add(dfeat, dfeat_next, accumulate=True)
+                ops.add(dR, dfeat_next, accumulate=True)
+            st['Sb'] = st['Ys'] = None
+
+            # ---- refine block backward on the T supervised windows --------------------------------------------
+            xs = []
+            for j in range(w):
+                xs += [Src(Hf, img_off=(U - hw + j) * N), Src(Hbk, img_off=(U - hw + j) * N)]
+                if P.pos:
+                    xs.append(Src(ctx.P4, img_off=(U - hw + j) * N))
+            k1, b1 = P.r1_wgrad.wkey, P.r1_wgrad.bkey
+            if P.pos:
+                dR1p = ops.zeros((T + 2 * hw) * N, H, W, P.C1p)
+                ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
+                a = acc(P.r2_wgrad.wkey)
+                acc(P.r2_wgrad.bkey)
+                ops.wgrad(P.r2_wgrad, [Src(st['R1'], img_off=(U - hw) * N)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
+                          grads[P.r2_wgrad.bkey], accumulate=a)
+                a = acc(k1)
+                acc(b1)
+                ops.wgrad(P.r1_wgrad, xs, [Src(dR1p, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                gsrc = dR1p
+                st['R1'] = None
+            else:
+                gsrc = ops.zeros((T + 2 * hw) * N, H, W, Cl)
+                ops.add(gsrc[hw * N:(hw + T) * N], dR)
+                a = acc(k1)
+                acc(b1)
+                ops.wgrad(P.r1_wgrad, xs, [Src(dR)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+            # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
+            ops.conv(P.r1_dgrad, [Src(gsrc, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                     dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+
+            # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
+            for d, top in (('forward', dHf), ('backward', dHb)):
+                sd = st[d]
+                Hb, Cb, Gb = sd['H'], sd['C'], sd['G']
+                Gd = [ops.empty(TN, H, W, 4 * hd) for hd in nf]
+                step = 1 if d == 'forward' else -1
+                order = range(U + T - 1, U - 1, -1) if d == 'forward' else range(U, U + T)
+                dh_next, dc_next = [None] * Lr, [None] * Lr
+                for k in order:
+                    fi = k - U
+                    prevk = k - step
+                    prev_grad = U <= prevk < U + T
+                    dx_above = None
+                    for l in range(Lr - 1, -1, -1):
+                        pl = P.lstm[(d, l)]
+                        hd, cx = pl['hd'], pl['cx']
+                        dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
+                        if dh_next[l] is not None:
+                            ops.add(dh, dh_next[l], accumulate=True)
+                        c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
+                        dg = Gd[l][fi * N:(fi + 1) * N]
+                        dcp = ops.empty(N, H, W, hd) if prev_grad else None
+                        ops.lstm_gates_bwd(dh, dc_next[l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg, dcp)
+                        dxbuf = ops.empty(N, H, W, cx) if l > 0 else dfeat[fi * N:(fi + 1) * N]
+                        dhp = None
+                        if cfg.memory:
+                            dsts = [Dst(dxbuf, cx, accumulate=(l == 0))]
+                            if prev_grad:
+                                dhp = ops.empty(N, H, W, hd)
+                                dsts.append(Dst(dhp, hd))
+                            ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
+                        else:
+                            tmp = ops.empty(N, H, W, cx)
+                            ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx, accumulate=(l == 0)), Dst(tmp, cx)])
+                            ops.add(dxbuf, tmp, accumulate=True)
+                        dh_next[l], dc_next[l] = dhp, dcp
+                        dx_above = dxbuf if l > 0 else None
+                # weight gradients of the direction's cells, batched over the T frames
+                for l in range(Lr):
+                    pl = P.lstm[(d, l)]
+                    xin = feat if l == 0 else Hb[l - 1]
+                    second = Src(Hb[l], img_off=(U - step) * N) if cfg.memory else Src(xin, img_off=U * N)
+                    wk, bk = pl['wgrad'].wkey, pl['wgrad'].bkey
+                    a = acc(wk)
+                    acc(bk)
+                    ops.wgrad(pl['wgrad'], [Src(xin, img_off=U * N), second], [Src(Gd[l])], TN, H, W, grads[wk], grads[bk],
+                              accumulate=a)
+                st[d] = None
+            dfeat_next = dfeat
+            ctx.stages[s] = None
+
+        # ---- input block backward (supervised frames only, refine_net.py:66-67) --------------------------------
+        xc = ctx.x_all[U * N:(U + T) * N]
+        ops.inconv_bwd(xc, params['in_block.conv.weight'], params['in_block.conv.bias'], params['in_block.prelu.weight'],
+                       dfeat_next, grads['in_block.conv.weight'], grads['in_block.conv.bias'], grads['in_block.prelu.weight'],
+                       accumulate=False)
+        return grads

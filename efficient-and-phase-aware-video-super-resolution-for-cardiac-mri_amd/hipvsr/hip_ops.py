@@ -1,0 +1,280 @@
+"""HIP backend of the RefineNet engine: thin tensor-level wrappers over the C ABI (include/refinenet_hip.h).
+
+PyTorch is used only for device memory (``torch.empty`` on the current device) and for the current HIP
+stream; every computation below is one of the hand-written gfx950 kernels.  No fallback: tensors that are
+not fp32 / contiguous / on a HIP device raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .plans import ConvPlan, Dst, Src, WgradPlan
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class HipOps:
+    name = 'hip'
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise L.HipKernelError(f'the HIP backend needs a HIP device, got {device}')
+        self.lib = L.load()
+        self._maps = {}        # id(plan) -> dict of device int32 arrays
+        self._packed = {}      # id(plan) -> (wp, biasp)
+        self._ws = {}
+
+    # ---- memory -------------------------------------------------------------------------------------
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise L.HipKernelError(f'expected contiguous fp32 tensors on {self.device}, got {t.dtype} '
+                                       f'contiguous={t.is_contiguous()} on {t.device}')
+
+    def _i32(self, lst):
+        return torch.tensor(lst, dtype=torch.int32, device=self.device)
+
+    def _workspace(self, key, nfloats):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nfloats:
+            t = self.empty(int(nfloats))
+            self._ws[key] = t
+        return t
+
+    def stack_inputs(self, inputs):
+        """list[F] of (N, Cin, H, W) -> (F*N, H, W, Cin) NHWC, frame-major (plumbing: one copy of the LR input)."""
+        x = torch.stack([t.to(self.device, torch.float32) for t in inputs], dim=0)          # (F, N, Cin, H, W)
+        F, N, Cin, H, W = x.shape
+        return x.permute(0, 1, 3, 4, 2).reshape(F * N, H, W, Cin).contiguous()
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def _plan_maps(self, plan):
+        m = self._maps.get(id(plan))
+        if m is None:
+            if isinstance(plan, ConvPlan):
+                m = dict(kbase=self._i32(plan.kbase), knv=self._i32(plan.knv), ktap=self._i32(plan.ktap),
+                         kcoff=self._i32(plan.kcoff), colmap=self._i32(plan.colmap))
+            else:
+                m = dict(rowmap=self._i32(plan.rowmap), colmap=self._i32(plan.colmap), xgrp=self._i32(plan.xgrp),
+                         ygrp=self._i32(plan.ygrp))
+            m['_plan'] = plan          # keeps id(plan) unique while cached
+            self._maps[id(plan)] = m
+        return m
+
+    def pack(self, plan: ConvPlan, w, b=None):
+        """Re-lay the OIHW weight (and bias) of ``plan`` into the kernel's [nk][Npad][16] slabs."""
+        self._chk(w, b)
+        if tuple(w.shape) != (plan.Cout, plan.Cin) + ((3, 3) if plan.ntaps == 9 else (1, 1)):
+            raise L.HipKernelError(f'{plan.name}: weight shape {tuple(w.shape)} does not match the plan')
+        m = self._plan_maps(plan)
+        buf = self._packed.get(id(plan))
+        if buf is None:
+            buf = (self.empty(plan.nk * plan.Npad * 16), self.empty(plan.Npad))
+            self._packed[id(plan)] = buf
+        wp, bp = buf
+        L.check(self.lib.rnh_pack_weights(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['kbase']), _ptr(m['knv']),
+                                          _ptr(m['ktap']), _ptr(m['kcoff']), _ptr(m['colmap']), plan.nk, plan.Npad,
+                                          plan.Cout, plan.Cin, plan.ntaps, plan.kstride, int(plan.transposed),
+                                          self._stream()), f'rnh_pack_weights({plan.name})')
+
+    # ---- descriptors --------------------------------------------------------------------------------
+    def _fill_src(self, dst, s: Src):
+        t = s.t
+        self._chk(t, s.add)
+        if s.add is not None and s.add.shape != t.shape:
+            raise L.HipKernelError('Src.add must have the geometry of Src.t')
+        dst.ptr, dst.ptr2 = t.data_ptr(), (s.add.data_ptr() if s.add is not None else None)
+        dst.C, dst.c0 = t.shape[-1], s.c0
+        dst.nch = t.shape[-1] - s.c0 if s.nch is None else s.nch
+        dst.img_off, dst.scale, dst.sub_y, dst.sub_x = s.img_off, s.scale, s.sub[0], s.sub[1]
+
+    # ---- convolution --------------------------------------------------------------------------------
+    def conv(self, plan: ConvPlan, srcs, B, H, W, dsts=None, ps=None, lstm=None):
+        """One rnh_conv_igemm launch.  ``dsts``: list[Dst] (STORE), ``ps``: (tensor, r) with the tensor
+        (B, rH, rW, cq) (PS), ``lstm``: dict(c_prev, h_out, c_out, gates_out, hd) (LSTM)."""
+        if id(plan) not in self._packed:
+            raise L.HipKernelError(f'{plan.name}: weights were not packed')
+        if len(srcs) != len(plan.ksegs):
+            raise L.HipKernelError(f'{plan.name}: {len(srcs)} sources for {len(plan.ksegs)} K segments')
+        a = L.ConvArgs()
+        for i, (s, sg) in enumerate(zip(srcs, plan.ksegs)):
+            self._fill_src(a.src[i], s)
+            if a.src[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: source {i} has {a.src[i].nch} channels, plan wants {sg.nch}')
+            self._check_src_range(a.src[i], s.t, B, H, W, plan.name)
+        wp, bp = self._packed[id(plan)]
+        a.nsrc, a.B, a.H, a.W, a.ntaps, a.nk = len(srcs), B, H, W, plan.ntaps, plan.nk
+        a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
+        a.Npad, a.epilogue, a.tile = plan.Npad, plan.epilogue, plan.tile
+        if plan.epilogue == L.EPI_STORE:
+            a.ndst = len(dsts)
+            tot = 0
+            for i, d in enumerate(dsts):
+                self._chk(d.t)
+                if tuple(d.t.shape[1:3]) != (H, W) or d.img_off < 0 or d.img_off + B > d.t.shape[0] or \
+                        d.c0 + d.ncols > d.t.shape[-1]:
+                    raise L.HipKernelError(f'{plan.name}: destination {i} geometry')
+                a.dst[i].ptr, a.dst[i].C, a.dst[i].c0 = d.t.data_ptr(), d.t.shape[-1], d.c0
+                a.dst[i].ncols, a.dst[i].accumulate, a.dst[i].img_off = d.ncols, int(d.accumulate), d.img_off
+                tot += d.ncols
+            if tot > plan.Npad:
+                raise L.HipKernelError(f'{plan.name}: destination columns exceed Npad')
+        elif plan.epilogue == L.EPI_PS:
+            t, r = ps
+            self._chk(t)
+            cq = t.shape[-1]
+            if tuple(t.shape) != (B, H * r, W * r, cq):
+                raise L.HipKernelError(f'{plan.name}: pixel-shuffle destination shape {tuple(t.shape)}')
+            a.ndst = 1
+            a.dst[0].ptr, a.dst[0].C, a.dst[0].c0, a.dst[0].ncols = t.data_ptr(), cq, 0, cq
+            a.ps_r, a.ps_cq = r, cq
+        else:
+            hd = lstm['hd']
+            for k in ('c_prev', 'h_out', 'c_out', 'gates_out'):
+                t = lstm.get(k)
+                self._chk(t)
+                if t is not None and tuple(t.shape) != (B, H, W, hd * (4 if k == 'gates_out' else 1)):
+                    raise L.HipKernelError(f'{plan.name}: {k} shape {tuple(t.shape)}')
+            a.hd = hd
+            a.c_prev, a.h_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out'])
+            a.c_out, a.gates_out = _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
+        L.check(self.lib.rnh_conv_igemm(C.byref(a), self._stream()), f'rnh_conv_igemm({plan.name})')
+
+    @staticmethod
+    def _check_src_range(d, t, B, H, W, who):
+        """Host-side shape check before a hand-written kernel reads through the descriptor."""
+        if t.dim() != 4 or t.shape[1] != H * d.scale or t.shape[2] != W * d.scale:
+            raise L.HipKernelError(f'{who}: source geometry {tuple(t.shape)} does not match output {H}x{W} x{d.scale}')
+        if d.img_off < 0 or d.img_off + B > t.shape[0]:
+            raise L.HipKernelError(f'{who}: source image range [{d.img_off}, {d.img_off + B}) outside {t.shape[0]}')
+
+    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
+        m = self._plan_maps(plan)
+        self._chk(dw, db)
+        if len(xsrcs) != len(plan.xsegs) or len(ysrcs) != len(plan.ysegs):
+            raise L.HipKernelError(f'{plan.name}: source count')
+        a = L.WgradArgs()
+        for i, (s, sg) in enumerate(zip(xsrcs, plan.xsegs)):
+            self._fill_src(a.xs[i], s)
+            if a.xs[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: x source {i} channels')
+            self._check_src_range(a.xs[i], s.t, B, H, W, plan.name)
+        for i, (s, sg) in enumerate(zip(ysrcs, plan.ysegs)):
+            self._fill_src(a.ys[i], s)
+            if a.ys[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: dy source {i} channels')
+            self._check_src_range(a.ys[i], s.t, B, H, W, plan.name)
+        nsplit = plan.nsplit(B * H * W)
+        slab = self._workspace('wgrad_slab', nsplit * plan.ntaps * plan.xcols_pad * plan.ycols_pad)
+        bslab = self._workspace('wgrad_bslab', nsplit * plan.ycols_pad) if db is not None else None
+        a.nxs, a.xcols_pad, a.nys, a.ycols_pad = len(xsrcs), plan.xcols_pad, len(ysrcs), plan.ycols_pad
+        a.xgrp, a.ygrp = m['xgrp'].data_ptr(), m['ygrp'].data_ptr()
+        a.B, a.H, a.W, a.ntaps, a.tile, a.nsplit = B, H, W, plan.ntaps, plan.tile, nsplit
+        a.slab, a.bslab = slab.data_ptr(), (bslab.data_ptr() if bslab is not None else None)
+        st = self._stream()
+        L.check(self.lib.rnh_conv_wgrad(C.byref(a), st), f'rnh_conv_wgrad({plan.name})')
+        L.check(self.lib.rnh_wgrad_reduce(_ptr(slab), _ptr(bslab), nsplit, plan.ntaps, plan.xcols_pad, plan.ycols_pad,
+                                          _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
+                                          int(accumulate), st), f'rnh_wgrad_reduce({plan.name})')
+
+    # ---- small kernels ------------------------------------------------------------------------------
+    def inconv_fwd(self, x, w, b, slope):
+        self._chk(x, w, b, slope)
+        B, H, W, Cin = x.shape
+        y = self.empty(B, H, W, w.shape[0])
+        L.check(self.lib.rnh_inconv_prelu_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(slope), _ptr(y), B, H, W, Cin, w.shape[0],
+                                              self._stream()), 'rnh_inconv_prelu_fwd')
+        return y
+
+    def inconv_bwd(self, x, w, b, slope, dy, dw, db, dslope, accumulate=False):
+        self._chk(x, w, b, slope, dy, dw, db, dslope)
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        if tuple(dy.shape) != (B, H, W, Cout):
+            raise L.HipKernelError('inconv_bwd: dy shape')
+        ws = self._workspace('inconv', self.lib.rnh_inconv_bwd_ws_floats(Cin, Cout))
+        L.check(self.lib.rnh_inconv_prelu_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(slope), _ptr(dy), _ptr(dw), _ptr(db),
+                                              _ptr(dslope), _ptr(ws), B, H, W, Cin, Cout, int(accumulate), self._stream()),
+                'rnh_inconv_prelu_bwd')
+
+    def outconv_fwd(self, x, w, b, out=None):
+        self._chk(x, w, b, out)
+        B, H, W, Cin = x.shape
+        y = out if out is not None else self.empty(B, H, W, w.shape[0])
+        if tuple(y.shape) != (B, H, W, w.shape[0]):
+            raise L.HipKernelError('outconv_fwd: out shape')
+        L.check(self.lib.rnh_outconv_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), B, H, W, Cin, w.shape[0], self._stream()),
+                'rnh_outconv_fwd')
+        return y
+
+    def outconv_dgrad(self, dy, w):
+        self._chk(dy, w)
+        B, H, W, Cout = dy.shape
+        dx = self.empty(B, H, W, w.shape[1])
+        L.check(self.lib.rnh_outconv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), B, H, W, w.shape[1], Cout, self._stream()),
+                'rnh_outconv_dgrad')
+        return dx
+
+    def outconv_wgrad(self, x, dy, dw, db, accumulate=False):
+        self._chk(x, dy, dw, db)
+        B, H, W, Cin = x.shape
+        Cout = dy.shape[-1]
+        ws = self._workspace('outconv', self.lib.rnh_outconv_wgrad_ws_floats(Cin, Cout))
+        L.check(self.lib.rnh_outconv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), B, H, W, Cin, Cout,
+                                           int(accumulate), self._stream()), 'rnh_outconv_wgrad')
+
+    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
+        self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev)
+        hd = dh.shape[-1]
+        npix = dh.numel() // hd
+        for t in (dc_next, c_prev, c_next, dc_prev):
+            if t is not None and t.shape != dh.shape:
+                raise L.HipKernelError('lstm_gates_bwd: state shapes')
+        if gates.numel() != 4 * dh.numel() or dgates.numel() != 4 * dh.numel():
+            raise L.HipKernelError('lstm_gates_bwd: gate shapes')
+        L.check(self.lib.rnh_lstm_gates_bwd(_ptr(dh), _ptr(dc_next), _ptr(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates),
+                                            _ptr(dc_prev), npix, hd, self._stream()), 'rnh_lstm_gates_bwd')
+
+    def add(self, out, a, b=None, c=None, accumulate=False):
+        self._chk(out, a, b, c)
+        n = out.numel()
+        for t in (a, b, c):
+            if t is not None and t.numel() != n:
+                raise L.HipKernelError('add: size mismatch')
+        L.check(self.lib.rnh_ew_add(_ptr(out), _ptr(a), _ptr(b), _ptr(c), n, int(accumulate), self._stream()), 'rnh_ew_add')
+        return out
+
+    def phase_plane(self, pos, N, F, H, W):
+        pos = pos.reshape(N, F).contiguous()
+        self._chk(pos)
+        out = self.empty(F * N, H, W, 4)
+        L.check(self.lib.rnh_phase_plane(_ptr(pos), _ptr(out), N, F, H, W, self._stream()), 'rnh_phase_plane')
+        return out
+
+    def loss(self, o, y, G, T, kind, eps, gscale=None, want_grad=False):
+        """o: (G*T, ...) outputs, y: (T, ...) targets.  Returns (loss[G*T], dO or None)."""
+        self._chk(o, y, gscale)
+        per = y.numel() // T
+        if o.numel() != G * T * per:
+            raise L.HipKernelError('loss: shapes')
+        loss = self.empty(G * T)
+        d_o = torch.empty_like(o) if want_grad else None
+        ws = self._workspace('loss', G * T * L.LOSS_BLOCKS)
+        L.check(self.lib.rnh_loss_fwd_bwd(_ptr(o), _ptr(y), _ptr(loss), _ptr(d_o), _ptr(gscale), _ptr(ws), G, T, per, kind,
+                                          float(eps), self._stream()), 'rnh_loss_fwd_bwd')
+        return loss, d_o

@@ -1,0 +1,108 @@
+"""ctypes binding of librefinenet_hip.so (the C ABI declared in include/refinenet_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``load()`` raises if the shared object is
+missing, and every wrapper raises ``HipKernelError`` on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
+
+MAX_SRC, MAX_DST = 16, 4
+EPI_STORE, EPI_PS, EPI_LSTM = 0, 1, 2
+TILE_128x128, TILE_128x128_G, TILE_256x64, TILE_128x160, TILE_64x128 = 0, 1, 2, 3, 4
+TILE_COLS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 64, TILE_128x160: 160, TILE_64x128: 128}
+TILE_ROWS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 256, TILE_128x160: 128, TILE_64x128: 64}
+LOSS_L1, LOSS_CHARBONNIER = 0, 1
+LOSS_BLOCKS = 64
+
+EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_reduce', 'rnh_inconv_prelu_fwd',
+           'rnh_inconv_prelu_bwd', 'rnh_inconv_bwd_ws_floats', 'rnh_outconv_fwd', 'rnh_outconv_dgrad',
+           'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_ew_add',
+           'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes']
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class Src(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('ptr2', C.c_void_p), ('C', C.c_int32), ('c0', C.c_int32), ('nch', C.c_int32),
+                ('img_off', C.c_int32), ('scale', C.c_int32), ('sub_y', C.c_int32), ('sub_x', C.c_int32),
+                ('_pad', C.c_int32)]
+
+
+class Dst(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('C', C.c_int32), ('c0', C.c_int32), ('ncols', C.c_int32),
+                ('accumulate', C.c_int32), ('img_off', C.c_int32), ('_pad', C.c_int32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('src', Src * MAX_SRC), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('ntaps', C.c_int32), ('nk', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p),
+                ('Npad', C.c_int32), ('epilogue', C.c_int32), ('tile', C.c_int32), ('ndst', C.c_int32),
+                ('dst', Dst * MAX_DST), ('ps_r', C.c_int32), ('ps_cq', C.c_int32), ('hd', C.c_int32),
+                ('_pad', C.c_int32), ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
+                ('gates_out', C.c_void_p)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [('xs', Src * MAX_SRC), ('nxs', C.c_int32), ('xcols_pad', C.c_int32), ('ys', Src * MAX_SRC),
+                ('nys', C.c_int32), ('ycols_pad', C.c_int32), ('xgrp', C.c_void_p), ('ygrp', C.c_void_p),
+                ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('ntaps', C.c_int32), ('tile', C.c_int32),
+                ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: build with csrc/build.sh or
+    ``__graft_entry__.build()``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipKernelError(f'{LIB_PATH} is missing: build it with csrc/build.sh (hipcc --offload-arch=gfx950); '
+                             'there is no fallback path')
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipKernelError(f'{LIB_PATH} does not export {name}')
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    lib.rnh_last_error.restype = C.c_char_p
+    lib.rnh_conv_igemm.argtypes = [C.POINTER(ConvArgs), vp]
+    lib.rnh_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
+    lib.rnh_wgrad_reduce.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]
+    lib.rnh_inconv_prelu_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_inconv_prelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_inconv_bwd_ws_floats.argtypes = [i32, i32]
+    lib.rnh_inconv_bwd_ws_floats.restype = i64
+    lib.rnh_outconv_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_outconv_dgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_outconv_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_outconv_wgrad_ws_floats.argtypes = [i32, i32]
+    lib.rnh_outconv_wgrad_ws_floats.restype = i64
+    lib.rnh_lstm_gates_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    lib.rnh_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, f32, vp]
+    lib.rnh_ew_add.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+    lib.rnh_phase_plane.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.rnh_struct_sizes.argtypes = [C.POINTER(C.c_int32 * 4)]
+    lib.rnh_struct_sizes.restype = None
+    sizes = (C.c_int32 * 4)()
+    lib.rnh_struct_sizes(C.byref(sizes))
+    mine = [C.sizeof(Src), C.sizeof(Dst), C.sizeof(ConvArgs), C.sizeof(WgradArgs)]
+    if list(sizes) != mine:
+        raise HipKernelError(f'struct layout mismatch between the binding {mine} and the library {list(sizes)}')
+    if lib.rnh_abi_version() != 1:
+        raise HipKernelError('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rnh_last_error().decode('utf-8', 'replace')
+        raise HipKernelError(f'{what} failed with code {rc}: {msg}')

@@ -1,0 +1,262 @@
+"""Backend-independent descriptions of the convolutions of RefineNet as implicit GEMMs.
+
+A ``ConvPlan`` says how the K dimension (source segments x 16-channel chunks x taps) and the column
+dimension of one convolution map onto the reference's OIHW weight tensor (reference
+src/model/nets/refine_net.py: conv definitions at :149-154, :191, :199-205, :235-241).  ``WgradPlan`` does
+the same for the rows / columns of a weight gradient.  The HIP backend turns the maps into device index
+arrays for ``rnh_pack_weights`` / ``rnh_wgrad_reduce``; the test double in tests/ evaluates them with
+torch ops, so that the maps themselves are checked against the oracle on CPU.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+from . import lib as L
+
+KC = 16   # channels per K step of the forward kernel
+
+
+@dataclass
+class Src:
+    """Python-level mirror of rnh_src_t: channels [c0, c0+nch) of an NHWC tensor (B, H, W, C)."""
+    t: object
+    c0: int = 0
+    nch: Optional[int] = None
+    img_off: int = 0
+    add: object = None
+    scale: int = 1
+    sub: tuple = (0, 0)
+
+
+@dataclass
+class Dst:
+    """Python-level mirror of rnh_dst_t."""
+    t: object
+    ncols: int
+    c0: int = 0
+    accumulate: bool = False
+    img_off: int = 0
+
+
+@dataclass
+class KSeg:
+    nch: int          # channels of the source tensor slice (multiple of 4)
+    nvalid: int       # how many of them correspond to real weight channels (<= nch)
+    kbase: int        # first index along the weight's K axis (Cin if not transposed, Cout if transposed)
+    kcoff: int = 0    # offset added to the column map for this segment
+
+
+def pick_tile(ncols):
+    if ncols <= 64:
+        return L.TILE_256x64
+    if ncols <= 128:
+        return L.TILE_128x128
+    if ncols <= 160:
+        return L.TILE_128x160
+    return L.TILE_128x128
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class ConvPlan:
+    """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
+
+    def __init__(self, name, wkey, bkey, wshape, ksegs: List[KSeg], colmap: List[int], tile=None,
+                 epilogue=L.EPI_STORE, transposed=False, kstride=1):
+        self.name, self.wkey, self.bkey = name, wkey, bkey
+        self.Cout, self.Cin, kh, kw = wshape
+        self.ntaps = kh * kw
+        assert self.ntaps in (1, 9)
+        self.ksegs, self.transposed, self.kstride, self.epilogue = ksegs, transposed, kstride, epilogue
+        self.tile = pick_tile(len(colmap)) if tile is None else tile
+        self.Npad = _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        self.colmap = list(colmap) + [-1] * (self.Npad - len(colmap))
+        self.kbase, self.knv, self.ktap, self.kcoff = [], [], [], []
+        for sg in ksegs:
+            assert sg.nch % 4 == 0 and 0 < sg.nvalid <= sg.nch
+            for ch in range((sg.nch + KC - 1) // KC):
+                for t in range(self.ntaps):
+                    self.kbase.append(sg.kbase + ch * KC * kstride)
+                    self.knv.append(max(0, min(KC, sg.nvalid - ch * KC)))
+                    self.ktap.append(t)
+                    self.kcoff.append(sg.kcoff)
+        self.nk = len(self.kbase)
+
+    def __repr__(self):
+        return f'ConvPlan({self.name}, nk={self.nk}, Npad={self.Npad}, tile={self.tile})'
+
+
+@dataclass
+class XSeg:
+    nch: int
+    nvalid: int
+    ci_base: int
+
+
+@dataclass
+class YSeg:
+    nch: int
+    nvalid: int
+    co_base: int
+    stride: int = 1
+
+
+def pick_wgrad_tile(nrows, ncols):
+    if 128 < ncols <= 160:
+        return L.TILE_128x160
+    if ncols <= 64:
+        return L.TILE_256x64 if nrows > 128 else L.TILE_64x128
+    if nrows <= 64:
+        return L.TILE_64x128
+    return L.TILE_128x128
+
+
+class WgradPlan:
+    """Row (forward input channel) / column (output channel) layout of one rnh_conv_wgrad call."""
+
+    def __init__(self, name, wkey, bkey, wshape, xsegs: List[XSeg], ysegs: List[YSeg], tile=None):
+        self.name, self.wkey, self.bkey = name, wkey, bkey
+        self.Cout, self.Cin, kh, kw = wshape
+        self.ntaps = kh * kw
+        self.xsegs, self.ysegs = xsegs, ysegs
+        rowmap, xgrp = [], []
+        for si, sg in enumerate(xsegs):
+            assert sg.nch % 4 == 0
+            rowmap += [sg.ci_base + c if c < sg.nvalid else -1 for c in range(sg.nch)]
+            xgrp += [(si << 16) | c for c in range(0, sg.nch, 4)]
+        colmap, ygrp = [], []
+        for si, sg in enumerate(ysegs):
+            assert sg.nch % 4 == 0
+            colmap += [sg.co_base + c * sg.stride if c < sg.nvalid else -1 for c in range(sg.nch)]
+            ygrp += [(si << 16) | c for c in range(0, sg.nch, 4)]
+        self.tile = pick_wgrad_tile(len(rowmap), len(colmap)) if tile is None else tile
+        self.xcols_pad = _pad_to(len(rowmap), L.TILE_ROWS[self.tile])
+        self.ycols_pad = _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        self.rowmap = rowmap + [-1] * (self.xcols_pad - len(rowmap))
+        self.colmap = colmap + [-1] * (self.ycols_pad - len(colmap))
+        self.xgrp = xgrp + [-1] * (self.xcols_pad // 4 - len(xgrp))
+        self.ygrp = ygrp + [-1] * (self.ycols_pad // 4 - len(ygrp))
+
+    def nsplit(self, npix):
+        tiles = (self.xcols_pad // L.TILE_ROWS[self.tile]) * (self.ycols_pad // L.TILE_COLS[self.tile]) * self.ntaps
+        steps = (npix + 15) // 16
+        want = max(1, -(-1536 // tiles))
+        return int(max(1, min(want, 64, steps)))
+
+
+# --------------------------------------------------------------------------------------------------------
+# the plans of one RefineNet configuration
+# --------------------------------------------------------------------------------------------------------
+def lstm_colmap(hd):
+    """Column n = tile*128 + gate*32 + j  <->  reference output channel gate*hd + tile*32 + j."""
+    cm = []
+    for tl in range((hd + 31) // 32):
+        for g in range(4):
+            for j in range(32):
+                hc = tl * 32 + j
+                cm.append(g * hd + hc if hc < hd else -1)
+    return cm
+
+
+def ps_colmap(cq, r):
+    """Column n = (i*r + j)*cq + c  <->  nn.PixelShuffle input channel c*r*r + i*r + j."""
+    return [(n % cq) * r * r + n // cq for n in range(cq * r * r)]
+
+
+def r4(n):
+    return _pad_to(n, 4)
+
+
+class NetPlans:
+    """All plans of one RefineNet configuration (``cfg`` has the reference constructor kwargs as attributes)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        nf = list(cfg.num_features)
+        self.nf, self.C, self.Cl, self.L = nf, nf[0], nf[-1], len(nf)
+        for c in nf:
+            if c % 4:
+                raise ValueError('num_features must be multiples of 4 for the HIP path')
+        self.lstm = {}
+        for d in ('forward', 'backward'):
+            for l, hd in enumerate(nf):
+                cx = nf[0] if l == 0 else nf[l - 1]
+                cin = cx + hd if cfg.memory else 2 * cx
+                wk, bk = f'{d}_lstm_block.cell_list.{l}.conv.weight', f'{d}_lstm_block.cell_list.{l}.conv.bias'
+                ws = (4 * hd, cin, 3, 3)
+                second = hd if cfg.memory else cx
+                full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lstm_colmap(hd),
+                                tile=L.TILE_128x128_G, epilogue=L.EPI_LSTM)
+                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lstm_colmap(hd), tile=L.TILE_128x128_G,
+                                 epilogue=L.EPI_LSTM) if cfg.memory else full
+                dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True)
+                wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
+                                  [YSeg(4 * hd, 4 * hd, 0)])
+                self.lstm[(d, l)] = dict(full=full, first=first, dgrad=dgrad, wgrad=wgrad, cx=cx, hd=hd, second=second)
+
+        Cl, w = self.Cl, cfg.refine_window_size
+        self.pos = bool(cfg.positional_encoding)
+        if self.pos:
+            C1 = 2 * Cl + 1
+            self.C1, self.C1p = C1, r4(C1)
+            ws1, ws2 = (C1, w * C1, 3, 3), (Cl, C1, 3, 3)
+            k1, b1 = 'refine_block.body.conv1.weight', 'refine_block.body.conv1.bias'
+            k2, b2 = 'refine_block.body.conv2.weight', 'refine_block.body.conv2.bias'
+            segs, xsegs = [], []
+            for j in range(w):
+                segs += [KSeg(Cl, Cl, j * C1), KSeg(Cl, Cl, j * C1 + Cl), KSeg(4, 1, j * C1 + 2 * Cl)]
+                xsegs += [XSeg(Cl, Cl, j * C1), XSeg(Cl, Cl, j * C1 + Cl), XSeg(4, 1, j * C1 + 2 * Cl)]
+            # conv1 writes C1p channels (the pad channels have zero weights and bias => zeros)
+            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs, list(range(C1)) + [-1] * (self.C1p - C1))
+            self.r2_fwd = ConvPlan('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
+            self.r2_dgrad = ConvPlan('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
+                                     list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
+            self.r2_wgrad = WgradPlan('refine2.wgrad', k2, b2, ws2, [XSeg(self.C1p, C1, 0)], [YSeg(Cl, Cl, 0)])
+            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs, [YSeg(self.C1p, C1, 0)])
+            self.r1_dgrad = ConvPlan('refine1.dgrad', k1, None, ws1, [KSeg(self.C1p, C1, 0, kcoff=j * C1) for j in range(w)],
+                                     list(range(2 * Cl)), transposed=True)
+        else:
+            ws1 = (Cl, w * 2 * Cl, 1, 1)
+            k1, b1 = 'refine_block.body.conv1.weight', 'refine_block.body.conv1.bias'
+            segs, xsegs = [], []
+            for j in range(w):
+                segs += [KSeg(Cl, Cl, j * 2 * Cl), KSeg(Cl, Cl, j * 2 * Cl + Cl)]
+                xsegs += [XSeg(Cl, Cl, j * 2 * Cl), XSeg(Cl, Cl, j * 2 * Cl + Cl)]
+            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs, list(range(Cl)))
+            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs, [YSeg(Cl, Cl, 0)])
+            self.r1_dgrad = ConvPlan('refine1.dgrad', k1, None, ws1, [KSeg(Cl, Cl, 0, kcoff=j * 2 * Cl) for j in range(w)],
+                                     list(range(2 * Cl)), transposed=True)
+
+        # upsampler: [(conv with PixelShuffle r)]* then the small last conv
+        C, s = self.C, cfg.upscale_factor
+        self.up = []
+        if s == 3:
+            rs = [3]
+        else:
+            rs = [2] * {2: 1, 4: 2, 8: 3}[s]
+        for i, r in enumerate(rs):
+            wk, bk = f'out_block.conv{i + 1}.weight', f'out_block.conv{i + 1}.bias'
+            ws = (r * r * C, C, 3, 3)
+            fwd = ConvPlan(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS)
+            dgrad = ConvPlan(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
+                             transposed=True, kstride=r * r)
+            wgrad = WgradPlan(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
+            self.up.append(dict(r=r, fwd=fwd, dgrad=dgrad, wgrad=wgrad))
+        self.last_w, self.last_b = f'out_block.conv{len(rs) + 1}.weight', f'out_block.conv{len(rs) + 1}.bias'
+
+    def conv_plans(self):
+        out = []
+        for v in self.lstm.values():
+            out += [v['full'], v['first'], v['dgrad']]
+        out += [self.r1_fwd, self.r1_dgrad]
+        if self.pos:
+            out += [self.r2_fwd, self.r2_dgrad]
+        for u in self.up:
+            out += [u['fwd'], u['dgrad']]
+        seen, uniq = set(), []
+        for p in out:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        return uniq

@@ -1,0 +1,207 @@
+/*
+ * refinenet_hip.h - C ABI of librefinenet_hip.so: the MI355X (gfx950) kernels of the RefineNet
+ * forward/backward hot path.
+ *
+ * Boundary.  The reference implements this path as stock PyTorch operators called from Python
+ * (reference src/model/nets/refine_net.py:61-344, src/runner/trainers/acdc_vsr_refinenet_trainer.py:41-47,
+ * 76-101).  Each entry point below replaces the ATen operator sequence of one reference call site; the
+ * call site it replaces is cited on the declaration.  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless the parameter comment says "host";
+ *   - activations are NHWC: tensor[b][y][x][c], b = frame * N + n ("image" index), c contiguous;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no allocation, no
+ *     synchronisation, graph-capture safe); workspaces are provided by the caller;
+ *   - return value: 0 on success, a negative RNH_E_* code on invalid arguments, a positive hipError_t if
+ *     the launch failed.  rnh_last_error() returns a static string for the last failure on this thread.
+ *   - channel counts, channel offsets and channel strides must be multiples of 4 (16-byte vector access).
+ */
+#ifndef REFINENET_HIP_H
+#define REFINENET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNH_ABI_VERSION 1
+
+#define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
+#define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
+#define RNH_E_RANGE    (-3)   /* too many sources / destinations, unsupported tile or mode         */
+#define RNH_E_WORKSPACE (-4)  /* workspace too small                                               */
+
+#define RNH_MAX_SRC 16
+#define RNH_MAX_DST 4
+
+/* One input operand of an implicit-GEMM convolution: `nch` channels [c0, c0+nch) of an NHWC tensor.
+ * The K dimension of the GEMM is the concatenation of all sources (this replaces torch.cat at
+ * refine_net.py:170,177,253).  Source image index = output image index + img_off.  With scale = r > 1 the
+ * source has r x the output resolution and pixel (y, x) reads (r*y + sub_y, r*x + sub_x): the inverse of
+ * nn.PixelShuffle(r), used by the backward of the upsampler (refine_net.py:200,204). */
+typedef struct rnh_src {
+    const float *ptr;    /* tensor base                                                           */
+    const float *ptr2;   /* optional second tensor of the same geometry, added element-wise; or 0 */
+    int32_t C;           /* channels per pixel of the tensor (stride)                             */
+    int32_t c0;          /* first channel used                                                    */
+    int32_t nch;         /* channels used                                                         */
+    int32_t img_off;     /* image offset relative to the output image index                       */
+    int32_t scale;       /* 1, or r for pixel-unshuffle gathering                                  */
+    int32_t sub_y, sub_x;
+    int32_t _pad;
+} rnh_src_t;
+
+/* One output segment: `ncols` consecutive GEMM columns go to channels [c0, c0+ncols) of an NHWC tensor. */
+typedef struct rnh_dst {
+    float *ptr;
+    int32_t C;           /* channel stride of the destination tensor                              */
+    int32_t c0;
+    int32_t ncols;
+    int32_t accumulate;  /* 0: store, 1: add to what is there                                     */
+    int32_t img_off;     /* destination image index = output image index + img_off               */
+    int32_t _pad;
+} rnh_dst_t;
+
+/* Epilogues of rnh_conv_igemm */
+#define RNH_EPI_STORE 0   /* bias add, store / accumulate into the destination segments           */
+#define RNH_EPI_PS    1   /* bias add, nn.PixelShuffle(ps_r) fused into the store (dst[0])        */
+#define RNH_EPI_LSTM  2   /* bias add, ConvLSTM gate math, writes h, c (and the gates for backward)*/
+
+/* Output-tile shapes (rows x columns of one workgroup) */
+#define RNH_TILE_128x128 0   /* 2x2 waves of 64x64          */
+#define RNH_TILE_128x128_G 1 /* 4x1 waves of 32x128 (LSTM: one wave holds the 4 gates of 32 channels) */
+#define RNH_TILE_256x64  2   /* 4x1 waves of 64x64          */
+#define RNH_TILE_128x160 3   /* 4x1 waves of 32x160         */
+#define RNH_TILE_64x128  4   /* 2x2 waves of 32x64 (rnh_conv_wgrad only) */
+
+typedef struct rnh_conv_args {
+    rnh_src_t src[RNH_MAX_SRC];
+    int32_t nsrc;
+    int32_t B, H, W;          /* output geometry: images, rows, columns                            */
+    int32_t ntaps;            /* 9 (3x3, padding 1) or 1 (1x1)                                    */
+    int32_t nk;               /* number of 16-channel K steps = sum_src ceil(nch/16) * ntaps       */
+    const float *wp;          /* packed weights [nk][Npad][16] from rnh_pack_weights               */
+    const float *bias;        /* packed bias [Npad] or 0                                           */
+    int32_t Npad;             /* padded column count, a multiple of the tile's column count        */
+    int32_t epilogue;         /* RNH_EPI_*                                                         */
+    int32_t tile;             /* RNH_TILE_*                                                        */
+    int32_t ndst;
+    rnh_dst_t dst[RNH_MAX_DST];
+    int32_t ps_r;             /* RNH_EPI_PS: upscale factor r; column n = (i*r+j)*ps_cq + c         */
+    int32_t ps_cq;            /* RNH_EPI_PS: channels after the shuffle                            */
+    /* RNH_EPI_LSTM: column n = tile*128 + gate*32 + j <-> hidden channel tile*32 + j, gate order i,f,o,g */
+    int32_t hd;               /* hidden channels                                                   */
+    int32_t _pad;
+    const float *c_prev;      /* [B][H][W][hd] or 0 (zero state)                                   */
+    float *h_out;             /* [B][H][W][hd]                                                     */
+    float *c_out;             /* [B][H][W][hd]                                                     */
+    float *gates_out;         /* [B][H][W][4*hd] post-activation i,f,o,g (channel = gate*hd + ch) or 0 */
+} rnh_conv_args_t;
+
+/* Implicit-GEMM 3x3 / 1x1 convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d at refine_net.py:149,151,154 (refine block), :199,203 (upsampler convs followed by
+ * PixelShuffle :200,204), :235-241 + :253-265 (ConvLSTM cell: cat, conv, split, sigmoid/tanh, state
+ * update) and, with transposed/flipped packed weights, their data gradients (aten::convolution_backward
+ * issued by loss.backward(), acdc_vsr_refinenet_trainer.py:46). */
+int rnh_conv_igemm(const rnh_conv_args_t *args /* host */, void *stream);
+
+/* Weight re-layout for rnh_conv_igemm: wp[ks][n][kk] = W[o][i][tap] (OIHW, reference state_dict layout)
+ *   not transposed: o = colmap[n] + kcoff[ks],     i = kbase[ks] + kk*kstride, tap = ktap[ks]
+ *   transposed    : o = kbase[ks] + kk*kstride,    i = colmap[n] + kcoff[ks],  tap = ntaps-1-ktap[ks]
+ * zero where colmap[n] < 0 or kk >= knv[ks].  biasp[n] = bias[colmap[n]] (only if bias != 0, not transposed).
+ * kbase/knv/ktap/kcoff/colmap are DEVICE int32 arrays (kcoff may be 0 = all zero). */
+int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
+                     const int32_t *kbase, const int32_t *knv, const int32_t *ktap, const int32_t *kcoff,
+                     const int32_t *colmap, int nk, int Npad, int Cout, int Cin, int ntaps, int kstride,
+                     int transposed, void *stream);
+
+typedef struct rnh_wgrad_args {
+    rnh_src_t xs[RNH_MAX_SRC];   /* forward input operand (rows of dW), tap-shifted                  */
+    int32_t nxs;
+    int32_t xcols_pad;           /* padded row count, multiple of the tile rows                      */
+    rnh_src_t ys[RNH_MAX_SRC];   /* output-gradient operand (columns of dW)                          */
+    int32_t nys;
+    int32_t ycols_pad;           /* padded column count, multiple of the tile columns                */
+    const int32_t *xgrp;         /* device [xcols_pad/4]: (src << 16) | channel, or -1 (zero)        */
+    const int32_t *ygrp;         /* device [ycols_pad/4]                                             */
+    int32_t B, H, W, ntaps;
+    int32_t tile;                /* RNH_TILE_128x128 or RNH_TILE_128x160                             */
+    int32_t nsplit;              /* pixel-range splits (grid.x)                                      */
+    float *slab;                 /* workspace [nsplit][ntaps][xcols_pad][ycols_pad]                  */
+    float *bslab;                /* workspace [nsplit][ycols_pad] (column sums = bias gradient) or 0 */
+} rnh_wgrad_args_t;
+
+/* Weight gradient dW[tap][ci][co] = sum_pixels X[p+tap][ci] * dY[p][co] as an MFMA GEMM whose K dimension
+ * is the pixel index, split over `nsplit` workgroups into partial slabs (deterministic, no atomics).
+ * Replaces the weight/bias part of aten::convolution_backward (loss.backward(), trainer :46). */
+int rnh_conv_wgrad(const rnh_wgrad_args_t *args /* host */, void *stream);
+
+/* Sum the partial slabs and scatter into the reference-layout gradient:
+ *   dw[(colmap[j]*Cin + rowmap[i])*ntaps + tap] (+)= sum_s slab[s][tap][i][j]   (rowmap/colmap < 0: skipped)
+ *   db[colmap[j]] (+)= sum_s bslab[s][j]                                         (if bslab and db)        */
+int rnh_wgrad_reduce(const float *slab, const float *bslab, int nsplit, int ntaps, int xcols_pad, int ycols_pad,
+                     const int32_t *rowmap, const int32_t *colmap, int Cin, float *dw, float *db, int accumulate,
+                     void *stream);
+
+/* _InBlock forward (refine_net.py:188-192): y = PReLU_a(conv3x3(x) + b), x NHWC [B][H][W][Cin] (any Cin),
+ * w OIHW [Cout][Cin][3][3], y NHWC [B][H][W][Cout], Cout % 4 == 0. */
+int rnh_inconv_prelu_fwd(const float *x, const float *w, const float *bias, const float *slope, float *y,
+                         int B, int H, int W, int Cin, int Cout, void *stream);
+
+/* _InBlock backward: recomputes the pre-activation, returns dW, db, dslope (stored, or accumulated).
+ * ws: workspace of rnh_inconv_bwd_ws_floats(Cin, Cout) floats. */
+int rnh_inconv_prelu_bwd(const float *x, const float *w, const float *bias, const float *slope, const float *dy,
+                         float *dw, float *db, float *dslope, float *ws, int B, int H, int W, int Cin, int Cout,
+                         int accumulate, void *stream);
+int64_t rnh_inconv_bwd_ws_floats(int Cin, int Cout);
+
+/* Last convolution of _OutBlock (refine_net.py:201,205), Cout = out_channels (small): HBM-bound direct
+ * convolution, x NHWC [B][H][W][Cin], y NHWC [B][H][W][Cout]. */
+int rnh_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                    int Cout, void *stream);
+/* Its data gradient dx[p][ci] = sum_{t,co} dy[p-t][co] w[co][ci][t] ... */
+int rnh_outconv_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout,
+                      void *stream);
+/* ... and weight / bias gradient (ws: rnh_outconv_wgrad_ws_floats floats). */
+int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, float *db, float *ws, int B, int H, int W, int Cin,
+                      int Cout, int accumulate, void *stream);
+int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout);
+
+/* Backward of the ConvLSTM gate math (refine_net.py:258-265): from dh', dc' and the saved post-activation
+ * gates, c_prev and c_next produce the pre-activation gate gradients [..][4*hd] (channel = gate*hd + ch,
+ * order i,f,o,g) and dc_prev.  dc_next / c_prev may be 0 (zero).  n = B*H*W pixels. */
+int rnh_lstm_gates_bwd(const float *dh, const float *dc_next, const float *gates, const float *c_prev,
+                       const float *c_next, float *dgates, float *dc_prev, int64_t npix, int hd, void *stream);
+
+/* Loss + gradient for all output groups at once.  Replaces the 3*S*T loss_fn(output, target) calls of
+ * AcdcVSRRefineNetTrainer._compute_losses (trainer :83-100) with torch.nn.L1Loss (kind 0) or
+ * CharbonnierLoss (kind 1, src/model/losses.py:32-34).
+ *   o: [G][T][per] outputs, y: [T][per] targets, per = N*C*sH*sW
+ *   loss[g*T + i] = mean(l(o - y));  do (optional) = gscale[g*T + i] * l'(o - y) / per
+ * (gscale = d(total loss)/d(loss[g*T+i]), e.g. discount_g / T).  ws: G*T*RNH_LOSS_BLOCKS floats. */
+#define RNH_LOSS_L1 0
+#define RNH_LOSS_CHARBONNIER 1
+#define RNH_LOSS_BLOCKS 64
+int rnh_loss_fwd_bwd(const float *o, const float *y, float *loss, float *d_o, const float *gscale /* device [G*T] */,
+                     float *ws, int G, int T, int64_t per, int kind, float eps, void *stream);
+
+/* out = (accumulate ? out : 0) + a (+ b) (+ c); n floats, n % 4 == 0.  b, c may be 0.
+ * Replaces the residual adds of refine_net.py:102,107,112 and the feature update :118-133. */
+int rnh_ew_add(float *out, const float *a, const float *b, const float *c, int64_t n, int accumulate, void *stream);
+
+/* Phase-code plane for the refine block (replaces pos_codes.repeat(...).permute(...), refine_net.py:168):
+ * out[(f*N + n)][y][x][0..3] = (pos[n*F + f], 0, 0, 0). */
+int rnh_phase_plane(const float *pos /* [N][F] */, float *out, int N, int F, int H, int W, void *stream);
+
+const char *rnh_last_error(void);
+int rnh_abi_version(void);
+/* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding
+ * check its struct mirrors. */
+void rnh_struct_sizes(int32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFINENET_HIP_H */

@@ -1,0 +1,106 @@
+"""Host logic on CPU: the engine's forward/backward scheduling and the GEMM index maps of hipvsr.plans, run
+over the torch test double (tests/torch_ops.py), against the golden vectors captured from the reference.
+
+This does NOT exercise the HIP kernels (tests/test_hip_*.py do, on the GPU box); it proves that what the
+engine asks the kernels to do is the reference's computation (reference src/model/nets/refine_net.py:61-135
+and the backward autograd derives from it).  Tolerance: fp32 re-association only (1e-5 abs on O(1) values).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hipvsr import lib as L
+from hipvsr.engine import RefineNetEngine
+from hipvsr.spec import NetConfig, state_dict_spec
+from torch_ops import TorchOps
+
+
+@pytest.fixture(scope='module')
+def g1(golden_dir):
+    return torch.load(os.path.join(golden_dir, 'g1_tiny.pt'), weights_only=False)
+
+
+def run_engine(c, kind=L.LOSS_L1, eps=1e-6):
+    cfg = NetConfig(**c['kwargs'])
+    ops = TorchOps('cpu')
+    eng = RefineNetEngine(cfg, ops)
+    params = {k: v.clone() for k, v in c['state_dict'].items()}
+    O_all, ctx = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
+    S, T = cfg.num_stages, len(c['targets'])
+    N = c['inputs'][0].shape[0]
+    G = 3 * S
+    y = torch.stack(c['targets'], 0).permute(0, 1, 3, 4, 2).contiguous()        # (T, N, sH, sW, Co)
+    gscale = torch.tensor([np.power(0.5, S - 1 - g // 3) / T for g in range(G) for _ in range(T)], dtype=torch.float32)
+    o = O_all.reshape(G * T, *O_all.shape[3:]) if False else O_all.reshape(G, T, N, *O_all.shape[3:])
+    losses, dO = ops.loss(o.reshape(G * T, -1), y.reshape(T, -1), G, T, kind, eps, gscale, want_grad=True)
+    total = (losses * gscale).sum()
+    grads = eng.backward(params, ctx, dO.reshape(O_all.shape))
+    return cfg, O_all, total, grads
+
+
+CASES = [f'x{s}_pos{p}_mem{m}' for s in (2, 3, 4) for p in (1, 0) for m in (1, 0)] + ['x8_pos1_mem1']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_engine_matches_reference_golden(g1, case):
+    c = g1[case]
+    cfg, O_all, total, grads = run_engine(c)
+    S, T = cfg.num_stages, len(c['targets'])
+    N = c['inputs'][0].shape[0]
+    assert list(grads.keys()) == list(state_dict_spec(cfg).keys())
+    for g in range(3 * S):
+        for i in range(T):
+            mine = O_all[g // 3, g % 3, i * N:(i + 1) * N].permute(0, 3, 1, 2)
+            torch.testing.assert_close(mine, c['outputs'][g][i], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(total, c['train_loss'], atol=1e-5, rtol=1e-5)
+    for k, gref in c['grads'].items():
+        if gref is None:
+            assert grads[k] is None
+            continue
+        assert not torch.isnan(grads[k]).any(), k
+        scale = float(gref.abs().max()) + 1e-12
+        err = float((grads[k] - gref).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+
+
+def test_engine_charbonnier(g1):
+    c = g1['x4_pos1_mem1']
+    _, _, total, grads = run_engine(c, kind=L.LOSS_CHARBONNIER)
+    torch.testing.assert_close(total, c['charbonnier_train_loss'], atol=1e-5, rtol=1e-5)
+    for k, gref in c['charbonnier_grads'].items():
+        if gref is not None:
+            scale = float(gref.abs().max()) + 1e-12
+            assert float((grads[k] - gref).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+def test_engine_flat_gradient_buffer(g1):
+    c = g1['x2_pos1_mem1']
+    cfg = NetConfig(**c['kwargs'])
+    ops = TorchOps('cpu')
+    eng = RefineNetEngine(cfg, ops)
+    params = {k: v.clone() for k, v in c['state_dict'].items()}
+    O_all, ctx = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
+    n = sum(int(np.prod(s)) for s in state_dict_spec(cfg).values())
+    flat = torch.zeros(n)
+    grads = eng.backward(params, ctx, torch.ones_like(O_all), flat=flat)
+    off = 0
+    for k, shp in state_dict_spec(cfg).items():
+        m = int(np.prod(shp))
+        if grads[k] is not None:
+            assert grads[k].data_ptr() == flat.data_ptr() + 4 * off
+            assert torch.equal(grads[k].reshape(-1), flat[off:off + m])
+        off += m
+
+
+def test_engine_errors():
+    base = dict(in_channels=1, out_channels=1, num_features=[8, 8])
+    with pytest.raises(ValueError, match='upscale factor'):
+        NetConfig(upscale_factor=5, **base)
+    with pytest.raises(ValueError, match='update_memory'):
+        NetConfig(num_updated_frames=2, update_memory=False, **base)
+    cfg = NetConfig(num_stages=2, update_memory=True, num_updated_frames=0, positional_encoding=True, **base)
+    eng = RefineNetEngine(cfg, TorchOps('cpu'))
+    with pytest.raises(IndexError):
+        eng.forward({}, [torch.zeros(1, 1, 4, 4)] * 6, torch.zeros(1, 6, 1), need_grad=False)

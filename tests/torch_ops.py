@@ -1,0 +1,207 @@
+"""TEST DOUBLE: a plain-PyTorch (CPU or GPU) implementation of the ``ops`` interface of hipvsr.engine.
+
+It exists only so that (a) the engine's forward/backward *scheduling* and the index maps of
+hipvsr.plans can be checked against the oracle on machines without a GPU, and (b) every HIP kernel can be
+compared, through the C ABI, against the semantics written here on random descriptors.  It lives under
+tests/ and is never importable from the product package.
+"""
+import torch
+import torch.nn.functional as F
+
+from hipvsr import lib as L
+from hipvsr.plans import ConvPlan, WgradPlan
+
+
+def gather_src(s, B):
+    """(B, H, W, nch) NHWC slice described by a plans.Src."""
+    t = s.t[s.img_off:s.img_off + B]
+    if s.add is not None:
+        t = t + s.add[s.img_off:s.img_off + B]
+    if s.scale > 1:
+        t = t[:, s.sub[0]::s.scale, s.sub[1]::s.scale]
+    nch = t.shape[-1] - s.c0 if s.nch is None else s.nch
+    return t[..., s.c0:s.c0 + nch]
+
+
+def effective_weight(plan: ConvPlan, w):
+    """[Npad][Ktot][kh][kw] weight equivalent to what rnh_pack_weights builds for ``plan``."""
+    kh = 3 if plan.ntaps == 9 else 1
+    ktot = sum(sg.nch for sg in plan.ksegs)
+    weff = torch.zeros(plan.Npad, ktot, kh, kh, dtype=w.dtype, device=w.device)
+    koff = 0
+    for sg in plan.ksegs:
+        for n, cm in enumerate(plan.colmap):
+            if cm < 0:
+                continue
+            cme = cm + sg.kcoff
+            for kk in range(sg.nvalid):
+                kidx = sg.kbase + kk * plan.kstride
+                if plan.transposed:
+                    weff[n, koff + kk] = torch.flip(w[kidx, cme], dims=(0, 1))
+                else:
+                    weff[n, koff + kk] = w[cme, kidx]
+        koff += sg.nch
+    return weff
+
+
+class TorchOps:
+    name = 'torch-double'
+
+    def __init__(self, device='cpu'):
+        self.device = torch.device(device)
+        self._w = {}
+
+    def empty(self, *shape):
+        return torch.full(shape, float('nan'), dtype=torch.float32, device=self.device)   # poison: catches unwritten reads
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def stack_inputs(self, inputs):
+        x = torch.stack([t.to(self.device, torch.float32) for t in inputs], dim=0)
+        Fr, N, Cin, H, W = x.shape
+        return x.permute(0, 1, 3, 4, 2).reshape(Fr * N, H, W, Cin).contiguous()
+
+    def pack(self, plan, w, b=None):
+        weff = effective_weight(plan, w.detach())
+        bp = None
+        if b is not None and not plan.transposed:
+            bp = torch.zeros(plan.Npad, dtype=torch.float32, device=self.device)
+            for n, cm in enumerate(plan.colmap):
+                if cm >= 0:
+                    bp[n] = b[cm]
+        self._w[id(plan)] = (weff, bp)
+
+    def conv(self, plan, srcs, B, H, W, dsts=None, ps=None, lstm=None):
+        weff, bp = self._w[id(plan)]
+        x = torch.cat([gather_src(s, B) for s in srcs], dim=-1).permute(0, 3, 1, 2)
+        assert x.shape[1] == weff.shape[1], (plan.name, x.shape, weff.shape)
+        y = F.conv2d(x, weff, bp if plan.bkey is not None else None, padding=1 if plan.ntaps == 9 else 0)
+        y = y.permute(0, 2, 3, 1)                     # (B, H, W, Npad)
+        if plan.epilogue == L.EPI_STORE:
+            col = 0
+            for d in dsts:
+                tgt = d.t[d.img_off:d.img_off + B, ..., d.c0:d.c0 + d.ncols]
+                val = y[..., col:col + d.ncols]
+                if d.accumulate:
+                    tgt += val
+                else:
+                    tgt.copy_(val)
+                col += d.ncols
+        elif plan.epilogue == L.EPI_PS:
+            t, r = ps
+            cq = t.shape[-1]
+            v = y[..., :cq * r * r].reshape(B, H, W, r, r, cq)          # column = (i*r + j)*cq + c
+            t.copy_(v.permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, cq))
+        else:
+            hd = lstm['hd']
+            nt = (hd + 31) // 32
+            v = y.reshape(B, H, W, nt, 4, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, nt * 32)[..., :hd]
+            gi, gf, go = torch.sigmoid(v[..., 0, :]), torch.sigmoid(v[..., 1, :]), torch.sigmoid(v[..., 2, :])
+            gg = torch.tanh(v[..., 3, :])
+            cp = lstm.get('c_prev')
+            cn = gf * cp + gi * gg if cp is not None else gi * gg
+            lstm['c_out'].copy_(cn)
+            lstm['h_out'].copy_(go * torch.tanh(cn))
+            if lstm.get('gates_out') is not None:
+                lstm['gates_out'].copy_(torch.cat([gi, gf, go, gg], dim=-1))
+
+    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
+        x = torch.cat([gather_src(s, B) for s in xsrcs], dim=-1).permute(0, 3, 1, 2)
+        dy = torch.cat([gather_src(s, B) for s in ysrcs], dim=-1).permute(0, 3, 1, 2)
+        kh = 3 if plan.ntaps == 9 else 1
+        w0 = torch.zeros(dy.shape[1], x.shape[1], kh, kh, dtype=torch.float32, device=self.device, requires_grad=True)
+        with torch.enable_grad():
+            F.conv2d(x.detach(), w0, padding=1 if kh == 3 else 0).backward(dy.detach())
+        g = w0.grad
+        if not accumulate:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        bsum = dy.sum(dim=(0, 2, 3))
+        for j, co in enumerate(plan.colmap[:dy.shape[1]]):
+            if co < 0:
+                continue
+            if db is not None:
+                db[co] += bsum[j]
+            for i, ci in enumerate(plan.rowmap[:x.shape[1]]):
+                if ci >= 0:
+                    dw[co, ci] += g[j, i]
+
+    def inconv_fwd(self, x, w, b, slope):
+        y = F.prelu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1), slope)
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    def inconv_bwd(self, x, w, b, slope, dy, dw, db, dslope, accumulate=False):
+        w_, b_, a_ = (t.detach().clone().requires_grad_(True) for t in (w, b, slope))
+        with torch.enable_grad():
+            y = F.prelu(F.conv2d(x.permute(0, 3, 1, 2), w_, b_, padding=1), a_)
+            y.backward(dy.permute(0, 3, 1, 2))
+        for tgt, g in ((dw, w_.grad), (db, b_.grad), (dslope, a_.grad)):
+            if accumulate:
+                tgt += g
+            else:
+                tgt.copy_(g)
+
+    def outconv_fwd(self, x, w, b, out=None):
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+        if out is None:
+            return y.contiguous()
+        out.copy_(y)
+        return out
+
+    def outconv_dgrad(self, dy, w):
+        return F.conv_transpose2d(dy.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).contiguous()
+
+    def outconv_wgrad(self, x, dy, dw, db, accumulate=False):
+        w_ = torch.zeros_like(dw).requires_grad_(True)
+        with torch.enable_grad():
+            F.conv2d(x.permute(0, 3, 1, 2), w_, padding=1).backward(dy.permute(0, 3, 1, 2))
+        gb = dy.sum(dim=(0, 1, 2))
+        if accumulate:
+            dw += w_.grad
+            db += gb
+        else:
+            dw.copy_(w_.grad)
+            db.copy_(gb)
+
+    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
+        hd = dh.shape[-1]
+        gi, gf, go, gg = (gates[..., k * hd:(k + 1) * hd] for k in range(4))
+        th = torch.tanh(c_next)
+        dct = dh * go * (1 - th * th)
+        if dc_next is not None:
+            dct = dct + dc_next
+        cp = c_prev if c_prev is not None else torch.zeros_like(dh)
+        dgates.copy_(torch.cat([dct * gg * gi * (1 - gi), dct * cp * gf * (1 - gf), dh * th * go * (1 - go),
+                                dct * gi * (1 - gg * gg)], dim=-1))
+        if dc_prev is not None:
+            dc_prev.copy_(dct * gf)
+
+    def add(self, out, a, b=None, c=None, accumulate=False):
+        v = a.clone()
+        if b is not None:
+            v = v + b
+        if c is not None:
+            v = v + c
+        if accumulate:
+            out += v
+        else:
+            out.copy_(v)
+        return out
+
+    def phase_plane(self, pos, N, Fr, H, W):
+        p = pos.reshape(N, Fr).to(self.device).t().reshape(Fr * N, 1, 1, 1).expand(Fr * N, H, W, 1)
+        return torch.cat([p, torch.zeros(Fr * N, H, W, 3, device=self.device)], dim=-1).contiguous()
+
+    def loss(self, o, y, G, T, kind, eps, gscale=None, want_grad=False):
+        per = y.numel() // T
+        d = o.reshape(G, T, per) - y.reshape(1, T, per)
+        if kind == L.LOSS_L1:
+            val, der = d.abs(), torch.sign(d)
+        else:
+            r = torch.sqrt(d * d + eps)
+            val, der = r, d / r
+        loss = val.mean(dim=-1).reshape(G * T)
+        d_o = (der * gscale.reshape(G, T, 1) / per).reshape(o.shape) if want_grad else None
+        return loss, d_o
