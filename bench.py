@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cine-frames/sec of the RefineNet x4 training step (forward + deep-supervision L1 loss +
+backward + gradient all-reduce + Adam step) on synthetic Gaussian cine stacks, BASELINE.json config 2:
+N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 -> 512x512, fp32.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W          (one rank per GPU, weak scaling: 8 samples per rank)
+
+Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
+ranks).  `roofline` prices the dominant kernel (the ConvLSTM cell implicit-GEMM, 45 % of the step's FLOPs) from
+HIP-event timing of that launch on this run; `cpu_baseline` times the CPU oracle (= the reference's computation,
+bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CUs x 2.4 GHz
+
+
+def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4):
+    """Algorithmic conv FLOPs (2*MAC) per LR pixel per sample, SURVEY.md section 8(d)."""
+    F = T + 2 * U
+    out_s = {4: 1492992, 2: 299520, 3: 673920}[scale]
+    fwd = F * 1152 + S * 2 * F * L * 589824 + S * (F - 4) * 1646298 + 3 * S * T * out_s
+    bwd = T * 1152 + 2 * S * 2 * T * L * 589824 + 2 * S * T * 1646298 + 2 * 3 * S * T * out_s
+    return fwd + bwd
+
+
+def make_net(dev, seed=0):
+    from src.model.nets import RefineNet
+    torch.manual_seed(seed)
+    net = RefineNet(in_channels=1, out_channels=1, num_features=[64, 64, 64], upscale_factor=4, num_stages=3,
+                    update_memory=True, num_updated_frames=6, refine_window_size=5, positional_encoding=True)
+    return net.to(dev).train()
+
+
+def synthetic_batch(dev, n, t, h, w, seed, u=6, s=4):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    F = t + 2 * u
+    inputs = [torch.randn(n, 1, h, w, generator=g, device=dev) for _ in range(F)]
+    targets = [torch.randn(n, 1, s * h, s * w, generator=g, device=dev) for _ in range(t)]
+    phi = torch.randint(0, 30, (n, 1), generator=g, device=dev).float()
+    k = torch.arange(F, device=dev).float().unsqueeze(0)
+    pos = torch.cos(2 * torch.pi * (k + phi) / 30.0).unsqueeze(-1)
+    return inputs, targets, pos
+
+
+def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
+    """Average duration of ONE ConvLSTM-cell launch (rnh_conv_igemm, LSTM epilogue) at the benchmark shape, by HIP
+    events on the stream the kernels run on (torch's current stream)."""
+    from hipvsr.plans import Src
+    eng = net._engine()
+    ops, pl = eng.ops, eng.plans.lstm[('forward', 1)]
+    hd, cx = pl['hd'], pl['cx']
+    params = {k: p.detach() for k, p in net.named_parameters()}
+    ops.pack(pl['full'], params[pl['full'].wkey], params[pl['full'].bkey])
+    x, hp, cp = (torch.randn(n, h, w, c, device=dev) for c in (cx, hd, hd))
+    ho, co = ops.empty(n, h, w, hd), ops.empty(n, h, w, hd)
+    go = ops.empty(n, h, w, 4 * hd)
+
+    def launch():
+        ops.conv(pl['full'], [Src(x), Src(hp)], n, h, w, lstm=dict(hd=hd, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))          # 589 824 FLOP per pixel at cx = hd = 64
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    prof = os.path.join(ROOT, 'profiles', 'lstm_kernel_hbm_bytes.json')
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)',
+            'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'avg_launch_ms': round(ms, 4), 'flop_per_launch': flops}
+
+
+def cpu_baseline():
+    """The oracle (bit-exact restatement of the reference) at BASELINE config 1 on the host cores: 1 warm-up + 2 timed
+    steps of forward + discounted L1 loss + backward (about 10-20 s)."""
+    from oracle import refinenet_oracle as orc
+    threads = torch.get_num_threads()
+    cfg = orc.exp1_x4_config()
+    sd = orc.init_state_dict(cfg, seed=20200526)
+    inputs, targets, pos = orc.synthetic_batch(cfg, n=1, t=3, h=64, w=64, seed=20200527)
+    orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
+    dt = (time.perf_counter() - t0) / reps
+    return {'value': round(3.0 / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'BASELINE config 1 (x4, N=1, T=3, F=15, 64x64->256x256, fp32), {reps} timed steps after 1 warm-up, '
+                      f'{dt:.2f} s/step, PyTorch CPU oracle == reference bit for bit',
+            'tflops': round(step_flops_per_lr_pixel(3) * 64 * 64 / dt / 1e12, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
+    ap.add_argument('--size', type=int, default=128, help='LR height = width')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    dev = torch.device(f'cuda:{local}')
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    from hipvsr import dp
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+
+    net = make_net(dev, seed=0)
+    dp.broadcast_parameters(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0)
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
+    tr.loss_weights = torch.tensor([1.0], device=dev)
+    inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + 2 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        _, loss, _ = tr.train_step(inputs, targets, pos)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, loss, _ = tr.train_step(inputs, targets, pos)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    n_global = args.batch * world
+    value = n_global * args.frames * args.steps / dt
+    flop_step = step_flops_per_lr_pixel(args.frames) * args.size * args.size * n_global
+
+    if rank == 0:
+        roof = lstm_kernel_roofline(net, dev, args.batch, args.size, args.size)
+        out = {
+            'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(value, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'RefineNet x4 training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
+                                   f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
+                                   f'{4 * args.size}x{4 * args.size}, fp32, exp1_x4 net (BASELINE config 2)',
+                       'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
+                       'input_frames_per_s': round(n_global * (args.frames + 12) * args.steps / dt, 2),
+                       'step_tflop': round(flop_step / 1e12, 2),
+                       'step_tflops_per_gpu': round(flop_step / world / (dt / args.steps) / 1e12, 2),
+                       'step_frac_of_f32_mfma_peak': round(flop_step / world / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       'final_loss': round(float(loss), 6)},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,3 @@
+from .losses import *    # noqa: F401,F403
+from .metrics import *   # noqa: F401,F403
+from .nets import *      # noqa: F401,F403

@@ -1,0 +1,97 @@
+"""``RefineNet`` with the reference's module surface, computed by the MI355X HIP kernels.
+
+Same constructor, same ``forward(inputs, pos_codes)`` contract and the same ``state_dict()`` (names, shapes,
+order, OIHW fp32) as reference src/model/nets/refine_net.py:10-135, so reference checkpoints load and
+``python -m src.main <yaml>`` constructs it by name.  The sub-modules below exist to own the parameters
+under the reference's names and default initialisation; they are never called - ``forward`` hands everything to
+``hipvsr.engine.RefineNetEngine`` through one autograd Function.  There is no PyTorch fallback: on a non-HIP
+device ``forward`` raises.
+"""
+import torch
+import torch.nn as nn
+
+from hipvsr.autograd import HipOutputs, RefineNetFn
+from hipvsr.spec import NetConfig, state_dict_spec, upsampler_layers
+from src.model.nets.base_net import BaseNet
+
+
+class _Conv(nn.Conv2d):
+    def forward(self, *a, **k):       # parameter holder only
+        raise RuntimeError('RefineNet sub-modules are parameter holders; call RefineNet.forward')
+
+
+def _lstm_block(cfg):
+    blk = nn.Module()
+    cells = []
+    nf = cfg.num_features
+    for i, hd in enumerate(nf):
+        cx = nf[0] if i == 0 else nf[i - 1]
+        cell = nn.Module()
+        cell.conv = _Conv(cx + hd if cfg.memory else 2 * cx, 4 * hd, kernel_size=3, padding=1, bias=True)
+        cells.append(cell)
+    blk.cell_list = nn.ModuleList(cells)
+    return blk
+
+
+class RefineNet(BaseNet):
+    def __init__(self, in_channels, out_channels, num_features, num_stages=1, refine_window_size=5, upscale_factor=4,
+                 update_memory=False, num_updated_frames=0, memory=True, positional_encoding=False):
+        super().__init__()
+        cfg = NetConfig(in_channels, out_channels, num_features, num_stages, refine_window_size, upscale_factor,
+                        update_memory, num_updated_frames, memory, positional_encoding)
+        if not isinstance(num_features, (list, tuple)) or len(num_features) < 1:
+            raise ValueError('Inconsistent list length.')
+        self.cfg = cfg
+        self.in_channels, self.out_channels, self.num_features = in_channels, out_channels, num_features
+        self.num_stages, self.refine_window_size, self.upscale_factor = num_stages, refine_window_size, upscale_factor
+        self.update_memory, self.num_updated_frames = update_memory, num_updated_frames
+
+        nf, cl, w = list(num_features), num_features[-1], refine_window_size
+        self.in_block = nn.Module()
+        self.in_block.conv = _Conv(in_channels, nf[0], kernel_size=3, padding=1)
+        self.in_block.prelu = nn.PReLU(num_parameters=1, init=0.2)
+        self.forward_lstm_block = _lstm_block(cfg)
+        self.backward_lstm_block = _lstm_block(cfg)
+        self.refine_block = nn.Module()
+        self.refine_block.body = nn.Module()
+        if positional_encoding:
+            c1 = 2 * cl + 1
+            self.refine_block.body.conv1 = _Conv(w * c1, c1, kernel_size=3, padding=1)
+            self.refine_block.body.conv2 = _Conv(c1, cl, kernel_size=3, padding=1)
+        else:
+            self.refine_block.body.conv1 = _Conv(w * 2 * cl, cl, kernel_size=1)
+        self.refine_block.prelu = nn.PReLU(num_parameters=1, init=0.2)     # registered, never applied (quirk Q1)
+        self.out_block = nn.Module()
+        for name, cout, cin, _ in upsampler_layers(cfg):
+            setattr(self.out_block, name, _Conv(cin, cout, kernel_size=3, padding=1))
+
+        self._param_names = list(state_dict_spec(cfg).keys())
+        got = [k for k, _ in self.named_parameters()]
+        assert got == self._param_names, (got, self._param_names)
+        self._eng = None
+        self._flat_grad = None
+
+    def _engine(self):
+        dev = self.in_block.conv.weight.device
+        if self._eng is None or self._eng.ops.device != dev:
+            if dev.type != 'cuda':
+                raise RuntimeError(f'RefineNet (HIP) needs its parameters on a HIP device; they are on {dev}. '
+                                   'There is no CPU path in this package.')
+            from hipvsr.engine import RefineNetEngine
+            from hipvsr.hip_ops import HipOps
+            self._eng = RefineNetEngine(self.cfg, HipOps(dev))
+        return self._eng
+
+    def forward(self, inputs, pos_codes):
+        params = [p for _, p in self.named_parameters()]
+        O_all = RefineNetFn.apply(self, list(inputs), pos_codes, *params)
+        S, _, TN = O_all.shape[:3]
+        N = inputs[0].shape[0]
+        T = TN // N
+        groups = []
+        for s in range(S):
+            for br in range(3):
+                groups.append([O_all[s, br, i * N:(i + 1) * N].permute(0, 3, 1, 2) for i in range(T)])
+        out = HipOutputs(groups)
+        out.packed, out.ops = O_all, self._engine().ops
+        return out

@@ -1,0 +1,99 @@
+"""Training / validation step of RefineNet (reference src/runner/trainers/acdc_vsr_refinenet_trainer.py:17-136):
+forward, deep-supervision loss (discount 0.5^(S-1-stage), mean over frames, sum over groups, :83-94; last group
+only in evaluation, :95-100), zero_grad / backward / step (:41-47), PSNR-style metrics on the denormalised last
+group (:103-120), running-mean log (:122-136).
+
+Differences, all inside this boundary: L1 / Charbonnier over all 3*S*T (output, target) pairs go through ONE
+fused HIP loss+gradient launch instead of 63 loss_fn calls; and under torch.distributed the gradients are
+averaged with one all-reduce before the optimizer step."""
+import functools
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from hipvsr import dp
+from hipvsr.autograd import fused_losses
+from src.runner.trainers.base_trainer import BaseTrainer
+from src.utils import denormalize
+
+
+class AcdcVSRRefineNetTrainer(BaseTrainer):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self._denormalize = functools.partial(denormalize, dataset='acdc')
+
+    def _get_inputs_targets(self, batch):
+        return batch['lr_imgs'], batch['hr_imgs'], batch['pos_code']
+
+    def train_step(self, inputs, targets, pos_codes):
+        """forward + loss + backward (+ gradient all-reduce) + optimizer step; returns (outputs, loss, losses)."""
+        outputs = self.net(inputs, pos_codes)
+        losses = self._compute_losses(outputs, targets)
+        loss = (torch.stack(losses) * self.loss_weights).sum()
+        self.optimizer.zero_grad()
+        loss.backward()
+        dp.allreduce_gradients(self.net)
+        self.optimizer.step()
+        return outputs, loss, losses
+
+    def _run_epoch(self, mode):
+        training = mode == 'training'
+        self.net.train(training)
+        loader = self.train_dataloader if training else self.valid_dataloader
+        bar = tqdm(loader, total=len(loader), desc=mode)
+        log, count = self._init_log(), 0
+        batch = outputs = None
+        for batch in bar:
+            batch = self._allocate_data(batch)
+            inputs, targets, pos_codes = self._get_inputs_targets(batch)
+            T = len(inputs)
+            if training:
+                outputs, loss, losses = self.train_step(inputs, targets, pos_codes)
+            else:
+                with torch.no_grad():
+                    outputs = self.net(inputs, pos_codes)
+                    losses = self._compute_losses(outputs, targets)
+                    loss = (torch.stack(losses) * self.loss_weights).sum()
+            metrics = self._compute_metrics(outputs, targets)
+            bs = loader.batch_size
+            self._update_log(log, bs, T, loss, losses, metrics)
+            count += bs * T
+            bar.set_postfix(**{k: f'{v / count: .3f}' for k, v in log.items()})
+        for k in log:
+            log[k] /= max(count, 1)
+        return log, batch, (outputs[-1] if outputs is not None else None)
+
+    def _compute_losses(self, outputs, targets):
+        G, T = len(outputs), len(targets)
+        losses = []
+        for loss_fn in self.loss_fns:
+            per_pair = fused_losses(outputs, targets, loss_fn)            # [G*T] or None
+            if self.net.training:
+                terms = []
+                for g in range(G):
+                    discount = np.power(0.5, (G // 3 - g // 3 - 1))
+                    if per_pair is not None:
+                        vals = per_pair[g * T:(g + 1) * T] * discount
+                    else:
+                        vals = torch.stack([loss_fn(o, t) * discount for o, t in zip(outputs[g], targets)])
+                    terms.append(vals.mean())
+                losses.append(torch.stack(terms).sum())
+            else:
+                if per_pair is not None:
+                    losses.append(per_pair[(G - 1) * T:].mean())
+                else:
+                    losses.append(torch.stack([loss_fn(o, t) for o, t in zip(outputs[-1], targets)]).mean())
+        return losses
+
+    def _compute_metrics(self, outputs, targets):
+        outs = [self._denormalize(o) for o in outputs[-1]]
+        tgts = [self._denormalize(t) for t in targets]
+        return [torch.stack([fn(o, t) for o, t in zip(outs, tgts)]).mean() for fn in self.metric_fns]
+
+    def _update_log(self, log, batch_size, T, loss, losses, metrics):
+        log['Loss'] += loss.item() * batch_size * T
+        for fn, v in zip(self.loss_fns, losses):
+            log[type(fn).__name__] += v.item() * batch_size * T
+        for fn, v in zip(self.metric_fns, metrics):
+            log[type(fn).__name__] += v.item() * batch_size * T

@@ -1,0 +1,198 @@
+"""Parity of the HIP path (through the C ABI) with the reference, on the GPU box.
+
+* golden vectors captured from the reference itself (tests/golden/g1_tiny.pt, g2_cfg1.pt, g5_edges.pt);
+* the oracle (oracle/refinenet_oracle.py) on seeded inputs at sizes it finishes in seconds;
+* kernel-level comparisons against the torch semantics in tests/torch_ops.py on shapes that exercise tile
+  tails, several M tiles, every epilogue and every tile shape.
+
+Tolerances (fp32, K up to 5 805 re-associated products): outputs atol 1e-4 / rtol 1e-4; gradients
+|delta| <= 1e-3 * max|g| (+1e-6); loss rtol 1e-5; PSNR |delta| < 0.01 dB (north_star).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refinenet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def g1(golden_dir):
+    return torch.load(os.path.join(golden_dir, 'g1_tiny.pt'), weights_only=False)
+
+
+CASES = [f'x{s}_pos{p}_mem{m}' for s in (2, 3, 4) for p in (1, 0) for m in (1, 0)] + ['x8_pos1_mem1']
+
+
+def _grad_close(mine, ref, name, rel=1e-3):
+    scale = float(ref.abs().max())
+    err = float((mine.detach().cpu() - ref).abs().max())
+    assert err <= rel * scale + 1e-6, (name, err, scale)
+
+
+def _module_step(kwargs, sd, inputs, targets, pos, loss_fn):
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    dev = _dev()
+    net = RefineNet(**kwargs)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.net, tr.loss_fns, tr.metric_fns = net, [loss_fn], []
+    net.train()
+    outs = net([x.to(dev) for x in inputs], pos.to(dev))
+    loss = tr._compute_losses(outs, [t.to(dev) for t in targets])[0]
+    net.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    return net, tr, outs, loss
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_module_forward_backward_vs_reference_golden(g1, case):
+    c = g1[case]
+    net, tr, outs, loss = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'],
+                                       torch.nn.L1Loss())
+    assert list(net.state_dict().keys()) == list(c['state_dict'].keys())
+    assert len(outs) == len(c['outputs'])
+    for go, gr in zip(outs, c['outputs']):
+        for a, b in zip(go, gr):
+            assert a.shape == b.shape
+            torch.testing.assert_close(a.detach().cpu(), b, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), c['train_loss'], atol=1e-6, rtol=1e-5)
+    for k, p in net.named_parameters():
+        if c['grads'][k] is None:
+            assert p.grad is None, k                    # quirk Q1
+        else:
+            _grad_close(p.grad, c['grads'][k], k)
+    # evaluation branch of the loss schedule
+    net.eval()
+    dev = _dev()
+    with torch.no_grad():
+        outs_e = net([x.to(dev) for x in c['inputs']], c['pos_codes'].to(dev))
+        le = tr._compute_losses(outs_e, [t.to(dev) for t in c['targets']])[0]
+    torch.testing.assert_close(le.cpu(), c['eval_loss'], atol=1e-6, rtol=1e-5)
+    for a, b in zip(outs_e[-1], c['eval_last']):
+        torch.testing.assert_close(a.cpu(), b, atol=1e-4, rtol=1e-4)
+
+
+def test_module_charbonnier_fused_loss(g1):
+    from src.model.losses import CharbonnierLoss
+    c = g1['x4_pos1_mem1']
+    net, _, _, loss = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'],
+                                   CharbonnierLoss(epsilon=1e-6))
+    torch.testing.assert_close(loss.detach().cpu(), c['charbonnier_train_loss'], atol=1e-6, rtol=1e-5)
+    for k, p in net.named_parameters():
+        if c['charbonnier_grads'][k] is not None:
+            _grad_close(p.grad, c['charbonnier_grads'][k], k)
+
+
+def test_unfused_loss_path_matches(g1):
+    """A loss the fused kernel does not serve (Huber) goes through loss_fn per pair and plain autograd views."""
+    from src.model.losses import HuberLoss
+    c = g1['x2_pos1_mem1']
+    net, _, outs, loss = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'],
+                                      HuberLoss(delta=0.5))
+    cfg = orc.Config(**c['kwargs'])
+    _, lref, gref = orc.step(c['state_dict'], cfg, [x.clone() for x in c['inputs']], c['targets'], c['pos_codes'],
+                             loss_fn=lambda o, t: orc.huber_loss(o, t, 0.5))
+    torch.testing.assert_close(loss.detach().cpu(), lref, atol=1e-6, rtol=1e-5)
+    for k, p in net.named_parameters():
+        if gref[k] is not None:
+            _grad_close(p.grad, gref[k], k)
+
+
+def test_whole_cycle_inference_golden(golden_dir):
+    """predictor-style evaluation: batch 1, F = 30 + 12 frames, odd 7x9 frames (g5)."""
+    from src.model.nets import RefineNet
+    r = torch.load(os.path.join(golden_dir, 'g5_edges.pt'), weights_only=False)['cycle']
+    dev = _dev()
+    net = RefineNet(**r['kwargs'])
+    net.load_state_dict(r['state_dict'])
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        last = net([x.to(dev) for x in r['inputs']], r['pos_codes'].to(dev))[-1]
+    assert len(last) == 30
+    for a, b in zip(last, r['last']):
+        torch.testing.assert_close(a.cpu(), b, atol=1e-4, rtol=1e-4)
+
+
+def test_cfg1_full_width_vs_reference_digest(golden_dir):
+    """BASELINE config 1: x4, N=1, T=3, 64x64 -> 256x256, num_features [64,64,64]; digests from the reference."""
+    r = torch.load(os.path.join(golden_dir, 'g2_cfg1.pt'), weights_only=False)
+    cfg = orc.exp1_x4_config()
+    sd = orc.init_state_dict(cfg, seed=r['seed_weights'])
+    inputs, targets, pos = orc.synthetic_batch(cfg, r['n'], r['t'], r['h'], r['w'], seed=r['seed_inputs'])
+    from src.model.metrics import PSNR
+    net, tr, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, torch.nn.L1Loss())
+    assert abs(float(loss) - r['train_loss']) <= 1e-5 * abs(r['train_loss'])
+    for g, grp in enumerate(outs):
+        for i, o in enumerate(grp):
+            torch.testing.assert_close(o.detach().cpu()[0, 0, 100:116, 100:116], r['out_crop'][g][i], atol=1e-4, rtol=1e-4)
+            assert abs(float(o.double().sum()) - r['out_sum'][g][i]) <= 1e-4 * r['out_abs_sum'][g][i]
+    for k, p in net.named_parameters():
+        if r['grad_l2'][k] is None:
+            assert p.grad is None
+        else:
+            assert abs(float(p.grad.double().norm()) - r['grad_l2'][k]) <= 1e-3 * r['grad_l2'][k], k
+            _grad_close(p.grad.flatten()[:16], r['grad_head'][k], k, rel=1e-2)
+    import functools
+    from src.utils import denormalize
+    tr.metric_fns = [PSNR().to(_dev())]
+    tr._denormalize = functools.partial(denormalize, dataset='acdc')
+    psnr = float(tr._compute_metrics(outs, [t.to(_dev()) for t in targets])[0])
+    assert abs(psnr - r['psnr']) < 0.01                                  # north_star: |delta PSNR| < 0.01 dB
+
+
+def test_kernels_vs_torch_semantics_on_ragged_shapes():
+    """Full-width channels (64) at 20x13 (no dimension a multiple of any tile), N=2, T=2: the HIP engine against the
+    same engine over the torch double - every kernel, every epilogue, M tails, multi-tile grids."""
+    from hipvsr.engine import RefineNetEngine
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.spec import NetConfig
+    from torch_ops import TorchOps
+    dev = _dev()
+    kw = dict(in_channels=1, out_channels=1, num_features=[64, 64], num_stages=2, refine_window_size=5, upscale_factor=4,
+              update_memory=True, num_updated_frames=2, positional_encoding=True)
+    cfg = NetConfig(**kw)
+    sd = orc.init_state_dict(orc.Config(**kw), seed=3)
+    inputs, targets, pos = orc.synthetic_batch(orc.Config(**kw), n=2, t=2, h=20, w=13, seed=4)
+    res = {}
+    for name, ops, d in (('hip', HipOps(dev), dev), ('ref', TorchOps('cpu'), torch.device('cpu'))):
+        eng = RefineNetEngine(cfg, ops)
+        params = {k: v.to(d) for k, v in sd.items()}
+        O, ctx = eng.forward(params, [x.to(d) for x in inputs], pos.to(d), need_grad=True)
+        g = torch.Generator('cpu').manual_seed(9)
+        dO = (torch.randn(O.shape, generator=g) * 1e-3).to(d)
+        grads = eng.backward(params, ctx, dO)
+        res[name] = (O.cpu(), {k: (v.cpu() if v is not None else None) for k, v in grads.items()})
+    torch.testing.assert_close(res['hip'][0], res['ref'][0], atol=1e-4, rtol=1e-4)
+    for k, v in res['ref'][1].items():
+        if v is not None:
+            _grad_close(res['hip'][1][k], v, k)
+
+
+def test_linearity_and_batch_independence_at_bench_width():
+    """Size-independent properties at the benchmark's channel width: (a) samples of a batch are independent
+    (quirk Q8): sample 0 of a batch of 2 equals the batch-of-1 result bit for bit; (b) the upsampler is affine:
+    out(a) + out(b) - out(0) == out(a + b) within fp32 rounding."""
+    from src.model.nets import RefineNet
+    dev = _dev()
+    cfg = orc.exp1_x4_config(num_updated_frames=2)
+    sd = orc.init_state_dict(cfg, seed=11)
+    net = RefineNet(**cfg)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    inputs, _, pos = orc.synthetic_batch(cfg, n=2, t=1, h=32, w=32, seed=12)
+    with torch.no_grad():
+        both = net([x.to(dev) for x in inputs], pos.to(dev))[-1][0]
+        one = net([x[:1].to(dev) for x in inputs], pos[:1].to(dev))[-1][0]
+    assert torch.equal(both[:1], one)
