@@ -61,40 +61,67 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const rnh_wgrad_args_t 
         ych[it] = code & 0xffff;
     }
 
+    // ---- per-element state: pre-offset source pointer, sc*C, and pixel coordinates advanced incrementally -----
+    // source pixel of output pixel (b, y, x), tap (dy, dx):  const + sc * ((b*H + y) * W*sc + x)   (no division in the loop)
+    const int s_begin = split * steps_per_split;
+    int s_end = s_begin + steps_per_split;
+    if (s_end > nsteps) s_end = nsteps;
+    const int xsc = P.xs[0].scale, ysc = P.ys[0].scale;          // uniform per operand (checked on the host)
+    const int xWs = W * xsc, yWs = W * ysc;
+    const int RH = P.B * H;                                       // number of global rows
+    const float *xptr[XIT], *yptr[YIT];
+    int xscC[XIT], xr[XIT], xy[XIT], xx[XIT], yscC[YIT], yr[YIT], yy[YIT], yx[YIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int p = s_begin * PK + xpp[it];
+        const int b = p / HW, rem = p - b * HW;
+        xy[it] = rem / W;
+        xx[it] = rem - xy[it] * W;
+        xr[it] = b * H + xy[it];
+        xptr[it] = nullptr;
+        xscC[it] = 0;
+        if (xsrc[it] >= 0) {
+            const rnh_src_t &S = P.xs[xsrc[it]];
+            const long cp = ((long)S.img_off * H * xsc + S.sub_y) * xWs + S.sub_x + (long)(dy * xWs + dx) * xsc;
+            xptr[it] = S.ptr + cp * S.C + S.c0 + xch[it];
+            xscC[it] = xsc * S.C;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < YIT; ++it) {
+        const int p = s_begin * PK + ypp[it];
+        const int b = p / HW, rem = p - b * HW;
+        yy[it] = rem / W;
+        yx[it] = rem - yy[it] * W;
+        yr[it] = b * H + yy[it];
+        yptr[it] = nullptr;
+        yscC[it] = 0;
+        if (ysrc[it] >= 0) {
+            const rnh_src_t &S = P.ys[ysrc[it]];
+            const long cp = ((long)S.img_off * H * ysc + S.sub_y) * yWs + S.sub_x;
+            yptr[it] = S.ptr + cp * S.C + S.c0 + ych[it];
+            yscC[it] = ysc * S.C;
+        }
+    }
+
     float4 rx[XIT], ry[YIT];
-    auto load_stage = [&](int step) {
-        const int p0 = step * PK;
+    auto load_stage = [&]() {          // loads the step the coordinates point at, then advances them by PK pixels
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int p = p0 + xpp[it];
-            if (xsrc[it] >= 0 && p < Mtot) {
-                const rnh_src_t &S = P.xs[xsrc[it]];
-                const int b = p / HW, rem = p - b * HW, y = rem / W, x = rem - y * W;
-                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) {
-                    const long pix = ((long)(b + S.img_off) * H * S.scale + (y + dy) * S.scale + S.sub_y) * (W * S.scale) +
-                                     (x + dx) * S.scale + S.sub_x;
-                    const long off = pix * S.C + S.c0 + xch[it];
-                    v = rnh_ld4(S.ptr + off);
-                    if (S.ptr2) v = v + rnh_ld4(S.ptr2 + off);
-                }
-            }
+            if (xptr[it] && xr[it] < RH && (unsigned)(xy[it] + dy) < (unsigned)H && (unsigned)(xx[it] + dx) < (unsigned)W)
+                v = rnh_ld4(xptr[it] + (long)(xr[it] * xWs + xx[it]) * xscC[it]);
             rx[it] = v;
+            xx[it] += PK;
+            while (xx[it] >= W) { xx[it] -= W; ++xr[it]; if (++xy[it] == H) xy[it] = 0; }
         }
 #pragma unroll
         for (int it = 0; it < YIT; ++it) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int p = p0 + ypp[it];
-            if (ysrc[it] >= 0 && p < Mtot) {
-                const rnh_src_t &S = P.ys[ysrc[it]];
-                const int b = p / HW, rem = p - b * HW, y = rem / W, x = rem - y * W;
-                const long pix = ((long)(b + S.img_off) * H * S.scale + y * S.scale + S.sub_y) * (W * S.scale) +
-                                 x * S.scale + S.sub_x;
-                const long off = pix * S.C + S.c0 + ych[it];
-                v = rnh_ld4(S.ptr + off);
-                if (S.ptr2) v = v + rnh_ld4(S.ptr2 + off);
-            }
+            if (yptr[it] && yr[it] < RH) v = rnh_ld4(yptr[it] + (long)(yr[it] * yWs + yx[it]) * yscC[it]);
             ry[it] = v;
+            yx[it] += PK;
+            while (yx[it] >= W) { yx[it] -= W; ++yr[it]; }
         }
     };
     auto store_stage = [&](int buf) {
@@ -145,16 +172,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const rnh_wgrad_args_t 
         }
     };
 
-    const int s_begin = split * steps_per_split;
-    int s_end = s_begin + steps_per_split;
-    if (s_end > nsteps) s_end = nsteps;
     if (s_begin < s_end) {
-        load_stage(s_begin);
+        load_stage();
         store_stage(0);
         __syncthreads();
         for (int st = s_begin; st < s_end; ++st) {
             const bool more = st + 1 < s_end;
-            if (more) load_stage(st + 1);
+            if (more) load_stage();
             compute((st - s_begin) & 1);
             if (more) store_stage((st - s_begin + 1) & 1);
             __syncthreads();
@@ -225,6 +249,10 @@ extern "C" int rnh_conv_wgrad(const rnh_wgrad_args_t *args, void *stream) {
         if (int e = rnh_check_src(a.xs[i], "rnh_conv_wgrad(x)")) return e;
     for (int i = 0; i < a.nys; ++i)
         if (int e = rnh_check_src(a.ys[i], "rnh_conv_wgrad(dy)")) return e;
+    for (int i = 0; i < a.nxs; ++i)
+        if (a.xs[i].ptr2 || a.xs[i].scale != a.xs[0].scale) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: x sources must share one scale and have no ptr2");
+    for (int i = 0; i < a.nys; ++i)
+        if (a.ys[i].ptr2 || a.ys[i].scale != a.ys[0].scale) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: dy sources must share one scale and have no ptr2");
     if (a.B < 1 || a.H < 1 || a.W < 1 || (a.ntaps != 9 && a.ntaps != 1)) RNH_FAIL(RNH_E_ARG, "rnh_conv_wgrad: bad geometry");
     if ((long)a.B * a.H * a.W >= (1L << 31) / 16) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: too many pixels");
     if (!a.slab || !a.xgrp || !a.ygrp || a.nsplit < 1 || a.nsplit > 65535) RNH_FAIL(RNH_E_ARG, "rnh_conv_wgrad: workspace / maps / nsplit");
@@ -234,6 +262,7 @@ extern "C" int rnh_conv_wgrad(const rnh_wgrad_args_t *args, void *stream) {
         case RNH_TILE_128x160: return launch_wgrad<4, 1, 1, 5>(a, st);
         case RNH_TILE_256x64:  return launch_wgrad<4, 1, 2, 2>(a, st);
         case RNH_TILE_64x128:  return launch_wgrad<2, 2, 1, 2>(a, st);
+        case RNH_TILE_64x256:  return launch_wgrad<1, 4, 2, 2>(a, st);
         default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: unsupported tile %d", a.tile);
     }
 }

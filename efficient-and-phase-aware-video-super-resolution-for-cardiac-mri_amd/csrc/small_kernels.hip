@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) outconv_dgrad_kernel(const float *dy, con
     }
 }
 
-constexpr int OW_BLOCKS = 1024;
+constexpr int OW_BLOCKS = 2048;
 // thread = (ci, sub): acc[co][t] += x[q][ci] * dy[q - t][co]; partial[block][co][ci][9] and db partial[block][co]
 __global__ void __launch_bounds__(256) outconv_wgrad_kernel(const float *x, const float *dy, float *ws, int B, int H, int W,
                                                             int Cin, int Cout) {
@@ -361,6 +361,82 @@ __global__ void __launch_bounds__(256) outconv_wgrad_kernel(const float *x, cons
                 for (int k = 0; k < nsub; ++k) s += red[k * Cin + ci];
                 if (t < 9) out[(co * Cin + ci) * 9 + t] = s;
                 else if (ci == 0) out[Cout * Cin * 9 + co] = s;
+            }
+        }
+    }
+}
+
+// Streaming version used when Cin % 4 == 0 and 256 % (Cin/4) == 0: thread = (4 input channels, pixel lane), four
+// pixels in flight per iteration (x is read exactly once, 16 B per lane), the 9 taps of dy come from L1.
+template <int COUT>
+__global__ void __launch_bounds__(256) outconv_wgrad_stream_kernel(const float *x, const float *dy, float *ws, int B, int H,
+                                                                   int W, int Cin) {
+    __shared__ float4 red[256];
+    constexpr int UNR = 4;
+    const int G = Cin >> 2, g = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+    float4 acc[COUT][9];
+    float dbp[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        dbp[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[co][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const long M = (long)B * H * W;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long q0 = (long)blockIdx.x * per;
+    long q1 = q0 + per;
+    if (q1 > M) q1 = M;
+    for (long qb = q0 + pl; qb < q1; qb += (long)PL * UNR) {
+        float4 xv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long q = qb + (long)u * PL;
+            xv[u] = q < q1 ? rnh_ld4(x + q * Cin + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long q = qb + (long)u * PL;
+            if (q >= q1) continue;
+            const int xx = (int)(q % W);
+            const int yy = (int)((q / W) % H);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy_ = t / 3 - 1, dx_ = t % 3 - 1;
+                if ((unsigned)(yy - dy_) >= (unsigned)H || (unsigned)(xx - dx_) >= (unsigned)W) continue;
+                const float *gp = dy + (q - dy_ * W - dx_) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float gv = gp[co];
+                    acc[co][t].x += xv[u].x * gv; acc[co][t].y += xv[u].y * gv;
+                    acc[co][t].z += xv[u].z * gv; acc[co][t].w += xv[u].w * gv;
+                }
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) dbp[co] += dy[q * COUT + co];
+            }
+        }
+    }
+    float *out = ws + (long)blockIdx.x * (COUT * Cin * 9 + COUT);
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            __syncthreads();
+            red[threadIdx.x] = t < 9 ? acc[co][t < 9 ? t : 0] : make_float4(dbp[co], 0.f, 0.f, 0.f);
+            __syncthreads();
+            if (pl == 0) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < PL; ++k) s = s + red[k * G + g];
+                if (t < 9) {
+                    out[(co * Cin + g * 4 + 0) * 9 + t] = s.x;
+                    out[(co * Cin + g * 4 + 1) * 9 + t] = s.y;
+                    out[(co * Cin + g * 4 + 2) * 9 + t] = s.z;
+                    out[(co * Cin + g * 4 + 3) * 9 + t] = s.w;
+                } else if (g == 0) {
+                    out[COUT * Cin * 9 + co] = s.x;
+                }
             }
         }
     }
@@ -580,7 +656,10 @@ extern "C" int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, flo
     if (Cin < 1 || Cin > 256) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_wgrad: Cin must be 1..256");
     if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_wgrad: Cout must be 1..%d", OC_MAX);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(outconv_wgrad_kernel, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin, Cout);
+    const bool stream_ok = (Cin % 4 == 0) && (256 % (Cin / 4) == 0);
+    if (stream_ok && Cout == 1) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<1>, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
+    else if (stream_ok && Cout == 2) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<2>, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
+    else hipLaunchKernelGGL(outconv_wgrad_kernel, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin, Cout);
     RNH_CHECK_LAUNCH("rnh_outconv_wgrad");
     hipLaunchKernelGGL(outconv_wgrad_reduce_kernel, dim3(grid_for(Cout * Cin * 9 + Cout)), dim3(256), 0, st, ws, OW_BLOCKS, dw, db,
                        Cin, Cout, accumulate);

@@ -108,7 +108,7 @@ def pick_wgrad_tile(nrows, ncols):
     if ncols <= 64:
         return L.TILE_256x64 if nrows > 128 else L.TILE_64x128
     if nrows <= 64:
-        return L.TILE_64x128
+        return L.TILE_64x256 if ncols >= 256 else L.TILE_64x128
     return L.TILE_128x128
 
 
@@ -141,8 +141,8 @@ class WgradPlan:
     def nsplit(self, npix):
         tiles = (self.xcols_pad // L.TILE_ROWS[self.tile]) * (self.ycols_pad // L.TILE_COLS[self.tile]) * self.ntaps
         steps = (npix + 15) // 16
-        want = max(1, -(-1536 // tiles))
-        return int(max(1, min(want, 64, steps)))
+        want = max(1, -(-1024 // tiles))          # about 4 workgroups per CU
+        return int(max(1, min(want, 128, steps)))
 
 
 # --------------------------------------------------------------------------------------------------------

@@ -75,6 +75,7 @@ typedef struct rnh_dst {
 #define RNH_TILE_256x64  2   /* 4x1 waves of 64x64          */
 #define RNH_TILE_128x160 3   /* 4x1 waves of 32x160         */
 #define RNH_TILE_64x128  4   /* 2x2 waves of 32x64 (rnh_conv_wgrad only) */
+#define RNH_TILE_64x256  5   /* 1x4 waves of 64x64 (rnh_conv_wgrad only) */
 
 typedef struct rnh_conv_args {
     rnh_src_t src[RNH_MAX_SRC];
@@ -127,7 +128,7 @@ typedef struct rnh_wgrad_args {
     const int32_t *xgrp;         /* device [xcols_pad/4]: (src << 16) | channel, or -1 (zero)        */
     const int32_t *ygrp;         /* device [ycols_pad/4]                                             */
     int32_t B, H, W, ntaps;
-    int32_t tile;                /* RNH_TILE_128x128 or RNH_TILE_128x160                             */
+    int32_t tile;                /* RNH_TILE_128x128, _128x160, _256x64, _64x128 or _64x256         */
     int32_t nsplit;              /* pixel-range splits (grid.x)                                      */
     float *slab;                 /* workspace [nsplit][ntaps][xcols_pad][ycols_pad]                  */
     float *bslab;                /* workspace [nsplit][ycols_pad] (column sums = bias gradient) or 0 */

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at BASELINE config 2 shapes (N=8, 128x128, T=7, F=19): times the individual
+rnh_conv_igemm / rnh_conv_wgrad launches the training step is made of and prints algorithmic TFLOP/s.
+GPU box only.   python tools/kbench.py [filter]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')
+for p in (ROOT, PKG):
+    sys.path.insert(0, p)
+import torch                                            # noqa: E402
+from hipvsr.hip_ops import HipOps                       # noqa: E402
+from hipvsr.plans import Dst, NetPlans, Src             # noqa: E402
+from hipvsr.spec import NetConfig, state_dict_spec      # noqa: E402
+
+dev = torch.device('cuda:0')
+cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True,
+                num_updated_frames=6, positional_encoding=True)
+P = NetPlans(cfg)
+ops = HipOps(dev)
+params = {k: torch.randn(*s, device=dev) * 0.05 for k, s in state_dict_spec(cfg).items()}
+for pl in P.conv_plans():
+    ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None)
+N, H, W, T, F = 8, 128, 128, 7, 19
+TN = T * N
+flt = sys.argv[1] if len(sys.argv) > 1 else ''
+
+
+def R(*shape):
+    return torch.randn(*shape, device=dev)
+
+
+def timeit(name, fn, flops, reps=5):
+    if flt and flt not in name:
+        return
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f'{name:28s} {ms:9.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s ({flops / ms / 1e9 / 157.3 * 100:5.1f}% of f32 MFMA peak)', flush=True)
+
+
+pl = P.lstm[('forward', 1)]
+x, hp, cp = R(N, H, W, 64), R(N, H, W, 64), R(N, H, W, 64)
+ho, co, go = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256)
+timeit('lstm.fwd', lambda: ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go)),
+       2.0 * N * H * W * 256 * 1152, 20)
+dg = R(N, H, W, 256)
+dx, dh = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64)
+timeit('lstm.dgrad', lambda: ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dx, 64), Dst(dh, 64)]), 2.0 * N * H * W * 128 * 2304, 20)
+xs, hs, gd = R(TN + N, H, W, 64), R(TN + N, H, W, 64), R(TN, H, W, 256)
+dw, db = ops.empty(256, 128, 3, 3), ops.empty(256)
+timeit('lstm.wgrad', lambda: ops.wgrad(pl['wgrad'], [Src(xs, img_off=N), Src(hs)], [Src(gd)], TN, H, W, dw, db), 2.0 * TN * H * W * 128 * 256 * 9)
+
+# upsampler conv2 at 256x256 (3 branches x T frames)
+B3 = 3 * TN
+u = P.up[1]
+y1 = R(B3, 2 * H, 2 * W, 64)
+y2 = ops.empty(B3, 4 * H, 4 * W, 64)
+timeit('up2.fwd(ps)', lambda: ops.conv(u['fwd'], [Src(y1)], B3, 2 * H, 2 * W, ps=(y2, 2)), 2.0 * B3 * 4 * H * W * 256 * 576, 3)
+ysrcs = [Src(y2, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
+dy1 = ops.empty(B3, 2 * H, 2 * W, 64)
+timeit('up2.dgrad', lambda: ops.conv(u['dgrad'], ysrcs, B3, 2 * H, 2 * W, dsts=[Dst(dy1, 64)]), 2.0 * B3 * 4 * H * W * 64 * 2304, 3)
+dwu, dbu = ops.empty(256, 64, 3, 3), ops.empty(256)
+timeit('up2.wgrad', lambda: ops.wgrad(u['wgrad'], [Src(y1)], ysrcs, B3, 2 * H, 2 * W, dwu, dbu), 2.0 * B3 * 4 * H * W * 64 * 256 * 9, 3)
+
+# refine block
+nwin = F - 4
+Hf, Hb, P4 = R(F * N, H, W, 64), R(F * N, H, W, 64), R(F * N, H, W, 4)
+srcs = []
+for j in range(5):
+    srcs += [Src(Hf, img_off=j * N), Src(Hb, img_off=j * N), Src(P4, img_off=j * N)]
+R1 = ops.empty(nwin * N, H, W, P.C1p)
+timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
+Rr = ops.empty(nwin * N, H, W, 64)
+timeit('refine2.fwd', lambda: ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)]), 2.0 * nwin * N * H * W * 64 * 129 * 9, 3)
+dR1p = R((T + 4) * N, H, W, P.C1p)
+xs1 = []
+for j in range(5):
+    xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P4, img_off=(4 + j) * N)]
+dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
+timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
+dHf, dHb = ops.zeros(TN, H, W, 64), ops.zeros(TN, H, W, 64)
+timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
+                                         dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9, 3)
+# HBM-bound tail
+yy = R(B3, 4 * H, 4 * W, 64)
+wl, bl = params[P.last_w], params[P.last_b]
+o = ops.empty(B3, 4 * H, 4 * W, 1)
+byt = B3 * 16 * H * W * 64 * 4
+for name, fn in (('outconv.fwd', lambda: ops.outconv_fwd(yy, wl, bl, out=o)), ('outconv.dgrad', lambda: ops.outconv_dgrad(o, wl)),
+                 ('outconv.wgrad', lambda: ops.outconv_wgrad(yy, o, torch.empty_like(wl), torch.empty_like(bl)))):
+    if flt and flt not in name:
+        continue
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f'{name:28s} {ms:9.3f} ms  {byt / ms / 1e9:7.2f} TB/s of the 64-channel HR tensor', flush=True)
