@@ -9,21 +9,42 @@
 // * Both slabs are staged through LDS as rows of 16 floats (4 x 16-B slots, slot XOR ((row>>2)&3) => the
 //   ds_read_b128 fragment reads are bank-conflict free) with register double buffering: the global loads of
 //   step k+1 are in flight while the MFMAs of step k run; one barrier per step.
-// * Inside a 16-channel chunk lane-half kh of the wave reads channels 8kh..8kh+7 with two 16-byte LDS reads;
-//   MFMA step s contracts channel s (kh = 0) and 8+s (kh = 1).  A and B use the same permutation, so the sum
-//   over K is unchanged.
+// * Inside a 16-channel chunk, MFMA step k (0..7) contracts channel 8*(k>>2) + 4*kh + (k&3) in lane-half kh:
+//   each lane needs two 16-byte pieces (channels 4kh..4kh+3 and 8+4kh..8+4kh+3) of its pixel, and the packed
+//   weights store a lane's 8 values contiguously ([ks][n][kh][8]).  A and B use the same permutation, so the
+//   sum over K is unchanged.
+// * DIRECT variant (RNH_TILE_DIRECT): no LDS and no barrier at all.  Every wave loads its own A and B
+//   fragments straight from global memory / L2 into registers in MFMA layout (the two lane-halves of a pixel
+//   read adjacent 16-byte pieces; a B fragment is one fully coalesced 2 KiB read), one K step ahead of the
+//   MFMAs.  The fp32 MFMA is slow enough (64 cycles per 512 B of operands) that L1/L2 feed it directly, and
+//   without workgroup barriers the waves of a SIMD never convoy behind each other's MFMA phases.
 // * Epilogues: bias + store/accumulate into up to 4 channel segments; PixelShuffle fused into the store;
 //   ConvLSTM gate math (the 4 gates of a hidden channel sit in the same lane of the 4 column tiles of a wave).
 #include "rnh_common.h"
 
 namespace {
 
-template <int WM, int WN, int MI, int NI, int EPI>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P, const int MT, const int NT) {
+// sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: about 1 ulp each; the epilogue runs
+// them 5 times per hidden element, and the libm versions cost 4x the instructions for digits the fp32 GEMM in
+// front of them does not have).  tanh(x) = 1 - 2 / (1 + e^{2x}) is exact at +-inf and loses nothing near 0 that the
+// 1e-7 relative error of the gates would not already hide.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float t = ax < 0.04f ? ax * (1.f - 0.33333334f * ax * ax) : 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * ax));
+    return copysignf(t, x);
+}
+
+// waves per SIMD the register allocator is asked to make room for (DIRECT: 3, or 2 for the 64x128 wave tile)
+template <int MI, int NI, bool DIRECT>
+constexpr int min_waves() { return DIRECT ? (MI * NI >= 8 ? 2 : (NI >= 5 ? 2 : 3)) : 1; }
+
+template <int WM, int WN, int MI, int NI, int EPI, bool DIRECT>
+__global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm_kernel(const rnh_conv_args_t P, const int MT, const int NT) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr int AIT = BM / 64;
     constexpr int BIT = (BN * 4 + 255) / 256;
-    constexpr int STAGE = (BM + BN) * 4;          // float4 per stage
+    constexpr int STAGE = DIRECT ? 1 : (BM + BN) * 4;          // float4 per stage
     __shared__ float4 lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,6 +57,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
     const int Mtot = P.B * HW;
     const int m0 = mt * BM, n0 = nt * BN;
 
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if constexpr (!DIRECT) {
     // ---- rows this thread stages ------------------------------------------------------------------
     int rb[AIT], ry[AIT], rx[AIT];
     bool rok[AIT];
@@ -121,14 +151,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
         }
     };
 
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     auto compute = [&](int buf) {
         const float4 *As = lds + buf * STAGE;
         const float4 *Bs = As + BM * 4;
@@ -136,7 +158,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int row = (wm * MI + i) * 32 + l31, sw = (row >> 2) & 3;
-            const float4 v0 = As[row * 4 + ((2 * kh) ^ sw)], v1 = As[row * 4 + ((2 * kh + 1) ^ sw)];
+            const float4 v0 = As[row * 4 + (kh ^ sw)], v1 = As[row * 4 + ((2 + kh) ^ sw)];
             a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
             a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
         }
@@ -172,6 +194,113 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
         __syncthreads();
     }
 
+    } else {
+    // ---- DIRECT: every lane owns MI pixel rows (A) and NI weight columns (B) -----------------------------
+    // All loads are raw buffer loads: a wave-uniform descriptor (base + 2 GiB window) plus a 32-bit per-lane byte
+    // offset; lanes outside the image / channel range get offset 0xFFFFFFFF, which the hardware range check turns
+    // into zeros - no branch, no select, so the prefetch of step k+1 stays in flight under the MFMAs of step k.
+    int rb[MI], ry[MI], rx[MI], rel[MI];
+    bool rok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + (wm * MI + i) * 32 + l31;
+        rok[i] = m < Mtot;
+        const int mm = rok[i] ? m : 0;
+        const int b = mm / HW, rem = mm - b * HW;
+        rb[i] = b;
+        ry[i] = rem / W;
+        rx[i] = rem - ry[i] * W;
+    }
+    int s = 0, ch = 0, t = 0;
+    __amdgpu_buffer_rsrc_t arsrc;
+    int aC4 = 0, anch = 0, asc = 1;
+    auto setup_src = [&](int si) {
+        const rnh_src_t &S = P.src[si];
+        const int Hs = H * S.scale, Ws = W * S.scale;
+        int spix[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            spix[i] = ((rb[i] + S.img_off) * Hs + ry[i] * S.scale + S.sub_y) * Ws + rx[i] * S.scale + S.sub_x;
+        // pixel index of the wave's first row minus one row and one column: every tap of every lane is at or after it
+        const int base_pix = __builtin_amdgcn_readfirstlane(spix[0]) - (Ws + 1) * S.scale;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rel[i] = rok[i] ? spix[i] - base_pix : 0;
+        arsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(S.ptr + S.c0 + (long)base_pix * S.C), 0, 0x7fffffff, 0x00020000);
+        aC4 = S.C * 4;
+        anch = S.nch;
+        asc = S.scale;
+    };
+    setup_src(0);
+    auto advance = [&]() {
+        if (++t == P.ntaps) {
+            t = 0;
+            if (++ch * 16 >= anch) {
+                ch = 0;
+                if (++s < P.nsrc) setup_src(s);
+            }
+        }
+    };
+    const __amdgpu_buffer_rsrc_t brsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(P.wp + ((long)n0 + wn * NI * 32) * 16), 0, 0x7fffffff, 0x00020000);
+    const int boff = (l31 * 16 + kh * 8) * 4;
+    const int kstride_bytes = P.Npad * 64;
+    auto load_frag = [&](f32x4 (&fa)[MI][2], f32x4 (&fb)[NI][2], int ks) {
+        int dy = 0, dx = 0;
+        if (P.ntaps == 9) {
+            dy = t / 3 - 1;
+            dx = t - (dy + 1) * 3 - 1;
+        }
+        const int cc = ch * 16 + 4 * kh;
+        const int tapoff = (dy * W * asc + dx) * asc;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const bool v = rok[i] && (unsigned)(ry[i] + dy) < (unsigned)H && (unsigned)(rx[i] + dx) < (unsigned)W;
+            const int o = (rel[i] + tapoff) * aC4 + cc * 4;
+            fa[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (v && cc < anch) ? o : -1, 0, 0));
+            fa[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (v && cc + 8 < anch) ? o + 32 : -1, 0, 0));
+        }
+        const int so = ks * kstride_bytes;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            fb[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff + j * 2048, so, 0));
+            fb[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff + j * 2048 + 16, so, 0));
+        }
+    };
+    auto mfma_frag = [&](const f32x4 (&fa)[MI][2], const f32x4 (&fb)[NI][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][e], fb[j][q][e], acc[i][j], 0, 0, 0);
+    };
+    {
+        f32x4 fa0[MI][2], fb0[NI][2], fa1[MI][2], fb1[NI][2];
+        const int nk = P.nk;
+        int ks = 0;
+        load_frag(fa0, fb0, 0);
+        for (; ks + 2 < nk; ks += 2) {          // steady state: no conditionals around the loads
+            advance();
+            load_frag(fa1, fb1, ks + 1);
+            mfma_frag(fa0, fb0);
+            advance();
+            load_frag(fa0, fb0, ks + 2);
+            mfma_frag(fa1, fb1);
+        }
+        if (ks + 2 == nk) {
+            advance();
+            load_frag(fa1, fb1, ks + 1);
+            mfma_frag(fa0, fb0);
+            mfma_frag(fa1, fb1);
+        } else {
+            mfma_frag(fa0, fb0);
+        }
+    }
+    }
+
     // ---- epilogue -----------------------------------------------------------------------------------------
     // accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if constexpr (EPI == RNH_EPI_LSTM) {
@@ -186,15 +315,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (m >= Mtot) continue;
-                const float gi = 1.f / (1.f + expf(-(acc[i][0][r] + bi)));
-                const float gf = 1.f / (1.f + expf(-(acc[i][1][r] + bf)));
-                const float go = 1.f / (1.f + expf(-(acc[i][2][r] + bo)));
-                const float gg = tanhf(acc[i][3][r] + bg);
+                const float gi = fast_sigmoid(acc[i][0][r] + bi);
+                const float gf = fast_sigmoid(acc[i][1][r] + bf);
+                const float go = fast_sigmoid(acc[i][2][r] + bo);
+                const float gg = fast_tanh(acc[i][3][r] + bg);
                 const long o = (long)m * P.hd + hc;
                 const float cp = P.c_prev ? P.c_prev[o] : 0.f;
                 const float cn = gf * cp + gi * gg;
                 P.c_out[o] = cn;
-                P.h_out[o] = go * tanhf(cn);
+                P.h_out[o] = go * fast_tanh(cn);
                 if (P.gates_out) {
                     float *gp = P.gates_out + (long)m * 4 * P.hd + hc;
                     gp[0] = gi;
@@ -254,7 +383,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const rnh_conv_args_t P
     }
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, bool DIRECT>
 int launch_tile(const rnh_conv_args_t &a, hipStream_t st) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     if (a.Npad % BN) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: Npad %d not a multiple of the tile's %d columns", a.Npad, BN);
@@ -263,14 +392,14 @@ int launch_tile(const rnh_conv_args_t &a, hipStream_t st) {
     const dim3 grid((unsigned)(MT * NT)), block(256);
     switch (a.epilogue) {
         case RNH_EPI_STORE:
-            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT);
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_STORE, DIRECT>), grid, block, 0, st, a, MT, NT);
             break;
         case RNH_EPI_PS:
-            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_PS>), grid, block, 0, st, a, MT, NT);
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_PS, DIRECT>), grid, block, 0, st, a, MT, NT);
             break;
         case RNH_EPI_LSTM:
             if constexpr (WN == 1 && NI == 4) {
-                hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT);
+                hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_LSTM, DIRECT>), grid, block, 0, st, a, MT, NT);
             } else {
                 RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: the LSTM epilogue needs RNH_TILE_128x128_G");
             }
@@ -309,11 +438,23 @@ extern "C" int rnh_conv_igemm(const rnh_conv_args_t *args, void *stream) {
             RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: pixel-shuffle args");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (a.tile & RNH_TILE_DIRECT) {
+        for (int i = 0; i < a.nsrc; ++i)
+            if (a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: the DIRECT variant does not take ptr2 sources");
+        switch (a.tile & ~RNH_TILE_DIRECT) {
+            case RNH_TILE_128x128:   return launch_tile<2, 2, 2, 2, true>(a, st);
+            case RNH_TILE_128x128_G: return launch_tile<4, 1, 1, 4, true>(a, st);
+            case RNH_TILE_256x64:    return launch_tile<4, 1, 2, 2, true>(a, st);
+            case RNH_TILE_128x160:   return launch_tile<4, 1, 1, 5, true>(a, st);
+            case RNH_TILE_256x128:   return launch_tile<4, 1, 2, 4, true>(a, st);
+            default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: unknown tile %d", a.tile);
+        }
+    }
     switch (a.tile) {
-        case RNH_TILE_128x128:   return launch_tile<2, 2, 2, 2>(a, st);
-        case RNH_TILE_128x128_G: return launch_tile<4, 1, 1, 4>(a, st);
-        case RNH_TILE_256x64:    return launch_tile<4, 1, 2, 2>(a, st);
-        case RNH_TILE_128x160:   return launch_tile<4, 1, 1, 5>(a, st);
+        case RNH_TILE_128x128:   return launch_tile<2, 2, 2, 2, false>(a, st);
+        case RNH_TILE_128x128_G: return launch_tile<4, 1, 1, 4, false>(a, st);
+        case RNH_TILE_256x64:    return launch_tile<4, 1, 2, 2, false>(a, st);
+        case RNH_TILE_128x160:   return launch_tile<4, 1, 1, 5, false>(a, st);
         default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: unknown tile %d", a.tile);
     }
 }

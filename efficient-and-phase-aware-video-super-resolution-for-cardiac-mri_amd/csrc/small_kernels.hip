@@ -48,7 +48,8 @@ __global__ void pack_weights_kernel(const float *w, const float *bias, float *wp
                                     int Cout, int Cin, int ntaps, int kstride, int transposed) {
     const long total = (long)nk * Npad * 16;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int kk = (int)(e & 15);
+        const int kp = (int)(e & 15);                                  // packed position = kh*8 + e8
+        const int kk = 8 * ((kp & 7) >> 2) + 4 * (kp >> 3) + (kp & 3);   // channel within the 16-channel chunk
         const long r = e >> 4;
         const int n = (int)(r % Npad), ks = (int)(r / Npad);
         const int cm = colmap[n];

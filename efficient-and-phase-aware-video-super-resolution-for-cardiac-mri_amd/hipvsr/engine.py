@@ -84,33 +84,38 @@ class RefineNetEngine:
         for s in range(S):
             st = dict(feat=feat)
             # ---- bidirectional ConvLSTM over the frames (refine_net.py:82-93) ----------------------------
-            for d in ('forward', 'backward'):
-                Hb = [ops.empty(F * N, H, W, hd) for hd in nf]
-                Cb = [ops.empty(F * N, H, W, hd) for hd in nf]
-                Gb = [ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None
-                order = range(F) if d == 'forward' else range(F - 1, -1, -1)
-                prev = None
-                for k in order:
+            # The two directions are independent until the refine block: they are issued frame by frame on two
+            # side streams so that the tail of one direction's launch overlaps the head of the other's.
+            dirs = ('forward', 'backward')
+            for d in dirs:
+                st[d] = dict(H=[ops.empty(F * N, H, W, hd) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
+                             G=[ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None)
+            ops.fork(2)
+            for idx in range(F):
+                for di, d in enumerate(dirs):
+                    k = idx if d == 'forward' else F - 1 - idx
+                    prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
+                    Hb, Cb, Gb = st[d]['H'], st[d]['C'], st[d]['G']
                     grad_frame = need_grad and U <= k < U + T
-                    for l in range(Lr):
-                        pl = P.lstm[(d, l)]
-                        xin = feat if l == 0 else Hb[l - 1]
-                        srcs = [Src(xin, img_off=k * N)]
-                        if cfg.memory:
-                            if prev is not None:
-                                srcs.append(Src(Hb[l], img_off=prev * N))
-                                plan = pl['full']
+                    with ops.side(di):
+                        for l in range(Lr):
+                            pl = P.lstm[(d, l)]
+                            xin = feat if l == 0 else Hb[l - 1]
+                            srcs = [Src(xin, img_off=k * N)]
+                            if cfg.memory:
+                                if prev is not None:
+                                    srcs.append(Src(Hb[l], img_off=prev * N))
+                                    plan = pl['full']
+                                else:
+                                    plan = pl['first']
                             else:
-                                plan = pl['first']
-                        else:
-                            srcs.append(Src(xin, img_off=k * N))
-                            plan = pl['full']
-                        ops.conv(plan, srcs, N, H, W, lstm=dict(
-                            hd=pl['hd'], c_prev=Cb[l][prev * N:(prev + 1) * N] if prev is not None else None,
-                            h_out=Hb[l][k * N:(k + 1) * N], c_out=Cb[l][k * N:(k + 1) * N],
-                            gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
-                    prev = k
-                st[d] = dict(H=Hb, C=Cb, G=Gb)
+                                srcs.append(Src(xin, img_off=k * N))
+                                plan = pl['full']
+                            ops.conv(plan, srcs, N, H, W, lstm=dict(
+                                hd=pl['hd'], c_prev=Cb[l][prev * N:(prev + 1) * N] if prev is not None else None,
+                                h_out=Hb[l][k * N:(k + 1) * N], c_out=Cb[l][k * N:(k + 1) * N],
+                                gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
+            ops.join(2)
             Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
 
             # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
@@ -252,53 +257,67 @@ class RefineNetEngine:
                      dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
 
             # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
-            for d, top in (('forward', dHf), ('backward', dHb)):
-                sd = st[d]
-                Hb, Cb, Gb = sd['H'], sd['C'], sd['G']
-                Gd = [ops.empty(TN, H, W, 4 * hd) for hd in nf]
-                step = 1 if d == 'forward' else -1
-                order = range(U + T - 1, U - 1, -1) if d == 'forward' else range(U, U + T)
-                dh_next, dc_next = [None] * Lr, [None] * Lr
-                for k in order:
+            # (both directions interleaved on two side streams, like the forward)
+            dirs = ('forward', 'backward')
+            tops = {'forward': dHf, 'backward': dHb}
+            Gd = {d: [ops.empty(TN, H, W, 4 * hd) for hd in nf] for d in dirs}
+            dfeat_d = {d: ops.empty(TN, H, W, C) for d in dirs}          # layer-0 input gradients per direction
+            dh_next = {d: [None] * Lr for d in dirs}
+            dc_next = {d: [None] * Lr for d in dirs}
+            ops.fork(2)
+            for idx in range(T):
+                for di, d in enumerate(dirs):
+                    step = 1 if d == 'forward' else -1
+                    k = U + T - 1 - idx if d == 'forward' else U + idx
+                    sd, top = st[d], tops[d]
+                    Hb, Cb, Gb = sd['H'], sd['C'], sd['G']
                     fi = k - U
                     prevk = k - step
                     prev_grad = U <= prevk < U + T
                     dx_above = None
-                    for l in range(Lr - 1, -1, -1):
+                    with ops.side(di):
+                        for l in range(Lr - 1, -1, -1):
+                            pl = P.lstm[(d, l)]
+                            hd, cx = pl['hd'], pl['cx']
+                            dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
+                            if dh_next[d][l] is not None:
+                                ops.add(dh, dh_next[d][l], accumulate=True)
+                            c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
+                            dg = Gd[d][l][fi * N:(fi + 1) * N]
+                            dcp = ops.empty(N, H, W, hd) if prev_grad else None
+                            ops.lstm_gates_bwd(dh, dc_next[d][l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg,
+                                               dcp)
+                            dxbuf = ops.empty(N, H, W, cx) if l > 0 else dfeat_d[d][fi * N:(fi + 1) * N]
+                            dhp = None
+                            if cfg.memory:
+                                dsts = [Dst(dxbuf, cx)]
+                                if prev_grad:
+                                    dhp = ops.empty(N, H, W, hd)
+                                    dsts.append(Dst(dhp, hd))
+                                ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
+                            else:
+                                tmp = ops.empty(N, H, W, cx)
+                                ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx), Dst(tmp, cx)])
+                                ops.add(dxbuf, tmp, accumulate=True)
+                            dh_next[d][l], dc_next[d][l] = dhp, dcp
+                            dx_above = dxbuf if l > 0 else None
+            # weight gradients of the cells, batched over the T frames
+            for di, d in enumerate(dirs):
+                step = 1 if d == 'forward' else -1
+                Hb = st[d]['H']
+                with ops.side(di):
+                    for l in range(Lr):
                         pl = P.lstm[(d, l)]
-                        hd, cx = pl['hd'], pl['cx']
-                        dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
-                        if dh_next[l] is not None:
-                            ops.add(dh, dh_next[l], accumulate=True)
-                        c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
-                        dg = Gd[l][fi * N:(fi + 1) * N]
-                        dcp = ops.empty(N, H, W, hd) if prev_grad else None
-                        ops.lstm_gates_bwd(dh, dc_next[l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg, dcp)
-                        dxbuf = ops.empty(N, H, W, cx) if l > 0 else dfeat[fi * N:(fi + 1) * N]
-                        dhp = None
-                        if cfg.memory:
-                            dsts = [Dst(dxbuf, cx, accumulate=(l == 0))]
-                            if prev_grad:
-                                dhp = ops.empty(N, H, W, hd)
-                                dsts.append(Dst(dhp, hd))
-                            ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
-                        else:
-                            tmp = ops.empty(N, H, W, cx)
-                            ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx, accumulate=(l == 0)), Dst(tmp, cx)])
-                            ops.add(dxbuf, tmp, accumulate=True)
-                        dh_next[l], dc_next[l] = dhp, dcp
-                        dx_above = dxbuf if l > 0 else None
-                # weight gradients of the direction's cells, batched over the T frames
-                for l in range(Lr):
-                    pl = P.lstm[(d, l)]
-                    xin = feat if l == 0 else Hb[l - 1]
-                    second = Src(Hb[l], img_off=(U - step) * N) if cfg.memory else Src(xin, img_off=U * N)
-                    wk, bk = pl['wgrad'].wkey, pl['wgrad'].bkey
-                    a = acc(wk)
-                    acc(bk)
-                    ops.wgrad(pl['wgrad'], [Src(xin, img_off=U * N), second], [Src(Gd[l])], TN, H, W, grads[wk], grads[bk],
-                              accumulate=a)
-                st[d] = None
+                        xin = feat if l == 0 else Hb[l - 1]
+                        second = Src(Hb[l], img_off=(U - step) * N) if cfg.memory else Src(xin, img_off=U * N)
+                        wk, bk = pl['wgrad'].wkey, pl['wgrad'].bkey
+                        a = acc(wk)
+                        acc(bk)
+                        ops.wgrad(pl['wgrad'], [Src(xin, img_off=U * N), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
+                                  accumulate=a)
+            ops.join(2)
+            ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
+            st['forward'] = st['backward'] = None
             dfeat_next = dfeat
             ctx.stages[s] = None
 

@@ -5,6 +5,7 @@ stream; every computation below is one of the hand-written gfx950 kernels.  No f
 not fp32 / contiguous / on a HIP device raise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -27,6 +28,9 @@ class HipOps:
         self._maps = {}        # id(plan) -> dict of device int32 arrays
         self._packed = {}      # id(plan) -> (wp, biasp)
         self._ws = {}
+        self._side = []
+        # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
+        self.direct = os.environ.get('RNH_DIRECT', '1') != '0'
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, *shape):
@@ -49,7 +53,27 @@ class HipOps:
     def _i32(self, lst):
         return torch.tensor(lst, dtype=torch.int32, device=self.device)
 
+    # ---- streams: the two LSTM directions run on side streams between fork() and join() ---------------------
+    def fork(self, n):
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream(self.device))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        for st in self._side[:n]:
+            st.wait_event(ev)
+
+    def side(self, i):
+        return torch.cuda.stream(self._side[i])
+
+    def join(self, n):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._side[:n]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            cur.wait_event(ev)
+
     def _workspace(self, key, nfloats):
+        key = (key, torch.cuda.current_stream(self.device).cuda_stream)      # one scratch buffer per stream
         t = self._ws.get(key)
         if t is None or t.numel() < nfloats:
             t = self.empty(int(nfloats))
@@ -120,7 +144,7 @@ class HipOps:
         wp, bp = self._packed[id(plan)]
         a.nsrc, a.B, a.H, a.W, a.ntaps, a.nk = len(srcs), B, H, W, plan.ntaps, plan.nk
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
-        a.Npad, a.epilogue, a.tile = plan.Npad, plan.epilogue, plan.tile
+        a.Npad, a.epilogue, a.tile = plan.Npad, plan.epilogue, plan.tile | (L.TILE_DIRECT if (self.direct and plan.epilogue != L.EPI_PS) else 0)
         if plan.epilogue == L.EPI_STORE:
             a.ndst = len(dsts)
             tot = 0

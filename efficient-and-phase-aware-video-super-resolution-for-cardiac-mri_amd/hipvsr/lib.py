@@ -14,6 +14,7 @@ EPI_STORE, EPI_PS, EPI_LSTM = 0, 1, 2
 TILE_128x128, TILE_128x128_G, TILE_256x64, TILE_128x160, TILE_64x128, TILE_64x256 = 0, 1, 2, 3, 4, 5
 TILE_COLS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 64, TILE_128x160: 160, TILE_64x128: 128, TILE_64x256: 256}
 TILE_ROWS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 256, TILE_128x160: 128, TILE_64x128: 64, TILE_64x256: 64}
+TILE_DIRECT = 16
 LOSS_L1, LOSS_CHARBONNIER = 0, 1
 LOSS_BLOCKS = 64
 

@@ -76,6 +76,9 @@ typedef struct rnh_dst {
 #define RNH_TILE_128x160 3   /* 4x1 waves of 32x160         */
 #define RNH_TILE_64x128  4   /* 2x2 waves of 32x64 (rnh_conv_wgrad only) */
 #define RNH_TILE_64x256  5   /* 1x4 waves of 64x64 (rnh_conv_wgrad only) */
+#define RNH_TILE_256x128 6   /* 4x1 waves of 64x128 (rnh_conv_igemm, DIRECT variant only; LSTM-capable) */
+#define RNH_TILE_DIRECT  16  /* OR-ed into `tile` for rnh_conv_igemm: fragments straight from global memory, no LDS,
+                                no barrier (same results bit for bit as the LDS-staged variant)                  */
 
 typedef struct rnh_conv_args {
     rnh_src_t src[RNH_MAX_SRC];

@@ -51,6 +51,16 @@ class TorchOps:
         self.device = torch.device(device)
         self._w = {}
 
+    def fork(self, n):
+        pass
+
+    def join(self, n):
+        pass
+
+    def side(self, i):
+        import contextlib
+        return contextlib.nullcontext()
+
     def empty(self, *shape):
         return torch.full(shape, float('nan'), dtype=torch.float32, device=self.device)   # poison: catches unwritten reads
 
