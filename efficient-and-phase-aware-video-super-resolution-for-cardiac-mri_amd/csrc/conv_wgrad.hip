@@ -1,35 +1,60 @@
-// Weight gradient of the 3x3 / 1x1 convolutions on the fp32 matrix cores.
+// Weight gradient of the 3x3 / 1x1 convolutions on the fp32 matrix cores, without LDS and without barriers.
 //
 //   dW[tap][i][j] = sum_p X[p + tap][i] * dY[p][j]        i: forward input channel, j: output channel
 //
-// A GEMM whose contraction index is the pixel: per workgroup one tap, one [rows x cols] tile of dW and one
-// contiguous range of pixels (grid.x = nsplit ranges); the partial tiles go to a slab and
-// rnh_wgrad_reduce sums them in a fixed order (bitwise reproducible, no float atomics).
-// Both operands are gathered from lists of NHWC sources exactly like the forward kernel's A operand (X is
-// tap-shifted; dY can be pixel-unshuffled), staged through LDS as [16 pixels][tile columns] and read with
-// ds_read_b32 (lane = channel, so consecutive lanes hit consecutive banks).
-// Column sums of dY (= the bias gradient) are taken from the staged dY tile by the tap-0 / row-tile-0 blocks.
+// A GEMM whose contraction index is the pixel.  One WAVE owns one work item = (pixel range, tap, 32*MI rows,
+// 32*NI columns): v_mfma_f32_32x32x2_f32 contracts two pixels per instruction, lane-half kh holding pixel
+// 2s + kh.  The operands come straight from global memory in MFMA layout: lane l of a half loads the MI
+// consecutive channels MI*l .. MI*l+MI-1 of its pixel as ONE 4*MI-byte load (the 32 lanes of a half read
+// 128*MI contiguous bytes), and register e of that load is the A operand of row tile e - i.e. row i of row tile
+// e is channel MI*i + e; the permutation is undone when the tile is written.  dY likewise with NI.  So one
+// 16-byte and one 8-byte load feed 8 MFMAs (512 cycles), D pixel pairs are prefetched while the previous D
+// are multiplied, and lanes whose pixel is outside the image (tap shift), outside the work item's range or in a
+// padding channel read a zero page instead of branching.
+// Partial tiles of the pixel ranges go to a slab; rnh_wgrad_reduce sums them in a fixed order (bitwise
+// reproducible, no float atomics).  Column sums of dY (= the bias gradient) fall out of the B operands of the
+// tap-0 / row-tile-0 work items.
 #include "rnh_common.h"
 
 namespace {
 
-constexpr int PK = 16;   // pixels per K step
+template <int N> struct Vec;
+template <> struct Vec<1> { typedef float T; };
+template <> struct Vec<2> { typedef float2 T; };
+template <> struct Vec<4> { typedef float4 T; };
 
-template <int WM, int WN, int MI, int NI>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const rnh_wgrad_args_t P, const int XT, const int YT,
-                                                         const int steps_per_split, const int nsteps) {
-    constexpr int BX = WM * MI * 32, BY = WN * NI * 32;      // tile rows (X channels) / columns (dY channels)
-    constexpr int XG = BX / 4, YG = BY / 4;                    // float4 groups per pixel row
-    constexpr int XIT = (PK * XG + 255) / 256, YIT = (PK * YG + 255) / 256;
-    constexpr int STAGE = PK * (BX + BY);                      // floats per stage
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+template <int N>
+__device__ __forceinline__ void unpack(const typename Vec<N>::T &v, float (&o)[N]) {
+    if constexpr (N == 1) o[0] = v;
+    if constexpr (N == 2) { o[0] = v.x; o[1] = v.y; }
+    if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int split = blockIdx.x;
-    const int xt = blockIdx.y / YT, yt = blockIdx.y - xt * YT;
-    const int tap = blockIdx.z;
+template <int MI, int NI, int D>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args_t P, const int RT, const int CT,
+                                                           const int chunk /* pixels per split, multiple of 4*D */) {
+    typedef typename Vec<MI>::T VA;
+    typedef typename Vec<NI>::T VB;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    // Work items of one pixel range (ntaps * RT * CT of them) read the same X / dY pixels: they are packed into
+    // consecutive workgroups of ONE XCD (workgroups are dealt round-robin over the 8 XCDs, so workgroup b and
+    // b + 8 share an L2), which makes the range stream from HBM once per XCD instead of once per work item.
+    const int ips = P.ntaps * RT * CT, bps = (ips + 3) >> 2;
+    int split, sub;
+    if ((P.nsplit & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = (j / bps) * 8 + xcd;
+        sub = j % bps;
+    } else {
+        split = blockIdx.x / bps;
+        sub = blockIdx.x % bps;
+    }
+    const int item = sub * 4 + (threadIdx.x >> 6);
+    if (item >= ips) return;                          // whole wave
+    const int ct = item % CT;
+    int r_ = item / CT;
+    const int rt = r_ % RT;
+    const int tap = r_ / RT;
     const int H = P.H, W = P.W, HW = H * W;
     const int Mtot = P.B * HW;
     int dy = 0, dx = 0;
@@ -37,105 +62,66 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const rnh_wgrad_args_t 
         dy = tap / 3 - 1;
         dx = tap - (dy + 1) * 3 - 1;
     }
+    const int pb = split * chunk;
+    int pe = pb + chunk;
+    if (pe > Mtot) pe = Mtot;
 
-    // ---- static per-thread column groups --------------------------------------------------------------
-    // X: element e = tid + 256*it -> pixel pp = e / XG, group g = e % XG
-    int xpp[XIT], xsrc[XIT], xch[XIT];
-    int ypp[YIT], ysrc[YIT], ych[YIT];
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int e = tid + 256 * it;
-        xpp[it] = e / XG;
-        const int g = e - xpp[it] * XG;
-        const int code = (e < PK * XG) ? P.xgrp[xt * XG + g] : -1;
-        xsrc[it] = code < 0 ? -1 : (code >> 16);
-        xch[it] = code & 0xffff;
+    // ---- per-lane operand descriptors ---------------------------------------------------------------------
+    // source pixel of output pixel (b, y, x) and tap (dy, dx):  const + sc * ((b*H + y) * W*sc + x)
+    const float *zp = P.zero_page;
+    const int xsc = P.xs[0].scale, ysc = P.ys[0].scale;           // uniform per operand (checked on the host)
+    const int xWs = W * xsc * xsc, yWs = W * ysc * ysc;             // pixel-index stride of one output row
+    const float *xbase = nullptr, *ybase = nullptr;
+    long xC = 0, yC = 0;
+    {
+        const int code = P.xgrp[rt * 32 + l31];
+        if (code >= 0) {
+            const rnh_src_t &S = P.xs[code >> 16];
+            const long cp = ((long)S.img_off * H * xsc + S.sub_y) * (W * xsc) + S.sub_x + (long)(dy * W * xsc + dx) * xsc;
+            xbase = S.ptr + cp * S.C + S.c0 + (code & 0xffff);
+            xC = S.C;
+        }
     }
-#pragma unroll
-    for (int it = 0; it < YIT; ++it) {
-        const int e = tid + 256 * it;
-        ypp[it] = e / YG;
-        const int g = e - ypp[it] * YG;
-        const int code = (e < PK * YG) ? P.ygrp[yt * YG + g] : -1;
-        ysrc[it] = code < 0 ? -1 : (code >> 16);
-        ych[it] = code & 0xffff;
+    {
+        const int code = P.ygrp[ct * 32 + l31];
+        if (code >= 0) {
+            const rnh_src_t &S = P.ys[code >> 16];
+            const long cp = ((long)S.img_off * H * ysc + S.sub_y) * (W * ysc) + S.sub_x;
+            ybase = S.ptr + cp * S.C + S.c0 + (code & 0xffff);
+            yC = S.C;
+        }
     }
-
-    // ---- per-element state: pre-offset source pointer, sc*C, and pixel coordinates advanced incrementally -----
-    // source pixel of output pixel (b, y, x), tap (dy, dx):  const + sc * ((b*H + y) * W*sc + x)   (no division in the loop)
-    const int s_begin = split * steps_per_split;
-    int s_end = s_begin + steps_per_split;
-    if (s_end > nsteps) s_end = nsteps;
-    const int xsc = P.xs[0].scale, ysc = P.ys[0].scale;          // uniform per operand (checked on the host)
-    const int xWs = W * xsc, yWs = W * ysc;
-    const int RH = P.B * H;                                       // number of global rows
-    const float *xptr[XIT], *yptr[YIT];
-    int xscC[XIT], xr[XIT], xy[XIT], xx[XIT], yscC[YIT], yr[YIT], yy[YIT], yx[YIT];
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int p = s_begin * PK + xpp[it];
+    // coordinates of this lane-half's next pixel: p = pb + kh, advanced by 2 per pixel pair
+    int p = pb + kh;
+    int cy, cx, cr;
+    {
         const int b = p / HW, rem = p - b * HW;
-        xy[it] = rem / W;
-        xx[it] = rem - xy[it] * W;
-        xr[it] = b * H + xy[it];
-        xptr[it] = nullptr;
-        xscC[it] = 0;
-        if (xsrc[it] >= 0) {
-            const rnh_src_t &S = P.xs[xsrc[it]];
-            const long cp = ((long)S.img_off * H * xsc + S.sub_y) * xWs + S.sub_x + (long)(dy * xWs + dx) * xsc;
-            xptr[it] = S.ptr + cp * S.C + S.c0 + xch[it];
-            xscC[it] = xsc * S.C;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < YIT; ++it) {
-        const int p = s_begin * PK + ypp[it];
-        const int b = p / HW, rem = p - b * HW;
-        yy[it] = rem / W;
-        yx[it] = rem - yy[it] * W;
-        yr[it] = b * H + yy[it];
-        yptr[it] = nullptr;
-        yscC[it] = 0;
-        if (ysrc[it] >= 0) {
-            const rnh_src_t &S = P.ys[ysrc[it]];
-            const long cp = ((long)S.img_off * H * ysc + S.sub_y) * yWs + S.sub_x;
-            yptr[it] = S.ptr + cp * S.C + S.c0 + ych[it];
-            yscC[it] = ysc * S.C;
-        }
+        cy = rem / W;
+        cx = rem - cy * W;
+        cr = b * H + cy;
     }
 
-    float4 rx[XIT], ry[YIT];
-    auto load_stage = [&]() {          // loads the step the coordinates point at, then advances them by PK pixels
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xptr[it] && xr[it] < RH && (unsigned)(xy[it] + dy) < (unsigned)H && (unsigned)(xx[it] + dx) < (unsigned)W)
-                v = rnh_ld4(xptr[it] + (long)(xr[it] * xWs + xx[it]) * xscC[it]);
-            rx[it] = v;
-            xx[it] += PK;
-            while (xx[it] >= W) { xx[it] -= W; ++xr[it]; if (++xy[it] == H) xy[it] = 0; }
-        }
-#pragma unroll
-        for (int it = 0; it < YIT; ++it) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yptr[it] && yr[it] < RH) v = rnh_ld4(yptr[it] + (long)(yr[it] * yWs + yx[it]) * yscC[it]);
-            ry[it] = v;
-            yx[it] += PK;
-            while (yx[it] >= W) { yx[it] -= W; ++yr[it]; }
-        }
+    struct Set {
+        VA a[D];
+        VB b[D];
     };
-    auto store_stage = [&](int buf) {
-        float *Xs = lds + buf * STAGE;
-        float *Ys = Xs + PK * BX;
+    auto load_set = [&](Set &F) {
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = tid + 256 * it;
-            if ((PK * XG) % 256 == 0 || e < PK * XG) rnh_st4(Xs + e * 4, rx[it]);
-        }
-#pragma unroll
-        for (int it = 0; it < YIT; ++it) {
-            const int e = tid + 256 * it;
-            if ((PK * YG) % 256 == 0 || e < PK * YG) rnh_st4(Ys + e * 4, ry[it]);
+        for (int d = 0; d < D; ++d) {
+            const bool in = p < pe;
+            const bool xv = in && xbase && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)W;
+            const float *pa = xv ? xbase + (long)(cr * xWs + cx * xsc) * xC : zp;
+            F.a[d] = *reinterpret_cast<const VA *>(pa);
+            const bool yv = in && ybase;
+            const float *pb_ = yv ? ybase + (long)(cr * yWs + cx * ysc) * yC : zp;
+            F.b[d] = *reinterpret_cast<const VB *>(pb_);
+            p += 2;
+            cx += 2;
+            while (cx >= W) {
+                cx -= W;
+                ++cr;
+                if (++cy == H) cy = 0;
+            }
         }
     };
 
@@ -146,58 +132,59 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const rnh_wgrad_args_t 
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const bool do_bias = P.bslab && tap == 0 && xt == 0 && tid < BY;
-    float bsum = 0.f;
-
-    auto compute = [&](int buf) {
-        const float *Xs = lds + buf * STAGE;
-        const float *Ys = Xs + PK * BX;
+    const bool do_bias = P.bslab && tap == 0 && rt == 0;
+    float bs[NI];
 #pragma unroll
-        for (int k = 0; k < PK / 2; ++k) {
+    for (int j = 0; j < NI; ++j) bs[j] = 0.f;
+
+    auto compute_set = [&](const Set &F) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
             float a[MI], b[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = Xs[(2 * k + kh) * BX + (wm * MI + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = Ys[(2 * k + kh) * BY + (wn * NI + j) * 32 + l31];
+            unpack<MI>(F.a[d], a);
+            unpack<NI>(F.b[d], b);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (do_bias) {
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
 #pragma unroll
-            for (int k = 0; k < PK; ++k) bsum += Ys[k * BY + tid];
+                for (int j = 0; j < NI; ++j) bs[j] += b[j];
+            }
         }
     };
 
-    if (s_begin < s_end) {
-        load_stage();
-        store_stage(0);
-        __syncthreads();
-        for (int st = s_begin; st < s_end; ++st) {
-            const bool more = st + 1 < s_end;
-            if (more) load_stage();
-            compute((st - s_begin) & 1);
-            if (more) store_stage((st - s_begin + 1) & 1);
-            __syncthreads();
+    // ---- main loop: two register sets, D pixel pairs each; loads past the range read the zero page ---------
+    {
+        Set F0, F1;
+        const int nsets2 = (chunk / (2 * D) + 1) / 2;            // pairs of sets covering the whole chunk
+        load_set(F0);
+        for (int it = 0; it < nsets2; ++it) {
+            load_set(F1);
+            compute_set(F0);
+            load_set(F0);
+            compute_set(F1);
         }
     }
 
-    // slab[((split*ntaps + tap) * xcols_pad + row) * ycols_pad + col]
-    float *out = P.slab + ((long)(split * P.ntaps + tap) * P.xcols_pad + xt * BX) * P.ycols_pad + yt * BY;
+    // ---- write the partial tile: row = MI*i + em, column = NI*j + en -------------------------------------------
+    float *out = P.slab + ((long)(split * P.ntaps + tap) * P.xcols_pad + rt * 32 * MI) * P.ycols_pad + ct * 32 * NI;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int em = 0; em < MI; ++em)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float *o = out + (long)(MI * i + em) * P.ycols_pad + NI * l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int col = (wn * NI + j) * 32 + l31;
-                out[(long)row * P.ycols_pad + col] = acc[i][j][r];
-            }
-    if (do_bias) P.bslab[(long)split * P.ycols_pad + yt * BY + tid] = bsum;
+            for (int en = 0; en < NI; ++en) o[en] = acc[em][en][r];
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int en = 0; en < NI; ++en) {
+            const float v = bs[en] + __shfl_xor(bs[en], 32, 64);
+            if (kh == 0) P.bslab[(long)split * P.ycols_pad + ct * 32 * NI + NI * l31 + en] = v;
+        }
+    }
 }
 
 __global__ void wgrad_reduce_kernel(const float *slab, const float *bslab, int nsplit, int ntaps, int XP, int YP,
@@ -225,16 +212,17 @@ __global__ void wgrad_reduce_kernel(const float *slab, const float *bslab, int n
     }
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int MI, int NI, int D>
 int launch_wgrad(const rnh_wgrad_args_t &a, hipStream_t st) {
-    constexpr int BX = WM * MI * 32, BY = WN * NI * 32;
-    if (a.xcols_pad % BX || a.ycols_pad % BY) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: padded sizes do not match the tile");
+    if (a.xcols_pad % (32 * MI) || a.ycols_pad % (32 * NI)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: padded sizes do not match the tile");
     const long M = (long)a.B * a.H * a.W;
-    const int nsteps = (int)((M + PK - 1) / PK);
-    const int sps = (nsteps + a.nsplit - 1) / a.nsplit;
-    const dim3 grid(a.nsplit, (a.xcols_pad / BX) * (a.ycols_pad / BY), a.ntaps), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MI, NI>), grid, block, 0, st, a, a.xcols_pad / BX, a.ycols_pad / BY, sps,
-                       nsteps);
+    const int q = 4 * D;
+    long chunk = (M + a.nsplit - 1) / a.nsplit;
+    chunk = (chunk + q - 1) / q * q;
+    const int RT = a.xcols_pad / (32 * MI), CT = a.ycols_pad / (32 * NI);
+    const long bps = ((long)a.ntaps * RT * CT + 3) / 4;            // workgroups per pixel range
+    const dim3 grid((unsigned)(a.nsplit * bps)), block(256);
+    hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D>), grid, block, 0, st, a, RT, CT, (int)chunk);
     RNH_CHECK_LAUNCH("rnh_conv_wgrad");
     return 0;
 }
@@ -255,14 +243,14 @@ extern "C" int rnh_conv_wgrad(const rnh_wgrad_args_t *args, void *stream) {
         if (a.ys[i].ptr2 || a.ys[i].scale != a.ys[0].scale) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: dy sources must share one scale and have no ptr2");
     if (a.B < 1 || a.H < 1 || a.W < 1 || (a.ntaps != 9 && a.ntaps != 1)) RNH_FAIL(RNH_E_ARG, "rnh_conv_wgrad: bad geometry");
     if ((long)a.B * a.H * a.W >= (1L << 31) / 16) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: too many pixels");
-    if (!a.slab || !a.xgrp || !a.ygrp || a.nsplit < 1 || a.nsplit > 65535) RNH_FAIL(RNH_E_ARG, "rnh_conv_wgrad: workspace / maps / nsplit");
+    if (!a.slab || !a.xgrp || !a.ygrp || !a.zero_page || a.nsplit < 1 || a.nsplit > 65535)
+        RNH_FAIL(RNH_E_ARG, "rnh_conv_wgrad: workspace / maps / zero page / nsplit");
     hipStream_t st = (hipStream_t)stream;
     switch (a.tile) {
-        case RNH_TILE_128x128: return launch_wgrad<2, 2, 2, 2>(a, st);
-        case RNH_TILE_128x160: return launch_wgrad<4, 1, 1, 5>(a, st);
-        case RNH_TILE_256x64:  return launch_wgrad<4, 1, 2, 2>(a, st);
-        case RNH_TILE_64x128:  return launch_wgrad<2, 2, 1, 2>(a, st);
-        case RNH_TILE_64x256:  return launch_wgrad<1, 4, 2, 2>(a, st);
+        case RNH_WTILE_128x64: return launch_wgrad<4, 2, 4>(a, st);
+        case RNH_WTILE_64x128: return launch_wgrad<2, 4, 4>(a, st);
+        case RNH_WTILE_64x64:  return launch_wgrad<2, 2, 8>(a, st);
+        case RNH_WTILE_128x32: return launch_wgrad<4, 1, 8>(a, st);
         default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: unsupported tile %d", a.tile);
     }
 }

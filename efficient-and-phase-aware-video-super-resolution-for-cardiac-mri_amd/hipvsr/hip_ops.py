@@ -29,6 +29,7 @@ class HipOps:
         self._packed = {}      # id(plan) -> (wp, biasp)
         self._ws = {}
         self._side = []
+        self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
         self.direct = os.environ.get('RNH_DIRECT', '1') != '0'
 
@@ -210,6 +211,7 @@ class HipOps:
         a.xgrp, a.ygrp = m['xgrp'].data_ptr(), m['ygrp'].data_ptr()
         a.B, a.H, a.W, a.ntaps, a.tile, a.nsplit = B, H, W, plan.ntaps, plan.tile, nsplit
         a.slab, a.bslab = slab.data_ptr(), (bslab.data_ptr() if bslab is not None else None)
+        a.zero_page = self._zero_page.data_ptr()
         st = self._stream()
         L.check(self.lib.rnh_conv_wgrad(C.byref(a), st), f'rnh_conv_wgrad({plan.name})')
         L.check(self.lib.rnh_wgrad_reduce(_ptr(slab), _ptr(bslab), nsplit, plan.ntaps, plan.xcols_pad, plan.ycols_pad,

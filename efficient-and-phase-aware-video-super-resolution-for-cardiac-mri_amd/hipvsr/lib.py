@@ -11,9 +11,10 @@ LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM = 0, 1, 2
-TILE_128x128, TILE_128x128_G, TILE_256x64, TILE_128x160, TILE_64x128, TILE_64x256 = 0, 1, 2, 3, 4, 5
-TILE_COLS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 64, TILE_128x160: 160, TILE_64x128: 128, TILE_64x256: 256}
-TILE_ROWS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 256, TILE_128x160: 128, TILE_64x128: 64, TILE_64x256: 64}
+TILE_128x128, TILE_128x128_G, TILE_256x64, TILE_128x160, TILE_256x128 = 0, 1, 2, 3, 6
+TILE_COLS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 64, TILE_128x160: 160, TILE_256x128: 128}
+TILE_ROWS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 256, TILE_128x160: 128, TILE_256x128: 256}
+WTILE_128x64, WTILE_64x128, WTILE_64x64 = 0x42, 0x24, 0x22      # rnh_conv_wgrad: MI << 4 | NI
 TILE_DIRECT = 16
 LOSS_L1, LOSS_CHARBONNIER = 0, 1
 LOSS_BLOCKS = 64
@@ -52,7 +53,7 @@ class WgradArgs(C.Structure):
     _fields_ = [('xs', Src * MAX_SRC), ('nxs', C.c_int32), ('xcols_pad', C.c_int32), ('ys', Src * MAX_SRC),
                 ('nys', C.c_int32), ('ycols_pad', C.c_int32), ('xgrp', C.c_void_p), ('ygrp', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('ntaps', C.c_int32), ('tile', C.c_int32),
-                ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p)]
+                ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p), ('zero_page', C.c_void_p)]
 
 
 _lib = None

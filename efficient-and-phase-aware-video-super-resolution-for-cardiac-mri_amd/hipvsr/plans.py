@@ -103,13 +103,11 @@ class YSeg:
 
 
 def pick_wgrad_tile(nrows, ncols):
-    if 128 < ncols <= 160:
-        return L.TILE_128x160
-    if ncols <= 64:
-        return L.TILE_256x64 if nrows > 128 else L.TILE_64x128
-    if nrows <= 64:
-        return L.TILE_64x256 if ncols >= 256 else L.TILE_64x128
-    return L.TILE_128x128
+    """(MI, NI): one wave computes 32*MI rows x 32*NI columns of dW."""
+    # padded area / relative efficiency of the tile (bytes loaded per MFMA, accumulators in flight)
+    cands = [((4, 2), 1.0), ((2, 4), 1.0), ((2, 2), 0.92), ((4, 1), 0.85)]
+    cost = lambda t: _pad_to(nrows, 32 * t[0][0]) * _pad_to(ncols, 32 * t[0][1]) / t[1]     # noqa: E731
+    return min(cands, key=cost)[0]
 
 
 class WgradPlan:
@@ -120,29 +118,35 @@ class WgradPlan:
         self.Cout, self.Cin, kh, kw = wshape
         self.ntaps = kh * kw
         self.xsegs, self.ysegs = xsegs, ysegs
+        nrows, ncols = sum(sg.nch for sg in xsegs), sum(sg.nch for sg in ysegs)
+        self.mi, self.ni = pick_wgrad_tile(nrows, ncols) if tile is None else tile
+        self.tile = (self.mi << 4) | self.ni
         rowmap, xgrp = [], []
         for si, sg in enumerate(xsegs):
             assert sg.nch % 4 == 0
             rowmap += [sg.ci_base + c if c < sg.nvalid else -1 for c in range(sg.nch)]
-            xgrp += [(si << 16) | c for c in range(0, sg.nch, 4)]
+            xgrp += [(si << 16) | c for c in range(0, sg.nch, self.mi)]          # one entry per lane slot
         colmap, ygrp = [], []
         for si, sg in enumerate(ysegs):
             assert sg.nch % 4 == 0
             colmap += [sg.co_base + c * sg.stride if c < sg.nvalid else -1 for c in range(sg.nch)]
-            ygrp += [(si << 16) | c for c in range(0, sg.nch, 4)]
-        self.tile = pick_wgrad_tile(len(rowmap), len(colmap)) if tile is None else tile
-        self.xcols_pad = _pad_to(len(rowmap), L.TILE_ROWS[self.tile])
-        self.ycols_pad = _pad_to(len(colmap), L.TILE_COLS[self.tile])
+            ygrp += [(si << 16) | c for c in range(0, sg.nch, self.ni)]
+        self.xcols_pad = _pad_to(len(rowmap), 32 * self.mi)
+        self.ycols_pad = _pad_to(len(colmap), 32 * self.ni)
         self.rowmap = rowmap + [-1] * (self.xcols_pad - len(rowmap))
         self.colmap = colmap + [-1] * (self.ycols_pad - len(colmap))
-        self.xgrp = xgrp + [-1] * (self.xcols_pad // 4 - len(xgrp))
-        self.ygrp = ygrp + [-1] * (self.ycols_pad // 4 - len(ygrp))
+        self.xgrp = xgrp + [-1] * (self.xcols_pad // self.mi - len(xgrp))
+        self.ygrp = ygrp + [-1] * (self.ycols_pad // self.ni - len(ygrp))
 
     def nsplit(self, npix):
-        tiles = (self.xcols_pad // L.TILE_ROWS[self.tile]) * (self.ycols_pad // L.TILE_COLS[self.tile]) * self.ntaps
-        steps = (npix + 15) // 16
-        want = max(1, -(-1024 // tiles))          # about 4 workgroups per CU
-        return int(max(1, min(want, 128, steps)))
+        items = (self.xcols_pad // (32 * self.mi)) * (self.ycols_pad // (32 * self.ni)) * self.ntaps
+        # Every wave does the same amount of work, so the launch should fill the chip exactly once: 256 CUs x the
+        # workgroups a CU holds (2 for the 128-accumulator tiles, 3 for the 64x64 one) and no partial second round.
+        bps = (items + 3) // 4                     # workgroups per pixel range
+        resident = 256 * (2 if self.mi * self.ni >= 8 else 3)
+        n = int(max(1, min(round(resident / bps), 256, (npix + 63) // 64)))
+        # ranges shared by few workgroups are packed per XCD by the kernel, which needs a multiple of 8 of them
+        return n // 8 * 8 if (n >= 8 and bps <= 16) else n
 
 
 # --------------------------------------------------------------------------------------------------------

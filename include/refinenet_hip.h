@@ -74,8 +74,6 @@ typedef struct rnh_dst {
 #define RNH_TILE_128x128_G 1 /* 4x1 waves of 32x128 (LSTM: one wave holds the 4 gates of 32 channels) */
 #define RNH_TILE_256x64  2   /* 4x1 waves of 64x64          */
 #define RNH_TILE_128x160 3   /* 4x1 waves of 32x160         */
-#define RNH_TILE_64x128  4   /* 2x2 waves of 32x64 (rnh_conv_wgrad only) */
-#define RNH_TILE_64x256  5   /* 1x4 waves of 64x64 (rnh_conv_wgrad only) */
 #define RNH_TILE_256x128 6   /* 4x1 waves of 64x128 (rnh_conv_igemm, DIRECT variant only; LSTM-capable) */
 #define RNH_TILE_DIRECT  16  /* OR-ed into `tile` for rnh_conv_igemm: fragments straight from global memory, no LDS,
                                 no barrier (same results bit for bit as the LDS-staged variant)                  */
@@ -121,24 +119,32 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
                      const int32_t *colmap, int nk, int Npad, int Cout, int Cin, int ntaps, int kstride,
                      int transposed, void *stream);
 
+/* Work-item shapes of rnh_conv_wgrad: one wave computes 32*MI rows x 32*NI columns of dW (code = MI << 4 | NI) */
+#define RNH_WTILE_128x64 0x42
+#define RNH_WTILE_64x128 0x24
+#define RNH_WTILE_64x64  0x22
+#define RNH_WTILE_128x32 0x41
+
 typedef struct rnh_wgrad_args {
-    rnh_src_t xs[RNH_MAX_SRC];   /* forward input operand (rows of dW), tap-shifted                  */
+    rnh_src_t xs[RNH_MAX_SRC];   /* forward input operand (rows of dW), tap-shifted; one common `scale`, no ptr2 */
     int32_t nxs;
-    int32_t xcols_pad;           /* padded row count, multiple of the tile rows                      */
-    rnh_src_t ys[RNH_MAX_SRC];   /* output-gradient operand (columns of dW)                          */
+    int32_t xcols_pad;           /* padded row count, multiple of 32*MI                              */
+    rnh_src_t ys[RNH_MAX_SRC];   /* output-gradient operand (columns of dW); one common `scale`, no ptr2 */
     int32_t nys;
-    int32_t ycols_pad;           /* padded column count, multiple of the tile columns                */
-    const int32_t *xgrp;         /* device [xcols_pad/4]: (src << 16) | channel, or -1 (zero)        */
-    const int32_t *ygrp;         /* device [ycols_pad/4]                                             */
+    int32_t ycols_pad;           /* padded column count, multiple of 32*NI                           */
+    const int32_t *xgrp;         /* device [xcols_pad/MI]: lane slot -> (src << 16) | first channel of its MI
+                                    consecutive channels, or -1 (zero rows)                          */
+    const int32_t *ygrp;         /* device [ycols_pad/NI], likewise with NI                          */
     int32_t B, H, W, ntaps;
-    int32_t tile;                /* RNH_TILE_128x128, _128x160, _256x64, _64x128 or _64x256         */
-    int32_t nsplit;              /* pixel-range splits (grid.x)                                      */
+    int32_t tile;                /* RNH_WTILE_*                                                      */
+    int32_t nsplit;              /* number of pixel ranges                                           */
     float *slab;                 /* workspace [nsplit][ntaps][xcols_pad][ycols_pad]                  */
     float *bslab;                /* workspace [nsplit][ycols_pad] (column sums = bias gradient) or 0 */
+    const float *zero_page;      /* device, >= 16 bytes of zeros, 16-byte aligned: what masked lanes read */
 } rnh_wgrad_args_t;
 
 /* Weight gradient dW[tap][ci][co] = sum_pixels X[p+tap][ci] * dY[p][co] as an MFMA GEMM whose K dimension
- * is the pixel index, split over `nsplit` workgroups into partial slabs (deterministic, no atomics).
+ * is the pixel index, split over `nsplit` pixel ranges into partial slabs (deterministic, no atomics).
  * Replaces the weight/bias part of aten::convolution_backward (loss.backward(), trainer :46). */
 int rnh_conv_wgrad(const rnh_wgrad_args_t *args /* host */, void *stream);
 
