@@ -84,21 +84,26 @@ class RefineNetEngine:
         for s in range(S):
             st = dict(feat=feat)
             # ---- bidirectional ConvLSTM over the frames (refine_net.py:82-93) ----------------------------
-            # The two directions are independent until the refine block: they are issued frame by frame on two
-            # side streams so that the tail of one direction's launch overlaps the head of the other's.
+            # One cell launch (N images) fills the chip for well under a millisecond, so its ramp-up and tail matter.
+            # Cell (direction d, layer l, frame k) only needs (d, l-1, k) and (d, l, k-1): every (d, l) gets its own
+            # stream, ordered along k by the stream and against the layer below by an event, and up to 2*L cells
+            # of the layer/frame wavefront run concurrently.
             dirs = ('forward', 'backward')
             for d in dirs:
                 st[d] = dict(H=[ops.empty(F * N, H, W, hd) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
                              G=[ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None)
-            ops.fork(2)
+            ops.fork(2 * Lr)
             for idx in range(F):
                 for di, d in enumerate(dirs):
                     k = idx if d == 'forward' else F - 1 - idx
                     prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
                     Hb, Cb, Gb = st[d]['H'], st[d]['C'], st[d]['G']
                     grad_frame = need_grad and U <= k < U + T
-                    with ops.side(di):
-                        for l in range(Lr):
+                    below = None
+                    for l in range(Lr):
+                        with ops.side(di * Lr + l):
+                            if below is not None:
+                                ops.wait(below)
                             pl = P.lstm[(d, l)]
                             xin = feat if l == 0 else Hb[l - 1]
                             srcs = [Src(xin, img_off=k * N)]
@@ -115,7 +120,8 @@ class RefineNetEngine:
                                 hd=pl['hd'], c_prev=Cb[l][prev * N:(prev + 1) * N] if prev is not None else None,
                                 h_out=Hb[l][k * N:(k + 1) * N], c_out=Cb[l][k * N:(k + 1) * N],
                                 gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
-            ops.join(2)
+                            below = ops.record() if l + 1 < Lr else None
+            ops.join(2 * Lr)
             Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
 
             # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
@@ -257,14 +263,17 @@ class RefineNetEngine:
                      dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
 
             # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
-            # (both directions interleaved on two side streams, like the forward)
+            # Same wavefront as the forward, reversed: cell (d, l, k) needs the input gradient of (d, l+1, k) (an
+            # event) and the state gradients of its own next-processed frame (stream order).  Buffers that cross
+            # streams are allocated here, before the fork.
             dirs = ('forward', 'backward')
             tops = {'forward': dHf, 'backward': dHb}
             Gd = {d: [ops.empty(TN, H, W, 4 * hd) for hd in nf] for d in dirs}
+            DX = {d: [ops.empty(TN, H, W, P.lstm[(d, l)]['cx']) if l > 0 else None for l in range(Lr)] for d in dirs}
             dfeat_d = {d: ops.empty(TN, H, W, C) for d in dirs}          # layer-0 input gradients per direction
             dh_next = {d: [None] * Lr for d in dirs}
             dc_next = {d: [None] * Lr for d in dirs}
-            ops.fork(2)
+            ops.fork(2 * Lr)
             for idx in range(T):
                 for di, d in enumerate(dirs):
                     step = 1 if d == 'forward' else -1
@@ -274,9 +283,11 @@ class RefineNetEngine:
                     fi = k - U
                     prevk = k - step
                     prev_grad = U <= prevk < U + T
-                    dx_above = None
-                    with ops.side(di):
-                        for l in range(Lr - 1, -1, -1):
+                    dx_above, above = None, None
+                    for l in range(Lr - 1, -1, -1):
+                        with ops.side(di * Lr + l):
+                            if above is not None:
+                                ops.wait(above)
                             pl = P.lstm[(d, l)]
                             hd, cx = pl['hd'], pl['cx']
                             dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
@@ -287,7 +298,7 @@ class RefineNetEngine:
                             dcp = ops.empty(N, H, W, hd) if prev_grad else None
                             ops.lstm_gates_bwd(dh, dc_next[d][l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg,
                                                dcp)
-                            dxbuf = ops.empty(N, H, W, cx) if l > 0 else dfeat_d[d][fi * N:(fi + 1) * N]
+                            dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
                             dhp = None
                             if cfg.memory:
                                 dsts = [Dst(dxbuf, cx)]
@@ -301,12 +312,13 @@ class RefineNetEngine:
                                 ops.add(dxbuf, tmp, accumulate=True)
                             dh_next[d][l], dc_next[d][l] = dhp, dcp
                             dx_above = dxbuf if l > 0 else None
-            # weight gradients of the cells, batched over the T frames
+                            above = ops.record() if l > 0 else None
+            # weight gradients of the cells, batched over the T frames (each on its cell's stream)
             for di, d in enumerate(dirs):
                 step = 1 if d == 'forward' else -1
                 Hb = st[d]['H']
-                with ops.side(di):
-                    for l in range(Lr):
+                for l in range(Lr):
+                    with ops.side(di * Lr + l):
                         pl = P.lstm[(d, l)]
                         xin = feat if l == 0 else Hb[l - 1]
                         second = Src(Hb[l], img_off=(U - step) * N) if cfg.memory else Src(xin, img_off=U * N)
@@ -315,7 +327,7 @@ class RefineNetEngine:
                         acc(bk)
                         ops.wgrad(pl['wgrad'], [Src(xin, img_off=U * N), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
                                   accumulate=a)
-            ops.join(2)
+            ops.join(2 * Lr)
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
             st['forward'] = st['backward'] = None
             dfeat_next = dfeat

@@ -66,6 +66,14 @@ class HipOps:
     def side(self, i):
         return torch.cuda.stream(self._side[i])
 
+    def record(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait(self, ev):
+        torch.cuda.current_stream(self.device).wait_event(ev)
+
     def join(self, n):
         cur = torch.cuda.current_stream(self.device)
         for st in self._side[:n]:
