@@ -102,12 +102,15 @@ def cpu_baseline():
     """The oracle (bit-exact restatement of the reference) at BASELINE config 1 on the host cores: 1 warm-up + 2 timed
     steps of forward + discounted L1 loss + backward (about 10-20 s)."""
     from oracle import refinenet_oracle as orc
-    threads = torch.get_num_threads()
+    # 16 threads is the fastest setting on the GPU box's host (2 x EPYC 9575F, 256 hardware threads): 0.88 s/step at
+    # 16 threads against 1.37 (8), 1.42 (32), 3.2 (64) and 10.6 (128) - the convolutions of one 64x64 sample are small
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     cfg = orc.exp1_x4_config()
     sd = orc.init_state_dict(cfg, seed=20200526)
     inputs, targets, pos = orc.synthetic_batch(cfg, n=1, t=3, h=64, w=64, seed=20200527)
     orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
-    reps = 2
+    reps = 10
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
@@ -186,7 +189,7 @@ def main():
                        'step_tflop': round(flop_step / 1e12, 2),
                        'step_tflops_per_gpu': round(flop_step / world / (dt / args.steps) / 1e12, 2),
                        'step_frac_of_f32_mfma_peak': round(flop_step / world / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                       'final_loss': round(float(loss), 6)},
+                       'final_loss': round(float(loss.detach()), 6)},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

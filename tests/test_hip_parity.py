@@ -133,7 +133,7 @@ def test_cfg1_full_width_vs_reference_digest(golden_dir):
     inputs, targets, pos = orc.synthetic_batch(cfg, r['n'], r['t'], r['h'], r['w'], seed=r['seed_inputs'])
     from src.model.metrics import PSNR
     net, tr, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, torch.nn.L1Loss())
-    assert abs(float(loss) - r['train_loss']) <= 1e-5 * abs(r['train_loss'])
+    assert abs(float(loss.detach()) - r['train_loss']) <= 1e-5 * abs(r['train_loss'])
     for g, grp in enumerate(outs):
         for i, o in enumerate(grp):
             torch.testing.assert_close(o.detach().cpu()[0, 0, 100:116, 100:116], r['out_crop'][g][i], atol=1e-4, rtol=1e-4)
@@ -196,3 +196,24 @@ def test_linearity_and_batch_independence_at_bench_width():
         both = net([x.to(dev) for x in inputs], pos.to(dev))[-1][0]
         one = net([x[:1].to(dev) for x in inputs], pos[:1].to(dev))[-1][0]
     assert torch.equal(both[:1], one)
+
+
+def test_src_main_trains_from_yaml(tmp_path):
+    """python -m src.main <yaml>: one epoch of training + validation on the synthetic cines, checkpoint written."""
+    import types
+    import yaml
+    from conftest import PKG
+    from src import main as M
+    cfg = yaml.safe_load(open(os.path.join(PKG, 'configs', 'refine_net_x4_synthetic.yaml')))
+    cfg['main']['saved_dir'] = str(tmp_path / 'run')
+    cfg['trainer']['kwargs']['num_epochs'] = 1
+    cfg['dataloader']['kwargs']['num_workers'] = 0
+    cfg['monitor']['kwargs']['saved_freq'] = 1
+    p = tmp_path / 'cfg.yaml'
+    p.write_text(yaml.safe_dump(cfg))
+    M.main(types.SimpleNamespace(config_path=p, test=False))
+    ck = torch.load(tmp_path / 'run' / 'checkpoints' / 'model_1.pth', map_location='cpu', weights_only=False)
+    assert set(ck) == {'net', 'optimizer', 'lr_scheduler', 'monitor', 'epoch', 'random_state', 'np_random_seeds'}
+    assert list(ck['net'].keys()) == list(orc.state_dict_spec(orc.exp1_x4_config()).keys())
+    log = (tmp_path / 'run' / 'log' / 'scalars.jsonl').read_text()
+    assert '"Loss"' in log and '"PSNR"' in log
