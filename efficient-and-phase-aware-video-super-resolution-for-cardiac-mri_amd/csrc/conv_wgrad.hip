@@ -30,7 +30,11 @@ __device__ __forceinline__ void unpack(const typename Vec<N>::T &v, float (&o)[N
     if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 }
 
-template <int MI, int NI, int D>
+// ROWS: W % (2*D) == 0 and chunk % W == 0 (host-checked).  Then every set of D pixel pairs lies inside one image
+// row, the pixel coordinates are wave-uniform (the lane-half's +1 pixel is folded into the lane's base pointer) and
+// live in scalar registers, and the D loads of a set differ by a constant stride: almost no vector ALU work is left
+// beside the MFMAs.  Otherwise (odd / tiny images) the coordinates are tracked per lane.
+template <int MI, int NI, int D, bool ROWS>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args_t P, const int RT, const int CT,
                                                            const int chunk /* pixels per split, multiple of 4*D */) {
     typedef typename Vec<MI>::T VA;
@@ -91,7 +95,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args
             yC = S.C;
         }
     }
-    // coordinates of this lane-half's next pixel: p = pb + kh, advanced by 2 per pixel pair
+    struct Set {
+        VA a[D];
+        VB b[D];
+    };
+    // generic path state: coordinates of this lane-half's next pixel p = pb + kh, advanced by 2 per pixel pair
     int p = pb + kh;
     int cy, cx, cr;
     {
@@ -100,27 +108,54 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args
         cx = rem - cy * W;
         cr = b * H + cy;
     }
+    // ROWS path state (wave-uniform): global row, row within the image, first pixel of the next set
+    int ur = pb / W, uy = ur % H, ux0 = 0;
+    const int rows_end = pe / W;                                    // pe is a multiple of W in ROWS mode
+    const float *xlane = xbase ? xbase + (long)kh * xsc * xC : nullptr;
+    const float *ylane = ybase ? ybase + (long)kh * ysc * yC : nullptr;
 
-    struct Set {
-        VA a[D];
-        VB b[D];
-    };
     auto load_set = [&](Set &F) {
+        if constexpr (ROWS) {
+            const bool rowin = ur < rows_end;
+            const bool xrow = rowin && xlane && (unsigned)(uy + dy) < (unsigned)H;
+            const float *xb = xrow ? xlane + ((long)ur * xWs + ux0 * xsc) * xC : zp;
+            const long xst = xrow ? 2 * xsc * xC : 0;
+            const bool yrow = rowin && ylane;
+            const float *yb = yrow ? ylane + ((long)ur * yWs + ux0 * ysc) * yC : zp;
+            const long yst = yrow ? 2 * ysc * yC : 0;
+            const bool cut_first = dx < 0 && ux0 == 0 && kh == 0;              // x - 1 < 0
+            const bool cut_last = dx > 0 && ux0 + 2 * D == W && kh == 1;       // x + 1 >= W
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const bool in = p < pe;
-            const bool xv = in && xbase && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)W;
-            const float *pa = xv ? xbase + (long)(cr * xWs + cx * xsc) * xC : zp;
-            F.a[d] = *reinterpret_cast<const VA *>(pa);
-            const bool yv = in && ybase;
-            const float *pb_ = yv ? ybase + (long)(cr * yWs + cx * ysc) * yC : zp;
-            F.b[d] = *reinterpret_cast<const VB *>(pb_);
-            p += 2;
-            cx += 2;
-            while (cx >= W) {
-                cx -= W;
-                ++cr;
-                if (++cy == H) cy = 0;
+            for (int d = 0; d < D; ++d) {
+                const float *pa = xb + d * xst;
+                if (d == 0) pa = cut_first ? zp : pa;
+                if (d == D - 1) pa = cut_last ? zp : pa;
+                F.a[d] = *reinterpret_cast<const VA *>(pa);
+                F.b[d] = *reinterpret_cast<const VB *>(yb + d * yst);
+            }
+            ux0 += 2 * D;                                   // branch-free row advance
+            const int wrap = ux0 == W;
+            ux0 = wrap ? 0 : ux0;
+            ur += wrap;
+            uy += wrap;
+            uy = uy == H ? 0 : uy;
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const bool in = p < pe;
+                const bool xv = in && xbase && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)W;
+                const float *pa = xv ? xbase + (long)(cr * xWs + cx * xsc) * xC : zp;
+                F.a[d] = *reinterpret_cast<const VA *>(pa);
+                const bool yv = in && ybase;
+                const float *pb_ = yv ? ybase + (long)(cr * yWs + cx * ysc) * yC : zp;
+                F.b[d] = *reinterpret_cast<const VB *>(pb_);
+                p += 2;
+                cx += 2;
+                while (cx >= W) {
+                    cx -= W;
+                    ++cr;
+                    if (++cy == H) cy = 0;
+                }
             }
         }
     };
@@ -216,13 +251,15 @@ template <int MI, int NI, int D>
 int launch_wgrad(const rnh_wgrad_args_t &a, hipStream_t st) {
     if (a.xcols_pad % (32 * MI) || a.ycols_pad % (32 * NI)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: padded sizes do not match the tile");
     const long M = (long)a.B * a.H * a.W;
-    const int q = 4 * D;
+    const bool rows = a.W % (2 * D) == 0;
+    const int q = rows ? 2 * a.W : 4 * D;           // rows: whole image rows per range (and 4*D divides 2*W)
     long chunk = (M + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + q - 1) / q * q;
     const int RT = a.xcols_pad / (32 * MI), CT = a.ycols_pad / (32 * NI);
     const long bps = ((long)a.ntaps * RT * CT + 3) / 4;            // workgroups per pixel range
     const dim3 grid((unsigned)(a.nsplit * bps)), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D>), grid, block, 0, st, a, RT, CT, (int)chunk);
+    if (rows) hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D, true>), grid, block, 0, st, a, RT, CT, (int)chunk);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D, false>), grid, block, 0, st, a, RT, CT, (int)chunk);
     RNH_CHECK_LAUNCH("rnh_conv_wgrad");
     return 0;
 }
