@@ -139,7 +139,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     dev = torch.device(f'cuda:{local}')
     torch.cuda.set_device(dev)
-    if world > 1:
+    if 'RANK' in os.environ:                      # launched by torchrun (also with one rank): RCCL process group
         dist.init_process_group('nccl', device_id=dev)
     from hipvsr import dp
     from src.runner.trainers import AcdcVSRRefineNetTrainer
@@ -195,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,11 +27,12 @@ def broadcast_parameters(module, src=0):
             off += p.numel()
 
 
-def allreduce_gradients(module, average=True):
+def allreduce_gradients(module, average=True, force=False):
     """Sum (and average) the gradients of ``module`` over all ranks with ONE collective.  Returns the number
-    of bytes reduced (0 when world size is 1)."""
+    of bytes reduced (0 when world size is 1, unless ``force`` runs the collective anyway - used to test the
+    RCCL path on a single GPU)."""
     ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_initialized()):
         return 0
     params = list(module.parameters())
     flat = getattr(module, '_flat_grad', None)

@@ -217,3 +217,25 @@ def test_src_main_trains_from_yaml(tmp_path):
     assert list(ck['net'].keys()) == list(orc.state_dict_spec(orc.exp1_x4_config()).keys())
     log = (tmp_path / 'run' / 'log' / 'scalars.jsonl').read_text()
     assert '"Loss"' in log and '"PSNR"' in log
+
+
+def test_rccl_allreduce_of_flat_gradient_single_rank(g1):
+    """The collective of the data-parallel path on the real backend (nccl = RCCL), world size 1: the flat gradient
+    buffer the engine writes is reduced in place and the parameter gradients (views of it) are unchanged."""
+    import torch.distributed as dist
+    from hipvsr import dp
+    c = g1['x2_pos1_mem1']
+    net, _, _, _ = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'], torch.nn.L1Loss())
+    before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=_dev())
+    try:
+        nbytes = dp.allreduce_gradients(net, force=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert nbytes == sum(p.numel() for p in net.parameters()) * 4       # in place over the engine's flat buffer
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, before[k])
