@@ -14,20 +14,34 @@
 // Partial tiles of the pixel ranges go to a slab; rnh_wgrad_reduce sums them in a fixed order (bitwise
 // reproducible, no float atomics).  Column sums of dY (= the bias gradient) fall out of the B operands of the
 // tap-0 / row-tile-0 work items.
+#include <type_traits>
 #include "rnh_common.h"
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N> struct Vec;
 template <> struct Vec<1> { typedef float T; };
-template <> struct Vec<2> { typedef float2 T; };
-template <> struct Vec<4> { typedef float4 T; };
+template <> struct Vec<2> { typedef f32x2 T; };
+template <> struct Vec<4> { typedef f32x4 T; };
 
 template <int N>
 __device__ __forceinline__ void unpack(const typename Vec<N>::T &v, float (&o)[N]) {
     if constexpr (N == 1) o[0] = v;
-    if constexpr (N == 2) { o[0] = v.x; o[1] = v.y; }
-    if constexpr (N == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    if constexpr (N == 2) { o[0] = v[0]; o[1] = v[1]; }
+    if constexpr (N == 4) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+}
+
+// Loads hidden from hipcc's scheduler (ROWS path).  hipcc sinks ordinary prefetch loads below the MFMAs that still
+// read the previous contents of their registers, which leaves them a quarter of a set of lead time; volatile asm
+// keeps program order, so the next set is in flight during the whole current one.  The matching wait_set() names
+// every destination register "+v": no consumer can be scheduled above it, and it waits with a COUNTED vmcnt that
+// leaves exactly the newer set's loads in flight.
+template <int N>
+__device__ __forceinline__ void gload(typename Vec<N>::T &dst, const float *p) {
+    if constexpr (N == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (N == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 
 // ROWS: W % (2*D) == 0 and chunk % W == 0 (host-checked).  Then every set of D pixel pairs lies inside one image
@@ -35,26 +49,29 @@ __device__ __forceinline__ void unpack(const typename Vec<N>::T &v, float (&o)[N
 // live in scalar registers, and the D loads of a set differ by a constant stride: almost no vector ALU work is left
 // beside the MFMAs.  Otherwise (odd / tiny images) the coordinates are tracked per lane.
 template <int MI, int NI, int D, bool ROWS>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args_t P, const int RT, const int CT,
+__global__ void __launch_bounds__(256, (MI * NI * 16 + 4 * D * (MI + NI) > 200 ? 1 : 2)) conv_wgrad_kernel(const rnh_wgrad_args_t P, const int RT, const int CT,
                                                            const int chunk /* pixels per split, multiple of 4*D */) {
     typedef typename Vec<MI>::T VA;
     typedef typename Vec<NI>::T VB;
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-    // Work items of one pixel range (ntaps * RT * CT of them) read the same X / dY pixels: they are packed into
-    // consecutive workgroups of ONE XCD (workgroups are dealt round-robin over the 8 XCDs, so workgroup b and
-    // b + 8 share an L2), which makes the range stream from HBM once per XCD instead of once per work item.
-    const int ips = P.ntaps * RT * CT, bps = (ips + 3) >> 2;
-    int split, sub;
+    // Work items of one pixel range (ntaps * RT * CT of them) read the same X / dY pixels, so a range should live on
+    // ONE XCD (workgroups are dealt round-robin over the 8 XCDs: workgroup b and b + 8 share an L2) and stream from
+    // HBM once.  Each XCD therefore owns nsplit/8 whole ranges, whose items are packed four to a workgroup without
+    // regard to range boundaries (at most 3 idle waves per XCD).
+    const int ips = P.ntaps * RT * CT;
+    int split, item;
     if ((P.nsplit & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        split = (j / bps) * 8 + xcd;
-        sub = j % bps;
+        const int xcd = blockIdx.x & 7, spx = P.nsplit >> 3;
+        const int li = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+        if (li >= spx * ips) return;                  // whole wave
+        split = xcd * spx + li / ips;
+        item = li % ips;
     } else {
-        split = blockIdx.x / bps;
-        sub = blockIdx.x % bps;
+        const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (li >= P.nsplit * ips) return;
+        split = li / ips;
+        item = li % ips;
     }
-    const int item = sub * 4 + (threadIdx.x >> 6);
-    if (item >= ips) return;                          // whole wave
     const int ct = item % CT;
     int r_ = item / CT;
     const int rt = r_ % RT;
@@ -130,8 +147,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args
                 const float *pa = xb + d * xst;
                 if (d == 0) pa = cut_first ? zp : pa;
                 if (d == D - 1) pa = cut_last ? zp : pa;
-                F.a[d] = *reinterpret_cast<const VA *>(pa);
-                F.b[d] = *reinterpret_cast<const VB *>(yb + d * yst);
+                gload<MI>(F.a[d], pa);
+                gload<NI>(F.b[d], yb + d * yst);
             }
             ux0 += 2 * D;                                   // branch-free row advance
             const int wrap = ux0 == W;
@@ -158,6 +175,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args
                 }
             }
         }
+    };
+
+    // counted wait for the loads of set F: at most KEEP younger loads may still be in flight afterwards
+    auto wait_set = [&](Set &F, auto keep) {
+        constexpr int KEEP = decltype(keep)::value;
+        static_assert(D == 4 || D == 8, "wait_set is written out for D = 4 and 8");
+        (void)F;
+        if constexpr (D == 4)
+            asm volatile("s_waitcnt vmcnt(%c8)"
+                         : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3])
+                         : "i"(KEEP));
+        else
+            asm volatile("s_waitcnt vmcnt(%c16)"
+                         : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.a[4]), "+v"(F.a[5]), "+v"(F.a[6]), "+v"(F.a[7]),
+                           "+v"(F.b[0]), "+v"(F.b[1]), "+v"(F.b[2]), "+v"(F.b[3]), "+v"(F.b[4]), "+v"(F.b[5]), "+v"(F.b[6]), "+v"(F.b[7])
+                         : "i"(KEEP));
     };
 
     f32x16 acc[MI][NI];
@@ -194,11 +227,65 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const rnh_wgrad_args
         Set F0, F1;
         const int nsets2 = (chunk / (2 * D) + 1) / 2;            // pairs of sets covering the whole chunk
         load_set(F0);
-        for (int it = 0; it < nsets2; ++it) {
-            load_set(F1);
-            compute_set(F0);
-            load_set(F0);
-            compute_set(F1);
+        if constexpr (ROWS) {
+            // One wave's instruction stream is [2 loads + their few address instructions of the NEXT set's pair d]
+            // [8 MFMAs of the CURRENT set's pair d], D times per set: the vector instructions issue in the shadow of
+            // the wave's own MFMAs (64 cycles each).  Measured the other way round - a load-only phase next to a
+            // partner wave that streams MFMAs - every vector instruction of the loader waited one MFMA slot (2800
+            // cycles for ~45 instructions against 2040 for the partner's 32 MFMAs; 510 cycles with the SIMD to
+            // itself): the matrix pipe idled a quarter of the time.  Each pair waits with vmcnt(2*D): exactly one
+            // whole set of younger loads stays in flight, so every load has a full set of MFMAs as lead time.
+            auto step = [&](Set &FL, Set &FC) {
+                const bool rowin = ur < rows_end;
+                const bool xrow = rowin && xlane && (unsigned)(uy + dy) < (unsigned)H;
+                const float *xb = xrow ? xlane + ((long)ur * xWs + ux0 * xsc) * xC : zp;
+                const long xst = xrow ? 2 * xsc * xC : 0;
+                const bool yrow = rowin && ylane;
+                const float *yb = yrow ? ylane + ((long)ur * yWs + ux0 * ysc) * yC : zp;
+                const long yst = yrow ? 2 * ysc * yC : 0;
+                const bool cut_first = dx < 0 && ux0 == 0 && kh == 0;              // x - 1 < 0
+                const bool cut_last = dx > 0 && ux0 + 2 * D == W && kh == 1;       // x + 1 >= W
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float *pa = xb + d * xst;
+                    if (d == 0) pa = cut_first ? zp : pa;
+                    if (d == D - 1) pa = cut_last ? zp : pa;
+                    gload<MI>(FL.a[d], pa);
+                    gload<NI>(FL.b[d], yb + d * yst);
+                    asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(FC.a[d]), "+v"(FC.b[d]) : "i"(2 * D));
+                    float a[MI], b[NI];
+                    unpack<MI>(FC.a[d], a);
+                    unpack<NI>(FC.b[d], b);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if (do_bias) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) bs[j] += b[j];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ux0 += 2 * D;                                   // branch-free row advance
+                const int wrap = ux0 == W;
+                ux0 = wrap ? 0 : ux0;
+                ur += wrap;
+                uy += wrap;
+                uy = uy == H ? 0 : uy;
+            };
+            for (int it = 0; it < nsets2; ++it) {
+                step(F1, F0);
+                step(F0, F1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the last, unused prefetch
+        } else {
+            for (int it = 0; it < nsets2; ++it) {
+                load_set(F1);
+                compute_set(F0);
+                load_set(F0);
+                compute_set(F1);
+            }
         }
     }
 
@@ -256,8 +343,9 @@ int launch_wgrad(const rnh_wgrad_args_t &a, hipStream_t st) {
     long chunk = (M + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + q - 1) / q * q;
     const int RT = a.xcols_pad / (32 * MI), CT = a.ycols_pad / (32 * NI);
-    const long bps = ((long)a.ntaps * RT * CT + 3) / 4;            // workgroups per pixel range
-    const dim3 grid((unsigned)(a.nsplit * bps)), block(256);
+    const long ips = (long)a.ntaps * RT * CT;                      // work items (waves) per pixel range
+    const long nblk = (a.nsplit & 7) == 0 ? 8 * ((a.nsplit / 8 * ips + 3) / 4) : (a.nsplit * ips + 3) / 4;
+    const dim3 grid((unsigned)nblk), block(256);
     if (rows) hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D, true>), grid, block, 0, st, a, RT, CT, (int)chunk);
     else hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI, D, false>), grid, block, 0, st, a, RT, CT, (int)chunk);
     RNH_CHECK_LAUNCH("rnh_conv_wgrad");
@@ -288,6 +376,8 @@ extern "C" int rnh_conv_wgrad(const rnh_wgrad_args_t *args, void *stream) {
         case RNH_WTILE_64x128: return launch_wgrad<2, 4, 4>(a, st);
         case RNH_WTILE_64x64:  return launch_wgrad<2, 2, 8>(a, st);
         case RNH_WTILE_128x32: return launch_wgrad<4, 1, 8>(a, st);
+        case RNH_WTILE_128x128: return launch_wgrad<4, 4, 8>(a, st);
+        case 0x824: return launch_wgrad<2, 4, 8>(a, st);          // experiment
         default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_wgrad: unsupported tile %d", a.tile);
     }
 }

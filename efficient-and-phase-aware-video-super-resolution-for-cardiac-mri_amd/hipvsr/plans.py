@@ -105,7 +105,7 @@ class YSeg:
 def pick_wgrad_tile(nrows, ncols):
     """(MI, NI): one wave computes 32*MI rows x 32*NI columns of dW."""
     # padded area / relative efficiency of the tile (bytes loaded per MFMA, accumulators in flight)
-    cands = [((4, 2), 1.0), ((2, 4), 1.0), ((2, 2), 0.92), ((4, 1), 0.85)]
+    cands = [((4, 4), 1.15), ((4, 2), 1.0), ((2, 4), 1.0), ((2, 2), 0.92), ((4, 1), 0.85)]
     cost = lambda t: _pad_to(nrows, 32 * t[0][0]) * _pad_to(ncols, 32 * t[0][1]) / t[1]     # noqa: E731
     return min(cands, key=cost)[0]
 
@@ -121,6 +121,10 @@ class WgradPlan:
         nrows, ncols = sum(sg.nch for sg in xsegs), sum(sg.nch for sg in ysegs)
         self.mi, self.ni = pick_wgrad_tile(nrows, ncols) if tile is None else tile
         self.tile = (self.mi << 4) | self.ni
+        import os
+        if os.environ.get('RNH_WGRAD_TILE'):              # experiments only: "MI,NI,Dcode"
+            mi, ni, dc = (int(v) for v in os.environ['RNH_WGRAD_TILE'].split(','))
+            self.mi, self.ni, self.tile = mi, ni, (dc << 8) | (mi << 4) | ni
         rowmap, xgrp = [], []
         for si, sg in enumerate(xsegs):
             assert sg.nch % 4 == 0
@@ -139,14 +143,18 @@ class WgradPlan:
         self.ygrp = ygrp + [-1] * (self.ycols_pad // self.ni - len(ygrp))
 
     def nsplit(self, npix):
+        import os
+        if os.environ.get('RNH_WGRAD_NSPLIT'):            # experiments only
+            return int(os.environ['RNH_WGRAD_NSPLIT'])
         items = (self.xcols_pad // (32 * self.mi)) * (self.ycols_pad // (32 * self.ni)) * self.ntaps
         # Every wave does the same amount of work, so the launch should fill the chip exactly once: 256 CUs x the
         # workgroups a CU holds (2 for the 128-accumulator tiles, 3 for the 64x64 one) and no partial second round.
-        bps = (items + 3) // 4                     # workgroups per pixel range
-        resident = 256 * (2 if self.mi * self.ni >= 8 else 3)
-        n = int(max(1, min(round(resident / bps), 256, (npix + 63) // 64)))
-        # ranges shared by few workgroups are packed per XCD by the kernel, which needs a multiple of 8 of them
-        return n // 8 * 8 if (n >= 8 and bps <= 16) else n
+        # resident waves on the chip: 1024 SIMDs x (1 for the 256-accumulator tile, 2 for 128, 3 for 64 accumulators)
+        acc = self.mi * self.ni
+        resident = 1024 * (1 if acc >= 16 else 3 if (self.mi, self.ni) == (2, 2) else 2)
+        n = int(max(1, min(resident // items, 256, (npix + 63) // 64)))
+        # the kernel packs whole ranges per XCD when their number is a multiple of 8
+        return n // 8 * 8 if n >= 8 else n
 
 
 # --------------------------------------------------------------------------------------------------------

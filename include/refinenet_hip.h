@@ -124,6 +124,7 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
 #define RNH_WTILE_64x128 0x24
 #define RNH_WTILE_64x64  0x22
 #define RNH_WTILE_128x32 0x41
+#define RNH_WTILE_128x128 0x44  /* one wave per SIMD: 256 accumulator registers, two 16-byte loads per 16 MFMAs */
 
 typedef struct rnh_wgrad_args {
     rnh_src_t xs[RNH_MAX_SRC];   /* forward input operand (rows of dW), tap-shifted; one common `scale`, no ptr2 */
