@@ -20,6 +20,7 @@
 //   without workgroup barriers the waves of a SIMD never convoy behind each other's MFMA phases.
 // * Epilogues: bias + store/accumulate into up to 4 channel segments; PixelShuffle fused into the store;
 //   ConvLSTM gate math (the 4 gates of a hidden channel sit in the same lane of the 4 column tiles of a wave).
+#include <type_traits>
 #include "rnh_common.h"
 
 namespace {
@@ -37,7 +38,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // waves per SIMD the register allocator is asked to make room for (DIRECT: 3, or 2 for the 64x128 wave tile)
 template <int MI, int NI, bool DIRECT>
-constexpr int min_waves() { return DIRECT ? (MI * NI >= 8 ? 2 : (NI >= 5 ? 2 : 3)) : 1; }
+constexpr int min_waves() { return DIRECT ? (MI * NI >= 8 ? 1 : 2) : 1; }
 
 template <int WM, int WN, int MI, int NI, int EPI, bool DIRECT>
 __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm_kernel(const rnh_conv_args_t P, const int MT, const int NT) {
@@ -212,7 +213,17 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         rx[i] = rem - ry[i] * W;
     }
     int s = 0, ch = 0, t = 0;
-    __amdgpu_buffer_rsrc_t arsrc;
+    // Buffer descriptors as plain SGPR quadruples (base, base_hi, 2 GiB window, raw-buffer flags) for the asm loads
+    auto make_desc = [&](const float *p) {
+        const unsigned long long u = (unsigned long long)p;
+        i32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+        d[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+        d[2] = 0x7fffffff;
+        d[3] = 0x00020000;
+        return d;
+    };
+    i32x4 adesc;
     int aC4 = 0, anch = 0, asc = 1;
     auto setup_src = [&](int si) {
         const rnh_src_t &S = P.src[si];
@@ -225,7 +236,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         const int base_pix = __builtin_amdgcn_readfirstlane(spix[0]) - (Ws + 1) * S.scale;
 #pragma unroll
         for (int i = 0; i < MI; ++i) rel[i] = rok[i] ? spix[i] - base_pix : 0;
-        arsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(S.ptr + S.c0 + (long)base_pix * S.C), 0, 0x7fffffff, 0x00020000);
+        adesc = make_desc(S.ptr + S.c0 + (long)base_pix * S.C);
         aC4 = S.C * 4;
         anch = S.nch;
         asc = S.scale;
@@ -240,11 +251,57 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             }
         }
     };
-    const __amdgpu_buffer_rsrc_t brsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(P.wp + ((long)n0 + wn * NI * 32) * 16), 0, 0x7fffffff, 0x00020000);
-    const int boff = (l31 * 16 + kh * 8) * 4;
+    const i32x4 bdesc = make_desc(P.wp + ((long)n0 + wn * NI * 32) * 16);
+    const int boff0 = (l31 * 16 + kh * 8) * 4, boff1 = boff0 + 4096, boff2 = boff0 + 8192;   // column tiles 0-1, 2-3, 4 (imm <= 4095)
     const int kstride_bytes = P.Npad * 64;
-    auto load_frag = [&](f32x4 (&fa)[MI][2], f32x4 (&fb)[NI][2], int ks) {
+
+    // The loads are volatile asm so that they stay where they are written: [a few loads of the NEXT K step] [MI*NI
+    // MFMAs of the current one], eight times per step.  A wave's vector instructions issue in the shadow of its own
+    // MFMAs (64 cycles each); a load-only phase beside another wave's MFMA stream would get one issue slot per MFMA
+    // (measured on the weight-gradient kernel).  Waits are counted: vmcnt(L/2) leaves the younger half-step of loads
+    // in flight, so every load has one whole K step of MFMAs as lead time.  The s_nop covers SALU->VMEM hazards on
+    // the descriptor / soffset registers, which hipcc does not pad inside asm.
+    struct Frag {
+        f32x4 a[MI][2];
+        f32x4 b[NI][2];
+    };
+    constexpr int LH = MI + NI;                       // loads per half step
+    auto lda = [&](f32x4 &dst, int voff) {
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(adesc) : "memory");
+    };
+    auto ldb = [&](f32x4 &dst, int j, int q, int soff) {
+        const int vo = j >= 4 ? boff2 : ((j & 2) ? boff1 : boff0);
+        if ((j & 1) == 0 && q == 0)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(bdesc), "s"(soff) : "memory");
+        else if ((j & 1) == 0)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(dst) : "v"(vo), "s"(bdesc), "s"(soff) : "memory");
+        else if (q == 0)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(dst) : "v"(vo), "s"(bdesc), "s"(soff) : "memory");
+        else
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:2064" : "=v"(dst) : "v"(vo), "s"(bdesc), "s"(soff) : "memory");
+    };
+    // every register of the half is named exactly once: a duplicate "+v" operand would make hipcc copy a register
+    // whose load has not landed yet
+    auto wait_half = [&](Frag &F, int q, auto keep) {
+        constexpr int KEEP = decltype(keep)::value;
+        static_assert((MI == 1 || MI == 2) && (NI == 2 || NI == 4 || NI == 5), "wait_half lists its operands explicitly");
+        if constexpr (MI == 2 && NI == 2)
+            asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(F.a[0][q]), "+v"(F.a[1][q]), "+v"(F.b[0][q]), "+v"(F.b[1][q]) : "i"(KEEP));
+        else if constexpr (MI == 1 && NI == 4)
+            asm volatile("s_waitcnt vmcnt(%c5)"
+                         : "+v"(F.a[0][q]), "+v"(F.b[0][q]), "+v"(F.b[1][q]), "+v"(F.b[2][q]), "+v"(F.b[3][q])
+                         : "i"(KEEP));
+        else if constexpr (MI == 1 && NI == 5)
+            asm volatile("s_waitcnt vmcnt(%c6)"
+                         : "+v"(F.a[0][q]), "+v"(F.b[0][q]), "+v"(F.b[1][q]), "+v"(F.b[2][q]), "+v"(F.b[3][q]), "+v"(F.b[4][q])
+                         : "i"(KEEP));
+        else if constexpr (MI == 2 && NI == 4)
+            asm volatile("s_waitcnt vmcnt(%c6)"
+                         : "+v"(F.a[0][q]), "+v"(F.a[1][q]), "+v"(F.b[0][q]), "+v"(F.b[1][q]), "+v"(F.b[2][q]), "+v"(F.b[3][q])
+                         : "i"(KEEP));
+    };
+    int voa[MI][2];                                   // byte offsets of the next step's A pieces (or -1: zeros)
+    auto next_offsets = [&]() {
         int dy = 0, dx = 0;
         if (P.ntaps == 9) {
             dy = t / 3 - 1;
@@ -256,47 +313,73 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         for (int i = 0; i < MI; ++i) {
             const bool v = rok[i] && (unsigned)(ry[i] + dy) < (unsigned)H && (unsigned)(rx[i] + dx) < (unsigned)W;
             const int o = (rel[i] + tapoff) * aC4 + cc * 4;
-            fa[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (v && cc < anch) ? o : -1, 0, 0));
-            fa[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (v && cc + 8 < anch) ? o + 32 : -1, 0, 0));
-        }
-        const int so = ks * kstride_bytes;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            fb[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff + j * 2048, so, 0));
-            fb[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff + j * 2048 + 16, so, 0));
+            voa[i][0] = (v && cc < anch) ? o : -1;
+            voa[i][1] = (v && cc + 8 < anch) ? o + 32 : -1;
         }
     };
-    auto mfma_frag = [&](const f32x4 (&fa)[MI][2], const f32x4 (&fb)[NI][2]) {
+    auto issue_a = [&](Frag &FL, int q) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int i = 0; i < MI; ++i) lda(FL.a[i][q], voa[i][q]);
+    };
+    auto issue_b = [&](Frag &FL, int q, int soff, int j0, int j1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int j = 0; j < NI; ++j)
+            if (j >= j0 && j < j1) ldb(FL.b[j][q], j, q, soff);
+    };
+    auto mfma_group = [&](const Frag &FC, int q, int e) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][e], fb[j][q][e], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FC.a[i][q][e], FC.b[j][q][e], acc[i][j], 0, 0, 0);
+    };
+    // one K step: multiply FC; if `issue`, load the next step (state s, ch, t already advanced) into FL meanwhile
+    auto step = [&](Frag &FL, Frag &FC, int ks_next, auto issue_t) {
+        constexpr bool ISSUE = decltype(issue_t)::value;
+        const int soff = ks_next * kstride_bytes;
+        if constexpr (ISSUE) next_offsets();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 0 || !ISSUE) {
+                if (q == 0) wait_half(FC, 0, std::integral_constant<int, LH>());
+                else wait_half(FC, 1, std::integral_constant<int, 0>());
+            } else {
+                wait_half(FC, 1, std::integral_constant<int, LH>());
+            }
+            mfma_group(FC, q, 0);
+            if constexpr (ISSUE) issue_a(FL, q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(FC, q, 1);
+            if constexpr (ISSUE) issue_b(FL, q, soff, 0, (NI + 1) / 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(FC, q, 2);
+            if constexpr (ISSUE) issue_b(FL, q, soff, (NI + 1) / 2, NI);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(FC, q, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     {
-        f32x4 fa0[MI][2], fb0[NI][2], fa1[MI][2], fb1[NI][2];
+        Frag F0, F1;
         const int nk = P.nk;
         int ks = 0;
-        load_frag(fa0, fb0, 0);
-        for (; ks + 2 < nk; ks += 2) {          // steady state: no conditionals around the loads
+        next_offsets();                               // K step 0
+        issue_a(F0, 0);
+        issue_b(F0, 0, 0, 0, NI);
+        issue_a(F0, 1);
+        issue_b(F0, 1, 0, 0, NI);
+        for (; ks + 2 < nk; ks += 2) {
             advance();
-            load_frag(fa1, fb1, ks + 1);
-            mfma_frag(fa0, fb0);
+            step(F1, F0, ks + 1, std::true_type());
             advance();
-            load_frag(fa0, fb0, ks + 2);
-            mfma_frag(fa1, fb1);
+            step(F0, F1, ks + 2, std::true_type());
         }
         if (ks + 2 == nk) {
             advance();
-            load_frag(fa1, fb1, ks + 1);
-            mfma_frag(fa0, fb0);
-            mfma_frag(fa1, fb1);
+            step(F1, F0, ks + 1, std::true_type());
+            step(F0, F1, 0, std::false_type());
         } else {
-            mfma_frag(fa0, fb0);
+            step(F1, F0, 0, std::false_type());
         }
     }
     }

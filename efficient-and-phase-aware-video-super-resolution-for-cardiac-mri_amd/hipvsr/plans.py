@@ -198,9 +198,11 @@ class NetPlans:
                 wk, bk = f'{d}_lstm_block.cell_list.{l}.conv.weight', f'{d}_lstm_block.cell_list.{l}.conv.bias'
                 ws = (4 * hd, cin, 3, 3)
                 second = hd if cfg.memory else cx
+                import os
+                ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 6 = 256x128
                 full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lstm_colmap(hd),
-                                tile=L.TILE_128x128_G, epilogue=L.EPI_LSTM)
-                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lstm_colmap(hd), tile=L.TILE_128x128_G,
+                                tile=ltile, epilogue=L.EPI_LSTM)
+                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lstm_colmap(hd), tile=ltile,
                                  epilogue=L.EPI_LSTM) if cfg.memory else full
                 dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True)
                 wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
