@@ -386,8 +386,53 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
 
     // ---- epilogue -----------------------------------------------------------------------------------------
     // accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if constexpr (EPI == RNH_EPI_LSTM) {
-        static_assert(EPI != RNH_EPI_LSTM || (WN == 1 && NI == 4), "LSTM epilogue wants the 4 gates in one wave");
+    if constexpr (EPI == RNH_EPI_LSTM && NI == 2) {
+        // 64-column gate groups: a wave's two column tiles are [i(16 ch) | f(16 ch)] and [o | g] of the same 16 hidden
+        // channels, so lane c (< 16) holds i, o and lane c + 16 holds f, g of channel c.  The halves swap what the
+        // other needs (lane c finishes accumulator registers 0-7, lane c + 16 registers 8-15), then each lane does
+        // the gate math of 8 pixels.
+        const int c16 = l31 & 15, hi = l31 >> 4;
+        const int hc = (n0 + wn * 64) / 4 + c16;
+        const int colA = n0 + wn * 64 + l31, colB = colA + 32;
+        const float bA = P.bias[colA], bB = P.bias[colB];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float gi[8], gf[8], go[8], gg[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float ownA_lo = acc[i][0][r] + bA, ownA_hi = acc[i][0][r + 8] + bA;
+                const float ownB_lo = acc[i][1][r] + bB, ownB_hi = acc[i][1][r + 8] + bB;
+                // lane c sends its registers 8-15 (i, o) and receives f, g of registers 0-7; lane c + 16 the reverse
+                const float gotA = __shfl_xor(hi ? ownA_lo : ownA_hi, 16, 64);
+                const float gotB = __shfl_xor(hi ? ownB_lo : ownB_hi, 16, 64);
+                gi[r] = hi ? gotA : ownA_lo;
+                gf[r] = hi ? ownA_hi : gotA;
+                go[r] = hi ? gotB : ownB_lo;
+                gg[r] = hi ? ownB_hi : gotB;
+            }
+            if (hc >= P.hd) continue;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = r + 8 * hi;                       // accumulator register this lane finishes
+                const int m = m0 + (wm * MI + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+                if (m >= Mtot) continue;
+                const float si = fast_sigmoid(gi[r]), sf = fast_sigmoid(gf[r]), so = fast_sigmoid(go[r]), tg = fast_tanh(gg[r]);
+                const long o = (long)m * P.hd + hc;
+                const float cp = P.c_prev ? P.c_prev[o] : 0.f;
+                const float cn = sf * cp + si * tg;
+                P.c_out[o] = cn;
+                P.h_out[o] = so * fast_tanh(cn);
+                if (P.gates_out) {
+                    float *gp = P.gates_out + (long)m * 4 * P.hd + hc;
+                    gp[0] = si;
+                    gp[P.hd] = sf;
+                    gp[2 * P.hd] = so;
+                    gp[3 * P.hd] = tg;
+                }
+            }
+        }
+    } else if constexpr (EPI == RNH_EPI_LSTM) {
+        static_assert(EPI != RNH_EPI_LSTM || (WN == 1 && NI == 4), "LSTM epilogue: 4x1 waves of 32x128, or 64-column tiles");
         const int hc = nt * 32 + l31;
         if (hc >= P.hd) return;
         const float bi = P.bias[n0 + l31], bf = P.bias[n0 + 32 + l31], bo = P.bias[n0 + 64 + l31],
@@ -481,7 +526,7 @@ int launch_tile(const rnh_conv_args_t &a, hipStream_t st) {
             hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_PS, DIRECT>), grid, block, 0, st, a, MT, NT);
             break;
         case RNH_EPI_LSTM:
-            if constexpr (WN == 1 && NI == 4) {
+            if constexpr ((WN == 1 && NI == 4) || NI == 2) {
                 hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MI, NI, RNH_EPI_LSTM, DIRECT>), grid, block, 0, st, a, MT, NT);
             } else {
                 RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: the LSTM epilogue needs RNH_TILE_128x128_G");
@@ -512,7 +557,10 @@ extern "C" int rnh_conv_igemm(const rnh_conv_args_t *args, void *stream) {
     if (nk != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: nk %d does not match the sources (%d)", a.nk, nk);
     if (a.epilogue == RNH_EPI_LSTM) {
         if (!a.h_out || !a.c_out || !a.bias || a.hd < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM epilogue args");
-        if (a.Npad != (a.hd + 31) / 32 * 128) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM Npad");
+        const int t_ = a.tile & ~RNH_TILE_DIRECT;
+        const bool g64 = t_ == RNH_TILE_128x128 || t_ == RNH_TILE_256x64;       // 64-column gate groups
+        if (!g64 && a.Npad != (a.hd + 31) / 32 * 128) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM Npad");
+        if (g64 && (a.Npad < (a.hd + 15) / 16 * 64)) RNH_FAIL(RNH_E_ARG, "rnh_conv_igemm: LSTM Npad (64-column groups)");
     } else {
         if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_RANGE, "rnh_conv_igemm: ndst %d", a.ndst);
         for (int i = 0; i < a.ndst; ++i)

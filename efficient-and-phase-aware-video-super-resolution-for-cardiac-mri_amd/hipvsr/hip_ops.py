@@ -32,6 +32,7 @@ class HipOps:
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
         self.direct = os.environ.get('RNH_DIRECT', '1') != '0'
+        self.direct_ps = os.environ.get('RNH_DIRECT_PS', '1') != '0'
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, *shape):
@@ -153,7 +154,7 @@ class HipOps:
         wp, bp = self._packed[id(plan)]
         a.nsrc, a.B, a.H, a.W, a.ntaps, a.nk = len(srcs), B, H, W, plan.ntaps, plan.nk
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
-        a.Npad, a.epilogue, a.tile = plan.Npad, plan.epilogue, plan.tile | (L.TILE_DIRECT if (self.direct and plan.epilogue != L.EPI_PS) else 0)
+        a.Npad, a.epilogue, a.tile = plan.Npad, plan.epilogue, plan.tile | (L.TILE_DIRECT if (self.direct and (plan.epilogue != L.EPI_PS or self.direct_ps)) else 0)
         if plan.epilogue == L.EPI_STORE:
             a.ndst = len(dsts)
             tot = 0

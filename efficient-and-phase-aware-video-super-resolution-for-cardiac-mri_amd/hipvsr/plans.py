@@ -171,6 +171,18 @@ def lstm_colmap(hd):
     return cm
 
 
+def lstm_colmap64(hd):
+    """64-column gate groups: column n = group*64 + tile*32 + half*16 + c  <->  gate (2*tile + half), channel group*16 + c."""
+    cm = []
+    for grp in range((hd + 15) // 16):
+        for tile in range(2):
+            for half in range(2):
+                for c in range(16):
+                    hc = grp * 16 + c
+                    cm.append((2 * tile + half) * hd + hc if hc < hd else -1)
+    return cm
+
+
 def ps_colmap(cq, r):
     """Column n = (i*r + j)*cq + c  <->  nn.PixelShuffle input channel c*r*r + i*r + j."""
     return [(n % cq) * r * r + n // cq for n in range(cq * r * r)]
@@ -199,10 +211,11 @@ class NetPlans:
                 ws = (4 * hd, cin, 3, 3)
                 second = hd if cfg.memory else cx
                 import os
-                ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 6 = 256x128
-                full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lstm_colmap(hd),
+                ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
+                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) else lstm_colmap(hd)
+                full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
                                 tile=ltile, epilogue=L.EPI_LSTM)
-                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lstm_colmap(hd), tile=ltile,
+                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
                                  epilogue=L.EPI_LSTM) if cfg.memory else full
                 dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True)
                 wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],

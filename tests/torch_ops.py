@@ -111,8 +111,12 @@ class TorchOps:
             t.copy_(v.permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, cq))
         else:
             hd = lstm['hd']
-            nt = (hd + 31) // 32
-            v = y.reshape(B, H, W, nt, 4, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, nt * 32)[..., :hd]
+            if plan.tile in (L.TILE_128x128, L.TILE_256x64):        # 64-column gate groups (plans.lstm_colmap64)
+                ng = (hd + 15) // 16
+                v = y[..., :ng * 64].reshape(B, H, W, ng, 4, 16).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, ng * 16)[..., :hd]
+            else:
+                nt = (hd + 31) // 32
+                v = y.reshape(B, H, W, nt, 4, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, nt * 32)[..., :hd]
             gi, gf, go = torch.sigmoid(v[..., 0, :]), torch.sigmoid(v[..., 1, :]), torch.sigmoid(v[..., 2, :])
             gg = torch.tanh(v[..., 3, :])
             cp = lstm.get('c_prev')
