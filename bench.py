@@ -189,7 +189,8 @@ def main():
                        'step_tflop': round(flop_step / 1e12, 2),
                        'step_tflops_per_gpu': round(flop_step / world / (dt / args.steps) / 1e12, 2),
                        'step_frac_of_f32_mfma_peak': round(flop_step / world / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                       'final_loss': round(float(loss.detach()), 6)},
+                       'final_loss': round(float(loss.detach()), 6),
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -219,6 +219,31 @@ def test_src_main_trains_from_yaml(tmp_path):
     assert '"Loss"' in log and '"PSNR"' in log
 
 
+@pytest.mark.parametrize('name,over,n,t,h,w', [
+    ('cfg4-like x2 T=5', dict(upscale_factor=2), 2, 5, 40, 24),
+    ('cfg5-like x4 phase code T=11', dict(), 1, 11, 48, 48),
+    ('x3', dict(upscale_factor=3, num_stages=2), 1, 2, 33, 20),
+])
+def test_other_baseline_configs_vs_oracle(name, over, n, t, h, w):
+    """BASELINE.json configs 4 and 5 (and x3) at full channel width and reduced spatial size, against the CPU oracle on
+    the same seeded inputs: all outputs, the loss and every parameter gradient."""
+    cfg = orc.exp1_x4_config(**over)
+    sd = orc.init_state_dict(cfg, seed=41)
+    inputs, targets, pos = orc.synthetic_batch(cfg, n, t, h, w, seed=42)
+    torch.set_num_threads(16)
+    ref_out, ref_loss, ref_grads = orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
+    net, _, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, torch.nn.L1Loss())
+    for go, gr in zip(outs, ref_out):
+        for a, b in zip(go, gr):
+            torch.testing.assert_close(a.detach().cpu(), b, atol=1e-4, rtol=1e-4)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    for k, p in net.named_parameters():
+        if ref_grads[k] is None:
+            assert p.grad is None
+        else:
+            _grad_close(p.grad, ref_grads[k], k)
+
+
 def test_rccl_allreduce_of_flat_gradient_single_rank(g1):
     """The collective of the data-parallel path on the real backend (nccl = RCCL), world size 1: the flat gradient
     buffer the engine writes is reduced in place and the parameter gradients (views of it) are unchanged."""
