@@ -20,7 +20,7 @@ def _ptr(t):
 class HipOps:
     name = 'hip'
 
-    def __init__(self, device):
+    def __init__(self, device, direct=None):
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.HipKernelError(f'the HIP backend needs a HIP device, got {device}')
@@ -31,7 +31,7 @@ class HipOps:
         self._side = []
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
-        self.direct = os.environ.get('RNH_DIRECT', '1') != '0'
+        self.direct = (os.environ.get('RNH_DIRECT', '1') != '0') if direct is None else bool(direct)
         self.direct_ps = os.environ.get('RNH_DIRECT_PS', '1') != '0'
 
     # ---- memory -------------------------------------------------------------------------------------

@@ -152,8 +152,10 @@ def test_cfg1_full_width_vs_reference_digest(golden_dir):
     assert abs(psnr - r['psnr']) < 0.01                                  # north_star: |delta PSNR| < 0.01 dB
 
 
-def test_kernels_vs_torch_semantics_on_ragged_shapes():
-    """Full-width channels (64) at 20x13 (no dimension a multiple of any tile), N=2, T=2: the HIP engine against the
+@pytest.mark.parametrize('direct', [True, False])
+def test_kernels_vs_torch_semantics_on_ragged_shapes(direct):
+    """Both variants of rnh_conv_igemm (DIRECT: fragments straight from global memory; LDS-staged).
+    Full-width channels (64) at 20x13 (no dimension a multiple of any tile), N=2, T=2: the HIP engine against the
     same engine over the torch double - every kernel, every epilogue, M tails, multi-tile grids."""
     from hipvsr.engine import RefineNetEngine
     from hipvsr.hip_ops import HipOps
@@ -166,7 +168,7 @@ def test_kernels_vs_torch_semantics_on_ragged_shapes():
     sd = orc.init_state_dict(orc.Config(**kw), seed=3)
     inputs, targets, pos = orc.synthetic_batch(orc.Config(**kw), n=2, t=2, h=20, w=13, seed=4)
     res = {}
-    for name, ops, d in (('hip', HipOps(dev), dev), ('ref', TorchOps('cpu'), torch.device('cpu'))):
+    for name, ops, d in (('hip', HipOps(dev, direct=direct), dev), ('ref', TorchOps('cpu'), torch.device('cpu'))):
         eng = RefineNetEngine(cfg, ops)
         params = {k: v.to(d) for k, v in sd.items()}
         O, ctx = eng.forward(params, [x.to(d) for x in inputs], pos.to(d), need_grad=True)
