@@ -155,7 +155,7 @@ class RefineNetEngine:
                 cur, h, wd = Y, h * r, wd * r
             ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=O_all[s].view(3 * TN, h, wd, cfg.out_channels))
             if need_grad:
-                st['Sb'], st['Ys'] = Sb, Ys
+                st['Sb'], st['Ys'] = Sb, Ys[:-1]          # the tail's output is not needed by the collapsed backward
                 ctx.stages.append(st)
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
@@ -207,11 +207,26 @@ class RefineNetEngine:
             # ---- upsampler backward (3 branches x T frames at once) -----------------------------------------
             sH, sW = dO_all.shape[3], dO_all.shape[4]
             dO = dO_all[s].view(3 * TN, sH, sW, cfg.out_channels)
-            a = acc(P.last_w)
+            # tail = last PixelShuffle conv + final conv: collapsed backward (csrc/uptail.hip) - the r*r*C-channel
+            # gradient between them is never formed
+            ut = P.up[-1]
+            rt = ut['r']
+            xin = Ys[len(P.up) - 2] if len(P.up) > 1 else Sb
+            h_in, w_in = xin.shape[1], xin.shape[2]
+            w2, b2, w3 = params[ut['wgrad'].wkey], params[ut['wgrad'].bkey], params[P.last_w]
+            G = ops.uptail_compose(w2, w3, rt)
+            D = ops.uptail_expand(dO, rt)
+            M = ops.empty(P.tail_m.Cout, C, 3, 3)
+            Sd = ops.empty(P.tail_m.Cout)
+            ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
+            a2 = acc(ut['wgrad'].wkey)
+            acc(ut['wgrad'].bkey)
+            a3 = acc(P.last_w)
             acc(P.last_b)
-            ops.outconv_wgrad(Ys[-1], dO, grads[P.last_w], grads[P.last_b], accumulate=a)
-            dcur = ops.outconv_dgrad(dO, params[P.last_w])
-            for ui in range(len(P.up) - 1, -1, -1):
+            ops.uptail_wcontract(M, Sd, w2, b2, w3, grads[ut['wgrad'].wkey], grads[ut['wgrad'].bkey], grads[P.last_w],
+                                 grads[P.last_b], rt, a2, a3)
+            dcur = ops.uptail_dgrad(dO, G, C, rt)
+            for ui in range(len(P.up) - 2, -1, -1):
                 u = P.up[ui]
                 r = u['r']
                 xin = Ys[ui - 1] if ui > 0 else Sb

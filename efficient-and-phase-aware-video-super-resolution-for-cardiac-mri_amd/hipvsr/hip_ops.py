@@ -273,6 +273,40 @@ class HipOps:
         L.check(self.lib.rnh_outconv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), B, H, W, Cin, Cout,
                                            int(accumulate), self._stream()), 'rnh_outconv_wgrad')
 
+    # ---- collapsed backward of the upsampler tail (csrc/uptail.hip) -----------------------------------------
+    def uptail_compose(self, w2, w3, r):
+        self._chk(w2, w3)
+        Co, Cq = w3.shape[0], w3.shape[1]
+        C1 = w2.shape[1]
+        G = self.empty(Co * 9 * (r + 2) * (r + 2) * C1)
+        L.check(self.lib.rnh_uptail_compose(_ptr(w2), _ptr(w3), _ptr(G), C1, Cq, r, Co, self._stream()), 'rnh_uptail_compose')
+        return G
+
+    def uptail_dgrad(self, d_o, G, C1, r):
+        self._chk(d_o, G)
+        B, Hh, Wh, Co = d_o.shape
+        if Hh % r or Wh % r:
+            raise L.HipKernelError('uptail_dgrad: output size not a multiple of r')
+        dy1 = self.empty(B, Hh // r, Wh // r, C1)
+        L.check(self.lib.rnh_uptail_dgrad(_ptr(d_o), _ptr(G), _ptr(dy1), B, Hh // r, Wh // r, C1, Co, r, self._stream()),
+                'rnh_uptail_dgrad')
+        return dy1
+
+    def uptail_expand(self, d_o, r):
+        self._chk(d_o)
+        B, Hh, Wh, Co = d_o.shape
+        Dc = (Co * (r + 2) * (r + 2) + 3) // 4 * 4
+        D = self.empty(B, Hh // r, Wh // r, Dc)
+        L.check(self.lib.rnh_uptail_expand(_ptr(d_o), _ptr(D), B, Hh // r, Wh // r, Co, r, Dc, self._stream()), 'rnh_uptail_expand')
+        return D
+
+    def uptail_wcontract(self, M, S, w2, b2, w3, dw2, db2, dw3, db3, r, acc2, acc3):
+        self._chk(M, S, w2, b2, w3, dw2, db2, dw3, db3)
+        Co, Cq = w3.shape[0], w3.shape[1]
+        L.check(self.lib.rnh_uptail_wcontract(_ptr(M), _ptr(S), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(dw2), _ptr(db2), _ptr(dw3),
+                                              _ptr(db3), w2.shape[1], Cq, r, Co, int(acc2), int(acc3), self._stream()),
+                'rnh_uptail_wcontract')
+
     def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
         self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev)
         hd = dh.shape[-1]

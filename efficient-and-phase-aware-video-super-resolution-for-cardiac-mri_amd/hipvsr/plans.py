@@ -271,6 +271,12 @@ class NetPlans:
             wgrad = WgradPlan(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
             self.up.append(dict(r=r, fwd=fwd, dgrad=dgrad, wgrad=wgrad))
         self.last_w, self.last_b = f'out_block.conv{len(rs) + 1}.weight', f'out_block.conv{len(rs) + 1}.bias'
+        # collapsed tail backward (csrc/uptail.hip): wgrad of the last PixelShuffle conv's input against the expanded
+        # output gradient D, whose (out_channels * (r+2)^2) columns replace the conv's r*r*C
+        rt, Co = rs[-1], cfg.out_channels
+        nd2 = Co * (rt + 2) * (rt + 2)
+        self.tail_dc = r4(nd2)
+        self.tail_m = WgradPlan('uptail.M', None, None, (nd2, C, 3, 3), [XSeg(C, C, 0)], [YSeg(self.tail_dc, nd2, 0)])
 
     def conv_plans(self):
         out = []

@@ -180,6 +180,24 @@ int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, float *db, flo
                       int Cout, int accumulate, void *stream);
 int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout);
 
+/* Backward of the upsampler's tail = [last conv + PixelShuffle(r)] -> [final conv C -> out_channels]
+ * (refine_net.py:199-205), collapsed algebraically because the tail is affine with out_channels (= 1) outputs
+ * (derivation in csrc/uptail.hip).  w2: OIHW (Cq*r*r, C1, 3, 3) weight of the last PixelShuffle conv, w3: OIHW
+ * (Co, Cq, 3, 3) weight of the final conv, d_o: gradient of the outputs, NHWC (B, r*Hm, r*Wm, Co); ND = r + 2.
+ *   rnh_uptail_compose : G[co][t2][delta][c1] (Co*9*ND*ND*C1 floats) from w2 and w3
+ *   rnh_uptail_dgrad   : dY1 (B, Hm, Wm, C1) = gradient w.r.t. the INPUT of the last PixelShuffle conv, from d_o and G
+ *   rnh_uptail_expand  : D (B, Hm, Wm, Dc), D[q][co*ND*ND + delta] = d_o[r*q + delta - 1][co] (0 outside; Dc >= Co*ND*ND,
+ *                        Dc % 4 == 0): the column operand of an rnh_conv_wgrad against the conv's input, which yields
+ *                        M (Co*ND*ND, C1, 3, 3) and, as its bias output, S = column sums of D
+ *   rnh_uptail_wcontract: dW2, db2, dW3, db3 (stored or accumulated) from M, S and the weights
+ * Replaces the aten::convolution_backward calls of those two convolutions and aten::pixel_unshuffle between them. */
+int rnh_uptail_compose(const float *w2, const float *w3, float *G, int C1, int Cq, int r, int Co, void *stream);
+int rnh_uptail_dgrad(const float *d_o, const float *G, float *dy1, int B, int Hm, int Wm, int C1, int Co, int r, void *stream);
+int rnh_uptail_expand(const float *d_o, float *D, int B, int Hm, int Wm, int Co, int r, int Dc, void *stream);
+int rnh_uptail_wcontract(const float *M, const float *S, const float *w2, const float *b2, const float *w3, float *dw2,
+                         float *db2, float *dw3, float *db3, int C1, int Cq, int r, int Co, int accumulate2,
+                         int accumulate3, void *stream);
+
 /* Backward of the ConvLSTM gate math (refine_net.py:258-265): from dh', dc' and the saved post-activation
  * gates, c_prev and c_next produce the pre-activation gate gradients [..][4*hd] (channel = gate*hd + ch,
  * order i,f,o,g) and dc_prev.  dc_next / c_prev may be 0 (zero).  n = B*H*W pixels. */

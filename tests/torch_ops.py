@@ -185,6 +185,51 @@ class TorchOps:
             dw.copy_(w_.grad)
             db.copy_(gb)
 
+    # ---- collapsed upsampler tail (semantics of csrc/uptail.hip, written independently with torch ops) ----------
+    def uptail_compose(self, w2, w3, r):
+        return dict(w2=w2, w3=w3, r=r)
+
+    def uptail_dgrad(self, d_o, G, C1, r):
+        dy2 = F.conv_transpose2d(d_o.permute(0, 3, 1, 2), G['w3'], padding=1)             # (B, Cq, rH, rW)
+        dz = F.pixel_unshuffle(dy2, r)                                                      # channel c*r*r + i*r + j
+        return F.conv_transpose2d(dz, G['w2'], padding=1).permute(0, 2, 3, 1).contiguous()
+
+    def uptail_expand(self, d_o, r):
+        B, Hh, Wh, Co = d_o.shape
+        nd = r + 2
+        dc = (Co * nd * nd + 3) // 4 * 4
+        pad = F.pad(d_o.permute(0, 3, 1, 2), (1, r, 1, r))                                  # index p + 1; zeros outside
+        D = torch.zeros(B, Hh // r, Wh // r, dc, device=self.device)
+        for co in range(Co):
+            for dyi in range(nd):
+                for dxi in range(nd):
+                    D[..., co * nd * nd + dyi * nd + dxi] = pad[:, co, dyi::r, dxi::r][:, :Hh // r, :Wh // r]
+        return D
+
+    def uptail_wcontract(self, M, S, w2, b2, w3, dw2, db2, dw3, db3, r, acc2, acc3):
+        Co, Cq = w3.shape[0], w3.shape[1]
+        C1, nd = w2.shape[1], r + 2
+        g2, gb2, g3, gb3 = torch.zeros_like(dw2), torch.zeros_like(db2), torch.zeros_like(dw3), torch.zeros_like(db3)
+        Mv = M.reshape(Co, nd, nd, C1, 3, 3)
+        Sv = S[:Co * nd * nd].reshape(Co, nd, nd)
+        w2v = w2.reshape(Cq, r, r, C1, 3, 3)
+        b2v = b2.reshape(Cq, r, r)
+        for i in range(r):
+            for j in range(r):
+                for ty in (-1, 0, 1):
+                    for tx in (-1, 0, 1):
+                        Md, Sd = Mv[:, i - ty + 1, j - tx + 1], Sv[:, i - ty + 1, j - tx + 1]     # (Co, C1, 3, 3), (Co,)
+                        w3t = w3[:, :, ty + 1, tx + 1]                                               # (Co, Cq)
+                        g2.view(Cq, r, r, C1, 3, 3)[:, i, j] += torch.einsum('oc,oxyz->cxyz', w3t, Md)
+                        gb2.view(Cq, r, r)[:, i, j] += torch.einsum('oc,o->c', w3t, Sd)
+                        g3[:, :, ty + 1, tx + 1] += torch.einsum('cxyz,oxyz->oc', w2v[:, i, j], Md) + Sd[:, None] * b2v[None, :, i, j]
+                gb3 += Sv[:, i + 1, j + 1]
+        for tgt, g, a in ((dw2, g2, acc2), (db2, gb2, acc2), (dw3, g3, acc3), (db3, gb3, acc3)):
+            if a:
+                tgt += g
+            else:
+                tgt.copy_(g)
+
     def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
         hd = dh.shape[-1]
         gi, gf, go, gg = (gates[..., k * hd:(k + 1) * hd] for k in range(4))
