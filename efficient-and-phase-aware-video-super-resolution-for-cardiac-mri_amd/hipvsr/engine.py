@@ -147,15 +147,25 @@ class RefineNetEngine:
             ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
             ops.add(Sb[2 * TN:], fc, R[(U - hw) * N:(U - hw + T) * N])
             cur, h, wd, Ys = Sb, H, W, []
-            for u in P.up:
+            fused_tail = ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)
+            for ui, u in enumerate(P.up):
                 r = u['r']
+                if fused_tail and ui == len(P.up) - 1:
+                    # last PixelShuffle conv + final conv as one composed 5x5 convolution (csrc/uptail.hip): the
+                    # r*r*C-channel tensor between them is never formed, neither here nor in the backward
+                    ops.uptail_fwd(cur, params[u['fwd'].wkey], params[u['fwd'].bkey], params[P.last_w], params[P.last_b], r,
+                                   O_all[s].view(3 * TN, h * r, wd * r, cfg.out_channels))
+                    cur = None
+                    break
                 Y = ops.empty(3 * TN, h * r, wd * r, C)
                 ops.conv(u['fwd'], [Src(cur)], 3 * TN, h, wd, ps=(Y, r))
                 Ys.append(Y)
                 cur, h, wd = Y, h * r, wd * r
-            ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=O_all[s].view(3 * TN, h, wd, cfg.out_channels))
+            if cur is not None:
+                ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=O_all[s].view(3 * TN, h, wd, cfg.out_channels))
+                Ys = Ys[:-1]                                  # the tail's output is not needed by the collapsed backward
             if need_grad:
-                st['Sb'], st['Ys'] = Sb, Ys[:-1]          # the tail's output is not needed by the collapsed backward
+                st['Sb'], st['Ys'] = Sb, Ys
                 ctx.stages.append(st)
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------

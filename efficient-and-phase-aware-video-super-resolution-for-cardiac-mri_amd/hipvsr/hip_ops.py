@@ -274,6 +274,21 @@ class HipOps:
                                            int(accumulate), self._stream()), 'rnh_outconv_wgrad')
 
     # ---- collapsed backward of the upsampler tail (csrc/uptail.hip) -----------------------------------------
+    def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
+        self._chk(y1, w2, b2, w3, b3, out)
+        B, Hm, Wm, C1 = y1.shape
+        Co, Cq = w3.shape[0], w3.shape[1]
+        if tuple(out.shape) != (B, Hm * r, Wm * r, Co) or tuple(w2.shape) != (Cq * r * r, C1, 3, 3):
+            raise L.HipKernelError('uptail_fwd: shapes')
+        ws = self._workspace('uptail_fwd', self.lib.rnh_uptail_fwd_ws_floats(C1, Cq, r, Co))
+        L.check(self.lib.rnh_uptail_fwd(_ptr(y1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(ws), B, Hm, Wm, C1, Cq, r, Co,
+                                        self._stream()), 'rnh_uptail_fwd')
+        return out
+
+    @staticmethod
+    def uptail_fwd_supported(r, Co):
+        return r in (2, 3) and Co == 1
+
     def uptail_compose(self, w2, w3, r):
         self._chk(w2, w3)
         Co, Cq = w3.shape[0], w3.shape[1]

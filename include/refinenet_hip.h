@@ -191,6 +191,13 @@ int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout);
  *                        M (Co*ND*ND, C1, 3, 3) and, as its bias output, S = column sums of D
  *   rnh_uptail_wcontract: dW2, db2, dW3, db3 (stored or accumulated) from M, S and the weights
  * Replaces the aten::convolution_backward calls of those two convolutions and aten::pixel_unshuffle between them. */
+/* Forward of the same tail: out (B, r*Hm, r*Wm, Co) = final_conv(PixelShuffle_r(conv(y1; w2, b2)); w3, b3) computed as one
+ * composed 5x5 convolution of y1 (B, Hm, Wm, C1) per output sub-position (the paths that leave the image are subtracted on its 1-pixel border);
+ * replaces refine_net.py:199-201 / :203-205 for the last PixelShuffle stage.  r in {2, 3}, Co == 1.
+ * ws: rnh_uptail_fwd_ws_floats(C1, Cq, r, Co) floats (the composed weights are rebuilt on every call). */
+int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                   float *ws, int B, int Hm, int Wm, int C1, int Cq, int r, int Co, void *stream);
+int64_t rnh_uptail_fwd_ws_floats(int C1, int Cq, int r, int Co);
 int rnh_uptail_compose(const float *w2, const float *w3, float *G, int C1, int Cq, int r, int Co, void *stream);
 int rnh_uptail_dgrad(const float *d_o, const float *G, float *dy1, int B, int Hm, int Wm, int C1, int Co, int r, void *stream);
 int rnh_uptail_expand(const float *d_o, float *D, int B, int Hm, int Wm, int Co, int r, int Dc, void *stream);

@@ -182,6 +182,29 @@ def test_kernels_vs_torch_semantics_on_ragged_shapes(direct):
             _grad_close(res['hip'][1][k], v, k)
 
 
+@pytest.mark.parametrize('r,B,Hm,Wm,C1,Cq', [(2, 2, 1, 1, 64, 64), (2, 1, 3, 2, 64, 64), (2, 2, 19, 37, 64, 64), (3, 1, 2, 5, 64, 64),
+                                             (3, 2, 17, 33, 64, 64), (2, 1, 40, 16, 32, 16), (3, 1, 16, 48, 16, 32)])
+def test_fused_tail_forward_vs_torch(r, B, Hm, Wm, C1, Cq):
+    """rnh_uptail_fwd (last PixelShuffle conv + final conv as one composed 5x5 convolution, exact path sums in the
+    border band) against conv2d -> pixel_shuffle -> conv2d, including images smaller than the band and tile tails."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(100 * r + Hm)
+    y1 = torch.randn(B, Hm, Wm, C1, generator=g)
+    w2 = torch.randn(Cq * r * r, C1, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(Cq * r * r, generator=g) * 0.1
+    w3 = torch.randn(1, Cq, 3, 3, generator=g) * 0.05
+    b3 = torch.randn(1, generator=g)
+    ref = F.conv2d(F.pixel_shuffle(F.conv2d(y1.permute(0, 3, 1, 2).double(), w2.double(), b2.double(), padding=1), r),
+                   w3.double(), b3.double(), padding=1).permute(0, 2, 3, 1)
+    out = torch.full((B, Hm * r, Wm * r, 1), float('nan'), device=dev)
+    ops.uptail_fwd(y1.to(dev), w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), r, out)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().double(), ref, atol=1e-4, rtol=1e-4)
+
+
 def test_linearity_and_batch_independence_at_bench_width():
     """Size-independent properties at the benchmark's channel width: (a) samples of a batch are independent
     (quirk Q8): sample 0 of a batch of 2 equals the batch-of-1 result bit for bit; (b) the upsampler is affine:

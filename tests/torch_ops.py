@@ -186,6 +186,15 @@ class TorchOps:
             db.copy_(gb)
 
     # ---- collapsed upsampler tail (semantics of csrc/uptail.hip, written independently with torch ops) ----------
+    def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
+        z = F.pixel_shuffle(F.conv2d(y1.permute(0, 3, 1, 2), w2, b2, padding=1), r)
+        out.copy_(F.conv2d(z, w3, b3, padding=1).permute(0, 2, 3, 1))
+        return out
+
+    @staticmethod
+    def uptail_fwd_supported(r, Co):
+        return r in (2, 3) and Co == 1
+
     def uptail_compose(self, w2, w3, r):
         return dict(w2=w2, w3=w3, r=r)
 

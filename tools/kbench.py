@@ -108,3 +108,8 @@ for name, fn in (('outconv.fwd', lambda: ops.outconv_fwd(yy, wl, bl, out=o)), ('
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
     print(f'{name:28s} {ms:9.3f} ms  {byt / ms / 1e9:7.2f} TB/s of the 64-channel HR tensor', flush=True)
+
+# collapsed tail forward (last PixelShuffle conv + final conv as one composed 5x5 convolution)
+if not flt or flt in 'uptail.fwd':
+    w2, b2 = params[u['fwd'].wkey], params[u['fwd'].bkey]
+    timeit('uptail.fwd', lambda: ops.uptail_fwd(y1, w2, b2, wl, bl, 2, o), 2.0 * B3 * 4 * H * W * 4 * 25 * 64, 3)
