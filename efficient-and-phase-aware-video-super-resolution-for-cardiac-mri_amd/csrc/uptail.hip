@@ -319,6 +319,253 @@ __global__ void __launch_bounds__(256) uptail_border_kernel(const float *y1, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Merged-offset form of the backward for out_channels == 1.  In dY1 and in M the pair (t2, delta) only enters
+// through the offset  off = delta - r*t2  in [-r-1, 2r]^2  (NOFF = 3r + 2 per axis) between the mid-resolution
+// pixel and the dO pixel it meets:
+//   dY1[q][c1]      = sum_off dO[r*q + off] * Kd[off][c1]            - (paths with q - t2 outside, border pixels only)
+//   M[dl][c1][t2]   = X[dl - r*t2][c1]                               - (terms with q' - t2 outside, border pixels only)
+//   X[off][c1]      = sum_q' Y1[q'][c1] * dO[r*q' + off],   S[dl] = SX[dl] = sum_q' dO[r*q' + dl]
+// 64 (r = 2) / 121 (r = 3) offsets instead of 9*ND*ND = 144 / 225 (t2, delta) pairs, and Y1 is read once, unshifted.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void uptail_compose_kd_kernel(const float *G, float *Kd, int C1, int r) {
+    const int ND = r + 2, NOFF = 3 * r + 2;
+    const int total = NOFF * NOFF * C1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int c1 = e % C1, off = e / C1;
+        const int offy = off / NOFF - (r + 1), offx = off % NOFF - (r + 1);
+        float s = 0.f;
+        for (int ty = -1; ty <= 1; ++ty) {
+            const int ddy = offy + r * ty;
+            if (ddy < -1 || ddy > r) continue;
+            for (int tx = -1; tx <= 1; ++tx) {
+                const int ddx = offx + r * tx;
+                if (ddx < -1 || ddx > r) continue;
+                s += G[((long)((ty + 1) * 3 + tx + 1) * ND * ND + (ddy + 1) * ND + ddx + 1) * C1 + c1];
+            }
+        }
+        Kd[e] = s;
+    }
+}
+
+// the k-th candidate of the 1-pixel border of an Hm x Wm image (rows first, then the columns without their ends)
+__device__ __forceinline__ bool border_pixel(int k, int Hm, int Wm, int &y, int &x) {
+    if (k < Wm) { y = 0; x = k; return true; }
+    k -= Wm;
+    if (k < Wm) { y = Hm - 1; x = k; return Hm > 1; }
+    k -= Wm;
+    if (k < Hm) { y = k; x = 0; return k > 0 && k < Hm - 1; }
+    k -= Hm;
+    y = k; x = Wm - 1;
+    return k > 0 && k < Hm - 1 && Wm > 1;
+}
+
+constexpr int DT = 16;            // 16x16 mid-resolution pixels per block, one pixel x CCH channels per thread
+
+// dO patch of the tile in LDS; Kd is wave-uniform (scalar loads), so the inner loop is 1 LDS read + CCH FMAs
+template <int CCH>
+__global__ void __launch_bounds__(256) uptail_dgrad_tile_kernel(const float *__restrict__ dO, const float *__restrict__ Kd,
+                                                                float *__restrict__ dY1, int Hm, int Wm, int C1, int r, int TX, int TY) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    const int NOFF = 3 * r + 2, PW = DT * r + 2 * r + 2;
+    const int tb = blockIdx.x;
+    const int b = tb / (TX * TY), trem = tb - b * TX * TY, tyb = trem / TX, txb = trem - tyb * TX;
+    const int y0 = tyb * DT, x0 = txb * DT, c0 = blockIdx.y * CCH;
+    const int Hh = Hm * r, Wh = Wm * r, hy0 = r * y0 - (r + 1), hx0 = r * x0 - (r + 1);
+    for (int e = threadIdx.x; e < PW * PW; e += 256) {
+        const int py = hy0 + e / PW, px = hx0 + e % PW;
+        patch[e] = ((unsigned)py < (unsigned)Hh && (unsigned)px < (unsigned)Wh) ? dO[((long)b * Hh + py) * Wh + px] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / DT, lx = threadIdx.x % DT, qy = y0 + ly, qx = x0 + lx;
+    float acc[CCH];
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
+    const float *pp = patch + (r * ly) * PW + r * lx;
+    const float *kp = Kd + c0;
+    for (int oy = 0; oy < NOFF; ++oy)
+        for (int ox = 0; ox < NOFF; ++ox) {
+            const float d = pp[oy * PW + ox];
+            const float *k = kp + (long)(oy * NOFF + ox) * C1;
+#pragma unroll
+            for (int c = 0; c < CCH; ++c) acc[c] = fmaf(d, k[c], acc[c]);
+        }
+    if (qy >= Hm || qx >= Wm) return;
+    float *o = dY1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c0;
+#pragma unroll
+    for (int c = 0; c < CCH; c += 4) rnh_st4(o + c, make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]));
+}
+
+// one wave per border pixel q: subtract the (t2, delta) paths whose q - t2 lies outside the image
+__global__ void __launch_bounds__(256) uptail_dgrad_border_kernel(const float *dO, const float *G, float *dY1, int B, int Hm, int Wm,
+                                                                  int C1, int r) {
+    const int ND = r + 2, Hh = Hm * r, Wh = Wm * r, nper = 2 * (Hm + Wm);
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)B * nper) return;
+    const int b = (int)(item / nper);
+    int qy, qx;
+    if (!border_pixel((int)(item - (long)b * nper), Hm, Wm, qy, qx)) return;
+    for (int c1 = lane; c1 < C1; c1 += 64) {
+        float s = 0.f;
+        for (int t2 = 0; t2 < 9; ++t2) {
+            const int sy = qy - (t2 / 3 - 1), sx = qx - (t2 % 3 - 1);
+            if ((unsigned)sy < (unsigned)Hm && (unsigned)sx < (unsigned)Wm) continue;       // this path exists
+            for (int dl = 0; dl < ND * ND; ++dl) {
+                const int py = sy * r + dl / ND - 1, px = sx * r + dl % ND - 1;
+                if ((unsigned)py >= (unsigned)Hh || (unsigned)px >= (unsigned)Wh) continue;
+                s += dO[((long)b * Hh + py) * Wh + px] * G[((long)t2 * ND * ND + dl) * C1 + c1];
+            }
+        }
+        dY1[(((long)b * Hm + qy) * Wm + qx) * C1 + c1] -= s;
+    }
+}
+
+// X and SX on the matrix cores: rows = 64 channels of Y1 (two 32-row tiles, row i of tile e = channel 2i + e, one
+// 8-byte load per lane), columns = offsets (NT 32-column tiles), contraction over pixels, two per v_mfma_f32_32x32x2.
+// A block walks 8x32-pixel tiles (persistent, grid-strided), each wave two rows of the tile; the dO patch of the tile is
+// in LDS and the column operand is gathered from it.  Partial sums per block go to a slab (deterministic reduction in
+// uptail_mfinish_kernel).
+constexpr int XTY = 8, XTX = 32;
+
+template <int R>
+__global__ void __launch_bounds__(256) uptail_xcorr_kernel(const float *__restrict__ y1, const float *__restrict__ dO,
+                                                           float *__restrict__ Xs, int B, int Hm, int Wm, int C1, int TX, int TY) {
+    constexpr int NOFF = 3 * R + 2, NO2 = NOFF * NOFF, NT = (NO2 + 31) / 32, PW = XTX * R + 2 * R + 2, PH = XTY * R + 2 * R + 2;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = threadIdx.x >> 6;
+    const int cg = blockIdx.y, Hh = Hm * R, Wh = Wm * R;
+    f32x16 acc[2][NT];
+    float sb[NT], bm[NT];
+    int boff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int off = 32 * j + l31;
+        const bool ok = off < NO2;
+        boff[j] = ok ? (off / NOFF) * PW + off % NOFF : 0;
+        bm[j] = ok ? 1.f : 0.f;
+        sb[j] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc[0][j][v] = 0.f; acc[1][j][v] = 0.f; }
+    }
+    const int ntiles = B * TX * TY;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / (TX * TY), trem = t - b * TX * TY, tyb = trem / TX, txb = trem - tyb * TX;
+        const int y0 = tyb * XTY, x0 = txb * XTX, hy0 = R * y0 - (R + 1), hx0 = R * x0 - (R + 1);
+        __syncthreads();
+        for (int e = threadIdx.x; e < PH * PW; e += 256) {
+            const int py = hy0 + e / PW, px = hx0 + e % PW;
+            sm[e] = ((unsigned)py < (unsigned)Hh && (unsigned)px < (unsigned)Wh) ? dO[((long)b * Hh + py) * Wh + px] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int ly = 2 * wave + rr, qy = y0 + ly;
+            if (qy >= Hm) break;
+            const float *yrow = y1 + (((long)b * Hm + qy) * Wm) * C1 + cg * 64 + 2 * l31;
+            const float *prow = sm + (R * ly) * PW;
+#pragma unroll 4
+            for (int s = 0; s < XTX / 2; ++s) {
+                const int lx = 2 * s + kh, qx = x0 + lx;
+                const bool pv = qx < Wm;
+                float2 a = make_float2(0.f, 0.f);
+                if (pv) a = *reinterpret_cast<const float2 *>(yrow + (long)qx * C1);
+                float bv[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bv[j] = pv ? prow[R * lx + boff[j]] * bm[j] : 0.f;
+                    sb[j] += bv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[j], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[j], acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // cross-wave sum in LDS ([offset][64 channels], then SX[offset]); the block's partial goes to its slab
+    float *red = sm, *sred = sm + NT * 32 * 64;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int i = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                        float *p = red + (32 * j + l31) * 64 + 2 * i + e;
+                        *p = (w == 0 ? 0.f : *p) + acc[e][j][v];
+                    }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float v = sb[j] + __shfl_xor(sb[j], 32, 64);
+                if (kh == 0) sred[32 * j + l31] = (w == 0 ? 0.f : sred[32 * j + l31]) + v;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int SLAB = NT * 32 * 64 + NT * 32;
+    float *slab = Xs + ((long)blockIdx.x * gridDim.y + cg) * SLAB;
+    for (int e = threadIdx.x; e < SLAB; e += 256) slab[e] = sm[e];
+}
+
+// Cs[chunk][t2][dl][c1] = sum over the chunk's border pixels q' with q' - t2 outside of Y1[q'][c1] * dO[r*(q' - t2) + delta]
+__global__ void __launch_bounds__(256) uptail_mborder_kernel(const float *y1, const float *dO, float *Cs, int B, int Hm, int Wm, int C1,
+                                                             int r, int ipc) {
+    const int ND = r + 2, Hh = Hm * r, Wh = Wm * r, nper = 2 * (Hm + Wm), C4 = C1 >> 2;
+    const int chunk = blockIdx.x, t2 = blockIdx.y, o = blockIdx.z * 256 + threadIdx.x;
+    if (o >= ND * ND * C4) return;
+    const int c4 = o % C4, dl = o / C4, ty = t2 / 3 - 1, tx = t2 % 3 - 1, ddy = dl / ND - 1, ddx = dl % ND - 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int b1 = min(B, (chunk + 1) * ipc);
+    if (t2 != 4)
+        for (int b = chunk * ipc; b < b1; ++b)
+            for (int k = 0; k < nper; ++k) {
+                int qy, qx;
+                if (!border_pixel(k, Hm, Wm, qy, qx)) continue;
+                const int sy = qy - ty, sx = qx - tx;
+                if ((unsigned)sy < (unsigned)Hm && (unsigned)sx < (unsigned)Wm) continue;   // counted by M as well
+                const int py = sy * r + ddy, px = sx * r + ddx;
+                if ((unsigned)py >= (unsigned)Hh || (unsigned)px >= (unsigned)Wh) continue;
+                const float d = dO[((long)b * Hh + py) * Wh + px];
+                const float4 a = rnh_ld4(y1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c4 * 4);
+                acc.x += d * a.x; acc.y += d * a.y; acc.z += d * a.z; acc.w += d * a.w;
+            }
+    rnh_st4(Cs + (((long)chunk * 9 + t2) * ND * ND + dl) * C1 + c4 * 4, acc);
+}
+
+// M[dl][c1][t2] = sum_blocks X[dl - r*t2][c1] - sum_chunks Cs[t2][dl][c1];  S[dl] = sum_blocks SX[dl]   (fixed order)
+__global__ void uptail_mfinish_kernel(const float *Xs, const float *Cs, float *M, float *S, int nblk, int ncg, int nchunk, int C1, int r,
+                                      int NT) {
+    const int ND = r + 2, NOFF = 3 * r + 2, nm = ND * ND * 9 * C1;
+    const long slabsz = (long)NT * 32 * 64 + NT * 32;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nm + ND * ND; e += gridDim.x * blockDim.x) {
+        if (e < nm) {
+            const int c1 = e % C1, t2 = (e / C1) % 9, dl = e / (9 * C1);
+            const int offy = dl / ND - 1 - r * (t2 / 3 - 1) + r + 1, offx = dl % ND - 1 - r * (t2 % 3 - 1) + r + 1;
+            const float *xp = Xs + (long)(c1 >> 6) * slabsz + (long)(offy * NOFF + offx) * 64 + (c1 & 63);
+            float s = 0.f;
+            for (int k = 0; k < nblk; ++k) s += xp[(long)k * ncg * slabsz];
+            if (t2 != 4) {
+                const float *cp = Cs + ((long)t2 * ND * ND + dl) * C1 + c1;
+                float c = 0.f;
+                for (int k = 0; k < nchunk; ++k) c += cp[(long)k * 9 * ND * ND * C1];
+                s -= c;
+            }
+            M[((long)dl * C1 + c1) * 9 + t2] = s;
+        } else {
+            const int dl = e - nm;
+            const float *xp = Xs + (long)NT * 32 * 64 + (dl / ND + r) * NOFF + dl % ND + r;
+            float s = 0.f;
+            for (int k = 0; k < nblk; ++k) s += xp[(long)k * ncg * slabsz];
+            S[dl] = s;
+        }
+    }
+}
+
 inline int grid_for(long n, int cap = 8192) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -326,11 +573,20 @@ inline int grid_for(long n, int cap = 8192) {
 
 }  // namespace
 
+extern "C" int64_t rnh_uptail_g_floats(int C1, int r, int Co) {
+    return (int64_t)Co * 9 * (r + 2) * (r + 2) * C1 + (Co == 1 ? (int64_t)(3 * r + 2) * (3 * r + 2) * C1 : 0);
+}
+
 extern "C" int rnh_uptail_compose(const float *w2, const float *w3, float *G, int C1, int Cq, int r, int Co, void *stream) {
     if (!w2 || !w3 || !G || C1 < 1 || Cq < 1 || r < 2 || r > 4 || Co < 1) RNH_FAIL(RNH_E_ARG, "rnh_uptail_compose: bad arguments");
-    hipLaunchKernelGGL(uptail_compose_kernel, dim3(grid_for((long)Co * 9 * (r + 2) * (r + 2) * C1)), dim3(256), 0, (hipStream_t)stream, w2,
-                       w3, G, C1, Cq, r, Co);
+    const long ng = (long)Co * 9 * (r + 2) * (r + 2) * C1;
+    hipLaunchKernelGGL(uptail_compose_kernel, dim3(grid_for(ng)), dim3(256), 0, (hipStream_t)stream, w2, w3, G, C1, Cq, r, Co);
     RNH_CHECK_LAUNCH("rnh_uptail_compose");
+    if (Co == 1) {                                       // merged-offset kernel Kd behind G
+        hipLaunchKernelGGL(uptail_compose_kd_kernel, dim3(grid_for((long)(3 * r + 2) * (3 * r + 2) * C1)), dim3(256), 0, (hipStream_t)stream,
+                           G, G + ng, C1, r);
+        RNH_CHECK_LAUNCH("rnh_uptail_compose(Kd)");
+    }
     return 0;
 }
 
@@ -369,6 +625,23 @@ extern "C" int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2,
 extern "C" int rnh_uptail_dgrad(const float *d_o, const float *G, float *dy1, int B, int Hm, int Wm, int C1, int Co, int r, void *stream) {
     if (!d_o || !G || !dy1 || B < 1 || Hm < 1 || Wm < 1 || Co < 1 || r < 2 || r > 4) RNH_FAIL(RNH_E_ARG, "rnh_uptail_dgrad: bad arguments");
     if (C1 & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_uptail_dgrad: C1 must be a multiple of 4");
+    if (Co == 1 && (C1 & 15) == 0) {                     // merged-offset tile kernel + border correction
+        const int TX = (Wm + DT - 1) / DT, TY = (Hm + DT - 1) / DT, PW = DT * r + 2 * r + 2;
+        const float *Kd = G + (long)9 * (r + 2) * (r + 2) * C1;
+        const size_t shp = (size_t)PW * PW * sizeof(float);
+        hipStream_t st = (hipStream_t)stream;
+        if ((C1 & 63) == 0)
+            hipLaunchKernelGGL((uptail_dgrad_tile_kernel<64>), dim3((unsigned)(B * TX * TY), C1 / 64), dim3(256), shp, st, d_o, Kd, dy1, Hm, Wm,
+                               C1, r, TX, TY);
+        else
+            hipLaunchKernelGGL((uptail_dgrad_tile_kernel<16>), dim3((unsigned)(B * TX * TY), C1 / 16), dim3(256), shp, st, d_o, Kd, dy1, Hm, Wm,
+                               C1, r, TX, TY);
+        RNH_CHECK_LAUNCH("rnh_uptail_dgrad(tile)");
+        const long nb = (long)B * 2 * (Hm + Wm);
+        hipLaunchKernelGGL(uptail_dgrad_border_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, d_o, G, dy1, B, Hm, Wm, C1, r);
+        RNH_CHECK_LAUNCH("rnh_uptail_dgrad(border)");
+        return 0;
+    }
     const size_t shm = (size_t)Co * 9 * (r + 2) * (r + 2) * C1 * sizeof(float);
     if (shm > 64 * 1024) RNH_FAIL(RNH_E_RANGE, "rnh_uptail_dgrad: composed weights (%zu bytes) do not fit in LDS", shm);
     hipLaunchKernelGGL(uptail_dgrad_kernel, dim3(grid_for((long)B * Hm * Wm * (C1 / 4), 4096)), dim3(256), shm, (hipStream_t)stream, d_o, G,
@@ -395,5 +668,47 @@ extern "C" int rnh_uptail_wcontract(const float *M, const float *S, const float 
     hipLaunchKernelGGL(uptail_wcontract_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, M, S, w2, b2, w3, dw2, db2, dw3, db3,
                        C1, Cq, r, Co, accumulate2, accumulate3);
     RNH_CHECK_LAUNCH("rnh_uptail_wcontract");
+    return 0;
+}
+
+extern "C" int rnh_uptail_xcorr_supported(int C1, int r, int Co) { return Co == 1 && (r == 2 || r == 3) && C1 > 0 && (C1 & 63) == 0; }
+
+static void xcorr_shape(int B, int Hm, int Wm, int r, int *TX, int *TY, int *nblk, int *nchunk, int *NT) {
+    *TX = (Wm + XTX - 1) / XTX;
+    *TY = (Hm + XTY - 1) / XTY;
+    const long nt = (long)B * *TX * *TY;
+    *nblk = (int)(nt < 512 ? nt : 512);
+    *nchunk = B < 256 ? B : 256;
+    *NT = ((3 * r + 2) * (3 * r + 2) + 31) / 32;
+}
+
+extern "C" int64_t rnh_uptail_xcorr_ws_floats(int B, int Hm, int Wm, int C1, int r) {
+    int TX, TY, nblk, nchunk, NT;
+    xcorr_shape(B, Hm, Wm, r, &TX, &TY, &nblk, &nchunk, &NT);
+    return (int64_t)nblk * (C1 / 64) * (NT * 32 * 64 + NT * 32) + (int64_t)nchunk * 9 * (r + 2) * (r + 2) * C1 + 64;
+}
+
+extern "C" int rnh_uptail_xcorr(const float *y1, const float *d_o, float *M, float *S, float *ws, int B, int Hm, int Wm, int C1, int r,
+                                void *stream) {
+    if (!y1 || !d_o || !M || !S || !ws || B < 1 || Hm < 1 || Wm < 1) RNH_FAIL(RNH_E_ARG, "rnh_uptail_xcorr: bad arguments");
+    if (!rnh_uptail_xcorr_supported(C1, r, 1)) RNH_FAIL(RNH_E_RANGE, "rnh_uptail_xcorr: built for r in {2, 3} and C1 a multiple of 64");
+    int TX, TY, nblk, nchunk, NT;
+    xcorr_shape(B, Hm, Wm, r, &TX, &TY, &nblk, &nchunk, &NT);
+    const int ncg = C1 / 64, ND = r + 2, ipc = (B + nchunk - 1) / nchunk;
+    nchunk = (B + ipc - 1) / ipc;
+    float *Xs = ws, *Cs = ws + (long)nblk * ncg * (NT * 32 * 64 + NT * 32);
+    hipStream_t st = (hipStream_t)stream;
+    const int PW = XTX * r + 2 * r + 2, PH = XTY * r + 2 * r + 2;
+    const size_t need = (size_t)NT * 32 * 65, patch = (size_t)PH * PW;
+    const size_t shm = (need > patch ? need : patch) * sizeof(float);
+    if (r == 2) hipLaunchKernelGGL((uptail_xcorr_kernel<2>), dim3(nblk, ncg), dim3(256), shm, st, y1, d_o, Xs, B, Hm, Wm, C1, TX, TY);
+    else hipLaunchKernelGGL((uptail_xcorr_kernel<3>), dim3(nblk, ncg), dim3(256), shm, st, y1, d_o, Xs, B, Hm, Wm, C1, TX, TY);
+    RNH_CHECK_LAUNCH("rnh_uptail_xcorr");
+    hipLaunchKernelGGL(uptail_mborder_kernel, dim3(nchunk, 9, (ND * ND * (C1 / 4) + 255) / 256), dim3(256), 0, st, y1, d_o, Cs, B, Hm, Wm, C1,
+                       r, ipc);
+    RNH_CHECK_LAUNCH("rnh_uptail_xcorr(border)");
+    hipLaunchKernelGGL(uptail_mfinish_kernel, dim3(grid_for((long)ND * ND * 9 * C1 + ND * ND)), dim3(256), 0, st, Xs, Cs, M, S, nblk, ncg,
+                       nchunk, C1, r, NT);
+    RNH_CHECK_LAUNCH("rnh_uptail_xcorr(finish)");
     return 0;
 }

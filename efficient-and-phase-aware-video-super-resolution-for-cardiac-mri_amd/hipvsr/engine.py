@@ -225,10 +225,13 @@ class RefineNetEngine:
             h_in, w_in = xin.shape[1], xin.shape[2]
             w2, b2, w3 = params[ut['wgrad'].wkey], params[ut['wgrad'].bkey], params[P.last_w]
             G = ops.uptail_compose(w2, w3, rt)
-            D = ops.uptail_expand(dO, rt)
-            M = ops.empty(P.tail_m.Cout, C, 3, 3)
-            Sd = ops.empty(P.tail_m.Cout)
-            ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
+            if ops.uptail_xcorr_supported(C, rt, cfg.out_channels):
+                M, Sd = ops.uptail_xcorr(xin, dO, rt)
+            else:
+                D = ops.uptail_expand(dO, rt)
+                M = ops.empty(P.tail_m.Cout, C, 3, 3)
+                Sd = ops.empty(P.tail_m.Cout)
+                ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
             a2 = acc(ut['wgrad'].wkey)
             acc(ut['wgrad'].bkey)
             a3 = acc(P.last_w)

@@ -293,7 +293,7 @@ class HipOps:
         self._chk(w2, w3)
         Co, Cq = w3.shape[0], w3.shape[1]
         C1 = w2.shape[1]
-        G = self.empty(Co * 9 * (r + 2) * (r + 2) * C1)
+        G = self.empty(self.lib.rnh_uptail_g_floats(C1, r, Co))
         L.check(self.lib.rnh_uptail_compose(_ptr(w2), _ptr(w3), _ptr(G), C1, Cq, r, Co, self._stream()), 'rnh_uptail_compose')
         return G
 
@@ -306,6 +306,22 @@ class HipOps:
         L.check(self.lib.rnh_uptail_dgrad(_ptr(d_o), _ptr(G), _ptr(dy1), B, Hh // r, Wh // r, C1, Co, r, self._stream()),
                 'rnh_uptail_dgrad')
         return dy1
+
+    def uptail_xcorr_supported(self, C1, r, Co):
+        return bool(self.lib.rnh_uptail_xcorr_supported(C1, r, Co))
+
+    def uptail_xcorr(self, y1, d_o, r):
+        """M (ND*ND, C1, 3, 3) and S (ND*ND) of the collapsed tail straight from the conv input and d_o (Co == 1)."""
+        self._chk(y1, d_o)
+        B, Hm, Wm, C1 = y1.shape
+        if tuple(d_o.shape) != (B, Hm * r, Wm * r, 1):
+            raise L.HipKernelError('uptail_xcorr: shapes')
+        nd2 = (r + 2) * (r + 2)
+        M, S = self.empty(nd2, C1, 3, 3), self.empty(nd2)
+        ws = self._workspace('uptail_xcorr', self.lib.rnh_uptail_xcorr_ws_floats(B, Hm, Wm, C1, r))
+        L.check(self.lib.rnh_uptail_xcorr(_ptr(y1), _ptr(d_o), _ptr(M), _ptr(S), _ptr(ws), B, Hm, Wm, C1, r, self._stream()),
+                'rnh_uptail_xcorr')
+        return M, S
 
     def uptail_expand(self, d_o, r):
         self._chk(d_o)

@@ -23,7 +23,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_inconv_prelu_bwd', 'rnh_inconv_bwd_ws_floats', 'rnh_outconv_fwd', 'rnh_outconv_dgrad',
            'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_ew_add',
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
-           'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats']
+           'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
+           'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr']
 
 
 class HipKernelError(RuntimeError):
@@ -96,6 +97,12 @@ def load():
     lib.rnh_uptail_fwd_ws_floats.argtypes = [i32, i32, i32, i32]
     lib.rnh_uptail_fwd_ws_floats.restype = i64
     lib.rnh_uptail_compose.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.rnh_uptail_g_floats.argtypes = [i32, i32, i32]
+    lib.rnh_uptail_g_floats.restype = i64
+    lib.rnh_uptail_xcorr_supported.argtypes = [i32, i32, i32]
+    lib.rnh_uptail_xcorr_ws_floats.argtypes = [i32, i32, i32, i32, i32]
+    lib.rnh_uptail_xcorr_ws_floats.restype = i64
+    lib.rnh_uptail_xcorr.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_dgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_wcontract.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]

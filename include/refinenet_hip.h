@@ -184,11 +184,16 @@ int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout);
  * (refine_net.py:199-205), collapsed algebraically because the tail is affine with out_channels (= 1) outputs
  * (derivation in csrc/uptail.hip).  w2: OIHW (Cq*r*r, C1, 3, 3) weight of the last PixelShuffle conv, w3: OIHW
  * (Co, Cq, 3, 3) weight of the final conv, d_o: gradient of the outputs, NHWC (B, r*Hm, r*Wm, Co); ND = r + 2.
- *   rnh_uptail_compose : G[co][t2][delta][c1] (Co*9*ND*ND*C1 floats) from w2 and w3
+ *   rnh_uptail_compose : G[co][t2][delta][c1] (Co*9*ND*ND*C1 floats) from w2 and w3 and, for Co == 1, behind it the
+ *                        merged-offset kernel Kd[(3r+2)^2][C1]; G holds rnh_uptail_g_floats(C1, r, Co) floats
  *   rnh_uptail_dgrad   : dY1 (B, Hm, Wm, C1) = gradient w.r.t. the INPUT of the last PixelShuffle conv, from d_o and G
  *   rnh_uptail_expand  : D (B, Hm, Wm, Dc), D[q][co*ND*ND + delta] = d_o[r*q + delta - 1][co] (0 outside; Dc >= Co*ND*ND,
  *                        Dc % 4 == 0): the column operand of an rnh_conv_wgrad against the conv's input, which yields
  *                        M (Co*ND*ND, C1, 3, 3) and, as its bias output, S = column sums of D
+ *   rnh_uptail_xcorr   : M and S directly from the conv's input y1 (B, Hm, Wm, C1) and d_o, without D: a 64-channel x
+ *                        (3r+2)^2-offset cross-correlation on the matrix cores + a border term.  Only where
+ *                        rnh_uptail_xcorr_supported(C1, r, Co) (Co == 1, r in {2, 3}, C1 % 64 == 0); ws:
+ *                        rnh_uptail_xcorr_ws_floats(B, Hm, Wm, C1, r) floats
  *   rnh_uptail_wcontract: dW2, db2, dW3, db3 (stored or accumulated) from M, S and the weights
  * Replaces the aten::convolution_backward calls of those two convolutions and aten::pixel_unshuffle between them. */
 /* Forward of the same tail: out (B, r*Hm, r*Wm, Co) = final_conv(PixelShuffle_r(conv(y1; w2, b2)); w3, b3) computed as one
@@ -199,6 +204,11 @@ int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2, const floa
                    float *ws, int B, int Hm, int Wm, int C1, int Cq, int r, int Co, void *stream);
 int64_t rnh_uptail_fwd_ws_floats(int C1, int Cq, int r, int Co);
 int rnh_uptail_compose(const float *w2, const float *w3, float *G, int C1, int Cq, int r, int Co, void *stream);
+int64_t rnh_uptail_g_floats(int C1, int r, int Co);
+int rnh_uptail_xcorr_supported(int C1, int r, int Co);
+int64_t rnh_uptail_xcorr_ws_floats(int B, int Hm, int Wm, int C1, int r);
+int rnh_uptail_xcorr(const float *y1, const float *d_o, float *M, float *S, float *ws, int B, int Hm, int Wm, int C1, int r,
+                     void *stream);
 int rnh_uptail_dgrad(const float *d_o, const float *G, float *dy1, int B, int Hm, int Wm, int C1, int Co, int r, void *stream);
 int rnh_uptail_expand(const float *d_o, float *D, int B, int Hm, int Wm, int Co, int r, int Dc, void *stream);
 int rnh_uptail_wcontract(const float *M, const float *S, const float *w2, const float *b2, const float *w3, float *dw2,

@@ -205,6 +205,35 @@ def test_fused_tail_forward_vs_torch(r, B, Hm, Wm, C1, Cq):
     torch.testing.assert_close(out.cpu().double(), ref, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('r,B,Hm,Wm,C1', [(2, 2, 1, 1, 64), (2, 1, 1, 7, 64), (2, 1, 5, 1, 16), (2, 3, 19, 37, 64), (3, 2, 17, 35, 64),
+                                          (2, 1, 33, 16, 128), (3, 1, 9, 40, 32), (4, 1, 6, 9, 16), (2, 2, 8, 6, 8)])
+def test_collapsed_tail_backward_kernels_vs_torch(r, B, Hm, Wm, C1):
+    """rnh_uptail_compose + rnh_uptail_dgrad (merged-offset tile kernel + border term where C1 % 16 == 0, generic kernel
+    otherwise) and rnh_uptail_xcorr (M, S on the matrix cores + border term) against the layer-by-layer torch backward,
+    on single-row / single-column images, tile tails and several persistent blocks."""
+    from hipvsr.hip_ops import HipOps
+    from torch_ops import TorchOps
+    dev = _dev()
+    ops, ref = HipOps(dev), TorchOps('cpu')
+    g = torch.Generator('cpu').manual_seed(7 * r + Hm + C1)
+    Cq = 8
+    y1 = torch.randn(B, Hm, Wm, C1, generator=g)
+    d_o = torch.randn(B, Hm * r, Wm * r, 1, generator=g)
+    w2 = torch.randn(Cq * r * r, C1, 3, 3, generator=g) * 0.1
+    w3 = torch.randn(1, Cq, 3, 3, generator=g) * 0.1
+    G = ops.uptail_compose(w2.to(dev), w3.to(dev), r)
+    dy1 = ops.uptail_dgrad(d_o.to(dev), G, C1, r)
+    torch.cuda.synchronize()
+    want = ref.uptail_dgrad(d_o, ref.uptail_compose(w2, w3, r), C1, r)
+    _grad_close(dy1, want, 'dY1', rel=2e-5)
+    if ops.uptail_xcorr_supported(C1, r, 1):
+        M, S = ops.uptail_xcorr(y1.to(dev), d_o.to(dev), r)
+        torch.cuda.synchronize()
+        Mr, Sr = ref.uptail_xcorr(y1, d_o, r)
+        _grad_close(M, Mr, "M", rel=2e-5)
+        _grad_close(S, Sr, "S", rel=2e-5)
+
+
 def test_linearity_and_batch_independence_at_bench_width():
     """Size-independent properties at the benchmark's channel width: (a) samples of a batch are independent
     (quirk Q8): sample 0 of a batch of 2 equals the batch-of-1 result bit for bit; (b) the upsampler is affine:

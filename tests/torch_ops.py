@@ -203,6 +203,20 @@ class TorchOps:
         dz = F.pixel_unshuffle(dy2, r)                                                      # channel c*r*r + i*r + j
         return F.conv_transpose2d(dz, G['w2'], padding=1).permute(0, 2, 3, 1).contiguous()
 
+    def uptail_xcorr_supported(self, C1, r, Co):
+        return Co == 1 and r in (2, 3) and C1 % 64 == 0
+
+    def uptail_xcorr(self, y1, d_o, r):
+        nd2 = (r + 2) * (r + 2)
+        D = self.uptail_expand(d_o, r)[..., :nd2]                                        # (B, Hm, Wm, ND*ND)
+        ypad = F.pad(y1, (0, 0, 1, 1, 1, 1))
+        Hm, Wm = y1.shape[1], y1.shape[2]
+        M = torch.zeros(nd2, y1.shape[3], 3, 3, device=self.device)
+        for ty in range(3):
+            for tx in range(3):
+                M[:, :, ty, tx] = torch.einsum('bhwd,bhwc->dc', D, ypad[:, ty:ty + Hm, tx:tx + Wm])
+        return M, D.sum(dim=(0, 1, 2))
+
     def uptail_expand(self, d_o, r):
         B, Hh, Wh, Co = d_o.shape
         nd = r + 2

@@ -113,3 +113,8 @@ for name, fn in (('outconv.fwd', lambda: ops.outconv_fwd(yy, wl, bl, out=o)), ('
 if not flt or flt in 'uptail.fwd':
     w2, b2 = params[u['fwd'].wkey], params[u['fwd'].bkey]
     timeit('uptail.fwd', lambda: ops.uptail_fwd(y1, w2, b2, wl, bl, 2, o), 2.0 * B3 * 4 * H * W * 4 * 25 * 64, 3)
+if not flt or flt in 'uptail.bwd':
+    w2 = params[u['fwd'].wkey]
+    G = ops.uptail_compose(w2, wl, 2)
+    timeit('uptail.dgrad', lambda: ops.uptail_dgrad(o, G, 64, 2), 2.0 * B3 * 4 * H * W * 64 * 64, 3)
+    timeit('uptail.xcorr', lambda: ops.uptail_xcorr(y1, o, 2), 2.0 * B3 * 4 * H * W * 64 * 64, 3)
