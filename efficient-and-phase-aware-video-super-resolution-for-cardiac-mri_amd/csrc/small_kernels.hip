@@ -208,9 +208,9 @@ __global__ void inconv_bwd_reduce_kernel(const float *ws, int nblocks, float *dw
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// last conv of the upsampler: Cin -> Cout (Cout <= 4), HBM-bound
+// last conv of the upsampler / side path of refine conv1's odd channel: Cin -> Cout (Cout <= 8), HBM-bound
 // ---------------------------------------------------------------------------------------------------------
-constexpr int OC_MAX = 4;
+constexpr int OC_MAX = 8;
 constexpr int OT = 16;                  // 16x16 output pixels per block
 constexpr int OROW = 20;                // 16 channels + 4 pad floats per halo pixel (conflict-free ds_read_b128)
 
@@ -419,17 +419,24 @@ __global__ void __launch_bounds__(256) outconv_wgrad_stream_kernel(const float *
             }
         }
     }
+    // pixel lanes of one channel group sit G lanes apart: butterfly inside the wave, then the 4 waves through LDS
     float *out = ws + (long)blockIdx.x * (COUT * Cin * 9 + COUT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, Gw = G < 64 ? G : 64;
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
+            float4 v = t < 9 ? acc[co][t < 9 ? t : 0] : make_float4(dbp[co], 0.f, 0.f, 0.f);
+            for (int m = Gw; m < 64; m <<= 1) {
+                v.x += __shfl_xor(v.x, m, 64); v.y += __shfl_xor(v.y, m, 64);
+                v.z += __shfl_xor(v.z, m, 64); v.w += __shfl_xor(v.w, m, 64);
+            }
             __syncthreads();
-            red[threadIdx.x] = t < 9 ? acc[co][t < 9 ? t : 0] : make_float4(dbp[co], 0.f, 0.f, 0.f);
+            if (lane < Gw) red[wave * 64 + lane] = v;
             __syncthreads();
-            if (pl == 0) {
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < PL; ++k) s = s + red[k * G + g];
+            if (threadIdx.x < G) {                       // G <= 64: wave 0
+                float4 s;
+                s = (red[g] + red[64 + g]) + (red[128 + g] + red[192 + g]);
                 if (t < 9) {
                     out[(co * Cin + g * 4 + 0) * 9 + t] = s.x;
                     out[(co * Cin + g * 4 + 1) * 9 + t] = s.y;
@@ -443,11 +450,19 @@ __global__ void __launch_bounds__(256) outconv_wgrad_stream_kernel(const float *
     }
 }
 
-__global__ void outconv_wgrad_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, int Cin, int Cout, int accumulate) {
+__global__ void __launch_bounds__(256) outconv_wgrad_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, int Cin, int Cout,
+                                                                   int accumulate) {
+    __shared__ float part[256];
     const int nw = Cout * Cin * 9, total = nw + Cout;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += ws[(long)b * total + e];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;          // 64 outputs x 4 slices of the block list
+    const int per = (nblocks + 3) / 4, b0 = sl * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (e < total)
+        for (int b = b0; b < b1; ++b) s += ws[(long)b * total + e];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        s = (part[threadIdx.x] + part[64 + threadIdx.x]) + (part[128 + threadIdx.x] + part[192 + threadIdx.x]);
         float *o = e < nw ? dw + e : db + (e - nw);
         *o = accumulate ? *o + s : s;
     }
@@ -568,6 +583,62 @@ __global__ void phase_plane_kernel(const float *pos, float *out, int N, int F, l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Side path of ONE output channel `co` of a convolution over J frame slots (refine conv1, channel 2*Cl: 129 = 4*32 + 1
+// columns would cost a fifth 32-column MFMA tile).  With z_s[f][p][j] = conv3x3(source s of frame f; w[co][slot j]):
+//   out[window i][p][co] = bias[co] + sum_j sum_s z_s[i + j][p][j]              (xcol_combine)
+// and in the backward E[f][p][j] = dy[window f - j][p][co] (0 outside) turns the weight gradient of that channel into
+// the J-output small-convolution gradient of each source (rnh_outconv_wgrad), every source frame read once.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void xcol_pack_kernel(const float *w, float *out, int Cin, int co, int J, int cstride, int c0, int nch, int nvalid) {
+    const int total = J * nch * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int t = e % 9, c = (e / 9) % nch, j = e / (9 * nch);
+        out[e] = c < nvalid ? w[((long)co * Cin + j * cstride + c0 + c) * 9 + t] : 0.f;
+    }
+}
+
+__global__ void xcol_unpack_kernel(const float *dwx, const float *dbx, float *dw, float *db, int Cin, int co, int J, int cstride, int c0,
+                                   int nch, int nvalid, int accumulate) {
+    const int total = J * nvalid * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + 1; e += gridDim.x * blockDim.x) {
+        if (e < total) {
+            const int t = e % 9, c = (e / 9) % nvalid, j = e / (9 * nvalid);
+            float *o = dw + ((long)co * Cin + j * cstride + c0 + c) * 9 + t;
+            const float v = dwx[((long)j * nch + c) * 9 + t];
+            *o = accumulate ? *o + v : v;
+        } else if (dbx) {
+            db[co] = accumulate ? db[co] + dbx[0] : dbx[0];
+        }
+    }
+}
+
+__global__ void xcol_combine_kernel(const float *z0, const float *z1, const float *z2, const float *bias, float *out, long npix, int N,
+                                    int nwin, int J, int C, int c0) {
+    const long total = (long)nwin * N * npix;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / npix, px = e - img * npix;
+        float s = bias[0];
+        for (int j = 0; j < J; ++j) {
+            const long o = ((img + (long)j * N) * npix + px) * J + j;
+            s += z0[o];
+            if (z1) s += z1[o];
+            if (z2) s += z2[o];
+        }
+        rnh_st4(out + e * C + c0, make_float4(s, 0.f, 0.f, 0.f));
+    }
+}
+
+__global__ void xcol_gather_kernel(const float *dy, float *E, long npix, int N, int nwin, int J, int C, int c) {
+    const long total = (long)(nwin + J - 1) * N * npix * J;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e % J);
+        const long q = e / J, img = q / npix, px = q - img * npix;
+        const int f = (int)(img / N), n = (int)(img - (long)f * N), k = f - j;
+        E[e] = (k >= 0 && k < nwin) ? dy[(((long)k * N + n) * npix + px) * C + c] : 0.f;
+    }
+}
+
 inline int grid_for(long work_items, int block = 256, int cap = 8192) {
     long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -658,12 +729,16 @@ extern "C" int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, flo
     if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_wgrad: Cout must be 1..%d", OC_MAX);
     hipStream_t st = (hipStream_t)stream;
     const bool stream_ok = (Cin % 4 == 0) && (256 % (Cin / 4) == 0);
-    if (stream_ok && Cout == 1) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<1>, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
-    else if (stream_ok && Cout == 2) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<2>, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
-    else hipLaunchKernelGGL(outconv_wgrad_kernel, dim3(OW_BLOCKS), dim3(256), 0, st, x, dy, ws, B, H, W, Cin, Cout);
+    // one round of blocks for small inputs, at most OW_BLOCKS (the workspace bound) for the high-resolution tensors
+    const long M = (long)B * H * W;
+    const int nb = (int)(M / 4096 < 512 ? 512 : (M / 4096 > OW_BLOCKS ? OW_BLOCKS : M / 4096));
+    if (stream_ok && Cout == 1) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
+    else if (stream_ok && Cout == 2) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<2>, dim3(nb), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
+    else if (stream_ok && Cout == 5) hipLaunchKernelGGL(outconv_wgrad_stream_kernel<5>, dim3(nb), dim3(256), 0, st, x, dy, ws, B, H, W, Cin);
+    else hipLaunchKernelGGL(outconv_wgrad_kernel, dim3(nb), dim3(256), 0, st, x, dy, ws, B, H, W, Cin, Cout);
     RNH_CHECK_LAUNCH("rnh_outconv_wgrad");
-    hipLaunchKernelGGL(outconv_wgrad_reduce_kernel, dim3(grid_for(Cout * Cin * 9 + Cout)), dim3(256), 0, st, ws, OW_BLOCKS, dw, db,
-                       Cin, Cout, accumulate);
+    hipLaunchKernelGGL(outconv_wgrad_reduce_kernel, dim3((Cout * Cin * 9 + Cout + 63) / 64), dim3(256), 0, st, ws, nb, dw, db, Cin, Cout,
+                       accumulate);
     RNH_CHECK_LAUNCH("rnh_outconv_wgrad(reduce)");
     return 0;
 }
@@ -706,5 +781,44 @@ extern "C" int rnh_phase_plane(const float *pos, float *out, int N, int F, int H
     hipLaunchKernelGGL(phase_plane_kernel, dim3(grid_for((long)N * F * H * W)), dim3(256), 0, (hipStream_t)stream, pos, out, N, F,
                        (long)H * W);
     RNH_CHECK_LAUNCH("rnh_phase_plane");
+    return 0;
+}
+
+extern "C" int rnh_xcol_pack(const float *w, float *out, int Cin, int co, int J, int cstride, int c0, int nch, int nvalid, void *stream) {
+    if (!w || !out || Cin < 1 || co < 0 || J < 1 || nch < 1 || nvalid < 1 || nvalid > nch || (J - 1) * cstride + c0 + nvalid > Cin)
+        RNH_FAIL(RNH_E_ARG, "rnh_xcol_pack: bad arguments");
+    hipLaunchKernelGGL(xcol_pack_kernel, dim3(grid_for((long)J * nch * 9)), dim3(256), 0, (hipStream_t)stream, w, out, Cin, co, J, cstride, c0,
+                       nch, nvalid);
+    RNH_CHECK_LAUNCH("rnh_xcol_pack");
+    return 0;
+}
+
+extern "C" int rnh_xcol_unpack(const float *dwx, const float *dbx, float *dw, float *db, int Cin, int co, int J, int cstride, int c0, int nch,
+                               int nvalid, int accumulate, void *stream) {
+    if (!dwx || !dw || (dbx && !db) || Cin < 1 || co < 0 || J < 1 || nch < 1 || nvalid < 1 || nvalid > nch ||
+        (J - 1) * cstride + c0 + nvalid > Cin)
+        RNH_FAIL(RNH_E_ARG, "rnh_xcol_unpack: bad arguments");
+    hipLaunchKernelGGL(xcol_unpack_kernel, dim3(grid_for((long)J * nvalid * 9 + 1)), dim3(256), 0, (hipStream_t)stream, dwx, dbx, dw, db, Cin,
+                       co, J, cstride, c0, nch, nvalid, accumulate);
+    RNH_CHECK_LAUNCH("rnh_xcol_unpack");
+    return 0;
+}
+
+extern "C" int rnh_xcol_combine(const float *z0, const float *z1, const float *z2, const float *bias, float *out, int64_t npix, int N,
+                                int nwin, int J, int C, int c0, void *stream) {
+    if (!z0 || !bias || !out || npix < 1 || N < 1 || nwin < 1 || J < 1 || c0 < 0 || c0 + 4 > C)
+        RNH_FAIL(RNH_E_ARG, "rnh_xcol_combine: bad arguments");
+    if ((C & 3) || (c0 & 3)) RNH_FAIL(RNH_E_ALIGN, "rnh_xcol_combine: C and c0 must be multiples of 4");
+    hipLaunchKernelGGL(xcol_combine_kernel, dim3(grid_for((long)nwin * N * npix)), dim3(256), 0, (hipStream_t)stream, z0, z1, z2, bias, out,
+                       (long)npix, N, nwin, J, C, c0);
+    RNH_CHECK_LAUNCH("rnh_xcol_combine");
+    return 0;
+}
+
+extern "C" int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, int nwin, int J, int C, int c, void *stream) {
+    if (!dy || !E || npix < 1 || N < 1 || nwin < 1 || J < 1 || c < 0 || c >= C) RNH_FAIL(RNH_E_ARG, "rnh_xcol_gather: bad arguments");
+    hipLaunchKernelGGL(xcol_gather_kernel, dim3(grid_for((long)(nwin + J - 1) * N * npix * J)), dim3(256), 0, (hipStream_t)stream, dy, E,
+                       (long)npix, N, nwin, J, C, c);
+    RNH_CHECK_LAUNCH("rnh_xcol_gather");
     return 0;
 }

@@ -134,7 +134,9 @@ class RefineNetEngine:
             R = ops.empty(nwin * N, H, W, Cl)
             if P.pos:
                 R1 = ops.empty(nwin * N, H, W, P.C1p)
-                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p)])
+                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+                if P.xcol:
+                    ops.refine_xcol_fwd([Hf, Hbk, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
                 ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
                 st['R1'] = R1 if need_grad else None
             else:
@@ -277,7 +279,11 @@ class RefineNetEngine:
                           grads[P.r2_wgrad.bkey], accumulate=a)
                 a = acc(k1)
                 acc(b1)
-                ops.wgrad(P.r1_wgrad, xs, [Src(dR1p, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                ops.wgrad(P.r1_wgrad, xs, [Src(dR1p, nch=P.r1_cols, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                if P.xcol:
+                    lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
+                    ops.refine_xcol_wgrad([Hf[lo:hi], Hbk[lo:hi], ctx.P4[lo:hi]], dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w,
+                                          Cl, a)
                 gsrc = dR1p
                 st['R1'] = None
             else:

@@ -273,6 +273,40 @@ class HipOps:
         L.check(self.lib.rnh_outconv_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), B, H, W, Cin, Cout,
                                            int(accumulate), self._stream()), 'rnh_outconv_wgrad')
 
+    # ---- side path of refine conv1's odd output channel 2*cl (csrc/small_kernels.hip, xcol_*) -----------------
+    _XCOL_SEGS = staticmethod(lambda cl: ((0, cl, cl), (cl, cl, cl), (2 * cl, 4, 1)))       # (c0, nch, nvalid) of h_fwd, h_bwd, phase
+
+    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl):
+        """R1[window i][..., 2*cl] = conv1 channel 2*cl over the J frame slots of srcs = (h_fwd, h_bwd, phase plane)."""
+        self._chk(w1, b1, R1, *srcs)
+        co, cs, Cin = 2 * cl, 2 * cl + 1, w1.shape[1]
+        nwin, H, W, C = R1.shape[0] // N, R1.shape[1], R1.shape[2], R1.shape[3]
+        zero, zs = self.zeros(J), []
+        for s, (c0, nch, nv) in zip(srcs, self._XCOL_SEGS(cl)):
+            if s.shape[0] != (nwin + J - 1) * N or s.shape[3] != nch:
+                raise L.HipKernelError('refine_xcol_fwd: source shape')
+            wx = self.empty(J, nch, 3, 3)
+            L.check(self.lib.rnh_xcol_pack(_ptr(w1), _ptr(wx), Cin, co, J, cs, c0, nch, nv, self._stream()), 'rnh_xcol_pack')
+            zs.append(self.outconv_fwd(s, wx, zero))
+        L.check(self.lib.rnh_xcol_combine(_ptr(zs[0]), _ptr(zs[1]), _ptr(zs[2]), b1.data_ptr() + 4 * co, _ptr(R1), H * W, N, nwin, J, C, co,
+                                          self._stream()), 'rnh_xcol_combine')
+
+    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
+        """Weight / bias gradient of conv1's channel 2*cl: srcs = the (nwin + J - 1)*N source frames of (h_fwd, h_bwd,
+        phase plane), dy = (nwin*N, H, W, C1p) gradient of conv1's output."""
+        self._chk(dy, dw1, db1, *srcs)
+        co, cs, Cin = 2 * cl, 2 * cl + 1, dw1.shape[1]
+        nwin, H, W, C = dy.shape[0] // N, dy.shape[1], dy.shape[2], dy.shape[3]
+        E = self.empty((nwin + J - 1) * N, H, W, J)
+        L.check(self.lib.rnh_xcol_gather(_ptr(dy), _ptr(E), H * W, N, nwin, J, C, co, self._stream()), 'rnh_xcol_gather')
+        for k, (s, (c0, nch, nv)) in enumerate(zip(srcs, self._XCOL_SEGS(cl))):
+            if s.shape[0] != (nwin + J - 1) * N or s.shape[3] != nch:
+                raise L.HipKernelError('refine_xcol_wgrad: source shape')
+            dwx, dbx = self.empty(J, nch, 3, 3), self.empty(J)
+            self.outconv_wgrad(s, E, dwx, dbx)
+            L.check(self.lib.rnh_xcol_unpack(_ptr(dwx), _ptr(dbx) if k == 0 else None, _ptr(dw1), _ptr(db1), Cin, co, J, cs, c0, nch, nv,
+                                             int(accumulate), self._stream()), 'rnh_xcol_unpack')
+
     # ---- collapsed backward of the upsampler tail (csrc/uptail.hip) -----------------------------------------
     def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
         self._chk(y1, w2, b2, w3, b3, out)

@@ -24,7 +24,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_ew_add',
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
-           'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr']
+           'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
+           'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather']
 
 
 class HipKernelError(RuntimeError):
@@ -103,6 +104,10 @@ def load():
     lib.rnh_uptail_xcorr_ws_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.rnh_uptail_xcorr_ws_floats.restype = i64
     lib.rnh_uptail_xcorr.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_xcol_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_xcol_unpack.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_xcol_combine.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
+    lib.rnh_xcol_gather.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_dgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_wcontract.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]

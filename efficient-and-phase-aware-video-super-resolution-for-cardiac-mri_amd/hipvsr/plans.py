@@ -7,6 +7,7 @@ the same for the rows / columns of a weight gradient.  The HIP backend turns the
 arrays for ``rnh_pack_weights`` / ``rnh_wgrad_reduce``; the test double in tests/ evaluates them with
 torch ops, so that the maps themselves are checked against the oracle on CPU.
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -224,6 +225,7 @@ class NetPlans:
 
         Cl, w = self.Cl, cfg.refine_window_size
         self.pos = bool(cfg.positional_encoding)
+        self.xcol = False
         if self.pos:
             C1 = 2 * Cl + 1
             self.C1, self.C1p = C1, r4(C1)
@@ -234,13 +236,19 @@ class NetPlans:
             for j in range(w):
                 segs += [KSeg(Cl, Cl, j * C1), KSeg(Cl, Cl, j * C1 + Cl), KSeg(4, 1, j * C1 + 2 * Cl)]
                 xsegs += [XSeg(Cl, Cl, j * C1), XSeg(Cl, Cl, j * C1 + Cl), XSeg(4, 1, j * C1 + 2 * Cl)]
-            # conv1 writes C1p channels (the pad channels have zero weights and bias => zeros)
-            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs, list(range(C1)) + [-1] * (self.C1p - C1))
+            # conv1 writes C1p channels (the pad channels have zero weights and bias => zeros).  C1 = 2*Cl + 1 is one more
+            # than a whole number of 32-column MFMA tiles when Cl % 32 == 0: that channel then takes the side path
+            # (HipOps.refine_xcol_fwd / _wgrad) and the GEMMs run on r1_cols = 2*Cl columns
+            self.xcol = C1 % 32 == 1 and Cl % 32 == 0 and os.environ.get('RNH_XCOL', '1') != '0'
+            self.r1_cols = C1 - 1 if self.xcol else self.C1p
+            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs,
+                                   list(range(C1 - 1)) if self.xcol else list(range(C1)) + [-1] * (self.C1p - C1))
             self.r2_fwd = ConvPlan('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
             self.r2_wgrad = WgradPlan('refine2.wgrad', k2, b2, ws2, [XSeg(self.C1p, C1, 0)], [YSeg(Cl, Cl, 0)])
-            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs, [YSeg(self.C1p, C1, 0)])
+            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs,
+                                      [YSeg(C1 - 1, C1 - 1, 0)] if self.xcol else [YSeg(self.C1p, C1, 0)])
             self.r1_dgrad = ConvPlan('refine1.dgrad', k1, None, ws1, [KSeg(self.C1p, C1, 0, kcoff=j * C1) for j in range(w)],
                                      list(range(2 * Cl)), transposed=True)
         else:

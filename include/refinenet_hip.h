@@ -168,7 +168,7 @@ int rnh_inconv_prelu_bwd(const float *x, const float *w, const float *bias, cons
                          int accumulate, void *stream);
 int64_t rnh_inconv_bwd_ws_floats(int Cin, int Cout);
 
-/* Last convolution of _OutBlock (refine_net.py:201,205), Cout = out_channels (small): HBM-bound direct
+/* Last convolution of _OutBlock (refine_net.py:201,205), Cout = out_channels (1..8): HBM-bound direct
  * convolution, x NHWC [B][H][W][Cin], y NHWC [B][H][W][Cout]. */
 int rnh_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
                     int Cout, void *stream);
@@ -179,6 +179,21 @@ int rnh_outconv_dgrad(const float *dy, const float *w, float *dx, int B, int H, 
 int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, float *db, float *ws, int B, int H, int W, int Cin,
                       int Cout, int accumulate, void *stream);
 int64_t rnh_outconv_wgrad_ws_floats(int Cin, int Cout);
+
+/* Side path of ONE output channel `co` of a convolution whose input is J frame slots of cstride channels each
+ * (_RefineBlock conv1, refine_net.py:150 / :176-182: 645 -> 129 channels, co = 128; 129 = 4*32 + 1 columns would cost
+ * a fifth 32-column MFMA tile).  z_s = rnh_outconv_fwd(source s over ALL frames, rnh_xcol_pack(w, co, slot weights)):
+ *   rnh_xcol_pack   : out (J, nch, 3, 3)[j][c][t] = w[co][j*cstride + c0 + c][t]  (0 for c >= nvalid)
+ *   rnh_xcol_combine: out[(i*N + n)][p][c0..c0+3] = (bias[0] + sum_j sum_s z_s[((i + j)*N + n)][p][j], 0, 0, 0), nwin windows
+ *   rnh_xcol_gather : E[((f*N + n)][p][j] = dy[((f - j)*N + n)][p][c] for 0 <= f - j < nwin, else 0; f < nwin + J - 1
+ *                     (then rnh_outconv_wgrad(source frames, E) is the channel's weight gradient per slot)
+ *   rnh_xcol_unpack : dw[co][j*cstride + c0 + c][t] (+)= dwx[j][c][t];  db[co] (+)= dbx[0] when dbx != 0 */
+int rnh_xcol_pack(const float *w, float *out, int Cin, int co, int J, int cstride, int c0, int nch, int nvalid, void *stream);
+int rnh_xcol_unpack(const float *dwx, const float *dbx, float *dw, float *db, int Cin, int co, int J, int cstride, int c0,
+                    int nch, int nvalid, int accumulate, void *stream);
+int rnh_xcol_combine(const float *z0, const float *z1, const float *z2, const float *bias, float *out, int64_t npix, int N,
+                     int nwin, int J, int C, int c0, void *stream);
+int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, int nwin, int J, int C, int c, void *stream);
 
 /* Backward of the upsampler's tail = [last conv + PixelShuffle(r)] -> [final conv C -> out_channels]
  * (refine_net.py:199-205), collapsed algebraically because the tail is affine with out_channels (= 1) outputs

@@ -104,3 +104,31 @@ def test_engine_errors():
     eng = RefineNetEngine(cfg, TorchOps('cpu'))
     with pytest.raises(IndexError):
         eng.forward({}, [torch.zeros(1, 1, 4, 4)] * 6, torch.zeros(1, 6, 1), need_grad=False)
+
+
+def test_engine_odd_channel_side_path_vs_oracle():
+    """num_features 32 => refine conv1 has 65 = 2*32 + 1 output channels: the GEMM plans cover 64 columns and the last
+    channel goes through refine_xcol_fwd / refine_xcol_wgrad.  Engine over the torch double against the oracle."""
+    from oracle import refinenet_oracle as orc
+    kw = dict(in_channels=1, out_channels=1, num_features=[32, 32], num_stages=2, refine_window_size=5, upscale_factor=2,
+              update_memory=True, num_updated_frames=2, positional_encoding=True)
+    ocfg = orc.Config(**kw)
+    sd = orc.init_state_dict(ocfg, seed=5)
+    inputs, targets, pos = orc.synthetic_batch(ocfg, n=2, t=2, h=6, w=5, seed=6)
+    c = dict(kwargs=kw, state_dict=sd, inputs=inputs, targets=targets, pos_codes=pos)
+    cfg, O_all, total, grads = run_engine(c)
+    from hipvsr.plans import NetPlans
+    assert NetPlans(cfg).xcol
+    outs, loss, gref = orc.step(sd, ocfg, [x.clone() for x in inputs], targets, pos)
+    torch.testing.assert_close(total, loss, atol=1e-5, rtol=1e-5)
+    N = 2
+    for g in range(3 * cfg.num_stages):
+        for i in range(2):
+            mine = O_all[g // 3, g % 3, i * N:(i + 1) * N].permute(0, 3, 1, 2)
+            torch.testing.assert_close(mine, outs[g][i], atol=2e-5, rtol=1e-5)
+    for k, gr in gref.items():
+        if gr is None:
+            assert grads[k] is None
+            continue
+        scale = float(gr.abs().max()) + 1e-12
+        assert float((grads[k] - gr).abs().max()) <= 2e-4 * scale + 1e-7, k

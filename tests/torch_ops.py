@@ -186,6 +186,37 @@ class TorchOps:
             db.copy_(gb)
 
     # ---- collapsed upsampler tail (semantics of csrc/uptail.hip, written independently with torch ops) ----------
+    @staticmethod
+    def _xcol_windows(srcs, N, J, nwin):
+        feats = []
+        for i in range(nwin):
+            parts = []
+            for j in range(J):
+                sl = slice((i + j) * N, (i + j + 1) * N)
+                parts += [srcs[0][sl], srcs[1][sl], srcs[2][sl][..., :1]]
+            feats.append(torch.cat(parts, dim=-1).permute(0, 3, 1, 2))
+        return feats
+
+    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl):
+        co, nwin = 2 * cl, R1.shape[0] // N
+        for i, f in enumerate(self._xcol_windows(srcs, N, J, nwin)):
+            R1[i * N:(i + 1) * N, ..., co] = F.conv2d(f, w1[co:co + 1], b1[co:co + 1], padding=1)[:, 0]
+            R1[i * N:(i + 1) * N, ..., co + 1:co + 4] = 0
+
+    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
+        co, nwin = 2 * cl, dy.shape[0] // N
+        w0 = torch.zeros(1, dw1.shape[1], 3, 3, device=self.device, requires_grad=True)
+        b0 = torch.zeros(1, device=self.device, requires_grad=True)
+        with torch.enable_grad():
+            for i, f in enumerate(self._xcol_windows(srcs, N, J, nwin)):
+                F.conv2d(f.detach(), w0, b0, padding=1).backward(dy[i * N:(i + 1) * N, ..., co].unsqueeze(1))
+        if accumulate:
+            dw1[co] += w0.grad[0]
+            db1[co] += b0.grad[0]
+        else:
+            dw1[co] = w0.grad[0]
+            db1[co] = b0.grad[0]
+
     def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
         z = F.pixel_shuffle(F.conv2d(y1.permute(0, 3, 1, 2), w2, b2, padding=1), r)
         out.copy_(F.conv2d(z, w3, b3, padding=1).permute(0, 2, 3, 1))

@@ -77,7 +77,9 @@ srcs = []
 for j in range(5):
     srcs += [Src(Hf, img_off=j * N), Src(Hb, img_off=j * N), Src(P4, img_off=j * N)]
 R1 = ops.empty(nwin * N, H, W, P.C1p)
-timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
+timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
+if P.xcol:
+    timeit('refine1.fwd.xcol', lambda: ops.refine_xcol_fwd([Hf, Hb, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, 5, 64), 2.0 * nwin * N * H * W * 645 * 9, 3)
 Rr = ops.empty(nwin * N, H, W, 64)
 timeit('refine2.fwd', lambda: ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)]), 2.0 * nwin * N * H * W * 64 * 129 * 9, 3)
 dR1p = R((T + 4) * N, H, W, P.C1p)
@@ -85,7 +87,10 @@ xs1 = []
 for j in range(5):
     xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P4, img_off=(4 + j) * N)]
 dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
-timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
+timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
+if P.xcol:
+    lo, hi = 4 * N, (4 + T + 4) * N
+    timeit('refine1.wgrad.xcol', lambda: ops.refine_xcol_wgrad([Hf[lo:hi], Hb[lo:hi], P4[lo:hi]], dR1p[2 * N:(2 + T) * N], dw1, db1, N, 5, 64, False), 2.0 * TN * H * W * 645 * 9, 3)
 dHf, dHb = ops.zeros(TN, H, W, 64), ops.zeros(TN, H, W, 64)
 timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
                                          dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9, 3)
