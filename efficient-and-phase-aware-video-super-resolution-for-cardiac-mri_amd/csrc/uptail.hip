@@ -185,38 +185,36 @@ __global__ void uptail_compose_fwd1_kernel(const float *w2, const float *b2, con
 
 __device__ __forceinline__ int floordiv(int a, int r) { return (a >= 0) ? a / r : -((-a + r - 1) / r); }
 
-__global__ void uptail_compose_fwd2_kernel(const float *Gf, const float *beta, float *Kf, float *bsum, int C1, int r, int Co) {
+// Kf[u][c1 (padded to a multiple of 16 with zeros)][o (sub-position, padded to an even count)], bsum[o]; Co == 1
+__global__ void uptail_compose_fwd2_kernel(const float *Gf, const float *beta, float *Kf, float *bsum, int C1, int C1p, int r, int NOP) {
     const int r2 = r * r;
-    const int nk = Co * r2 * 25 * C1, nb = Co * r2;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nk + nb; e += gridDim.x * blockDim.x) {
-        if (e < nk) {                                        // Kf[co][ij0][u][c1]
-            const int c1 = e % C1;
-            int q = e / C1;
-            const int u = q % 25;
-            q /= 25;
-            const int ij0 = q % r2, co = q / r2;
-            const int i0 = ij0 / r, j0 = ij0 % r, uy = u / 5 - 2, ux = u % 5 - 2;
+    const int nk = 25 * C1p * NOP;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nk + r2; e += gridDim.x * blockDim.x) {
+        if (e < nk) {
+            const int ij0 = e % NOP, c1 = (e / NOP) % C1p, u = e / (NOP * C1p);
             float s = 0.f;
-            for (int t3 = 0; t3 < 9; ++t3) {
-                const int ay = i0 + t3 / 3 - 1, ax = j0 + t3 % 3 - 1;
-                const int fy = floordiv(ay, r), fx = floordiv(ax, r);
-                const int ij = (ay - fy * r) * r + (ax - fx * r);
-                const int t2y = uy - fy, t2x = ux - fx;
-                if (t2y < -1 || t2y > 1 || t2x < -1 || t2x > 1) continue;
-                const int t2 = (t2y + 1) * 3 + t2x + 1;
-                s += Gf[((((long)co * 9 + t2) * r2 + ij) * 9 + t3) * C1 + c1];
+            if (ij0 < r2 && c1 < C1) {
+                const int i0 = ij0 / r, j0 = ij0 % r, uy = u / 5 - 2, ux = u % 5 - 2;
+                for (int t3 = 0; t3 < 9; ++t3) {
+                    const int ay = i0 + t3 / 3 - 1, ax = j0 + t3 % 3 - 1;
+                    const int fy = floordiv(ay, r), fx = floordiv(ax, r);
+                    const int ij = (ay - fy * r) * r + (ax - fx * r);
+                    const int t2y = uy - fy, t2x = ux - fx;
+                    if (t2y < -1 || t2y > 1 || t2x < -1 || t2x > 1) continue;
+                    const int t2 = (t2y + 1) * 3 + t2x + 1;
+                    s += Gf[(((long)t2 * r2 + ij) * 9 + t3) * C1 + c1];
+                }
             }
             Kf[e] = s;
         } else {
-            const int idx = e - nk;
-            const int ij0 = idx % r2, co = idx / r2, i0 = ij0 / r, j0 = ij0 % r;
+            const int ij0 = e - nk, i0 = ij0 / r, j0 = ij0 % r;
             float s = 0.f;
             for (int t3 = 0; t3 < 9; ++t3) {
                 const int ay = i0 + t3 / 3 - 1, ax = j0 + t3 % 3 - 1;
                 const int fy = floordiv(ay, r), fx = floordiv(ax, r);
-                s += beta[(co * r2 + (ay - fy * r) * r + (ax - fx * r)) * 9 + t3];
+                s += beta[((ay - fy * r) * r + (ax - fx * r)) * 9 + t3];
             }
-            bsum[idx] = s;
+            bsum[ij0] = s;
         }
     }
 }
@@ -225,21 +223,22 @@ constexpr int UT = 16;            // 16x16 mid-resolution pixels per block
 constexpr int UROW = 20;          // 16 channels + 4 pad floats per halo pixel
 constexpr int UH = UT + 4;        // halo tile edge
 
-template <int R, int CO>
-__global__ void __launch_bounds__(256) uptail_fwd_kernel(const float *y1, const float *Kf, const float *bsum, const float *b3,
-                                                         float *out, int B, int Hm, int Wm, int C1, int TX, int TY) {
-    constexpr int R2 = R * R, NO = R2 * CO;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *tile = sm;                                  // [UH*UH][UROW]
-    float *skf = sm + UH * UH * UROW;                  // [NO][25][16]
+// thread = one mid-resolution pixel, all r*r sub-positions; the 16-channel chunk of its 5x5 neighbourhood comes from
+// the LDS tile (4 ds_read_b128 per tap), the composed weights are wave-uniform and arrive through scalar loads
+template <int R>
+__global__ void __launch_bounds__(256) uptail_fwd_kernel(const float *__restrict__ y1, const float *__restrict__ Kf,
+                                                         const float *__restrict__ bsum, const float *__restrict__ b3,
+                                                         float *__restrict__ out, int B, int Hm, int Wm, int C1, int C1p, int TX, int TY) {
+    constexpr int R2 = R * R, NOP = (R2 + 1) & ~1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];           // [UH*UH][UROW]
     const int tb = blockIdx.x;
     const int b = tb / (TX * TY), trem = tb - b * TX * TY, tyb = trem / TX, txb = trem - tyb * TX;
     const int y0 = tyb * UT, x0 = txb * UT;
     const int ly = threadIdx.x / UT, lx = threadIdx.x % UT;
     const int qy = y0 + ly, qx = x0 + lx;
-    float acc[NO];
+    float acc[NOP];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+    for (int o = 0; o < NOP; ++o) acc[o] = 0.f;
     for (int c0 = 0; c0 < C1; c0 += 16) {
         __syncthreads();
         for (int e = threadIdx.x; e < UH * UH * 4; e += 256) {
@@ -250,32 +249,25 @@ __global__ void __launch_bounds__(256) uptail_fwd_kernel(const float *y1, const 
                 v = rnh_ld4(y1 + (((long)b * Hm + gy) * Wm + gx) * C1 + c0 + q4 * 4);
             rnh_st4(tile + hp * UROW + q4 * 4, v);
         }
-        for (int e = threadIdx.x; e < NO * 25 * 16; e += 256) {
-            const int c = e & 15, ou = e >> 4;
-            skf[e] = (c0 + c < C1) ? Kf[(long)ou * C1 + c0 + c] : 0.f;
-        }
         __syncthreads();
-#pragma unroll 5
-        for (int u = 0; u < 25; ++u) {
-            const float *tp = tile + ((ly + u / 5) * UH + lx + u % 5) * UROW;
-            const float4 x0v = rnh_ld4(tp), x1v = rnh_ld4(tp + 4), x2v = rnh_ld4(tp + 8), x3v = rnh_ld4(tp + 12);
+        for (int uy = 0; uy < 5; ++uy)
+            for (int ux = 0; ux < 5; ++ux) {
+                const float *tp = tile + ((ly + uy) * UH + lx + ux) * UROW;
+                const float4 x0v = rnh_ld4(tp), x1v = rnh_ld4(tp + 4), x2v = rnh_ld4(tp + 8), x3v = rnh_ld4(tp + 12);
+                const float xs[16] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w,
+                                      x2v.x, x2v.y, x2v.z, x2v.w, x3v.x, x3v.y, x3v.z, x3v.w};
+                const float *k = Kf + ((long)(uy * 5 + ux) * C1p + c0) * NOP;
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                const float *kp = skf + (o * 25 + u) * 16;
-                const float4 k0 = rnh_ld4(kp), k1 = rnh_ld4(kp + 4), k2 = rnh_ld4(kp + 8), k3 = rnh_ld4(kp + 12);
-                acc[o] += x0v.x * k0.x + x0v.y * k0.y + x0v.z * k0.z + x0v.w * k0.w + x1v.x * k1.x + x1v.y * k1.y + x1v.z * k1.z +
-                          x1v.w * k1.w + x2v.x * k2.x + x2v.y * k2.y + x2v.z * k2.z + x2v.w * k2.w + x3v.x * k3.x + x3v.y * k3.y +
-                          x3v.z * k3.z + x3v.w * k3.w;
+                for (int c = 0; c < 16; ++c)
+#pragma unroll
+                    for (int o = 0; o < NOP; ++o) acc[o] = fmaf(xs[c], k[c * NOP + o], acc[o]);
             }
-        }
     }
     if (qy >= Hm || qx >= Wm) return;
     const int Hh = Hm * R, Wh = Wm * R;
 #pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        const int co = o / R2, ij0 = o % R2;
-        out[(((long)b * Hh + qy * R + ij0 / R) * Wh + qx * R + ij0 % R) * CO + co] = acc[o] + bsum[o] + b3[co];
-    }
+    for (int o = 0; o < R2; ++o)
+        out[((long)b * Hh + qy * R + o / R) * Wh + qx * R + o % R] = acc[o] + bsum[o] + b3[0];
 }
 
 // The composed 5x5 kernel sums every (t3, t2) path; for an output pixel ON the border of the r-times larger image the
@@ -591,8 +583,8 @@ extern "C" int rnh_uptail_compose(const float *w2, const float *w3, float *G, in
 }
 
 extern "C" int64_t rnh_uptail_fwd_ws_floats(int C1, int Cq, int r, int Co) {
-    const int64_t r2 = r * r;
-    return Co * 9 * r2 * 9 * C1 + Co * r2 * 9 + Co * r2 * 25 * C1 + Co * r2 + 64;
+    const int64_t r2 = r * r, C1p = (C1 + 15) & ~15, NOP = (r2 + 1) & ~1;
+    return Co * 9 * r2 * 9 * C1 + Co * r2 * 9 + 25 * C1p * NOP + r2 + 64;
 }
 
 extern "C" int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2, const float *w3, const float *b3, float *out, float *ws,
@@ -601,20 +593,20 @@ extern "C" int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2,
         RNH_FAIL(RNH_E_ARG, "rnh_uptail_fwd: bad arguments");
     if (C1 & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_uptail_fwd: C1 must be a multiple of 4");
     if (!((r == 2 || r == 3) && Co == 1)) RNH_FAIL(RNH_E_RANGE, "rnh_uptail_fwd: built for r in {2, 3} and out_channels == 1");
-    const int r2 = r * r;
-    float *Gf = ws, *beta = Gf + (long)Co * 9 * r2 * 9 * C1, *Kf = beta + Co * r2 * 9, *bsum = Kf + (long)Co * r2 * 25 * C1;
+    const int r2 = r * r, C1p = (C1 + 15) & ~15, NOP = (r2 + 1) & ~1;
+    float *Gf = ws, *beta = Gf + (long)9 * r2 * 9 * C1, *Kf = beta + r2 * 9, *bsum = Kf + (long)25 * C1p * NOP;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(uptail_compose_fwd1_kernel, dim3(grid_for((long)Co * 9 * r2 * 9 * C1 + Co * r2 * 9)), dim3(256), 0, st, w2, b2, w3, Gf,
-                       beta, C1, Cq, r, Co);
+    hipLaunchKernelGGL(uptail_compose_fwd1_kernel, dim3(grid_for((long)9 * r2 * 9 * C1 + r2 * 9)), dim3(256), 0, st, w2, b2, w3, Gf, beta, C1,
+                       Cq, r, Co);
     RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 1)");
-    hipLaunchKernelGGL(uptail_compose_fwd2_kernel, dim3(grid_for((long)Co * r2 * 25 * C1 + Co * r2)), dim3(256), 0, st, Gf, beta, Kf, bsum,
-                       C1, r, Co);
+    hipLaunchKernelGGL(uptail_compose_fwd2_kernel, dim3(grid_for((long)25 * C1p * NOP + r2)), dim3(256), 0, st, Gf, beta, Kf, bsum, C1, C1p, r,
+                       NOP);
     RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 2)");
     const int TX = (Wm + UT - 1) / UT, TY = (Hm + UT - 1) / UT;
-    const size_t shm = ((size_t)UH * UH * UROW + (size_t)r2 * Co * 25 * 16) * sizeof(float);
+    const size_t shm = (size_t)UH * UH * UROW * sizeof(float);
     const dim3 grid((unsigned)(B * TX * TY)), block(256);
-    if (r == 2) hipLaunchKernelGGL((uptail_fwd_kernel<2, 1>), grid, block, shm, st, y1, Kf, bsum, b3, out, B, Hm, Wm, C1, TX, TY);
-    else hipLaunchKernelGGL((uptail_fwd_kernel<3, 1>), grid, block, shm, st, y1, Kf, bsum, b3, out, B, Hm, Wm, C1, TX, TY);
+    if (r == 2) hipLaunchKernelGGL((uptail_fwd_kernel<2>), grid, block, shm, st, y1, Kf, bsum, b3, out, B, Hm, Wm, C1, C1p, TX, TY);
+    else hipLaunchKernelGGL((uptail_fwd_kernel<3>), grid, block, shm, st, y1, Kf, bsum, b3, out, B, Hm, Wm, C1, C1p, TX, TY);
     RNH_CHECK_LAUNCH("rnh_uptail_fwd");
     const long nborder = (long)B * (2 * Wm * r + 2 * (Hm * r - 2));
     hipLaunchKernelGGL(uptail_border_kernel, dim3((unsigned)((nborder + 3) / 4)), dim3(256), 0, st, y1, Gf, beta, out, B, Hm, Wm, C1, r, Co);
