@@ -1,0 +1,451 @@
+// 3x3 convolution (padding 1) in Winograd form F(2x2, 3x3) on fp32 MFMA for gfx950 - rnh_conv_wino.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 independent GEMMs (one per position xi of the 4x4 transform domain) of [tiles x C] x [C x N]: 4 MACs per output
+// pixel and (c, n) pair instead of 9, i.e. 2.25x fewer MFMA passes than the implicit GEMM of conv_igemm.hip.  The
+// price is vector work next to the matrix cores (measured with tools/issue_density.hip: a wave sustains one 8-byte
+// load and one packed add per v_mfma_f32_32x32x2_f32 at about 75 % of the MFMA peak), so everything is fused:
+//
+//   * one wave = 32 tiles (rows of the MFMA) x 32 output columns x all 16 xi: 256 accumulator registers (the
+//     unified 512-register file of a wave that has its SIMD to itself), so the output transform happens in registers
+//     and the transform domain never touches memory;
+//   * the input transform B^T d B is computed on the fly: per step of 4 channels a lane loads the 4x4 patch of its
+//     tile as 16 raw 8-byte buffer loads (channels 2kh, 2kh+1 of the step for lane-half kh; lanes outside the image
+//     carry offset 0xFFFFFFFF and the range check returns the zero padding) and spends 32 packed adds;
+//   * the weights arrive pre-transformed from rnh_wino_pack_weights as U[step][xi][n][4] (8 bytes per lane and xi);
+//   * the 4 waves of a workgroup take 4 column groups of the same 32 tiles.  With the ConvLSTM column order
+//     (plans.lstm_colmap) these are the 4 gates of 32 hidden channels: every wave activates its gate, the gates meet
+//     in LDS and each wave finishes one pixel of every tile (c' = f c + i g, h' = o tanh c').
+//
+// Same operand conventions as rnh_conv_igemm (rnh_conv_args_t: multi-source K without concatenation, destination
+// segments, packed bias); sources must have scale 1.  Epilogues: RNH_EPI_STORE, RNH_EPI_LSTM.
+#include "rnh_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float w_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float w_tanh(float x) {
+    const float ax = fabsf(x);
+    const float t = ax < 0.04f ? ax * (1.f - 0.33333334f * ax * ax) : 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * ax));
+    return copysignf(t, x);
+}
+
+// U[s][xi][n][q] = (G g G^T)[xi] for input channel kbase[s] + q*kstride and output column n
+__global__ void wino_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kbase, const int *knv,
+                                 const int *kcoff, const int *colmap, int ns, int Npad, int Cout, int Cin, int kstride, int transposed) {
+    const long total = (long)ns * 16 * Npad * 4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Npad; e += (long)gridDim.x * blockDim.x) {
+        if (e >= total) {
+            const int n = (int)(e - total);
+            if (biasp) biasp[n] = (bias && !transposed && colmap[n] >= 0) ? bias[colmap[n]] : 0.f;
+            continue;
+        }
+        const int q = (int)(e & 3), n = (int)((e >> 2) % Npad), xi = (int)((e / (4 * (long)Npad)) & 15), s = (int)(e / (64 * (long)Npad));
+        const int col = colmap[n];
+        float v = 0.f;
+        if (col >= 0 && q < knv[s]) {
+            const int k = kbase[s] + q * kstride, c = col + (kcoff ? kcoff[s] : 0);
+            const float *g = transposed ? w + ((long)k * Cin + c) * 9 : w + ((long)c * Cin + k) * 9;
+            const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+            const int xy = xi >> 2, xx = xi & 3;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    const int t = a * 3 + b;
+                    v += G[xy][a] * G[xx][b] * g[transposed ? 8 - t : t];
+                }
+        }
+        wp[e] = v;
+    }
+}
+
+// wave-uniform descriptor: base + 2 GiB window, raw buffer (the readfirstlanes keep it in SGPRs - no waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wdesc(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x2 wld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+#ifdef RNH_STAMPS
+__device__ unsigned long long g_wino_stamps[8];
+#define WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WSTAMP(i)
+#endif
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
+    __shared__ __attribute__((aligned(16))) float stage[2 * 16 * 32 * 18];     // 73.7 KB; the LSTM gate exchange reuses it
+    float *xch = stage;
+    __shared__ int tpix[32];                                  // top-left output pixel of the block's tiles (epilogue)
+    WSTAMP(0);
+#ifdef RNH_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] = 0;
+#endif
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = threadIdx.x >> 6;
+    const int bid = rnh_xcd_remap(blockIdx.x, MT * NT);
+    const int mt = bid / NT, nt = bid - mt * NT;
+    const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
+    const int m0 = mt * 32;
+
+    // ---- staging: the 4x4 patches of the block's 32 tiles, 16 channels at a time, through LDS ------------------
+    // (lanes of one tile row sit 2 pixels = 512 B apart in memory: loading patches per lane would touch 32 cache
+    // lines per instruction.)  Thread = patch pixel pp of tiles tsub, tsub + 4, ...: 16-byte loads, 64 B per pixel.
+    // LDS layout [patch pixel][tile][18]: the 8-byte reads of a half-wave (32 tiles, stride 18 floats) cover all 64
+    // banks exactly once.
+    const int q4 = threadIdx.x & 3, pp = (threadIdx.x >> 2) & 15, tsub = threadIdx.x >> 6;
+    const int pi = pp >> 2, pj = pp & 3;
+    const int t0 = m0 < ntiles ? m0 : 0;
+    const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
+    const int base_pix = (img0 * H + 2 * ty0 - 1) * W - 1;      // at or before every pixel the block touches
+    int pixrel[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = m0 + tsub + 4 * i;
+        const bool tok = t < ntiles;
+        const int tt = tok ? t : t0;
+        const int img = tt / (TY * TX), trem = tt - img * TY * TX, ty = trem / TX, tx = trem - ty * TX;
+        const int y = 2 * ty - 1 + pi, x = 2 * tx - 1 + pj;
+        const bool ok = tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        pixrel[i] = ok ? (img * H + y) * W + x - base_pix : -1;
+    }
+    // loader state: source and 16-channel chunk inside it
+    int si = 0, cchunk = 0, nchunk = (P.src[0].nch + 15) >> 4, nchs = P.src[0].nch;
+    int voff[8];
+    __amdgpu_buffer_rsrc_t adesc;
+    auto setup_src = [&](int sidx) {
+        const rnh_src_t &S = P.src[sidx];
+        adesc = wdesc(S.ptr + S.c0 + ((long)S.img_off * H * W + base_pix) * S.C);
+        const int C4 = S.C * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) voff[i] = pixrel[i] < 0 ? -1 : pixrel[i] * C4 + q4 * 16;
+        nchunk = (S.nch + 15) >> 4;
+        nchs = S.nch;
+    };
+    setup_src(0);
+    f32x4 stg[8];
+    auto gload = [&]() {                                   // next chunk of the source list -> registers
+        const bool qok = cchunk * 16 + q4 * 4 < nchs;       // a source may end in a partial chunk (multiple of 4 channels)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(adesc, qok ? voff[i] : -1, cchunk * 64, 0));
+        if (++cchunk == nchunk) {
+            cchunk = 0;
+            if (++si < P.nsrc) setup_src(si);
+        }
+    };
+    constexpr int CHS = 18, BUF = 16 * 32 * CHS;
+    auto sts = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float *o = stage + buf * BUF + (pp * 32 + tsub + 4 * i) * CHS + q4 * 4;
+            *reinterpret_cast<f32x2 *>(o) = f32x2{stg[i][0], stg[i][1]};
+            *reinterpret_cast<f32x2 *>(o + 2) = f32x2{stg[i][2], stg[i][3]};
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t bdesc = wdesc(P.wp + (long)((nt * 4 + wave) * 32) * 4);
+    const int boff = (l31 * 4 + 2 * kh) * 4;
+    const int xistride = P.Npad * 16;                       // bytes between two transform positions of one step
+    auto loadb = [&](f32x2 *u, int s) {
+#ifdef WX_NOB
+        if (s > 0) return;
+#endif
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) u[xi] = wld2(bdesc, boff, (s * 16 + xi) * xistride);
+    };
+    auto loadd = [&](f32x2 *d, int buf, int q) {            // the lane's patch, channels 4q + 2kh, +1 of the staged chunk
+        const float *src = stage + buf * BUF + l31 * CHS + q * 4 + 2 * kh;
+#ifdef WX_NOD
+        if (q > 0 || buf) return;
+#endif
+#pragma unroll
+        for (int p = 0; p < 16; ++p) d[p] = *reinterpret_cast<const f32x2 *>(src + p * 32 * CHS);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
+
+    auto compute = [&](const f32x2 *d, const f32x2 *u) {
+        // V = B^T d B on two channels at once (packed adds)
+        f32x2 tq[16], V[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            tq[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            tq[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+            tq[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
+            V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
+            V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
+            V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
+        }
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi].x, u[xi].x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi].y, u[xi].y, acc[xi], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop over 16-channel chunks; chunk c+1 travels global -> registers under the MFMAs of chunk c ----
+    // P.nk counts 4-channel steps; the chunk list follows the sources (a source of nch channels = ceil(nch/16) chunks,
+    // the last one possibly short)
+    int nchunks_total = 0;
+    for (int i = 0; i < P.nsrc; ++i) nchunks_total += (P.src[i].nch + 15) >> 4;
+    int csi = 0, cleft = P.src[0].nch;                      // compute-side view of the source list
+    f32x2 d0[16], d1[16], u0[16], u1[16];
+    if (threadIdx.x < 32) {
+        const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
+        const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
+        tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
+    }
+    WSTAMP(1);
+    gload();
+    sts(0);
+    __syncthreads();
+    WSTAMP(2);
+    int s = 0;                                               // global 4-channel step index (weights)
+    loadb(u0, 0);
+    for (int c = 0; c < nchunks_total; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks_total) gload();
+        const int nq = cleft >= 16 ? 4 : cleft >> 2;          // steps in this chunk
+        cleft -= 16;
+        if (cleft <= 0 && ++csi < P.nsrc) cleft = P.src[csi].nch;
+        loadd(d0, buf, 0);
+        for (int q = 0; q < nq; q += 2) {
+            const bool more1 = q + 1 < nq, more2 = q + 2 < nq;
+            if (more1) { loadd(d1, buf, q + 1); }
+            if (s + 1 < P.nk) loadb(u1, s + 1);
+            compute(d0, u0);
+            ++s;
+            if (more1) {
+                if (more2) loadd(d0, buf, q + 2);
+                if (s + 1 < P.nk) loadb(u0, s + 1);
+                compute(d1, u1);
+                ++s;
+            } else {
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) u0[xi] = u1[xi];
+            }
+        }
+#ifdef RNH_STAMPS
+        const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+        if (c + 1 < nchunks_total) sts(buf ^ 1);
+        __syncthreads();
+#ifdef RNH_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] += __builtin_readcyclecounter() - ts0;
+#endif
+    }
+
+    WSTAMP(3);
+    // ---- output transform Y = A^T M A per accumulator register, then the epilogue -------------------------------
+    const int ncol = (nt * 4 + wave) * 32 + l31;
+    const float bv = P.bias ? P.bias[ncol] : 0.f;
+    auto out4 = [&](int v, float *Y) {
+        float sq[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sq[0][j] = acc[0 * 4 + j][v] + acc[1 * 4 + j][v] + acc[2 * 4 + j][v];
+            sq[1][j] = acc[1 * 4 + j][v] - acc[2 * 4 + j][v] - acc[3 * 4 + j][v];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            Y[a * 2 + 0] = sq[a][0] + sq[a][1] + sq[a][2] + bv;
+            Y[a * 2 + 1] = sq[a][1] - sq[a][2] - sq[a][3] + bv;
+        }
+    };
+    // pixel (top-left output of the tile) and validity of row v of the MFMA tile
+    auto tile_of = [&](int v, int &pix, bool &okx, bool &oky) -> bool {
+        const int tr = m0 + (v & 3) + 8 * (v >> 2) + 4 * kh;
+        if (tr >= ntiles) return false;
+        const int im = tr / (TY * TX), rr = tr - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
+        pix = (im * H + 2 * yy) * W + 2 * xx;
+        oky = 2 * yy + 1 < H;
+        okx = 2 * xx + 1 < W;
+        return true;
+    };
+
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        const int hd = P.hd, hc = nt * 32 + l31;
+        // every row of the MFMA tile is whole and inside (the usual case): straight-line code, no per-element predicates
+        const bool full = m0 + 32 <= ntiles && !(H & 1) && !(W & 1) && nt * 32 + 32 <= hd;
+        const int p2 = wave, poff2 = (p2 >> 1) * W + (p2 & 1);
+        float cpv[16];
+        if (full) {
+            // state of the pixel this lane finishes in phase 2: loaded now, needed after the barrier
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                cpv[v] = P.c_prev ? P.c_prev[((long)tpix[trl] + poff2) * hd + hc] : 0.f;
+            }
+        }
+        // phase 1: every wave activates its gate (wave 0..3 = i, f, o, g) and parks it in LDS (and in gates_out)
+        if (full) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float Y[4];
+                out4(v, Y);
+                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                float *gp = P.gates_out ? P.gates_out + (long)tpix[trl] * 4 * hd + wave * hd + hc : nullptr;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float g = wave == 3 ? w_tanh(Y[p]) : w_sigmoid(Y[p]);
+                    xch[((wave * 32 + trl) * 4 + p) * 32 + l31] = g;
+                    if (gp) gp[(long)((p >> 1) * W + (p & 1)) * 4 * hd] = g;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float Y[4];
+                out4(v, Y);
+                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                int pix;
+                bool okx, oky;
+                const bool ok = tile_of(v, pix, okx, oky) && hc < hd;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float g = wave == 3 ? w_tanh(Y[p]) : w_sigmoid(Y[p]);
+                    xch[((wave * 32 + trl) * 4 + p) * 32 + l31] = g;
+                    if (P.gates_out && ok && ((p & 1) == 0 || okx) && ((p >> 1) == 0 || oky))
+                        P.gates_out[((long)pix + (p >> 1) * W + (p & 1)) * 4 * hd + wave * hd + hc] = g;
+                }
+            }
+        }
+        __syncthreads();
+        WSTAMP(4);
+        // phase 2: wave w finishes output pixel w of every tile
+        if (full) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                const float gi = xch[((0 * 32 + trl) * 4 + p2) * 32 + l31], gf = xch[((1 * 32 + trl) * 4 + p2) * 32 + l31];
+                const float go = xch[((2 * 32 + trl) * 4 + p2) * 32 + l31], gg = xch[((3 * 32 + trl) * 4 + p2) * 32 + l31];
+                const long o = ((long)tpix[trl] + poff2) * hd + hc;
+                const float cn = gf * cpv[v] + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * w_tanh(cn);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                int pix;
+                bool okx, oky;
+                if (!tile_of(v, pix, okx, oky) || hc >= hd) continue;
+                if (((p2 & 1) && !okx) || ((p2 >> 1) && !oky)) continue;
+                const float gi = xch[((0 * 32 + trl) * 4 + p2) * 32 + l31], gf = xch[((1 * 32 + trl) * 4 + p2) * 32 + l31];
+                const float go = xch[((2 * 32 + trl) * 4 + p2) * 32 + l31], gg = xch[((3 * 32 + trl) * 4 + p2) * 32 + l31];
+                const long o = ((long)pix + poff2) * hd + hc;
+                const float cp = P.c_prev ? P.c_prev[o] : 0.f;
+                const float cn = gf * cp + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * w_tanh(cn);
+            }
+        }
+        WSTAMP(5);
+    } else {
+        // destination segment of this lane's column
+        int seg = -1, cbase = 0;
+        for (int d = 0; d < P.ndst; ++d) {
+            if (seg < 0 && ncol < cbase + P.dst[d].ncols) seg = d;
+            if (seg < 0) cbase += P.dst[d].ncols;
+        }
+        if (seg < 0) return;
+        const rnh_dst_t &D = P.dst[seg];
+        float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float Y[4];
+            out4(v, Y);
+            int pix;
+            bool okx, oky;
+            if (!tile_of(v, pix, okx, oky)) continue;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (((p & 1) && !okx) || ((p >> 1) && !oky)) continue;
+                float *o = dp + ((long)pix + (p >> 1) * W + (p & 1)) * D.C;
+                *o = D.accumulate ? *o + Y[p] : Y[p];
+            }
+        }
+    }
+}
+
+inline int wgrid_for(long n, int cap = 8192) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#ifdef RNH_STAMPS
+extern "C" int rnh_debug_wino_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_stamps), sizeof(g_wino_stamps));
+}
+#endif
+
+extern "C" int rnh_wino_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kbase, const int32_t *knv,
+                                     const int32_t *kcoff, const int32_t *colmap, int ns, int Npad, int Cout, int Cin, int kstride,
+                                     int transposed, void *stream) {
+    if (!w || !wp || !kbase || !knv || !colmap || ns < 1 || Npad < 1 || Cout < 1 || Cin < 1 || kstride < 1)
+        RNH_FAIL(RNH_E_ARG, "rnh_wino_pack_weights: bad arguments");
+    if (Npad % 128) RNH_FAIL(RNH_E_RANGE, "rnh_wino_pack_weights: Npad must be a multiple of 128");
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(wgrid_for((long)ns * 16 * Npad * 4 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias, wp,
+                       biasp, kbase, knv, kcoff, colmap, ns, Npad, Cout, Cin, kstride, transposed);
+    RNH_CHECK_LAUNCH("rnh_wino_pack_weights");
+    return 0;
+}
+
+extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: null args");
+    const rnh_conv_args_t &a = *args;
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
+    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
+    if (a.Npad < 128 || a.Npad % 128) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 128");
+    int steps = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
+        if (a.src[i].scale != 1 || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: sources with scale 1 and no second pointer only");
+        if ((a.src[i].C & 1) || (a.src[i].c0 & 1)) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: 8-byte aligned channel ranges");
+        steps += a.src[i].nch / 4;
+    }
+    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
+    const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
+    const long ntiles = (long)a.B * TY * TX;
+    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
+    const int MT = (int)((ntiles + 31) / 32), NT = a.Npad / 128;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(MT * NT)), block(256);
+    switch (a.epilogue) {
+        case RNH_EPI_STORE:
+            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
+            for (int d = 0; d < a.ndst; ++d)
+                if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
+            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_LSTM:
+            if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
+            if (a.Npad != 128 * ((a.hd + 31) / 32)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (plans.lstm_colmap)");
+            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        default:
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+    }
+    RNH_CHECK_LAUNCH("rnh_conv_wino");
+    return 0;
+}

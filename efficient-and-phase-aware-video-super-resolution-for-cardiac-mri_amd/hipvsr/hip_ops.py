@@ -103,6 +103,8 @@ class HipOps:
             if isinstance(plan, ConvPlan):
                 m = dict(kbase=self._i32(plan.kbase), knv=self._i32(plan.knv), ktap=self._i32(plan.ktap),
                          kcoff=self._i32(plan.kcoff), colmap=self._i32(plan.colmap))
+                if plan.wino:
+                    m.update(wkbase=self._i32(plan.wkbase), wknv=self._i32(plan.wknv), wkcoff=self._i32(plan.wkcoff))
             else:
                 m = dict(rowmap=self._i32(plan.rowmap), colmap=self._i32(plan.colmap), xgrp=self._i32(plan.xgrp),
                          ygrp=self._i32(plan.ygrp))
@@ -118,9 +120,15 @@ class HipOps:
         m = self._plan_maps(plan)
         buf = self._packed.get(id(plan))
         if buf is None:
-            buf = (self.empty(plan.nk * plan.Npad * 16), self.empty(plan.Npad))
+            buf = (self.empty(plan.wns * 16 * plan.Npad * 4 if plan.wino else plan.nk * plan.Npad * 16), self.empty(plan.Npad))
             self._packed[id(plan)] = buf
         wp, bp = buf
+        if plan.wino:
+            L.check(self.lib.rnh_wino_pack_weights(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['wkbase']), _ptr(m['wknv']),
+                                                   _ptr(m['wkcoff']), _ptr(m['colmap']), plan.wns, plan.Npad, plan.Cout, plan.Cin,
+                                                   plan.kstride, int(plan.transposed), self._stream()),
+                    f'rnh_wino_pack_weights({plan.name})')
+            return
         L.check(self.lib.rnh_pack_weights(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['kbase']), _ptr(m['knv']),
                                           _ptr(m['ktap']), _ptr(m['kcoff']), _ptr(m['colmap']), plan.nk, plan.Npad,
                                           plan.Cout, plan.Cin, plan.ntaps, plan.kstride, int(plan.transposed),
@@ -187,6 +195,12 @@ class HipOps:
             a.hd = hd
             a.c_prev, a.h_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out'])
             a.c_out, a.gates_out = _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
+        if plan.wino:
+            if any(s_.scale != 1 or s_.add is not None for s_ in srcs):
+                raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes plain sources only')
+            a.nk = plan.wns
+            L.check(self.lib.rnh_conv_wino(C.byref(a), self._stream()), f'rnh_conv_wino({plan.name})')
+            return
         L.check(self.lib.rnh_conv_igemm(C.byref(a), self._stream()), f'rnh_conv_igemm({plan.name})')
 
     @staticmethod

@@ -64,7 +64,7 @@ class ConvPlan:
     """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
 
     def __init__(self, name, wkey, bkey, wshape, ksegs: List[KSeg], colmap: List[int], tile=None,
-                 epilogue=L.EPI_STORE, transposed=False, kstride=1):
+                 epilogue=L.EPI_STORE, transposed=False, kstride=1, wino=False):
         self.name, self.wkey, self.bkey = name, wkey, bkey
         self.Cout, self.Cin, kh, kw = wshape
         self.ntaps = kh * kw
@@ -83,6 +83,16 @@ class ConvPlan:
                     self.ktap.append(t)
                     self.kcoff.append(sg.kcoff)
         self.nk = len(self.kbase)
+        # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
+        self.wino = bool(wino) and self.ntaps == 9 and epilogue in (L.EPI_STORE, L.EPI_LSTM) and self.Npad % 128 == 0
+        if self.wino:
+            self.wkbase, self.wknv, self.wkcoff = [], [], []
+            for sg in ksegs:
+                for q in range(sg.nch // 4):
+                    self.wkbase.append(sg.kbase + q * 4 * kstride)
+                    self.wknv.append(max(0, min(4, sg.nvalid - q * 4)))
+                    self.wkcoff.append(sg.kcoff)
+            self.wns = len(self.wkbase)
 
     def __repr__(self):
         return f'ConvPlan({self.name}, nk={self.nk}, Npad={self.Npad}, tile={self.tile})'
@@ -211,13 +221,13 @@ class NetPlans:
                 wk, bk = f'{d}_lstm_block.cell_list.{l}.conv.weight', f'{d}_lstm_block.cell_list.{l}.conv.bias'
                 ws = (4 * hd, cin, 3, 3)
                 second = hd if cfg.memory else cx
-                import os
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) else lstm_colmap(hd)
+                wino = os.environ.get('RNH_WINO', '0') != '0' and ltile == L.TILE_128x128_G
                 full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
-                                tile=ltile, epilogue=L.EPI_LSTM)
+                                tile=ltile, epilogue=L.EPI_LSTM, wino=wino)
                 first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
-                                 epilogue=L.EPI_LSTM) if cfg.memory else full
+                                 epilogue=L.EPI_LSTM, wino=wino) if cfg.memory else full
                 dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True)
                 wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
                                   [YSeg(4 * hd, 4 * hd, 0)])

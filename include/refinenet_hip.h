@@ -119,6 +119,18 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
                      const int32_t *colmap, int nk, int Npad, int Cout, int Cin, int ntaps, int kstride,
                      int transposed, void *stream);
 
+/* The same 3x3 convolution in Winograd form F(2x2, 3x3) (csrc/conv_wino.hip): 16 GEMMs in the transform domain, 2.25x
+ * fewer MFMA passes; input and output transforms fused (nothing of the transform domain reaches memory).  Same
+ * rnh_conv_args_t, with: ntaps = 9; every source scale 1, ptr2 = 0, nch % 4 == 0; nk = number of 4-channel steps
+ * (sum_src nch/4); wp from rnh_wino_pack_weights; Npad a multiple of 128; tile ignored; epilogue RNH_EPI_STORE or
+ * RNH_EPI_LSTM.  Results differ from rnh_conv_igemm by fp32 rounding of the transforms only. */
+int rnh_conv_wino(const rnh_conv_args_t *args /* host */, void *stream);
+/* wp[s][xi][n][q] = (G g G^T)[xi], g = the 3x3 filter of (column n, input channel kbase[s] + q*kstride) - the mapping
+ * conventions of rnh_pack_weights with 4-channel steps (q >= knv[s]: zero); biasp[n] as there. */
+int rnh_wino_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kbase,
+                          const int32_t *knv, const int32_t *kcoff, const int32_t *colmap, int ns, int Npad, int Cout,
+                          int Cin, int kstride, int transposed, void *stream);
+
 /* Work-item shapes of rnh_conv_wgrad: one wave computes 32*MI rows x 32*NI columns of dW (code = MI << 4 | NI) */
 #define RNH_WTILE_128x64 0x42
 #define RNH_WTILE_64x128 0x24

@@ -1,0 +1,32 @@
+"""Cycle stamps of block 0 of the Winograd ConvLSTM kernel (library built with -DRNH_STAMPS into lib_stamps.so)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')
+sys.path[:0] = [ROOT, PKG]
+os.environ['RNH_WINO'] = '1'
+import torch
+from hipvsr import lib as L
+L.LIB_PATH = os.path.join(PKG, 'hipvsr', 'lib_stamps.so')
+from hipvsr.hip_ops import HipOps
+from hipvsr.plans import NetPlans, Src
+from hipvsr.spec import NetConfig, state_dict_spec
+dev = torch.device('cuda:0')
+cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True, num_updated_frames=6, positional_encoding=True)
+P = NetPlans(cfg); ops = HipOps(dev)
+params = {k: torch.randn(*s, device=dev) * 0.05 for k, s in state_dict_spec(cfg).items()}
+pl = P.lstm[('forward', 1)]
+ops.pack(pl['full'], params[pl['full'].wkey], params[pl['full'].bkey])
+N, H, W = 8, 128, 128
+x, hp, cp = (torch.randn(N, H, W, 64, device=dev) for _ in range(3))
+ho, co, go = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256)
+for _ in range(3):
+    ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 8)()
+ops.lib.rnh_debug_wino_stamps.argtypes = [ctypes.c_void_p]
+ops.lib.rnh_debug_wino_stamps(buf)
+z = list(buf)
+names = ['start', 'setup done', 'first chunk staged', 'loop done', 'gates exchanged', 'end']
+for i in range(1, 6):
+    print(f'{names[i]:22s} +{z[i] - z[i - 1]:8d} cycles (total {z[i] - z[0]})')
+print('inside the loop: staging stores + barrier', z[6], 'cycles')
