@@ -21,6 +21,7 @@
 // Same operand conventions as rnh_conv_igemm (rnh_conv_args_t: multi-source K without concatenation, destination
 // segments, packed bias); sources must have scale 1.  Epilogues: RNH_EPI_STORE, RNH_EPI_LSTM.
 #include "rnh_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -69,6 +70,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wdesc(const float *p) {
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
+// the same descriptor as a plain SGPR quadruple for the asm loads
+__device__ __forceinline__ i32x4 sdesc(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+    d[2] = 0x7fffffff;
+    d[3] = 0x00020000;
+    return d;
+}
 __device__ __forceinline__ f32x2 wld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
@@ -95,79 +106,120 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
     const int m0 = mt * 32;
 
-    // ---- staging: the 4x4 patches of the block's 32 tiles, 16 channels at a time, through LDS ------------------
-    // (lanes of one tile row sit 2 pixels = 512 B apart in memory: loading patches per lane would touch 32 cache
-    // lines per instruction.)  Thread = patch pixel pp of tiles tsub, tsub + 4, ...: 16-byte loads, 64 B per pixel.
-    // LDS layout [patch pixel][tile][18]: the 8-byte reads of a half-wave (32 tiles, stride 18 floats) cover all 64
-    // banks exactly once.
-    const int q4 = threadIdx.x & 3, pp = (threadIdx.x >> 2) & 15, tsub = threadIdx.x >> 6;
-    const int pi = pp >> 2, pj = pp & 3;
+    // ---- staging: B^T d B of the block's 32 tiles, 16 channels at a time, through LDS ---------------------------
+    // (Lanes of one MFMA row block sit 2 pixels = 512 B apart in memory: loading patches per lane would touch 32 cache
+    // lines per instruction; and the four waves of the block need the same transformed patches.)  Thread = (tile ts,
+    // channel pair cp of the chunk): 16 8-byte loads (the 8 threads of a tile read 64 contiguous bytes per pixel), the
+    // input transform once per block, 16 8-byte LDS writes.  LDS layout [xi][tile][18]: the 8-byte reads of a
+    // half-wave (32 tiles, stride 18 floats) cover all 64 banks exactly once.
+    const int ts = threadIdx.x >> 3, cp = threadIdx.x & 7;
     const int t0 = m0 < ntiles ? m0 : 0;
     const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
     const int base_pix = (img0 * H + 2 * ty0 - 1) * W - 1;      // at or before every pixel the block touches
-    int pixrel[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int t = m0 + tsub + 4 * i;
+    int pixrel[16];
+    {
+        const int t = m0 + ts;
         const bool tok = t < ntiles;
         const int tt = tok ? t : t0;
         const int img = tt / (TY * TX), trem = tt - img * TY * TX, ty = trem / TX, tx = trem - ty * TX;
-        const int y = 2 * ty - 1 + pi, x = 2 * tx - 1 + pj;
-        const bool ok = tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        pixrel[i] = ok ? (img * H + y) * W + x - base_pix : -1;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int y = 2 * ty - 1 + (p >> 2), x = 2 * tx - 1 + (p & 3);
+            const bool ok = tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            pixrel[p] = ok ? (img * H + y) * W + x - base_pix : -1;
+        }
     }
     // loader state: source and 16-channel chunk inside it
-    int si = 0, cchunk = 0, nchunk = (P.src[0].nch + 15) >> 4, nchs = P.src[0].nch;
-    int voff[8];
-    __amdgpu_buffer_rsrc_t adesc;
+    int si = 0, cchunk = 0, nchunk = P.src[0].nch >> 4;
+    int voff[16];
+    i32x4 adesc;
     auto setup_src = [&](int sidx) {
         const rnh_src_t &S = P.src[sidx];
-        adesc = wdesc(S.ptr + S.c0 + ((long)S.img_off * H * W + base_pix) * S.C);
+        adesc = sdesc(S.ptr + S.c0 + ((long)S.img_off * H * W + base_pix) * S.C);
         const int C4 = S.C * 4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) voff[i] = pixrel[i] < 0 ? -1 : pixrel[i] * C4 + q4 * 16;
-        nchunk = (S.nch + 15) >> 4;
-        nchs = S.nch;
+        for (int p = 0; p < 16; ++p) voff[p] = pixrel[p] < 0 ? -1 : pixrel[p] * C4 + cp * 8;
+        nchunk = S.nch >> 4;
     };
     setup_src(0);
-    f32x4 stg[8];
-    auto gload = [&]() {                                   // next chunk of the source list -> registers
-        const bool qok = cchunk * 16 + q4 * 4 < nchs;       // a source may end in a partial chunk (multiple of 4 channels)
+
+    // All vector-memory and LDS reads of the loop are volatile asm: they stay where they are written (hipcc sinks
+    // plain loads to their first use and then waits for each one with vmcnt(0) / lgkmcnt(0) between two MFMAs), and the
+    // waits are counted by hand.  Each wait names the registers it covers exactly once as "+v" operands, which is what
+    // orders their uses behind it.
+    f32x2 stg[16];
+    auto gload = [&]() {                                   // next chunk of the source list -> registers (16 loads)
+        const int soff = __builtin_amdgcn_readfirstlane(cchunk * 64);
+        asm volatile("s_nop 4" ::: "memory");              // SGPR descriptor / offset written shortly before
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(adesc, qok ? voff[i] : -1, cchunk * 64, 0));
+        for (int p = 0; p < 16; ++p)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(stg[p]) : "v"(voff[p]), "s"(adesc), "s"(soff) : "memory");
         if (++cchunk == nchunk) {
             cchunk = 0;
             if (++si < P.nsrc) setup_src(si);
         }
     };
     constexpr int CHS = 18, BUF = 16 * 32 * CHS;
-    auto sts = [&](int buf) {
+    auto xform_store = [&](int buf) {                       // V = B^T d B on the thread's two channels, to LDS
+        asm volatile("s_waitcnt vmcnt(16)"
+                     : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
+                       "+v"(stg[8]), "+v"(stg[9]), "+v"(stg[10]), "+v"(stg[11]), "+v"(stg[12]), "+v"(stg[13]), "+v"(stg[14]),
+                       "+v"(stg[15]));
+        f32x2 tq[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float *o = stage + buf * BUF + (pp * 32 + tsub + 4 * i) * CHS + q4 * 4;
-            *reinterpret_cast<f32x2 *>(o) = f32x2{stg[i][0], stg[i][1]};
-            *reinterpret_cast<f32x2 *>(o + 2) = f32x2{stg[i][2], stg[i][3]};
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = stg[0 * 4 + j] - stg[2 * 4 + j];
+            tq[1 * 4 + j] = stg[1 * 4 + j] + stg[2 * 4 + j];
+            tq[2 * 4 + j] = stg[2 * 4 + j] - stg[1 * 4 + j];
+            tq[3 * 4 + j] = stg[1 * 4 + j] - stg[3 * 4 + j];
+        }
+        float *o = stage + buf * BUF + ts * CHS + 2 * cp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * 32 * CHS) = tq[i * 4 + 0] - tq[i * 4 + 2];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * 32 * CHS) = tq[i * 4 + 1] + tq[i * 4 + 2];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * 32 * CHS) = tq[i * 4 + 2] - tq[i * 4 + 1];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * 32 * CHS) = tq[i * 4 + 1] - tq[i * 4 + 3];
         }
     };
 
-    const __amdgpu_buffer_rsrc_t bdesc = wdesc(P.wp + (long)((nt * 4 + wave) * 32) * 4);
-    const int boff = (l31 * 4 + 2 * kh) * 4;
+    const i32x4 bdesc = sdesc(P.wp + (long)((nt * 4 + wave) * 32) * 4);
     const int xistride = P.Npad * 16;                       // bytes between two transform positions of one step
-    auto loadb = [&](f32x2 *u, int s) {
+    int boffx[16];                                          // per-lane byte offset of the 16 positions inside a step
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) boffx[xi] = (l31 * 4 + 2 * kh) * 4 + xi * xistride;
+    auto loadb = [&](f32x2 *u, int sb) {                    // transformed weights of step sb: 16 loads
 #ifdef WX_NOB
-        if (s > 0) return;
+        if (sb > 0) return;
 #endif
+        const int soff = __builtin_amdgcn_readfirstlane(sb * 16 * xistride);
+        asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) u[xi] = wld2(bdesc, boff, (s * 16 + xi) * xistride);
+        for (int xi = 0; xi < 16; ++xi)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(u[xi]) : "v"(boffx[xi]), "s"(bdesc), "s"(soff) : "memory");
     };
-    auto loadd = [&](f32x2 *d, int buf, int q) {            // the lane's patch, channels 4q + 2kh, +1 of the staged chunk
-        const float *src = stage + buf * BUF + l31 * CHS + q * 4 + 2 * kh;
-#ifdef WX_NOD
-        if (q > 0 || buf) return;
+    const unsigned lds0 = (unsigned)(size_t)stage;          // LDS byte address of the staging area
+    const unsigned vlane = lds0 + (l31 * CHS + 2 * kh) * 4;
+    auto loadv = [&](f32x2 *V, int buf, int q) {            // the lane's tile, channels 4q + 2kh, +1 of the staged chunk
+        const unsigned adr = vlane + buf * BUF * 4 + q * 16;
+#define RNH_DSR(xi) asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(V[xi]) : "v"(adr), "i"((xi) * 32 * CHS * 4) : "memory")
+        RNH_DSR(0); RNH_DSR(1); RNH_DSR(2); RNH_DSR(3); RNH_DSR(4); RNH_DSR(5); RNH_DSR(6); RNH_DSR(7);
+        RNH_DSR(8); RNH_DSR(9); RNH_DSR(10); RNH_DSR(11); RNH_DSR(12); RNH_DSR(13); RNH_DSR(14); RNH_DSR(15);
+#undef RNH_DSR
+    };
+    auto wait_lds = [&](f32x2 *V) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]),
+                       "+v"(V[9]), "+v"(V[10]), "+v"(V[11]), "+v"(V[12]), "+v"(V[13]), "+v"(V[14]), "+v"(V[15]));
+    };
+    auto wait_vm = [&](f32x2 *u, auto keep) {
+#ifdef WX_NOB
+        return;
 #endif
-#pragma unroll
-        for (int p = 0; p < 16; ++p) d[p] = *reinterpret_cast<const f32x2 *>(src + p * 32 * CHS);
+        asm volatile("s_waitcnt vmcnt(%c16)"
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8]),
+                       "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15])
+                     : "i"(decltype(keep)::value));
     };
 
     f32x16 acc[16];
@@ -176,23 +228,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
 
-    auto compute = [&](const f32x2 *d, const f32x2 *u) {
-        // V = B^T d B on two channels at once (packed adds)
-        f32x2 tq[16], V[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tq[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-            tq[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-            tq[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-            tq[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
-            V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
-            V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
-            V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
-        }
+    auto compute = [&](const f32x2 *V, const f32x2 *u) {
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi].x, u[xi].x, acc[xi], 0, 0, 0);
@@ -200,13 +236,11 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         }
     };
 
-    // ---- main loop over 16-channel chunks; chunk c+1 travels global -> registers under the MFMAs of chunk c ----
-    // P.nk counts 4-channel steps; the chunk list follows the sources (a source of nch channels = ceil(nch/16) chunks,
-    // the last one possibly short)
+    // ---- main loop over 16-channel chunks (4 steps of 4 channels); chunk c+1 travels global -> registers under the
+    // MFMAs of chunk c and is transformed into the other LDS buffer at its end ---------------------------------------
     int nchunks_total = 0;
-    for (int i = 0; i < P.nsrc; ++i) nchunks_total += (P.src[i].nch + 15) >> 4;
-    int csi = 0, cleft = P.src[0].nch;                      // compute-side view of the source list
-    f32x2 d0[16], d1[16], u0[16], u1[16];
+    for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch >> 4;
+    f32x2 V0[16], V1[16], u0[16], u1[16];
     if (threadIdx.x < 32) {
         const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
         const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
@@ -214,43 +248,63 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     }
     WSTAMP(1);
     gload();
-    sts(0);
+    loadb(u0, 0);                                            // 16 loads younger than the staging loads: vmcnt(16) in xform_store
+    xform_store(0);
     __syncthreads();
     WSTAMP(2);
     int s = 0;                                               // global 4-channel step index (weights)
-    loadb(u0, 0);
+    const int last = P.nk - 1;
+    loadv(V0, 0, 0);
+    using K16 = std::integral_constant<int, 16>;
+    using K32 = std::integral_constant<int, 32>;
     for (int c = 0; c < nchunks_total; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks_total) gload();
-        const int nq = cleft >= 16 ? 4 : cleft >> 2;          // steps in this chunk
-        cleft -= 16;
-        if (cleft <= 0 && ++csi < P.nsrc) cleft = P.src[csi].nch;
-        loadd(d0, buf, 0);
-        for (int q = 0; q < nq; q += 2) {
-            const bool more1 = q + 1 < nq, more2 = q + 2 < nq;
-            if (more1) { loadd(d1, buf, q + 1); }
-            if (s + 1 < P.nk) loadb(u1, s + 1);
-            compute(d0, u0);
-            ++s;
-            if (more1) {
-                if (more2) loadd(d0, buf, q + 2);
-                if (s + 1 < P.nk) loadb(u0, s + 1);
-                compute(d1, u1);
-                ++s;
-            } else {
-#pragma unroll
-                for (int xi = 0; xi < 16; ++xi) u0[xi] = u1[xi];
-            }
+        const bool more = c + 1 < nchunks_total;
+        // step 0: [staging loads of the next chunk] [weights of step 1] | MFMAs of step 0
+        wait_lds(V0);
+        loadv(V1, buf, 1);
+        if (more) {
+            gload();
+            loadb(u1, s + 1);
+            wait_vm(u0, K32());
+        } else {
+            loadb(u1, s + 1);
+            wait_vm(u0, K16());
         }
+        compute(V0, u0);
+        // step 1
+        wait_lds(V1);
+        loadv(V0, buf, 2);
+        loadb(u0, s + 2);
+        wait_vm(u1, K16());
+        compute(V1, u1);
+        // step 2
+        wait_lds(V0);
+        loadv(V1, buf, 3);
+        loadb(u1, s + 3);
+        wait_vm(u0, K16());
+        compute(V0, u0);
+        // step 3: the weights of the next chunk's first step (past the end: the last step again, unused)
+        // and the transform of the staged chunk into the other LDS buffer (nobody reads it during this chunk): plain
+        // code in front of the MFMAs, so that hipcc interleaves its packed adds and LDS writes with them
+        wait_lds(V1);
+        loadb(u0, s + 4 < last ? s + 4 : last);
+        wait_vm(u1, K16());
+        if (more) xform_store(buf ^ 1);
+        compute(V1, u1);
+        s += 4;
 #ifdef RNH_STAMPS
         const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
-        if (c + 1 < nchunks_total) sts(buf ^ 1);
-        __syncthreads();
+        // LDS writes done, then the barrier - not __syncthreads(), whose fence would also wait (vmcnt(0)) for the
+        // weight prefetch that was just issued
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) loadv(V0, buf ^ 1, 0);
 #ifdef RNH_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] += __builtin_readcyclecounter() - ts0;
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last, unused weight prefetch
 
     WSTAMP(3);
     // ---- output transform Y = A^T M A per accumulator register, then the epilogue -------------------------------
@@ -294,19 +348,30 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
                 cpv[v] = P.c_prev ? P.c_prev[((long)tpix[trl] + poff2) * hd + hc] : 0.f;
             }
         }
-        // phase 1: every wave activates its gate (wave 0..3 = i, f, o, g) and parks it in LDS (and in gates_out)
+        // phase 1: every wave activates its gate (wave 0..3 = i, f, o, g) and parks it in LDS (and in gates_out).
+        // Four accumulator registers at a time: 16 independent exp / rcp chains for the one wave on this SIMD.
         if (full) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float Y[4];
-                out4(v, Y);
-                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
-                float *gp = P.gates_out ? P.gates_out + (long)tpix[trl] * 4 * hd + wave * hd + hc : nullptr;
+            for (int v0 = 0; v0 < 16; v0 += 4) {
+                float Y[4][4], g[4][4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float g = wave == 3 ? w_tanh(Y[p]) : w_sigmoid(Y[p]);
-                    xch[((wave * 32 + trl) * 4 + p) * 32 + l31] = g;
-                    if (gp) gp[(long)((p >> 1) * W + (p & 1)) * 4 * hd] = g;
+                for (int dv = 0; dv < 4; ++dv) out4(v0 + dv, Y[dv]);
+                if (wave == 3) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) g[e >> 2][e & 3] = w_tanh(Y[e >> 2][e & 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) g[e >> 2][e & 3] = w_sigmoid(Y[e >> 2][e & 3]);
+                }
+#pragma unroll
+                for (int dv = 0; dv < 4; ++dv) {
+                    const int v = v0 + dv, trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
+                    float *gp = P.gates_out ? P.gates_out + (long)tpix[trl] * 4 * hd + wave * hd + hc : nullptr;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        xch[((wave * 32 + trl) * 4 + p) * 32 + l31] = g[dv][p];
+                        if (gp) gp[(long)((p >> 1) * W + (p & 1)) * 4 * hd] = g[dv][p];
+                    }
                 }
             }
         } else {
@@ -421,7 +486,7 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     for (int i = 0; i < a.nsrc; ++i) {
         if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
         if (a.src[i].scale != 1 || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: sources with scale 1 and no second pointer only");
-        if ((a.src[i].C & 1) || (a.src[i].c0 & 1)) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: 8-byte aligned channel ranges");
+        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
         steps += a.src[i].nch / 4;
     }
     if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);

@@ -84,7 +84,8 @@ class ConvPlan:
                     self.kcoff.append(sg.kcoff)
         self.nk = len(self.kbase)
         # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
-        self.wino = bool(wino) and self.ntaps == 9 and epilogue in (L.EPI_STORE, L.EPI_LSTM) and self.Npad % 128 == 0
+        self.wino = bool(wino) and self.ntaps == 9 and epilogue in (L.EPI_STORE, L.EPI_LSTM) and self.Npad % 128 == 0 and \
+            all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in ksegs)
         if self.wino:
             self.wkbase, self.wknv, self.wkcoff = [], [], []
             for sg in ksegs:
@@ -223,12 +224,13 @@ class NetPlans:
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) else lstm_colmap(hd)
-                wino = os.environ.get('RNH_WINO', '0') != '0' and ltile == L.TILE_128x128_G
+                wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G
                 full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
                                 tile=ltile, epilogue=L.EPI_LSTM, wino=wino)
                 first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
                                  epilogue=L.EPI_LSTM, wino=wino) if cfg.memory else full
-                dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True)
+                dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
+                                 wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
                 wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
                                   [YSeg(4 * hd, 4 * hd, 0)])
                 self.lstm[(d, l)] = dict(full=full, first=first, dgrad=dgrad, wgrad=wgrad, cx=cx, hd=hd, second=second)

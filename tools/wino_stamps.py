@@ -20,7 +20,7 @@ N, H, W = 8, 128, 128
 x, hp, cp = (torch.randn(N, H, W, 64, device=dev) for _ in range(3))
 ho, co, go = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256)
 for _ in range(3):
-    ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
+    ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=(None if os.environ.get('NOGATES') else go)))
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8)()
 ops.lib.rnh_debug_wino_stamps.argtypes = [ctypes.c_void_p]
