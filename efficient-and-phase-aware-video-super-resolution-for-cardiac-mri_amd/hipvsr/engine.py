@@ -134,7 +134,11 @@ class RefineNetEngine:
             R = ops.empty(nwin * N, H, W, Cl)
             if P.pos:
                 R1 = ops.empty(nwin * N, H, W, P.C1p)
-                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+                if P.r1_wino:
+                    ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+                    ops.conv(P.r1_fwd_p, [sc for sc in srcs if sc.t is P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols, accumulate=True)])
+                else:
+                    ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                 if P.xcol:
                     ops.refine_xcol_fwd([Hf, Hbk, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
                 ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
@@ -293,8 +297,15 @@ class RefineNetEngine:
                 acc(b1)
                 ops.wgrad(P.r1_wgrad, xs, [Src(dR)], TN, H, W, grads[k1], grads[b1], accumulate=a)
             # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
-            ops.conv(P.r1_dgrad, [Src(gsrc, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
-                     dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+            if P.r1_wino:
+                nm = P.r1_cols
+                ops.conv(P.r1_dgrad_h, [Src(gsrc, nch=nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                         dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+                ops.conv(P.r1_dgrad_x, [Src(gsrc, c0=nm, nch=P.C1p - nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                         dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+            else:
+                ops.conv(P.r1_dgrad, [Src(gsrc, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                         dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
 
             # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
             # Same wavefront as the forward, reversed: cell (d, l, k) needs the input gradient of (d, l+1, k) (an

@@ -237,7 +237,7 @@ class NetPlans:
 
         Cl, w = self.Cl, cfg.refine_window_size
         self.pos = bool(cfg.positional_encoding)
-        self.xcol = False
+        self.xcol = self.r1_wino = False
         if self.pos:
             C1 = 2 * Cl + 1
             self.C1, self.C1p = C1, r4(C1)
@@ -255,6 +255,21 @@ class NetPlans:
             self.r1_cols = C1 - 1 if self.xcol else self.C1p
             self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs,
                                    list(range(C1 - 1)) if self.xcol else list(range(C1)) + [-1] * (self.C1p - C1))
+            # Winograd split of the two big refine convolutions (only together with the side path, which leaves 2*Cl
+            # columns / K channels): the hidden-state sources go through rnh_conv_wino, the 4-channel phase planes (forward)
+            # and the odd channel of dR1 (data gradient) through the implicit GEMM, accumulating into the same output
+            self.r1_wino = self.xcol and (2 * Cl) % 128 == 0 and os.environ.get('RNH_WINO', '1') != '0' and \
+                os.environ.get('RNH_WINO_REFINE', '1') != '0'
+            if self.r1_wino:
+                hsegs = [sg for sg in segs if sg.nch == Cl]
+                psegs = [sg for sg in segs if sg.nch == 4]
+                self.r1_fwd_h = ConvPlan('refine1.fwd.h', k1, b1, ws1, hsegs, list(range(C1 - 1)), wino=True)
+                self.r1_fwd_p = ConvPlan('refine1.fwd.p', k1, None, ws1, psegs, list(range(C1 - 1)))
+                self.r1_dgrad_h = ConvPlan('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
+                                           list(range(2 * Cl)), transposed=True, wino=True)
+                self.r1_dgrad_x = ConvPlan('refine1.dgrad.x', k1, None, ws1,
+                                           [KSeg(self.C1p - C1 + 1, 1, C1 - 1, kcoff=j * C1) for j in range(w)], list(range(2 * Cl)),
+                                           transposed=True)
             self.r2_fwd = ConvPlan('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
@@ -303,6 +318,8 @@ class NetPlans:
         for v in self.lstm.values():
             out += [v['full'], v['first'], v['dgrad']]
         out += [self.r1_fwd, self.r1_dgrad]
+        if self.r1_wino:
+            out += [self.r1_fwd_h, self.r1_fwd_p, self.r1_dgrad_h, self.r1_dgrad_x]
         if self.pos:
             out += [self.r2_fwd, self.r2_dgrad]
         for u in self.up:
