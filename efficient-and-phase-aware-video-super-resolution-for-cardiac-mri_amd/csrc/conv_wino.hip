@@ -19,7 +19,7 @@
 //     in LDS and each wave finishes one pixel of every tile (c' = f c + i g, h' = o tanh c').
 //
 // Same operand conventions as rnh_conv_igemm (rnh_conv_args_t: multi-source K without concatenation, destination
-// segments, packed bias); sources must have scale 1.  Epilogues: RNH_EPI_STORE, RNH_EPI_LSTM.
+// segments, packed bias, pixel-unshuffled sources of one common scale).  Epilogues: STORE, PS, LSTM.
 #include "rnh_common.h"
 #include <type_traits>
 
@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     __shared__ __attribute__((aligned(16))) float stage[2 * 16 * 32 * 18];     // 73.7 KB; the LSTM gate exchange reuses it
     float *xch = stage;
     __shared__ int tpix[32];                                  // top-left output pixel of the block's tiles (epilogue)
+    __shared__ int tcoord[32];                                // the same as (image << 20 | y << 10 | x), -1: no such tile
     WSTAMP(0);
 #ifdef RNH_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] = 0;
@@ -115,7 +116,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     const int ts = threadIdx.x >> 3, cp = threadIdx.x & 7;
     const int t0 = m0 < ntiles ? m0 : 0;
     const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
-    const int base_pix = (img0 * H + 2 * ty0 - 1) * W - 1;      // at or before every pixel the block touches
+    // sources may be the (sub_y, sub_x) phase of a scale-times larger image (pixel-unshuffle fused into the load);
+    // one scale for all sources, the phase goes into the descriptor base
+    const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
+    const int base_pix = (img0 * Hs + (2 * ty0 - 1) * sc) * Ws - sc;   // at or before every pixel the block touches
     int pixrel[16];
     {
         const int t = m0 + ts;
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         for (int p = 0; p < 16; ++p) {
             const int y = 2 * ty - 1 + (p >> 2), x = 2 * tx - 1 + (p & 3);
             const bool ok = tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            pixrel[p] = ok ? (img * H + y) * W + x - base_pix : -1;
+            pixrel[p] = ok ? (img * Hs + y * sc) * Ws + x * sc - base_pix : -1;
         }
     }
     // loader state: source and 16-channel chunk inside it
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     i32x4 adesc;
     auto setup_src = [&](int sidx) {
         const rnh_src_t &S = P.src[sidx];
-        adesc = sdesc(S.ptr + S.c0 + ((long)S.img_off * H * W + base_pix) * S.C);
+        adesc = sdesc(S.ptr + S.c0 + ((long)S.img_off * Hs * Ws + base_pix + S.sub_y * Ws + S.sub_x) * S.C);
         const int C4 = S.C * 4;
 #pragma unroll
         for (int p = 0; p < 16; ++p) voff[p] = pixrel[p] < 0 ? -1 : pixrel[p] * C4 + cp * 8;
@@ -147,13 +151,29 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     // plain loads to their first use and then waits for each one with vmcnt(0) / lgkmcnt(0) between two MFMAs), and the
     // waits are counted by hand.  Each wait names the registers it covers exactly once as "+v" operands, which is what
     // orders their uses behind it.
+    // Eight 8-byte buffer loads in ONE asm statement: the SGPR operands (descriptor, offset) may have been written by
+    // SALU / v_readfirstlane just before, and a VMEM instruction reading such a register needs 5 wait states that hipcc
+    // does not add around inline asm; inside one statement nothing can be scheduled between the s_nop and the loads.
+    auto ld8 = [&](f32x2 *dst, const int *vo, const i32x4 &desc, int soff) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx2 %0, %8, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %1, %9, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %2, %10, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %3, %11, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %4, %12, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %5, %13, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %6, %14, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %7, %15, %16, %17 offen"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7])
+            : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]), "s"(desc), "s"(soff)
+            : "memory");
+    };
     f32x2 stg[16];
     auto gload = [&]() {                                   // next chunk of the source list -> registers (16 loads)
         const int soff = __builtin_amdgcn_readfirstlane(cchunk * 64);
-        asm volatile("s_nop 4" ::: "memory");              // SGPR descriptor / offset written shortly before
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(stg[p]) : "v"(voff[p]), "s"(adesc), "s"(soff) : "memory");
+        ld8(stg, voff, adesc, soff);
+        ld8(stg + 8, voff + 8, adesc, soff);
         if (++cchunk == nchunk) {
             cchunk = 0;
             if (++si < P.nsrc) setup_src(si);
@@ -189,14 +209,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) boffx[xi] = (l31 * 4 + 2 * kh) * 4 + xi * xistride;
     auto loadb = [&](f32x2 *u, int sb) {                    // transformed weights of step sb: 16 loads
-#ifdef WX_NOB
-        if (sb > 0) return;
-#endif
         const int soff = __builtin_amdgcn_readfirstlane(sb * 16 * xistride);
-        asm volatile("s_nop 4" ::: "memory");
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
-            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(u[xi]) : "v"(boffx[xi]), "s"(bdesc), "s"(soff) : "memory");
+        ld8(u, boffx, bdesc, soff);
+        ld8(u + 8, boffx + 8, bdesc, soff);
     };
     const unsigned lds0 = (unsigned)(size_t)stage;          // LDS byte address of the staging area
     const unsigned vlane = lds0 + (l31 * CHS + 2 * kh) * 4;
@@ -213,9 +228,6 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
                        "+v"(V[9]), "+v"(V[10]), "+v"(V[11]), "+v"(V[12]), "+v"(V[13]), "+v"(V[14]), "+v"(V[15]));
     };
     auto wait_vm = [&](f32x2 *u, auto keep) {
-#ifdef WX_NOB
-        return;
-#endif
         asm volatile("s_waitcnt vmcnt(%c16)"
                      : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8]),
                        "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15])
@@ -245,6 +257,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
         const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
         tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
+        tcoord[threadIdx.x] = tr < ntiles ? (im << 20) | (2 * yy << 10) | (2 * xx) : -1;
     }
     WSTAMP(1);
     gload();
@@ -253,24 +266,24 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     __syncthreads();
     WSTAMP(2);
     int s = 0;                                               // global 4-channel step index (weights)
-    const int last = P.nk - 1;
     loadv(V0, 0, 0);
     using K16 = std::integral_constant<int, 16>;
-    using K32 = std::integral_constant<int, 32>;
-    for (int c = 0; c < nchunks_total; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < nchunks_total;
+    using K0 = std::integral_constant<int, 0>;
+    // One chunk = 4 steps.  The loop body (every chunk but the last) has no branch: a register that is the target of an
+    // asynchronous asm load must have exactly one definition per iteration, or hipcc reconciles the definitions at the
+    // join with v_mov copies - executed before the load has landed (observed: about one workgroup in 10^5 summed
+    // stale operands).  The last chunk is peeled off through the same lambda.
+    auto chunk = [&](const int buf, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
         // step 0: [staging loads of the next chunk] [weights of step 1] | MFMAs of step 0
         wait_lds(V0);
         loadv(V1, buf, 1);
-        if (more) {
-            gload();
-            loadb(u1, s + 1);
-            wait_vm(u0, K32());
-        } else {
-            loadb(u1, s + 1);
-            wait_vm(u0, K16());
-        }
+        // (the staging loads are issued behind the wait, not in front of it: a staging load whose 64 lanes are all
+        // outside the image never goes to memory and returns ahead of older loads, so it must not be among the loads
+        // a counted wait leaves in flight)
+        wait_vm(u0, K0());
+        if constexpr (more) gload();
+        loadb(u1, s + 1);
         compute(V0, u0);
         // step 1
         wait_lds(V1);
@@ -284,27 +297,26 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         loadb(u1, s + 3);
         wait_vm(u0, K16());
         compute(V0, u0);
-        // step 3: the weights of the next chunk's first step (past the end: the last step again, unused)
-        // and the transform of the staged chunk into the other LDS buffer (nobody reads it during this chunk): plain
-        // code in front of the MFMAs, so that hipcc interleaves its packed adds and LDS writes with them
+        // step 3: the weights of the next chunk's first step and the transform of the staged chunk into the other LDS
+        // buffer (nobody reads it during this chunk): plain code in front of the MFMAs, so that hipcc interleaves its
+        // packed adds and LDS writes with them.  Nothing is prefetched past the end.
         wait_lds(V1);
-        loadb(u0, s + 4 < last ? s + 4 : last);
-        wait_vm(u1, K16());
-        if (more) xform_store(buf ^ 1);
+        if constexpr (more) {
+            loadb(u0, s + 4);
+            wait_vm(u1, K16());
+            xform_store(buf ^ 1);
+        } else {
+            wait_vm(u1, K0());
+        }
         compute(V1, u1);
         s += 4;
-#ifdef RNH_STAMPS
-        const unsigned long long ts0 = __builtin_readcyclecounter();
-#endif
         // LDS writes done, then the barrier - not __syncthreads(), whose fence would also wait (vmcnt(0)) for the
         // weight prefetch that was just issued
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (more) loadv(V0, buf ^ 1, 0);
-#ifdef RNH_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] += __builtin_readcyclecounter() - ts0;
-#endif
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last, unused weight prefetch
+        if constexpr (more) loadv(V0, buf ^ 1, 0);
+    };
+    for (int c = 0; c + 1 < nchunks_total; ++c) chunk(c & 1, std::true_type());
+    chunk((nchunks_total - 1) & 1, std::false_type());
 
     WSTAMP(3);
     // ---- output transform Y = A^T M A per accumulator register, then the epilogue -------------------------------
@@ -425,27 +437,67 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         }
         WSTAMP(5);
     } else {
-        // destination segment of this lane's column
-        int seg = -1, cbase = 0;
-        for (int d = 0; d < P.ndst; ++d) {
-            if (seg < 0 && ncol < cbase + P.dst[d].ncols) seg = d;
-            if (seg < 0) cbase += P.dst[d].ncols;
-        }
-        if (seg < 0) return;
-        const rnh_dst_t &D = P.dst[seg];
-        float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
+        if constexpr (EPI == RNH_EPI_PS) {
+            // column n = (i*r + j)*cq + c  ->  pixel (r*y + i, r*x + j), channel c of the (B, rH, rW, cq) destination
+            const int r = P.ps_r, cq = P.ps_cq;
+            if (ncol >= cq * r * r) return;
+            const int sub = ncol / cq, c = ncol - sub * cq, pi = sub / r, pj = sub - pi * r;
+            float *dp = P.dst[0].ptr + c;
+            const long Wr = (long)W * r;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            float Y[4];
-            out4(v, Y);
-            int pix;
-            bool okx, oky;
-            if (!tile_of(v, pix, okx, oky)) continue;
+            for (int v = 0; v < 16; ++v) {
+                float Y[4];
+                out4(v, Y);
+                const int tc = tcoord[(v & 3) + 8 * (v >> 2) + 4 * kh];
+                if (tc < 0) continue;
+                const int im = tc >> 20, yy = (tc >> 10) & 1023, xx = tc & 1023;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (((p & 1) && !okx) || ((p >> 1) && !oky)) continue;
-                float *o = dp + ((long)pix + (p >> 1) * W + (p & 1)) * D.C;
-                *o = D.accumulate ? *o + Y[p] : Y[p];
+                for (int p = 0; p < 4; ++p) {
+                    const int y = yy + (p >> 1), x = xx + (p & 1);
+                    if (y >= H || x >= W) continue;
+                    dp[(((long)im * H + y) * r + pi) * Wr * cq + ((long)x * r + pj) * cq] = Y[p];
+                }
+            }
+        } else {
+            // destination segment of this lane's column
+            int seg = -1, cbase = 0;
+            for (int d = 0; d < P.ndst; ++d) {
+                if (seg < 0 && ncol < cbase + P.dst[d].ncols) seg = d;
+                if (seg < 0) cbase += P.dst[d].ncols;
+            }
+            if (seg < 0) return;
+            const rnh_dst_t &D = P.dst[seg];
+            float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
+            const bool full = m0 + 32 <= ntiles && !(H & 1) && !(W & 1);
+            if (full) {                                          // no per-element predicates
+                const long rowC = (long)W * D.C;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float Y[4];
+                    out4(v, Y);
+                    float *o = dp + (long)tpix[(v & 3) + 8 * (v >> 2) + 4 * kh] * D.C;
+                    if (D.accumulate) {
+                        const float a0 = o[0], a1 = o[D.C], a2 = o[rowC], a3 = o[rowC + D.C];
+                        o[0] = a0 + Y[0]; o[D.C] = a1 + Y[1]; o[rowC] = a2 + Y[2]; o[rowC + D.C] = a3 + Y[3];
+                    } else {
+                        o[0] = Y[0]; o[D.C] = Y[1]; o[rowC] = Y[2]; o[rowC + D.C] = Y[3];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float Y[4];
+                    out4(v, Y);
+                    int pix;
+                    bool okx, oky;
+                    if (!tile_of(v, pix, okx, oky)) continue;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        if (((p & 1) && !okx) || ((p >> 1) && !oky)) continue;
+                        float *o = dp + ((long)pix + (p >> 1) * W + (p & 1)) * D.C;
+                        *o = D.accumulate ? *o + Y[p] : Y[p];
+                    }
+                }
             }
         }
     }
@@ -485,13 +537,14 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     int steps = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
-        if (a.src[i].scale != 1 || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: sources with scale 1 and no second pointer only");
+        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
         if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
         steps += a.src[i].nch / 4;
     }
     if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
     const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
     const long ntiles = (long)a.B * TY * TX;
+    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: at most 2047 images of 1023 x 1023");
     if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
     const int MT = (int)((ntiles + 31) / 32), NT = a.Npad / 128;
     hipStream_t st = (hipStream_t)stream;
@@ -502,6 +555,11 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
             for (int d = 0; d < a.ndst; ++d)
                 if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
             hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_PS:
+            if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
+            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         case RNH_EPI_LSTM:
             if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");

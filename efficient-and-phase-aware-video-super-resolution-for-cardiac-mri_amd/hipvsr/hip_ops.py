@@ -196,8 +196,8 @@ class HipOps:
             a.c_prev, a.h_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out'])
             a.c_out, a.gates_out = _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
         if plan.wino:
-            if any(s_.scale != 1 or s_.add is not None for s_ in srcs):
-                raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes plain sources only')
+            if any(s_.scale != srcs[0].scale or s_.add is not None for s_ in srcs):
+                raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes sources of one scale, without a second operand')
             a.nk = plan.wns
             L.check(self.lib.rnh_conv_wino(C.byref(a), self._stream()), f'rnh_conv_wino({plan.name})')
             return

@@ -84,7 +84,7 @@ class ConvPlan:
                     self.kcoff.append(sg.kcoff)
         self.nk = len(self.kbase)
         # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
-        self.wino = bool(wino) and self.ntaps == 9 and epilogue in (L.EPI_STORE, L.EPI_LSTM) and self.Npad % 128 == 0 and \
+        self.wino = bool(wino) and self.ntaps == 9 and self.Npad % 128 == 0 and \
             all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in ksegs)
         if self.wino:
             self.wkbase, self.wknv, self.wkcoff = [], [], []
@@ -300,7 +300,8 @@ class NetPlans:
         for i, r in enumerate(rs):
             wk, bk = f'out_block.conv{i + 1}.weight', f'out_block.conv{i + 1}.bias'
             ws = (r * r * C, C, 3, 3)
-            fwd = ConvPlan(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS)
+            fwd = ConvPlan(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS,
+                           wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
             dgrad = ConvPlan(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
                              transposed=True, kstride=r * r)
             wgrad = WgradPlan(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
