@@ -318,3 +318,56 @@ def test_rccl_allreduce_of_flat_gradient_single_rank(g1):
     for k, p in net.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, before[k])
+
+
+def test_phase_plane_sources_many_images_vs_torch():
+    """Five 4-channel phase-plane sources over 30 images of 128x128 (the geometry of refine conv1 at BASELINE
+    config 2 with N = 2): half of the operand loads of such a call have all 64 lanes out of range.  The hardware
+    returns those ahead of older loads, which broke the counted waits of the implicit-GEMM kernel at this size
+    (whole workgroups summed stale registers; small shapes never showed it)."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import NetConfig, state_dict_spec
+    dev = _dev()
+    cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True,
+                    num_updated_frames=6, positional_encoding=True)
+    P, ops = NetPlans(cfg), HipOps(dev)
+    assert P.r1_wino
+    g = torch.Generator('cpu').manual_seed(5)
+    w1 = (torch.randn(state_dict_spec(cfg)[P.r1_fwd_p.wkey], generator=g) * 0.05).to(dev)
+    ops.pack(P.r1_fwd_p, w1, None)
+    N, H, W, Fr = 2, 128, 128, 19
+    B = (Fr - 4) * N
+    P4 = torch.zeros(Fr * N, H, W, 4, device=dev)
+    P4[..., 0] = torch.randn(Fr * N, 1, 1, generator=g).to(dev)
+    out = torch.zeros(B, H, W, 132, device=dev)
+    ops.conv(P.r1_fwd_p, [Src(P4, img_off=j * N) for j in range(5)], B, H, W, dsts=[Dst(out, 128, accumulate=True)])
+    torch.cuda.synchronize()
+    x = torch.cat([P4[j * N:j * N + B, ..., :1] for j in range(5)], -1).permute(0, 3, 1, 2).cpu()
+    ref = F.conv2d(x, w1[:128, [j * 129 + 128 for j in range(5)]].cpu(), None, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(out[..., :128].cpu(), ref, atol=1e-5, rtol=1e-5)
+
+
+def test_training_step_is_bitwise_repeatable():
+    """No atomics anywhere: the same step must give the same bits.  30 repetitions of BASELINE config 1 caught both
+    races that the asm-scheduled kernels had (tools/race_check.py, tools/race_kernel.py are the long versions)."""
+    from src.model.nets import RefineNet
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    net = RefineNet(**cfg)
+    net.load_state_dict(orc.init_state_dict(cfg, seed=1))
+    net = net.to(dev).train()
+    inputs, targets, pos = orc.synthetic_batch(cfg, 1, 3, 64, 64, seed=2)
+    xs, ys, pc = [x.to(dev) for x in inputs], [y.to(dev) for y in targets], pos.to(dev)
+    ref = None
+    for r in range(30):
+        net.zero_grad()
+        outs = net(xs, pc)
+        sum((o - y).abs().mean() for grp in outs for o, y in zip(grp, ys)).backward()
+        torch.cuda.synchronize()
+        cur = [o.detach().clone() for grp in outs for o in grp] + [p.grad.clone() for p in net.parameters() if p.grad is not None]
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(cur, ref)), r
