@@ -38,10 +38,14 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
     F = T + 2 * U
     out_s = {4: 1492992, 2: 299520, 3: 673920}[scale]
     out_f, out_b = out_s, 2 * out_s
+    w = 4.0 / 9.0 if executed else 1.0        # convolutions that run in Winograd form execute 4/9 of their direct FLOPs
     if executed and scale == 4:
-        out_f, out_b = 294912 + 51200, 2 * 294912 + 65536
-    fwd = F * 1152 + S * 2 * F * L * 589824 + S * (F - 4) * 1646298 + 3 * S * T * out_f
-    bwd = T * 1152 + 2 * S * 2 * T * L * 589824 + 2 * S * T * 1646298 + 3 * S * T * out_b
+        out_f, out_b = w * 294912 + 51200, 294912 + 294912 + 65536           # up1 fwd Winograd; up1 dgrad/wgrad direct
+    lstm_f, lstm_b = w * 589824, w * 589824 + 589824                          # fwd, dgrad Winograd; wgrad direct
+    r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
+    ref_f, ref_b = w * r1 + r2, w * r1 + r1 + 2 * r2
+    fwd = F * 1152 + S * 2 * F * L * lstm_f + S * (F - 4) * ref_f + 3 * S * T * out_f
+    bwd = T * 1152 + S * 2 * T * L * lstm_b + S * T * ref_b + 3 * S * T * out_b
     return fwd + bwd
 
 
@@ -89,7 +93,10 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))          # 589 824 FLOP per pixel at cx = hd = 64
+    wino = bool(getattr(pl['full'], 'wino', False))
+    flops_alg = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))      # 589 824 FLOP per pixel at cx = hd = 64 (direct form)
+    # what the matrix cores execute: the Winograd F(2x2,3x3) kernel runs 16 GEMMs over n*h*w/4 tiles = 4/9 of the above
+    flops = flops_alg * 4.0 / 9.0 if wino else flops_alg
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
     prof = os.path.join(ROOT, 'profiles', 'lstm_kernel_hbm_bytes.json')
@@ -98,10 +105,12 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
             traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
-    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)',
-            'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-            'avg_launch_ms': round(ms, 4), 'flop_per_launch': flops}
+    name = 'conv_wino_kernel<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
+        'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)'
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'avg_launch_ms': round(ms, 4),
+            'flop_per_launch': flops, 'executed_mfma_flop_per_launch': flops, 'direct_form_flop_per_launch': flops_alg,
+            'direct_form_equivalent_tflops': round(flops_alg / (ms * 1e-3) / 1e12, 2)}
 
 
 def cpu_baseline():

@@ -63,7 +63,7 @@ B3 = 3 * TN
 u = P.up[1]
 y1 = R(B3, 2 * H, 2 * W, 64)
 y2 = ops.empty(B3, 4 * H, 4 * W, 64)
-timeit('up2.fwd(ps)', lambda: ops.conv(u['fwd'], [Src(y1)], B3, 2 * H, 2 * W, ps=(y2, 2)), 2.0 * B3 * 4 * H * W * 256 * 576, 3)
+timeit('up.fwd(ps,256^2)', lambda: ops.conv(u['fwd'], [Src(y1)], B3, 2 * H, 2 * W, ps=(y2, 2)), 2.0 * B3 * 4 * H * W * 256 * 576, 3)
 ysrcs = [Src(y2, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
 dy1 = ops.empty(B3, 2 * H, 2 * W, 64)
 timeit('up2.dgrad', lambda: ops.conv(u['dgrad'], ysrcs, B3, 2 * H, 2 * W, dsts=[Dst(dy1, 64)]), 2.0 * B3 * 4 * H * W * 64 * 2304, 3)
@@ -77,7 +77,12 @@ srcs = []
 for j in range(5):
     srcs += [Src(Hf, img_off=j * N), Src(Hb, img_off=j * N), Src(P4, img_off=j * N)]
 R1 = ops.empty(nwin * N, H, W, P.C1p)
-timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
+if P.r1_wino:
+    hs, ps = [sc for sc in srcs if sc.t is not P4], [sc for sc in srcs if sc.t is P4]
+    timeit('refine1.fwd.h(wino)', lambda: ops.conv(P.r1_fwd_h, hs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 128 * 640 * 9, 3)
+    timeit('refine1.fwd.p', lambda: ops.conv(P.r1_fwd_p, ps, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols, accumulate=True)]), 2.0 * nwin * N * H * W * 128 * 5 * 9, 3)
+else:
+    timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
 if P.xcol:
     timeit('refine1.fwd.xcol', lambda: ops.refine_xcol_fwd([Hf, Hb, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, 5, 64), 2.0 * nwin * N * H * W * 645 * 9, 3)
 Rr = ops.empty(nwin * N, H, W, 64)
@@ -92,8 +97,14 @@ if P.xcol:
     lo, hi = 4 * N, (4 + T + 4) * N
     timeit('refine1.wgrad.xcol', lambda: ops.refine_xcol_wgrad([Hf[lo:hi], Hb[lo:hi], P4[lo:hi]], dR1p[2 * N:(2 + T) * N], dw1, db1, N, 5, 64, False), 2.0 * TN * H * W * 645 * 9, 3)
 dHf, dHb = ops.zeros(TN, H, W, 64), ops.zeros(TN, H, W, 64)
-timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
-                                         dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9, 3)
+if P.r1_wino:
+    timeit('refine1.dgrad.h(wino)', lambda: ops.conv(P.r1_dgrad_h, [Src(dR1p, nch=128, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
+                                                     dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 640 * 9, 3)
+    timeit('refine1.dgrad.x', lambda: ops.conv(P.r1_dgrad_x, [Src(dR1p, c0=128, nch=4, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
+                                               dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 5 * 9, 3)
+else:
+    timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
+                                             dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9, 3)
 # HBM-bound tail
 yy = R(B3, 4 * H, 4 * W, 64)
 wl, bl = params[P.last_w], params[P.last_b]
