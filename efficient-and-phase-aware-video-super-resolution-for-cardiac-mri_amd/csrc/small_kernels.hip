@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256) outconv_wgrad_reduce_kernel(const float *
 // ---------------------------------------------------------------------------------------------------------
 // ConvLSTM gate backward
 // ---------------------------------------------------------------------------------------------------------
-__global__ void lstm_gates_bwd_kernel(const float *dh, const float *dcn, const float *gates, const float *cprev,
+__global__ void lstm_gates_bwd_kernel(const float *dh, const float *dh2, const float *dcn, const float *gates, const float *cprev,
                                       const float *cnext, float *dgates, float *dcprev, long npix, int hd) {
     const int G = hd >> 2;
     const long total = npix * G;
@@ -479,7 +479,11 @@ __global__ void lstm_gates_bwd_kernel(const float *dh, const float *dcn, const f
         const int g = (int)(e % G);
         const long p = e / G;
         const long o = p * hd + g * 4, og = p * 4 * hd + g * 4;
-        const float4 vdh = rnh_ld4(dh + o);
+        float4 vdh = rnh_ld4(dh + o);
+        if (dh2) {                                              // dh' arrives in two parts (layer above + next frame)
+            const float4 v2 = rnh_ld4(dh2 + o);
+            vdh.x += v2.x; vdh.y += v2.y; vdh.z += v2.z; vdh.w += v2.w;
+        }
         const float4 vdc = dcn ? rnh_ld4(dcn + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 vcp = cprev ? rnh_ld4(cprev + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 vcn = rnh_ld4(cnext + o);
@@ -743,11 +747,11 @@ extern "C" int rnh_outconv_wgrad(const float *x, const float *dy, float *dw, flo
     return 0;
 }
 
-extern "C" int rnh_lstm_gates_bwd(const float *dh, const float *dc_next, const float *gates, const float *c_prev,
+extern "C" int rnh_lstm_gates_bwd(const float *dh, const float *dh2, const float *dc_next, const float *gates, const float *c_prev,
                                   const float *c_next, float *dgates, float *dc_prev, int64_t npix, int hd, void *stream) {
     if (!dh || !gates || !c_next || !dgates || npix < 1 || hd < 1) RNH_FAIL(RNH_E_ARG, "rnh_lstm_gates_bwd: bad arguments");
     if (hd & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_lstm_gates_bwd: hd must be a multiple of 4");
-    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for(npix * (hd / 4))), dim3(256), 0, (hipStream_t)stream, dh, dc_next,
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for(npix * (hd / 4))), dim3(256), 0, (hipStream_t)stream, dh, dh2, dc_next,
                        gates, c_prev, c_next, dgates, dc_prev, (long)npix, hd);
     RNH_CHECK_LAUNCH("rnh_lstm_gates_bwd");
     return 0;

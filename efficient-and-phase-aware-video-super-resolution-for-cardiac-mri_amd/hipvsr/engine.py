@@ -336,13 +336,11 @@ class RefineNetEngine:
                             pl = P.lstm[(d, l)]
                             hd, cx = pl['hd'], pl['cx']
                             dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
-                            if dh_next[d][l] is not None:
-                                ops.add(dh, dh_next[d][l], accumulate=True)
                             c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
                             dg = Gd[d][l][fi * N:(fi + 1) * N]
                             dcp = ops.empty(N, H, W, hd) if prev_grad else None
                             ops.lstm_gates_bwd(dh, dc_next[d][l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg,
-                                               dcp)
+                                               dcp, dh2=dh_next[d][l])
                             dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
                             dhp = None
                             if cfg.memory:

@@ -386,16 +386,16 @@ class HipOps:
                                               _ptr(db3), w2.shape[1], Cq, r, Co, int(acc2), int(acc3), self._stream()),
                 'rnh_uptail_wcontract')
 
-    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
-        self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev)
+    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=None):
+        self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2)
         hd = dh.shape[-1]
         npix = dh.numel() // hd
-        for t in (dc_next, c_prev, c_next, dc_prev):
+        for t in (dc_next, c_prev, c_next, dc_prev, dh2):
             if t is not None and t.shape != dh.shape:
                 raise L.HipKernelError('lstm_gates_bwd: state shapes')
         if gates.numel() != 4 * dh.numel() or dgates.numel() != 4 * dh.numel():
             raise L.HipKernelError('lstm_gates_bwd: gate shapes')
-        L.check(self.lib.rnh_lstm_gates_bwd(_ptr(dh), _ptr(dc_next), _ptr(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates),
+        L.check(self.lib.rnh_lstm_gates_bwd(_ptr(dh), _ptr(dh2), _ptr(dc_next), _ptr(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates),
                                             _ptr(dc_prev), npix, hd, self._stream()), 'rnh_lstm_gates_bwd')
 
     def add(self, out, a, b=None, c=None, accumulate=False):

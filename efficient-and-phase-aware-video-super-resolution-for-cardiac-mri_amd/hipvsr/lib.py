@@ -90,7 +90,7 @@ def load():
     lib.rnh_outconv_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_outconv_wgrad_ws_floats.argtypes = [i32, i32]
     lib.rnh_outconv_wgrad_ws_floats.restype = i64
-    lib.rnh_lstm_gates_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    lib.rnh_lstm_gates_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.rnh_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, f32, vp]
     lib.rnh_ew_add.argtypes = [vp, vp, vp, vp, i64, i32, vp]
     lib.rnh_phase_plane.argtypes = [vp, vp, i32, i32, i32, i32, vp]

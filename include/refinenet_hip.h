@@ -245,7 +245,7 @@ int rnh_uptail_wcontract(const float *M, const float *S, const float *w2, const 
 /* Backward of the ConvLSTM gate math (refine_net.py:258-265): from dh', dc' and the saved post-activation
  * gates, c_prev and c_next produce the pre-activation gate gradients [..][4*hd] (channel = gate*hd + ch,
  * order i,f,o,g) and dc_prev.  dc_next / c_prev may be 0 (zero).  n = B*H*W pixels. */
-int rnh_lstm_gates_bwd(const float *dh, const float *dc_next, const float *gates, const float *c_prev,
+int rnh_lstm_gates_bwd(const float *dh, const float *dh2 /* 0 or a second summand of dh' */, const float *dc_next, const float *gates, const float *c_prev,
                        const float *c_next, float *dgates, float *dc_prev, int64_t npix, int hd, void *stream);
 
 /* Loss + gradient for all output groups at once.  Replaces the 3*S*T loss_fn(output, target) calls of

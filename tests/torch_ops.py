@@ -284,8 +284,10 @@ class TorchOps:
             else:
                 tgt.copy_(g)
 
-    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev):
+    def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=None):
         hd = dh.shape[-1]
+        if dh2 is not None:
+            dh = dh + dh2
         gi, gf, go, gg = (gates[..., k * hd:(k + 1) * hd] for k in range(4))
         th = torch.tanh(c_next)
         dct = dh * go * (1 - th * th)
