@@ -643,6 +643,49 @@ __global__ void xcol_gather_kernel(const float *dy, float *E, long npix, int N, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Phase planes of refine conv1 as a bias field.  The plane of frame slot j is the constant p[f + j][n] inside the
+// image (zero padding outside), so its 3x3 convolution is p times the sum of the taps that stay inside the image -
+// one of 16 border classes per pixel (bit 0: first row, 1: last row, 2: first column, 3: last column).
+//   T[cls][j][co] = sum_{taps inside} w[co][j*cstride + c0][tap];   out[img][p][co] += sum_j p[(i + j)*N + n] * T[cls(p)][j][co]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void phase_bias_table_kernel(const float *w, float *T, int Cin, int J, int cstride, int c0, int ncols) {
+    const int total = 16 * J * ncols;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int co = e % ncols, j = (e / ncols) % J, cls = e / (ncols * J);
+        const float *g = w + ((long)co * Cin + j * cstride + c0) * 9;
+        float s = 0.f;
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool out = (dy < 0 && (cls & 1)) || (dy > 0 && (cls & 2)) || (dx < 0 && (cls & 4)) || (dx > 0 && (cls & 8));
+            if (!out) s += g[t];
+        }
+        T[e] = s;
+    }
+}
+
+__global__ void phase_bias_add_kernel(float *out, const float *planes, const float *T, int H, int W, int N, int nwin, int J, int C,
+                                      int ncols) {
+    const long npix = (long)H * W;
+    const int G = ncols >> 2;
+    const long total = (long)nwin * N * npix * G;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e % G);
+        const long q = e / G, img = q / npix, px = q - img * npix;
+        const int y = (int)(px / W), x = (int)(px - (long)y * W);
+        const int cls = (y == 0) | ((y == H - 1) << 1) | ((x == 0) << 2) | ((x == W - 1) << 3);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < J; ++j) {
+            const float p = planes[(img + (long)j * N) * npix * 4];                 // channel 0 of pixel 0 of that frame's plane
+            const float4 t = rnh_ld4(T + ((long)cls * J + j) * ncols + g * 4);
+            acc.x += p * t.x; acc.y += p * t.y; acc.z += p * t.z; acc.w += p * t.w;
+        }
+        float *o = out + q * C + g * 4;
+        const float4 v = rnh_ld4(o);
+        rnh_st4(o, make_float4(v.x + acc.x, v.y + acc.y, v.z + acc.z, v.w + acc.w));
+    }
+}
+
 inline int grid_for(long work_items, int block = 256, int cap = 8192) {
     long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -824,5 +867,20 @@ extern "C" int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, i
     hipLaunchKernelGGL(xcol_gather_kernel, dim3(grid_for((long)(nwin + J - 1) * N * npix * J)), dim3(256), 0, (hipStream_t)stream, dy, E,
                        (long)npix, N, nwin, J, C, c);
     RNH_CHECK_LAUNCH("rnh_xcol_gather");
+    return 0;
+}
+
+extern "C" int rnh_phase_bias_add(float *out, const float *planes, const float *w, float *ws, int H, int W, int N, int nwin, int J, int Cin,
+                                  int cstride, int c0, int C, int ncols, void *stream) {
+    if (!out || !planes || !w || !ws || H < 1 || W < 1 || N < 1 || nwin < 1 || J < 1 || ncols < 4 || ncols > C ||
+        (J - 1) * cstride + c0 >= Cin)
+        RNH_FAIL(RNH_E_ARG, "rnh_phase_bias_add: bad arguments");
+    if ((ncols & 3) || (C & 3)) RNH_FAIL(RNH_E_ALIGN, "rnh_phase_bias_add: ncols and C must be multiples of 4");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(phase_bias_table_kernel, dim3(grid_for(16L * J * ncols)), dim3(256), 0, st, w, ws, Cin, J, cstride, c0, ncols);
+    RNH_CHECK_LAUNCH("rnh_phase_bias_add(table)");
+    hipLaunchKernelGGL(phase_bias_add_kernel, dim3(grid_for((long)nwin * N * H * W * (ncols / 4), 256, 32768)), dim3(256), 0, st, out, planes,
+                       ws, H, W, N, nwin, J, C, ncols);
+    RNH_CHECK_LAUNCH("rnh_phase_bias_add");
     return 0;
 }

@@ -136,7 +136,7 @@ class RefineNetEngine:
                 R1 = ops.empty(nwin * N, H, W, P.C1p)
                 if P.r1_wino:
                     ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
-                    ops.conv(P.r1_fwd_p, [sc for sc in srcs if sc.t is P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols, accumulate=True)])
+                    ops.refine_phase_bias(R1, P4, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
                 else:
                     ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                 if P.xcol:

@@ -305,6 +305,16 @@ class HipOps:
         L.check(self.lib.rnh_xcol_combine(_ptr(zs[0]), _ptr(zs[1]), _ptr(zs[2]), b1.data_ptr() + 4 * co, _ptr(R1), H * W, N, nwin, J, C, co,
                                           self._stream()), 'rnh_xcol_combine')
 
+    def refine_phase_bias(self, R1, P4, w1, N, J, cl, ncols):
+        """R1[..., :ncols] += conv1 over the J phase planes (input channel 2*cl of every frame slot), as a bias field."""
+        self._chk(R1, P4, w1)
+        nwin, H, W, C = R1.shape[0] // N, R1.shape[1], R1.shape[2], R1.shape[3]
+        if P4.shape[0] != (nwin + J - 1) * N or tuple(P4.shape[1:]) != (H, W, 4):
+            raise L.HipKernelError('refine_phase_bias: plane shape')
+        ws = self._workspace('phase_bias', 16 * J * ncols)
+        L.check(self.lib.rnh_phase_bias_add(_ptr(R1), _ptr(P4), _ptr(w1), _ptr(ws), H, W, N, nwin, J, w1.shape[1], 2 * cl + 1, 2 * cl, C,
+                                            ncols, self._stream()), 'rnh_phase_bias_add')
+
     def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
         """Weight / bias gradient of conv1's channel 2*cl: srcs = the (nwin + J - 1)*N source frames of (h_fwd, h_bwd,
         phase plane), dy = (nwin*N, H, W, C1p) gradient of conv1's output."""

@@ -207,6 +207,15 @@ int rnh_xcol_combine(const float *z0, const float *z1, const float *z2, const fl
                      int nwin, int J, int C, int c0, void *stream);
 int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, int nwin, int J, int C, int c, void *stream);
 
+/* Phase planes of _RefineBlock conv1 (refine_net.py:168-177: pos_codes repeated over H x W, concatenated as channel
+ * 2*Cl of every frame slot) as a bias field: inside the image the plane of slot j is the constant p, so its 3x3
+ * convolution is p times the sum of the taps that stay inside - 16 border classes per pixel.
+ *   out (nwin*N, H, W, C)[img = i*N + n][p][0..ncols) += sum_j planes[((i + j)*N + n)][0][0][0] * T[cls(p)][j][.]
+ * planes: (F*N, H, W, 4) from rnh_phase_plane; w: OIHW (., Cin, 3, 3), slot j's plane is input channel j*cstride + c0;
+ * ws: 16*J*ncols floats (T, rebuilt on every call). */
+int rnh_phase_bias_add(float *out, const float *planes, const float *w, float *ws, int H, int W, int N, int nwin, int J,
+                       int Cin, int cstride, int c0, int C, int ncols, void *stream);
+
 /* Backward of the upsampler's tail = [last conv + PixelShuffle(r)] -> [final conv C -> out_channels]
  * (refine_net.py:199-205), collapsed algebraically because the tail is affine with out_channels (= 1) outputs
  * (derivation in csrc/uptail.hip).  w2: OIHW (Cq*r*r, C1, 3, 3) weight of the last PixelShuffle conv, w3: OIHW

@@ -203,6 +203,13 @@ class TorchOps:
             R1[i * N:(i + 1) * N, ..., co] = F.conv2d(f, w1[co:co + 1], b1[co:co + 1], padding=1)[:, 0]
             R1[i * N:(i + 1) * N, ..., co + 1:co + 4] = 0
 
+    def refine_phase_bias(self, R1, P4, w1, N, J, cl, ncols):
+        nwin = R1.shape[0] // N
+        for i in range(nwin):
+            x = torch.cat([P4[(i + j) * N:(i + j + 1) * N, ..., :1] for j in range(J)], dim=-1).permute(0, 3, 1, 2)
+            wp = w1[:ncols, [j * (2 * cl + 1) + 2 * cl for j in range(J)]]
+            R1[i * N:(i + 1) * N, ..., :ncols] += F.conv2d(x, wp, None, padding=1).permute(0, 2, 3, 1)
+
     def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
         co, nwin = 2 * cl, dy.shape[0] // N
         w0 = torch.zeros(1, dw1.shape[1], 3, 3, device=self.device, requires_grad=True)

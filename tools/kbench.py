@@ -80,7 +80,7 @@ R1 = ops.empty(nwin * N, H, W, P.C1p)
 if P.r1_wino:
     hs, ps = [sc for sc in srcs if sc.t is not P4], [sc for sc in srcs if sc.t is P4]
     timeit('refine1.fwd.h(wino)', lambda: ops.conv(P.r1_fwd_h, hs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 128 * 640 * 9, 3)
-    timeit('refine1.fwd.p', lambda: ops.conv(P.r1_fwd_p, ps, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols, accumulate=True)]), 2.0 * nwin * N * H * W * 128 * 5 * 9, 3)
+    timeit('refine1.fwd.phase-bias', lambda: ops.refine_phase_bias(R1, P4, params[P.r1_fwd_h.wkey], N, 5, 64, P.r1_cols), 2.0 * nwin * N * H * W * 128 * 5 * 9, 3)
 else:
     timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
 if P.xcol:
