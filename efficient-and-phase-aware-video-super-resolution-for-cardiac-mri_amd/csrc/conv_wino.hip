@@ -91,12 +91,18 @@ __device__ unsigned long long g_wino_stamps[8];
 #define WSTAMP(i)
 #endif
 
-template <int EPI>
+// TG = tile groups per workgroup.  TG = 1: 32 tiles x 128 columns (4 waves = 4 column groups), 16-channel chunks.
+// TG = 2 (convolutions with 64-column multiples, e.g. the 64-channel data gradients): 64 tiles x 64 columns, wave =
+// (tile group, column group), 8-channel chunks so that the staging still is one (tile, channel pair) per thread.
+template <int EPI, int TG>
 __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
-    __shared__ __attribute__((aligned(16))) float stage[2 * 16 * 32 * 18];     // 73.7 KB; the LSTM gate exchange reuses it
+    constexpr int TILES = 32 * TG, CPC = 8 / TG, CH = 2 * CPC, SPC = 4 / TG, CG = 4 / TG;   // tiles, channel pairs / channels / steps per chunk, column groups
+    constexpr int CHS = 2 * CPC + 2, BUF = 16 * TILES * CHS;                                // LDS row of one (xi, tile); floats per buffer
+    static_assert(EPI != RNH_EPI_LSTM || TG == 1, "the gate exchange needs the four column groups of one tile group");
+    __shared__ __attribute__((aligned(16))) float stage[2 * BUF > 16384 ? 2 * BUF : 16384];   // 73.7 / 81.9 KB; the LSTM gate exchange reuses it
     float *xch = stage;
-    __shared__ int tpix[32];                                  // top-left output pixel of the block's tiles (epilogue)
-    __shared__ int tcoord[32];                                // the same as (image << 20 | y << 10 | x), -1: no such tile
+    __shared__ int tpix[TILES];                               // top-left output pixel of the block's tiles (epilogue)
+    __shared__ int tcoord[TILES];                             // the same as (image << 20 | y << 10 | x), -1: no such tile
     WSTAMP(0);
 #ifdef RNH_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) g_wino_stamps[6] = 0;
@@ -105,7 +111,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     const int bid = rnh_xcd_remap(blockIdx.x, MT * NT);
     const int mt = bid / NT, nt = bid - mt * NT;
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
-    const int m0 = mt * 32;
+    const int m0 = mt * TILES;
+    const int tg = wave / CG, cg = wave - tg * CG;            // this wave's tile group and column group
 
     // ---- staging: B^T d B of the block's 32 tiles, 16 channels at a time, through LDS ---------------------------
     // (Lanes of one MFMA row block sit 2 pixels = 512 B apart in memory: loading patches per lane would touch 32 cache
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     // channel pair cp of the chunk): 16 8-byte loads (the 8 threads of a tile read 64 contiguous bytes per pixel), the
     // input transform once per block, 16 8-byte LDS writes.  LDS layout [xi][tile][18]: the 8-byte reads of a
     // half-wave (32 tiles, stride 18 floats) cover all 64 banks exactly once.
-    const int ts = threadIdx.x >> 3, cp = threadIdx.x & 7;
+    const int ts = threadIdx.x / CPC, cp = threadIdx.x % CPC;
     const int t0 = m0 < ntiles ? m0 : 0;
     const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
     // sources may be the (sub_y, sub_x) phase of a scale-times larger image (pixel-unshuffle fused into the load);
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         }
     }
     // loader state: source and 16-channel chunk inside it
-    int si = 0, cchunk = 0, nchunk = P.src[0].nch >> 4;
+    int si = 0, cchunk = 0, nchunk = P.src[0].nch / CH;
     int voff[16];
     i32x4 adesc;
     auto setup_src = [&](int sidx) {
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         const int C4 = S.C * 4;
 #pragma unroll
         for (int p = 0; p < 16; ++p) voff[p] = pixrel[p] < 0 ? -1 : pixrel[p] * C4 + cp * 8;
-        nchunk = S.nch >> 4;
+        nchunk = S.nch / CH;
     };
     setup_src(0);
 
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     };
     f32x2 stg[16];
     auto gload = [&]() {                                   // next chunk of the source list -> registers (16 loads)
-        const int soff = __builtin_amdgcn_readfirstlane(cchunk * 64);
+        const int soff = __builtin_amdgcn_readfirstlane(cchunk * CH * 4);
         ld8(stg, voff, adesc, soff);
         ld8(stg + 8, voff + 8, adesc, soff);
         if (++cchunk == nchunk) {
@@ -179,7 +186,6 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             if (++si < P.nsrc) setup_src(si);
         }
     };
-    constexpr int CHS = 18, BUF = 16 * 32 * CHS;
     auto xform_store = [&](int buf) {                       // V = B^T d B on the thread's two channels, to LDS
         asm volatile("s_waitcnt vmcnt(16)"
                      : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
@@ -196,14 +202,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         float *o = stage + buf * BUF + ts * CHS + 2 * cp;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * 32 * CHS) = tq[i * 4 + 0] - tq[i * 4 + 2];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * 32 * CHS) = tq[i * 4 + 1] + tq[i * 4 + 2];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * 32 * CHS) = tq[i * 4 + 2] - tq[i * 4 + 1];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * 32 * CHS) = tq[i * 4 + 1] - tq[i * 4 + 3];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * TILES * CHS) = tq[i * 4 + 0] - tq[i * 4 + 2];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * TILES * CHS) = tq[i * 4 + 1] + tq[i * 4 + 2];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * TILES * CHS) = tq[i * 4 + 2] - tq[i * 4 + 1];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * TILES * CHS) = tq[i * 4 + 1] - tq[i * 4 + 3];
         }
     };
 
-    const i32x4 bdesc = sdesc(P.wp + (long)((nt * 4 + wave) * 32) * 4);
+    const i32x4 bdesc = sdesc(P.wp + (long)((nt * CG + cg) * 32) * 4);
     const int xistride = P.Npad * 16;                       // bytes between two transform positions of one step
     int boffx[16];                                          // per-lane byte offset of the 16 positions inside a step
 #pragma unroll
@@ -214,10 +220,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         ld8(u + 8, boffx + 8, bdesc, soff);
     };
     const unsigned lds0 = (unsigned)(size_t)stage;          // LDS byte address of the staging area
-    const unsigned vlane = lds0 + (l31 * CHS + 2 * kh) * 4;
+    const unsigned vlane = lds0 + ((tg * 32 + l31) * CHS + 2 * kh) * 4;
     auto loadv = [&](f32x2 *V, int buf, int q) {            // the lane's tile, channels 4q + 2kh, +1 of the staged chunk
         const unsigned adr = vlane + buf * BUF * 4 + q * 16;
-#define RNH_DSR(xi) asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(V[xi]) : "v"(adr), "i"((xi) * 32 * CHS * 4) : "memory")
+#define RNH_DSR(xi) asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(V[xi]) : "v"(adr), "i"((xi) * TILES * CHS * 4) : "memory")
         RNH_DSR(0); RNH_DSR(1); RNH_DSR(2); RNH_DSR(3); RNH_DSR(4); RNH_DSR(5); RNH_DSR(6); RNH_DSR(7);
         RNH_DSR(8); RNH_DSR(9); RNH_DSR(10); RNH_DSR(11); RNH_DSR(12); RNH_DSR(13); RNH_DSR(14); RNH_DSR(15);
 #undef RNH_DSR
@@ -251,9 +257,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     // ---- main loop over 16-channel chunks (4 steps of 4 channels); chunk c+1 travels global -> registers under the
     // MFMAs of chunk c and is transformed into the other LDS buffer at its end ---------------------------------------
     int nchunks_total = 0;
-    for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch >> 4;
+    for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch / CH;
     f32x2 V0[16], V1[16], u0[16], u1[16];
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < TILES) {
         const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
         const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
         tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
@@ -285,31 +291,33 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         if constexpr (more) gload();
         loadb(u1, s + 1);
         compute(V0, u0);
-        // step 1
-        wait_lds(V1);
-        loadv(V0, buf, 2);
-        loadb(u0, s + 2);
-        wait_vm(u1, K16());
-        compute(V1, u1);
-        // step 2
-        wait_lds(V0);
-        loadv(V1, buf, 3);
-        loadb(u1, s + 3);
-        wait_vm(u0, K16());
-        compute(V0, u0);
-        // step 3: the weights of the next chunk's first step and the transform of the staged chunk into the other LDS
+        if constexpr (SPC == 4) {
+            // step 1
+            wait_lds(V1);
+            loadv(V0, buf, 2);
+            loadb(u0, s + 2);
+            wait_vm(u1, K16());
+            compute(V1, u1);
+            // step 2
+            wait_lds(V0);
+            loadv(V1, buf, 3);
+            loadb(u1, s + 3);
+            wait_vm(u0, K16());
+            compute(V0, u0);
+        }
+        // last step: the weights of the next chunk's first step and the transform of the staged chunk into the other LDS
         // buffer (nobody reads it during this chunk): plain code in front of the MFMAs, so that hipcc interleaves its
         // packed adds and LDS writes with them.  Nothing is prefetched past the end.
         wait_lds(V1);
         if constexpr (more) {
-            loadb(u0, s + 4);
+            loadb(u0, s + SPC);
             wait_vm(u1, K16());
             xform_store(buf ^ 1);
         } else {
             wait_vm(u1, K0());
         }
         compute(V1, u1);
-        s += 4;
+        s += SPC;
         // LDS writes done, then the barrier - not __syncthreads(), whose fence would also wait (vmcnt(0)) for the
         // weight prefetch that was just issued
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -320,7 +328,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
 
     WSTAMP(3);
     // ---- output transform Y = A^T M A per accumulator register, then the epilogue -------------------------------
-    const int ncol = (nt * 4 + wave) * 32 + l31;
+    const int ncol = (nt * CG + cg) * 32 + l31;
+    const int trow0 = tg * 32;                                  // first row of this wave's tile group in tpix / tcoord
     const float bv = P.bias ? P.bias[ncol] : 0.f;
     auto out4 = [&](int v, float *Y) {
         float sq[2][4];
@@ -337,7 +346,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     };
     // pixel (top-left output of the tile) and validity of row v of the MFMA tile
     auto tile_of = [&](int v, int &pix, bool &okx, bool &oky) -> bool {
-        const int tr = m0 + (v & 3) + 8 * (v >> 2) + 4 * kh;
+        const int tr = m0 + trow0 + (v & 3) + 8 * (v >> 2) + 4 * kh;
         if (tr >= ntiles) return false;
         const int im = tr / (TY * TX), rr = tr - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
         pix = (im * H + 2 * yy) * W + 2 * xx;
@@ -448,7 +457,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             for (int v = 0; v < 16; ++v) {
                 float Y[4];
                 out4(v, Y);
-                const int tc = tcoord[(v & 3) + 8 * (v >> 2) + 4 * kh];
+                const int tc = tcoord[trow0 + (v & 3) + 8 * (v >> 2) + 4 * kh];
                 if (tc < 0) continue;
                 const int im = tc >> 20, yy = (tc >> 10) & 1023, xx = tc & 1023;
 #pragma unroll
@@ -468,14 +477,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             if (seg < 0) return;
             const rnh_dst_t &D = P.dst[seg];
             float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
-            const bool full = m0 + 32 <= ntiles && !(H & 1) && !(W & 1);
+            const bool full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1);
             if (full) {                                          // no per-element predicates
                 const long rowC = (long)W * D.C;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     float Y[4];
                     out4(v, Y);
-                    float *o = dp + (long)tpix[(v & 3) + 8 * (v >> 2) + 4 * kh] * D.C;
+                    float *o = dp + (long)tpix[trow0 + (v & 3) + 8 * (v >> 2) + 4 * kh] * D.C;
                     if (D.accumulate) {
                         const float a0 = o[0], a1 = o[D.C], a2 = o[rowC], a3 = o[rowC + D.C];
                         o[0] = a0 + Y[0]; o[D.C] = a1 + Y[1]; o[rowC] = a2 + Y[2]; o[rowC + D.C] = a3 + Y[3];
@@ -521,7 +530,7 @@ extern "C" int rnh_wino_pack_weights(const float *w, const float *bias, float *w
                                      int transposed, void *stream) {
     if (!w || !wp || !kbase || !knv || !colmap || ns < 1 || Npad < 1 || Cout < 1 || Cin < 1 || kstride < 1)
         RNH_FAIL(RNH_E_ARG, "rnh_wino_pack_weights: bad arguments");
-    if (Npad % 128) RNH_FAIL(RNH_E_RANGE, "rnh_wino_pack_weights: Npad must be a multiple of 128");
+    if (Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino_pack_weights: Npad must be a multiple of 64");
     hipLaunchKernelGGL(wino_pack_kernel, dim3(wgrid_for((long)ns * 16 * Npad * 4 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias, wp,
                        biasp, kbase, knv, kcoff, colmap, ns, Npad, Cout, Cin, kstride, transposed);
     RNH_CHECK_LAUNCH("rnh_wino_pack_weights");
@@ -533,12 +542,13 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     const rnh_conv_args_t &a = *args;
     if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
     if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
-    if (a.Npad < 128 || a.Npad % 128) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 128");
+    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 64");
+    const int TG = a.Npad % 128 ? 2 : 1;              // 64-column multiples: two tile groups x two column groups per workgroup
     int steps = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
         if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
-        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
+        if (a.src[i].nch & (TG == 1 ? 15 : 7)) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of %d", 16 / TG);
         steps += a.src[i].nch / 4;
     }
     if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
@@ -546,7 +556,7 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     const long ntiles = (long)a.B * TY * TX;
     if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: at most 2047 images of 1023 x 1023");
     if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
-    const int MT = (int)((ntiles + 31) / 32), NT = a.Npad / 128;
+    const int MT = (int)((ntiles + 32 * TG - 1) / (32 * TG)), NT = a.Npad / (TG == 1 ? 128 : 64);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(MT * NT)), block(256);
     switch (a.epilogue) {
@@ -554,17 +564,19 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
             if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
             for (int d = 0; d < a.ndst; ++d)
                 if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
-            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
+            if (TG == 1) hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_STORE, 1>), grid, block, 0, st, a, MT, NT, TX, TY);
+            else hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_STORE, 2>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         case RNH_EPI_PS:
             if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
                 RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
-            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY);
+            if (TG == 1) hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_PS, 1>), grid, block, 0, st, a, MT, NT, TX, TY);
+            else hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_PS, 2>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         case RNH_EPI_LSTM:
             if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
             if (a.Npad != 128 * ((a.hd + 31) / 32)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (plans.lstm_colmap)");
-            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY);
+            hipLaunchKernelGGL((conv_wino_kernel<RNH_EPI_LSTM, 1>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         default:
             RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);

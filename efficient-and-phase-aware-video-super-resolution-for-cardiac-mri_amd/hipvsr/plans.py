@@ -84,8 +84,9 @@ class ConvPlan:
                     self.kcoff.append(sg.kcoff)
         self.nk = len(self.kbase)
         # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
-        self.wino = bool(wino) and self.ntaps == 9 and self.Npad % 128 == 0 and \
-            all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in ksegs)
+        # (128-column multiples: 16-channel chunks; other 64-column multiples: the two-tile-group variant, 8-channel chunks)
+        self.wino = bool(wino) and self.ntaps == 9 and self.Npad % 64 == 0 and \
+            all(sg.nch % (16 if self.Npad % 128 == 0 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
         if self.wino:
             self.wkbase, self.wknv, self.wkcoff = [], [], []
             for sg in ksegs:
@@ -303,7 +304,8 @@ class NetPlans:
             fwd = ConvPlan(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS,
                            wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
             dgrad = ConvPlan(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
-                             transposed=True, kstride=r * r)
+                             transposed=True, kstride=r * r,
+                             wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
             wgrad = WgradPlan(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
             self.up.append(dict(r=r, fwd=fwd, dgrad=dgrad, wgrad=wgrad))
         self.last_w, self.last_b = f'out_block.conv{len(rs) + 1}.weight', f'out_block.conv{len(rs) + 1}.bias'
