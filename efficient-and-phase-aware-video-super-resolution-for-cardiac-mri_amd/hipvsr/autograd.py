@@ -20,7 +20,8 @@ class RefineNetFn(torch.autograd.Function):
         names = module._param_names
         pd = {n: p.detach() for n, p in zip(names, params)}
         need = any(ctx.needs_input_grad[3:])          # False under torch.no_grad() and for frozen parameters
-        O_all, ectx = eng.forward(pd, inputs, pos_codes, need_grad=need)
+        O_all, ectx = eng.forward(pd, inputs, pos_codes, need_grad=need,
+                                  last_only=bool(getattr(module, 'last_group_only', False)) and not need)
         ctx.module, ctx.ectx, ctx.pd = module, ectx, pd
         return O_all
 

@@ -54,9 +54,11 @@ class RefineNetEngine:
                 self.ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None)
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, params, inputs, pos_codes, need_grad):
+    def forward(self, params, inputs, pos_codes, need_grad, last_only=False):
         """inputs: list[F] of (N, Cin, H, W) tensors; pos_codes: (N, F, 1).
-        Returns (O_all, ctx): O_all is (S, 3, T*N, sH, sW, Cout) with image index i*N + n."""
+        Returns (O_all, ctx): O_all is (S, 3, T*N, sH, sW, Cout) with image index i*N + n.
+        last_only (inference, reference predictor acdc_vsr_refinenet_predictor.py:62 consumes outputs[-1] only): the
+        upsampler runs for the fused group of the last stage alone; the other 3*S - 1 groups of O_all stay unwritten."""
         ops, cfg, P = self.ops, self.cfg, self.plans
         U, S, hw, w = cfg.num_updated_frames, cfg.num_stages, self.hw, cfg.refine_window_size
         F = len(inputs)
@@ -147,28 +149,38 @@ class RefineNetEngine:
                 ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R, Cl)])
 
             # ---- three output groups through the upsampler (refine_net.py:100-113, :194-205) --------------
-            Sb = ops.empty(3 * TN, H, W, C)
             fc = feat[U * N:(U + T) * N]
-            ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
-            ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
-            ops.add(Sb[2 * TN:], fc, R[(U - hw) * N:(U - hw + T) * N])
-            cur, h, wd, Ys = Sb, H, W, []
+            skip_up = last_only and not need_grad
+            if skip_up and s < S - 1:
+                nb = 0                                        # no output group of this stage is consumed
+            elif skip_up:
+                nb = 1                                        # the fused group only
+                Sb = ops.empty(TN, H, W, C)
+                ops.add(Sb, fc, R[(U - hw) * N:(U - hw + T) * N])
+            else:
+                nb = 3
+                Sb = ops.empty(3 * TN, H, W, C)
+                ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
+                ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
+                ops.add(Sb[2 * TN:], fc, R[(U - hw) * N:(U - hw + T) * N])
+            Oview = O_all[s] if nb == 3 else O_all[s, 2:3]
+            cur, h, wd, Ys = (Sb if nb else None), H, W, []
             fused_tail = ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)
-            for ui, u in enumerate(P.up):
+            for ui, u in enumerate(P.up if nb else []):
                 r = u['r']
                 if fused_tail and ui == len(P.up) - 1:
                     # last PixelShuffle conv + final conv as one composed 5x5 convolution (csrc/uptail.hip): the
                     # r*r*C-channel tensor between them is never formed, neither here nor in the backward
                     ops.uptail_fwd(cur, params[u['fwd'].wkey], params[u['fwd'].bkey], params[P.last_w], params[P.last_b], r,
-                                   O_all[s].view(3 * TN, h * r, wd * r, cfg.out_channels))
+                                   Oview.reshape(nb * TN, h * r, wd * r, cfg.out_channels))
                     cur = None
                     break
-                Y = ops.empty(3 * TN, h * r, wd * r, C)
-                ops.conv(u['fwd'], [Src(cur)], 3 * TN, h, wd, ps=(Y, r))
+                Y = ops.empty(nb * TN, h * r, wd * r, C)
+                ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, r))
                 Ys.append(Y)
                 cur, h, wd = Y, h * r, wd * r
             if cur is not None:
-                ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=O_all[s].view(3 * TN, h, wd, cfg.out_channels))
+                ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=Oview.reshape(nb * TN, h, wd, cfg.out_channels))
                 Ys = Ys[:-1]                                  # the tail's output is not needed by the collapsed backward
             if need_grad:
                 st['Sb'], st['Ys'] = Sb, Ys

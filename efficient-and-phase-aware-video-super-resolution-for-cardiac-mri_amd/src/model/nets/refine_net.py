@@ -88,9 +88,16 @@ class RefineNet(BaseNet):
         S, _, TN = O_all.shape[:3]
         N = inputs[0].shape[0]
         T = TN // N
+        # inference shortcut (not in the reference's module; its predictor consumes outputs[-1] only,
+        # acdc_vsr_refinenet_predictor.py:62): with `net.last_group_only = True` and no gradient required, the other
+        # 3*S - 1 output groups are not computed and are returned as None
+        only_last = bool(getattr(self, 'last_group_only', False)) and not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
         groups = []
         for s in range(S):
             for br in range(3):
+                if only_last and not (s == S - 1 and br == 2):
+                    groups.append(None)
+                    continue
                 groups.append([O_all[s, br, i * N:(i + 1) * N].permute(0, 3, 1, 2) for i in range(T)])
         out = HipOutputs(groups)
         out.packed, out.ops = O_all, self._engine().ops

@@ -132,3 +132,14 @@ def test_engine_odd_channel_side_path_vs_oracle():
             continue
         scale = float(gr.abs().max()) + 1e-12
         assert float((grads[k] - gr).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+def test_engine_last_group_only(g1):
+    """Inference shortcut: only the fused group of the last stage goes through the upsampler."""
+    c = g1['x4_pos1_mem1']
+    cfg = NetConfig(**c['kwargs'])
+    eng = RefineNetEngine(cfg, TorchOps('cpu'))
+    params = {k: v.clone() for k, v in c['state_dict'].items()}
+    full, _ = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=False)
+    last, _ = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=False, last_only=True)
+    assert torch.equal(last[-1, 2], full[-1, 2])

@@ -371,3 +371,25 @@ def test_training_step_is_bitwise_repeatable():
             ref = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(cur, ref)), r
+
+
+def test_last_group_only_inference(g1):
+    """`net.last_group_only = True` under no_grad: outputs[-1] is bit-identical to the full forward, the other groups are
+    not computed (None); with gradients enabled the flag is ignored."""
+    from src.model.nets import RefineNet
+    dev = _dev()
+    c = g1['x4_pos1_mem1']
+    net = RefineNet(**c['kwargs'])
+    net.load_state_dict(c['state_dict'])
+    net = net.to(dev).eval()
+    xs, pc = [x.to(dev) for x in c['inputs']], c['pos_codes'].to(dev)
+    with torch.no_grad():
+        full = net(xs, pc)
+        net.last_group_only = True
+        last = net(xs, pc)
+    assert all(g is None for g in last[:-1]) and len(last) == len(full)
+    for a, b in zip(last[-1], full[-1]):
+        assert torch.equal(a, b)
+    net.train()
+    out = net(xs, pc)
+    assert all(g is not None for g in out)
