@@ -1,0 +1,358 @@
+// Weight gradient of a 3x3 convolution in Winograd form F(3x3, 2x2) on fp32 MFMA - rnh_wino_wgrad.
+//
+//   dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G        d: 4x4 input patch, dY: 2x2 output-gradient tile
+//
+// 16 GEMMs dU_xi[ci][co] = sum_tiles V_xi[tile][ci] * Z_xi[tile][co] (contraction over tiles, two per
+// v_mfma_f32_32x32x2_f32) instead of 9 contractions over pixels: 4/9 of the multiplications of conv_wgrad.hip.  One wave
+// = 32 input channels x 32 output channels x all 16 xi (256 accumulators) over a range of tile rows; a lane is one input
+// channel (A operand) and one output channel (B operand) of the two tiles of a step and computes both transforms itself
+// (its 16 + 4 operand loads are 128-byte rows of 32 consecutive channels).
+//
+// No border cases in the kernel: the inputs are first gathered into one zero-padded tensor xp (B, H+2, W+2, Cx)
+// (rnh_wino_wgrad does that; it also removes the multi-source handling from the inner loop), so every load is in
+// range - which the hand-counted waits need (a buffer load with all lanes out of range returns ahead of older loads).
+// The loop body is branch-free, every register set has one asynchronous definition site and nothing is prefetched past
+// the end (see conv_wino.hip for what goes wrong otherwise; tests/test_isa_guards.py checks the generated code).
+// Partial sums per tile-row range go to a slab; rnh_wino_wgrad's reduction sums them in fixed order and applies G^T . G.
+#include "rnh_common.h"
+#include <type_traits>
+
+namespace {
+
+__global__ void wino_pad_kernel(const rnh_wgrad_args_t P, float *xp, int Cx) {
+    const int H = P.H, W = P.W, Hp = H + 2, Wp = W + 2, C4 = Cx >> 2;
+    const long total = (long)P.B * Hp * Wp * C4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long q = e / C4;
+        const int x = (int)(q % Wp) - 1, y = (int)((q / Wp) % Hp) - 1;
+        const long b = q / ((long)Wp * Hp);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            int cc = c, s = 0;
+            while (cc >= P.xs[s].nch) cc -= P.xs[s++].nch;
+            const rnh_src_t &S = P.xs[s];
+            v = rnh_ld4(S.ptr + (((b + S.img_off) * H + y) * W + x) * S.C + S.c0 + cc);
+        }
+        rnh_st4(xp + e * 4, v);
+    }
+}
+
+__device__ __forceinline__ i32x4 wdesc64(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+    d[2] = 0x7fffffff;
+    d[3] = 0x00020000;
+    return d;
+}
+
+struct WSet {
+    float xa[16], xb[16];     // 4x4 patches of the lane's input channel, tiles a and b
+    float ya[4], yb[4];       // 2x2 output-gradient tiles of the lane's output channel
+};
+
+__global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args_t P, const float *xp, const int Cx, const int Cy,
+                                                            const int KS, const int rows_per) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int RT = Cx >> 5, CT = Cy >> 5;
+    // (the wave index is wave-uniform, but only a readfirstlane tells the compiler so: everything derived from it -
+    // tile-row ranges, descriptors - must live in scalar registers)
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= KS * RT * CT) return;                         // whole waves only; no barrier in this kernel
+    const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
+    const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Hp = H + 2, Wp = W + 2;
+    const int rows_total = P.B * TY;
+    const int r0 = ks * rows_per, r1 = min(rows_total, r0 + rows_per);
+
+    // ---- output-gradient source of this column tile -----------------------------------------------------------
+    int ysrc = 0, cy0 = ct * 32;
+    while (cy0 >= P.ys[ysrc].nch) cy0 -= P.ys[ysrc++].nch;
+    const rnh_src_t &Y = P.ys[ysrc];
+    const int sc = Y.scale, Hs = H * sc, Ws = W * sc;
+
+    // per-lane constant offsets inside one group of 4 tiles (8 pixels): tile a = 4g + kh, tile b = 4g + 2 + kh
+    int vx[2][4], vy[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[t][j] = ((2 * (kh + 2 * t) + j) * Cx + rt * 32 + l31) * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
+    }
+    // loader state: tile row r (= image * TY + ty) and group g; descriptors are re-based per tile row
+    int lr = r0, lg = 0;
+    i32x4 xdesc, ydesc;
+    auto rebase = [&]() {
+        const int img = lr / TY, ty = lr - img * TY;
+        xdesc = wdesc64(xp + ((long)img * Hp + 2 * ty) * Wp * Cx);
+        ydesc = wdesc64(Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C);
+    };
+    rebase();
+    const int xrow = Wp * Cx * 4, xgrp = 8 * Cx * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
+
+    auto ld8x = [&](float *da, float *db, int i, int soff) {      // patch row i of both tiles
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %8, %16, %17 offen\n\t"
+            "buffer_load_dword %1, %9, %16, %17 offen\n\t"
+            "buffer_load_dword %2, %10, %16, %17 offen\n\t"
+            "buffer_load_dword %3, %11, %16, %17 offen\n\t"
+            "buffer_load_dword %4, %12, %16, %17 offen\n\t"
+            "buffer_load_dword %5, %13, %16, %17 offen\n\t"
+            "buffer_load_dword %6, %14, %16, %17 offen\n\t"
+            "buffer_load_dword %7, %15, %16, %17 offen"
+            : "=&v"(da[i * 4 + 0]), "=&v"(da[i * 4 + 1]), "=&v"(da[i * 4 + 2]), "=&v"(da[i * 4 + 3]), "=&v"(db[i * 4 + 0]),
+              "=&v"(db[i * 4 + 1]), "=&v"(db[i * 4 + 2]), "=&v"(db[i * 4 + 3])
+            : "v"(vx[0][0]), "v"(vx[0][1]), "v"(vx[0][2]), "v"(vx[0][3]), "v"(vx[1][0]), "v"(vx[1][1]), "v"(vx[1][2]), "v"(vx[1][3]),
+              "s"(xdesc), "s"(soff)
+            : "memory");
+    };
+    auto ld8y = [&](float *ya, float *yb, int s0, int s1) {       // both rows of both 2x2 tiles
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %8, %12, %13 offen\n\t"
+            "buffer_load_dword %1, %9, %12, %13 offen\n\t"
+            "buffer_load_dword %2, %8, %12, %14 offen\n\t"
+            "buffer_load_dword %3, %9, %12, %14 offen\n\t"
+            "buffer_load_dword %4, %10, %12, %13 offen\n\t"
+            "buffer_load_dword %5, %11, %12, %13 offen\n\t"
+            "buffer_load_dword %6, %10, %12, %14 offen\n\t"
+            "buffer_load_dword %7, %11, %12, %14 offen"
+            : "=&v"(ya[0]), "=&v"(ya[1]), "=&v"(ya[2]), "=&v"(ya[3]), "=&v"(yb[0]), "=&v"(yb[1]), "=&v"(yb[2]), "=&v"(yb[3])
+            : "v"(vy[0][0]), "v"(vy[0][1]), "v"(vy[1][0]), "v"(vy[1][1]), "s"(ydesc), "s"(s0), "s"(s1)
+            : "memory");
+    };
+    auto issue = [&](WSet &S) {                                   // 40 loads of the loader's (row, group), then advance
+        const int gx = __builtin_amdgcn_readfirstlane(lg * xgrp), gy = __builtin_amdgcn_readfirstlane(lg * ygrp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ld8x(S.xa, S.xb, i, gx + i * xrow);
+        ld8y(S.ya, S.yb, gy, gy + yrow);
+        if (++lg == G) {
+            lg = 0;
+            if (++lr < r1) rebase();
+        }
+    };
+    auto wait = [&](WSet &S, auto keep) {                          // the set's 40 loads have landed (in-order returns)
+        asm volatile("s_waitcnt vmcnt(%c20)"
+                     : "+v"(S.xa[0]), "+v"(S.xa[1]), "+v"(S.xa[2]), "+v"(S.xa[3]), "+v"(S.xa[4]), "+v"(S.xa[5]), "+v"(S.xa[6]), "+v"(S.xa[7]),
+                       "+v"(S.xa[8]), "+v"(S.xa[9]), "+v"(S.xa[10]), "+v"(S.xa[11]), "+v"(S.xa[12]), "+v"(S.xa[13]), "+v"(S.xa[14]),
+                       "+v"(S.xa[15]), "+v"(S.ya[0]), "+v"(S.ya[1]), "+v"(S.ya[2]), "+v"(S.ya[3])
+                     : "i"(decltype(keep)::value));
+        asm volatile(""
+                     : "+v"(S.xb[0]), "+v"(S.xb[1]), "+v"(S.xb[2]), "+v"(S.xb[3]), "+v"(S.xb[4]), "+v"(S.xb[5]), "+v"(S.xb[6]), "+v"(S.xb[7]),
+                       "+v"(S.xb[8]), "+v"(S.xb[9]), "+v"(S.xb[10]), "+v"(S.xb[11]), "+v"(S.xb[12]), "+v"(S.xb[13]), "+v"(S.xb[14]),
+                       "+v"(S.xb[15]), "+v"(S.yb[0]), "+v"(S.yb[1]), "+v"(S.yb[2]), "+v"(S.yb[3]));
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
+    float bsum = 0.f;
+
+    auto tile_mfma = [&](const float *d, const float *y) {
+        float tq[16], V[16], tz[8], Z[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                              // V = B^T d B
+            tq[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            tq[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            tq[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+            tq[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
+            V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
+            V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
+            V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {                              // Z = A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]
+            tz[0 * 2 + b] = y[0 * 2 + b];
+            tz[1 * 2 + b] = y[0 * 2 + b] + y[1 * 2 + b];
+            tz[2 * 2 + b] = y[0 * 2 + b] - y[1 * 2 + b];
+            tz[3 * 2 + b] = -y[1 * 2 + b];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Z[i * 4 + 0] = tz[i * 2 + 0];
+            Z[i * 4 + 1] = tz[i * 2 + 0] + tz[i * 2 + 1];
+            Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
+            Z[i * 4 + 3] = -tz[i * 2 + 1];
+        }
+        bsum += (y[0] + y[1]) + (y[2] + y[3]);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi], Z[xi], acc[xi], 0, 0, 0);
+    };
+    auto compute = [&](const WSet &S) {
+        tile_mfma(S.xa, S.ya);
+        tile_mfma(S.xb, S.yb);
+    };
+
+    // ---- main loop: NIT = rows * G steps of 4 tiles each (NIT is even: the host requires an even G) ---------------
+    // Two register sets: S1 takes the even steps, S0 the odd ones; the first compute(S0) runs on zeros.  Each set is
+    // waited for at the END of the other set's MFMAs, so that nothing is in flight at the loop edge: hipcc may put
+    // v_mov copies of loop-carried registers there, and a copy of a register whose load is still in flight reads stale
+    // data (conv_wino.hip; tests/test_isa_guards.py checks the generated code).
+    const int NIT = (r1 - r0) * G;
+    using K0 = std::integral_constant<int, 0>;
+    WSet S0, S1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S0.xa[i] = S0.xb[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S0.ya[i] = S0.yb[i] = 0.f;
+    for (int it = 0; it < NIT; it += 2) {
+        // (scheduling barriers: hipcc is free to move the MFMAs and the transform arithmetic across a volatile asm,
+        // which would turn "wait at the end" into "wait right after the issue")
+        issue(S1);                    // step it
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S0);                  // step it - 1 (zeros the first time)
+        __builtin_amdgcn_sched_barrier(0);
+        wait(S1, K0());
+        issue(S0);                    // step it + 1
+        __builtin_amdgcn_sched_barrier(0);
+        compute(S1);
+        __builtin_amdgcn_sched_barrier(0);
+        wait(S0, K0());
+    }
+    if (NIT > 0) compute(S0);
+
+    // ---- partial sums to the slab: [ks][xi][row][col] ---------------------------------------------------------
+    float *out = P.slab + (((long)ks * 16) * Cx + rt * 32) * Cy + ct * 32 + l31;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * kh;
+            out[((long)xi * Cx + row) * Cy] = acc[xi][v];
+        }
+    if (P.bslab && rt == 0) {
+        const float b = bsum + __shfl_xor(bsum, 32, 64);
+        if (kh == 0) P.bslab[(long)ks * Cy + ct * 32 + l31] = b;
+    }
+}
+
+// dw[(colmap[co]*Cin + rowmap[ci])*9 + 3a + b] (+)= (G^T dU G)[a][b], dU = sum over the slabs;  db[colmap[co]] (+)= sum bslab
+__global__ void wino_wgrad_reduce_kernel(const float *slab, const float *bslab, int KS, int Cx, int Cy, const int *rowmap,
+                                         const int *colmap, int Cin, float *dw, float *db, int accumulate) {
+    const long total = (long)Cx * Cy;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Cy; e += (long)gridDim.x * blockDim.x) {
+        if (e >= total) {
+            const int co = colmap[e - total];
+            if (bslab && db && co >= 0) {
+                float s = 0.f;
+                for (int k = 0; k < KS; ++k) s += bslab[(long)k * Cy + (e - total)];
+                db[co] = accumulate ? db[co] + s : s;
+            }
+            continue;
+        }
+        const int j = (int)(e % Cy), i = (int)(e / Cy);
+        const int ci = rowmap[i], co = colmap[j];
+        if (ci < 0 || co < 0) continue;
+        float U[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            float s = 0.f;
+            for (int k = 0; k < KS; ++k) s += slab[(((long)k * 16 + xi) * Cx + i) * Cy + j];
+            U[xi] = s;
+        }
+        // G^T (4x4) G with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+        float T[3][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            T[0][x] = U[0 * 4 + x] + 0.5f * (U[1 * 4 + x] + U[2 * 4 + x]);
+            T[1][x] = 0.5f * (U[1 * 4 + x] - U[2 * 4 + x]);
+            T[2][x] = 0.5f * (U[1 * 4 + x] + U[2 * 4 + x]) + U[3 * 4 + x];
+        }
+        float *o = dw + ((long)co * Cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float g0 = T[a][0] + 0.5f * (T[a][1] + T[a][2]), g1 = 0.5f * (T[a][1] - T[a][2]),
+                        g2 = 0.5f * (T[a][1] + T[a][2]) + T[a][3];
+            o[a * 3 + 0] = accumulate ? o[a * 3 + 0] + g0 : g0;
+            o[a * 3 + 1] = accumulate ? o[a * 3 + 1] + g1 : g1;
+            o[a * 3 + 2] = accumulate ? o[a * 3 + 2] + g2 : g2;
+        }
+    }
+}
+
+inline int wg_grid_for(long n, int cap = 16384) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+struct WinoWgradShape {
+    int Cx, Cy, KS, rows_per;
+};
+
+bool wino_wgrad_shape(const rnh_wgrad_args_t &a, WinoWgradShape *s) {
+    if (a.nxs < 1 || a.nys < 1 || a.nxs > RNH_MAX_SRC || a.nys > RNH_MAX_SRC) return false;
+    if ((a.H & 1) || (a.W & 15) || a.ntaps != 9) return false;          // W % 16: an even number of 4-tile groups per row
+    int Cx = 0, Cy = 0;
+    for (int i = 0; i < a.nxs; ++i) {
+        if ((a.xs[i].nch & 31) || a.xs[i].scale != 1 || a.xs[i].ptr2) return false;
+        Cx += a.xs[i].nch;
+    }
+    for (int i = 0; i < a.nys; ++i) {
+        if ((a.ys[i].nch & 31) || a.ys[i].ptr2 || a.ys[i].scale != a.ys[0].scale) return false;
+        Cy += a.ys[i].nch;
+    }
+    const long rows = (long)a.B * (a.H / 2);
+    const int items = (Cx / 32) * (Cy / 32);
+    long ks = 1024 / items;
+    if (ks < 1) ks = 1;
+    if (ks > rows) ks = rows;
+    if (ks > 256) ks = 256;
+    s->Cx = Cx;
+    s->Cy = Cy;
+    s->KS = (int)ks;
+    s->rows_per = (int)((rows + ks - 1) / ks);
+    s->KS = (int)((rows + s->rows_per - 1) / s->rows_per);
+    return true;
+}
+
+}  // namespace
+
+extern "C" int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args) {
+    WinoWgradShape s;
+    return args && wino_wgrad_shape(*args, &s);
+}
+
+/* floats: [0] padded input copy, [1] slab, [2] bias slab */
+extern "C" int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t *out3) {
+    WinoWgradShape s;
+    if (!args || !out3 || !wino_wgrad_shape(*args, &s)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad_ws_floats: shape not supported");
+    out3[0] = (int64_t)args->B * (args->H + 2) * (args->W + 2) * s.Cx;
+    out3[1] = (int64_t)s.KS * 16 * s.Cx * s.Cy;
+    out3[2] = (int64_t)s.KS * s.Cy;
+    return 0;
+}
+
+extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int32_t *rowmap, const int32_t *colmap, int Cin, float *dw,
+                              float *db, int accumulate, void *stream) {
+    WinoWgradShape s;
+    if (!args || !xp || !rowmap || !colmap || !dw) RNH_FAIL(RNH_E_ARG, "rnh_wino_wgrad: bad arguments");
+    const rnh_wgrad_args_t &a = *args;
+    if (!wino_wgrad_shape(a, &s)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad: shape not supported (rnh_wino_wgrad_supported)");
+    if (!a.slab || (db && !a.bslab)) RNH_FAIL(RNH_E_ARG, "rnh_wino_wgrad: workspaces missing");
+    for (int i = 0; i < a.nxs; ++i)
+        if (int rc = rnh_check_src(a.xs[i], "rnh_wino_wgrad")) return rc;
+    for (int i = 0; i < a.nys; ++i)
+        if (int rc = rnh_check_src(a.ys[i], "rnh_wino_wgrad")) return rc;
+    if ((long)(a.H + 2) * (a.W + 2) * s.Cx * 4 * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad: image too large for 32-bit row offsets");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wino_pad_kernel, dim3(wg_grid_for((long)a.B * (a.H + 2) * (a.W + 2) * (s.Cx / 4), 65536)), dim3(256), 0, st, a, xp, s.Cx);
+    RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");
+    rnh_wgrad_args_t b = a;
+    if (!db) b.bslab = nullptr;
+    const int items = s.KS * (s.Cx / 32) * (s.Cy / 32);
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
+    RNH_CHECK_LAUNCH("rnh_wino_wgrad");
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(wg_grid_for((long)s.Cx * s.Cy + s.Cy)), dim3(256), 0, st, a.slab, b.bslab, s.KS, s.Cx,
+                       s.Cy, rowmap, colmap, Cin, dw, db, accumulate);
+    RNH_CHECK_LAUNCH("rnh_wino_wgrad(reduce)");
+    return 0;
+}

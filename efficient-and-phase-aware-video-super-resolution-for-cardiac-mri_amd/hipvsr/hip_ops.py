@@ -33,6 +33,7 @@ class HipOps:
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
         self.direct = (os.environ.get('RNH_DIRECT', '1') != '0') if direct is None else bool(direct)
         self.direct_ps = os.environ.get('RNH_DIRECT_PS', '1') != '0'
+        self.wino_wgrad = os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0'
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, *shape):
@@ -227,6 +228,19 @@ class HipOps:
             if a.ys[i].nch != sg.nch:
                 raise L.HipKernelError(f'{plan.name}: dy source {i} channels')
             self._check_src_range(a.ys[i], s.t, B, H, W, plan.name)
+        a.B, a.H, a.W, a.ntaps, a.nxs, a.nys = B, H, W, plan.ntaps, len(xsrcs), len(ysrcs)
+        if self.wino_wgrad and all(sg.nvalid == sg.nch for sg in plan.xsegs) and all(sg.nvalid == sg.nch for sg in plan.ysegs) and \
+                self.lib.rnh_wino_wgrad_supported(C.byref(a)):
+            # Winograd form F(3x3, 2x2): zero-padded gathered copy of the inputs, 16 GEMMs over tiles, fixed-order reduction
+            sz = (C.c_int64 * 3)()
+            L.check(self.lib.rnh_wino_wgrad_ws_floats(C.byref(a), sz), 'rnh_wino_wgrad_ws_floats')
+            xp = self._workspace('wino_xp', sz[0])
+            slab = self._workspace('wgrad_slab', sz[1])
+            bslab = self._workspace('wgrad_bslab', sz[2]) if db is not None else None
+            a.slab, a.bslab = slab.data_ptr(), (bslab.data_ptr() if bslab is not None else None)
+            L.check(self.lib.rnh_wino_wgrad(C.byref(a), _ptr(xp), _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
+                                            int(accumulate), self._stream()), f'rnh_wino_wgrad({plan.name})')
+            return
         nsplit = plan.nsplit(B * H * W)
         slab = self._workspace('wgrad_slab', nsplit * plan.ntaps * plan.xcols_pad * plan.ycols_pad)
         bslab = self._workspace('wgrad_bslab', nsplit * plan.ycols_pad) if db is not None else None

@@ -161,6 +161,18 @@ typedef struct rnh_wgrad_args {
  * Replaces the weight/bias part of aten::convolution_backward (loss.backward(), trainer :46). */
 int rnh_conv_wgrad(const rnh_wgrad_args_t *args /* host */, void *stream);
 
+/* The same weight gradient in Winograd form F(3x3, 2x2) (csrc/wgrad_wino.hip): dg = G^T [sum_tiles (B^T d B) .* (A dY A^T)] G,
+ * 16 GEMMs over tiles, 4/9 of the multiplications.  Takes the xs / ys / B / H / W / ntaps / slab / bslab fields of
+ * rnh_wgrad_args_t (rows and columns in the natural order of the sources; xgrp, ygrp, tile, nsplit, zero_page unused).
+ * Supported (rnh_wino_wgrad_supported): 3x3, H even, W % 16 == 0, every source channel count a multiple of 32, x sources
+ * of scale 1, one common scale for the dy sources.  Workspaces: rnh_wino_wgrad_ws_floats -> {xp (zero-padded gathered
+ * copy of the inputs), slab, bslab} in floats.  The reduction (fixed order) scatters like rnh_wgrad_reduce:
+ * dw[(colmap[j]*Cin + rowmap[i])*9 + tap], db[colmap[j]]. */
+int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args /* host */);
+int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args /* host */, int64_t *out3 /* host: xp, slab, bslab */);
+int rnh_wino_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, const int32_t *rowmap, const int32_t *colmap, int Cin,
+                   float *dw, float *db, int accumulate, void *stream);
+
 /* Sum the partial slabs and scatter into the reference-layout gradient:
  *   dw[(colmap[j]*Cin + rowmap[i])*ntaps + tap] (+)= sum_s slab[s][tap][i][j]   (rowmap/colmap < 0: skipped)
  *   db[colmap[j]] (+)= sum_s bslab[s][j]                                         (if bslab and db)        */
