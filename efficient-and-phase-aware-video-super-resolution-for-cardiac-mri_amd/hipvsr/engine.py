@@ -295,7 +295,13 @@ class RefineNetEngine:
                           grads[P.r2_wgrad.bkey], accumulate=a)
                 a = acc(k1)
                 acc(b1)
-                ops.wgrad(P.r1_wgrad, xs, [Src(dR1p, nch=P.r1_cols, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                ysrc = [Src(dR1p, nch=P.r1_cols, img_off=hw * N)]
+                if P.r1_wino:
+                    # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
+                    ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
+                    ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
+                else:
+                    ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                 if P.xcol:
                     lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
                     ops.refine_xcol_wgrad([Hf[lo:hi], Hbk[lo:hi], ctx.P4[lo:hi]], dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w,

@@ -266,6 +266,8 @@ class NetPlans:
                 psegs = [sg for sg in segs if sg.nch == 4]
                 self.r1_fwd_h = ConvPlan('refine1.fwd.h', k1, b1, ws1, hsegs, list(range(C1 - 1)), wino=True)
                 self.r1_fwd_p = ConvPlan('refine1.fwd.p', k1, None, ws1, psegs, list(range(C1 - 1)))
+                self.r1_wgrad_h = WgradPlan('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
+                self.r1_wgrad_p = WgradPlan('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_dgrad_h = ConvPlan('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
                                            list(range(2 * Cl)), transposed=True, wino=True)
                 self.r1_dgrad_x = ConvPlan('refine1.dgrad.x', k1, None, ws1,

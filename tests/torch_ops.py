@@ -134,19 +134,16 @@ class TorchOps:
         with torch.enable_grad():
             F.conv2d(x.detach(), w0, padding=1 if kh == 3 else 0).backward(dy.detach())
         g = w0.grad
-        if not accumulate:
-            dw.zero_()
-            if db is not None:
-                db.zero_()
+        # like the kernels' reductions: only the (co, ci) entries the plan maps are written (stored or accumulated)
         bsum = dy.sum(dim=(0, 2, 3))
         for j, co in enumerate(plan.colmap[:dy.shape[1]]):
             if co < 0:
                 continue
             if db is not None:
-                db[co] += bsum[j]
+                db[co] = db[co] + bsum[j] if accumulate else bsum[j]
             for i, ci in enumerate(plan.rowmap[:x.shape[1]]):
                 if ci >= 0:
-                    dw[co, ci] += g[j, i]
+                    dw[co, ci] = dw[co, ci] + g[j, i] if accumulate else g[j, i]
 
     def inconv_fwd(self, x, w, b, slope):
         y = F.prelu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1), slope)

@@ -92,7 +92,11 @@ xs1 = []
 for j in range(5):
     xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P4, img_off=(4 + j) * N)]
 dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
-timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
+if P.r1_wino:
+    timeit('refine1.wgrad.h(wino)', lambda: ops.wgrad(P.r1_wgrad_h, [sc for sc in xs1 if sc.t is not P4], [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 128 * 640 * 9, 3)
+    timeit('refine1.wgrad.p', lambda: ops.wgrad(P.r1_wgrad_p, [sc for sc in xs1 if sc.t is P4], [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, None), 2.0 * TN * H * W * 128 * 5 * 9, 3)
+else:
+    timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
 if P.xcol:
     lo, hi = 4 * N, (4 + T + 4) * N
     timeit('refine1.wgrad.xcol', lambda: ops.refine_xcol_wgrad([Hf[lo:hi], Hb[lo:hi], P4[lo:hi]], dR1p[2 * N:(2 + T) * N], dw1, db1, N, 5, 64, False), 2.0 * TN * H * W * 645 * 9, 3)
