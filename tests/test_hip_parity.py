@@ -393,3 +393,50 @@ def test_last_group_only_inference(g1):
     net.train()
     out = net(xs, pc)
     assert all(g is not None for g in out)
+
+
+@pytest.mark.parametrize('which', ['lstm', 'up', 'refine'])
+def test_winograd_weight_gradient_vs_pixel_contraction(which):
+    """rnh_wino_wgrad (F(3x3,2x2): padded gather, transforms per lane, G^T.G in the reduction) against rnh_conv_wgrad
+    on the same operands: ConvLSTM (two 64-channel sources, 256 columns, bias), PixelShuffle conv (dy gathered from the
+    2x larger tensor, strided column map) and refine conv1's hidden-state rows (ten sources with frame offsets)."""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import NetConfig
+    dev = _dev()
+    cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True,
+                    num_updated_frames=6, positional_encoding=True)
+    P = NetPlans(cfg)
+    g = torch.Generator('cpu').manual_seed(17)
+    R = lambda *s: torch.randn(*s, generator=g).to(dev)                       # noqa: E731
+    B, H, W = 3, 6, 32
+    if which == 'lstm':
+        plan = P.lstm[('forward', 1)]['wgrad']
+        xs = [Src(R(B + 1, H, W, 64), img_off=1), Src(R(B + 1, H, W, 64))]
+        ys = [Src(R(B, H, W, 256))]
+        shape, bias = (256, 128, 3, 3), True
+    elif which == 'up':
+        plan = P.up[0]['wgrad']
+        xs = [Src(R(B, H, W, 64))]
+        big = R(B, 2 * H, 2 * W, 64)
+        ys = [Src(big, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
+        shape, bias = (256, 64, 3, 3), True
+    else:
+        plan = P.r1_wgrad_h
+        Hf, Hb = R(B + 4, H, W, 64), R(B + 4, H, W, 64)
+        xs = []
+        for j in range(5):
+            xs += [Src(Hf, img_off=j), Src(Hb, img_off=j)]
+        ys = [Src(R(B, H, W, 132), nch=128)]
+        shape, bias = (129, 645, 3, 3), True
+    res = []
+    for wino in (True, False):
+        ops = HipOps(dev)
+        ops.wino_wgrad = wino
+        dw, db = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
+        ops.wgrad(plan, xs, ys, B, H, W, dw, db if bias else None)
+        torch.cuda.synchronize()
+        res.append((dw.cpu(), db.cpu()))
+    _grad_close(res[0][0], res[1][0], 'dw', rel=1e-5)
+    _grad_close(res[0][1], res[1][1], 'db', rel=1e-5)
+    assert float(res[1][0].abs().max()) > 0
