@@ -40,10 +40,10 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
     out_f, out_b = out_s, 2 * out_s
     w = 4.0 / 9.0 if executed else 1.0        # convolutions that run in Winograd form execute 4/9 of their direct FLOPs
     if executed and scale == 4:
-        out_f, out_b = w * 294912 + 51200, 294912 + 294912 + 65536           # up1 fwd Winograd; up1 dgrad/wgrad direct
-    lstm_f, lstm_b = w * 589824, w * 589824 + 589824                          # fwd, dgrad Winograd; wgrad direct
+        out_f, out_b = w * 294912 + 51200, 2 * w * 294912 + 65536             # first PixelShuffle conv: fwd, dgrad, wgrad Winograd; tail collapsed
+    lstm_f, lstm_b = w * 589824, 2 * w * 589824                               # fwd, dgrad, wgrad Winograd
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
-    ref_f, ref_b = w * r1 + r2, w * r1 + r1 + 2 * r2
+    ref_f, ref_b = w * r1 + r2, 2 * w * r1 + 2 * r2                           # conv1 Winograd (fwd, dgrad, wgrad), conv2 direct
     fwd = F * 1152 + S * 2 * F * L * lstm_f + S * (F - 4) * ref_f + 3 * S * T * out_f
     bwd = T * 1152 + S * 2 * T * L * lstm_b + S * T * ref_b + 3 * S * T * out_b
     return fwd + bwd

@@ -19,22 +19,22 @@
 
 namespace {
 
-__global__ void wino_pad_kernel(const rnh_wgrad_args_t P, float *xp, int Cx) {
+// one workgroup per padded image row: zero border, interior gathered from the sources (16 bytes per thread)
+__global__ void __launch_bounds__(256) wino_pad_kernel(const rnh_wgrad_args_t P, float *xp, int Cx) {
     const int H = P.H, W = P.W, Hp = H + 2, Wp = W + 2, C4 = Cx >> 2;
-    const long total = (long)P.B * Hp * Wp * C4;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C4) * 4;
-        const long q = e / C4;
-        const int x = (int)(q % Wp) - 1, y = (int)((q / Wp) % Hp) - 1;
-        const long b = q / ((long)Wp * Hp);
+    const int row = blockIdx.x, b = row / Hp, y = row - b * Hp - 1;
+    float *dst = xp + (long)row * Wp * Cx;
+    const bool inside = (unsigned)y < (unsigned)H;
+    for (int e = threadIdx.x; e < Wp * C4; e += 256) {
+        const int xq = e / C4, c = (e - xq * C4) * 4, x = xq - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+        if (inside && (unsigned)x < (unsigned)W) {
             int cc = c, s = 0;
             while (cc >= P.xs[s].nch) cc -= P.xs[s++].nch;
             const rnh_src_t &S = P.xs[s];
-            v = rnh_ld4(S.ptr + (((b + S.img_off) * H + y) * W + x) * S.C + S.c0 + cc);
+            v = rnh_ld4(S.ptr + ((((long)b + S.img_off) * H + y) * W + x) * S.C + S.c0 + cc);
         }
-        rnh_st4(xp + e * 4, v);
+        rnh_st4(dst + (long)e * 4, v);
     }
 }
 
@@ -235,8 +235,17 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args
     }
 }
 
-// dw[(colmap[co]*Cin + rowmap[ci])*9 + 3a + b] (+)= (G^T dU G)[a][b], dU = sum over the slabs;  db[colmap[co]] (+)= sum bslab
-__global__ void wino_wgrad_reduce_kernel(const float *slab, const float *bslab, int KS, int Cx, int Cy, const int *rowmap,
+// stage 1: U[xi][ci][co] = sum over the tile-row ranges, in fixed order (one thread per element: coalesced, 16*Cx*Cy threads)
+__global__ void wino_wgrad_sum_kernel(const float *slab, float *U, int KS, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < KS; ++k) s += slab[(long)k * n + e];
+        U[e] = s;
+    }
+}
+
+// stage 2: dw[(colmap[co]*Cin + rowmap[ci])*9 + 3a + b] (+)= (G^T U G)[a][b];  db[colmap[co]] (+)= sum bslab
+__global__ void wino_wgrad_reduce_kernel(const float *U, const float *bslab, int KS, int Cx, int Cy, const int *rowmap,
                                          const int *colmap, int Cin, float *dw, float *db, int accumulate) {
     const long total = (long)Cx * Cy;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Cy; e += (long)gridDim.x * blockDim.x) {
@@ -252,20 +261,16 @@ __global__ void wino_wgrad_reduce_kernel(const float *slab, const float *bslab, 
         const int j = (int)(e % Cy), i = (int)(e / Cy);
         const int ci = rowmap[i], co = colmap[j];
         if (ci < 0 || co < 0) continue;
-        float U[16];
+        float Uv[16];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            float s = 0.f;
-            for (int k = 0; k < KS; ++k) s += slab[(((long)k * 16 + xi) * Cx + i) * Cy + j];
-            U[xi] = s;
-        }
+        for (int xi = 0; xi < 16; ++xi) Uv[xi] = U[((long)xi * Cx + i) * Cy + j];
         // G^T (4x4) G with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
         float T[3][4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            T[0][x] = U[0 * 4 + x] + 0.5f * (U[1 * 4 + x] + U[2 * 4 + x]);
-            T[1][x] = 0.5f * (U[1 * 4 + x] - U[2 * 4 + x]);
-            T[2][x] = 0.5f * (U[1 * 4 + x] + U[2 * 4 + x]) + U[3 * 4 + x];
+            T[0][x] = Uv[0 * 4 + x] + 0.5f * (Uv[1 * 4 + x] + Uv[2 * 4 + x]);
+            T[1][x] = 0.5f * (Uv[1 * 4 + x] - Uv[2 * 4 + x]);
+            T[2][x] = 0.5f * (Uv[1 * 4 + x] + Uv[2 * 4 + x]) + Uv[3 * 4 + x];
         }
         float *o = dw + ((long)co * Cin + ci) * 9;
 #pragma unroll
@@ -326,7 +331,7 @@ extern "C" int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t *o
     WinoWgradShape s;
     if (!args || !out3 || !wino_wgrad_shape(*args, &s)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad_ws_floats: shape not supported");
     out3[0] = (int64_t)args->B * (args->H + 2) * (args->W + 2) * s.Cx;
-    out3[1] = (int64_t)s.KS * 16 * s.Cx * s.Cy;
+    out3[1] = (int64_t)(s.KS + 1) * 16 * s.Cx * s.Cy;          // partial slabs + their sum
     out3[2] = (int64_t)s.KS * s.Cy;
     return 0;
 }
@@ -344,15 +349,20 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
         if (int rc = rnh_check_src(a.ys[i], "rnh_wino_wgrad")) return rc;
     if ((long)(a.H + 2) * (a.W + 2) * s.Cx * 4 * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad: image too large for 32-bit row offsets");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wino_pad_kernel, dim3(wg_grid_for((long)a.B * (a.H + 2) * (a.W + 2) * (s.Cx / 4), 65536)), dim3(256), 0, st, a, xp, s.Cx);
+    hipLaunchKernelGGL(wino_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, s.Cx);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");
     rnh_wgrad_args_t b = a;
     if (!db) b.bslab = nullptr;
     const int items = s.KS * (s.Cx / 32) * (s.Cy / 32);
     hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad");
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(wg_grid_for((long)s.Cx * s.Cy + s.Cy)), dim3(256), 0, st, a.slab, b.bslab, s.KS, s.Cx,
-                       s.Cy, rowmap, colmap, Cin, dw, db, accumulate);
+    // the sums go behind the partial slabs in the same workspace (rnh_wino_wgrad_ws_floats sizes it for KS + 1 slabs)
+    const long nU = (long)16 * s.Cx * s.Cy;
+    float *U = a.slab + (long)s.KS * nU;
+    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(wg_grid_for(nU)), dim3(256), 0, st, a.slab, U, s.KS, nU);
+    RNH_CHECK_LAUNCH("rnh_wino_wgrad(sum)");
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(wg_grid_for((long)s.Cx * s.Cy + s.Cy)), dim3(256), 0, st, U, b.bslab, s.KS, s.Cx, s.Cy,
+                       rowmap, colmap, Cin, dw, db, accumulate);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad(reduce)");
     return 0;
 }
