@@ -94,8 +94,13 @@ class RefineNetEngine:
             for d in dirs:
                 st[d] = dict(H=[ops.empty(F * N, H, W, hd) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
                              G=[ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None)
+            # In the last stage nothing reads the hidden states past the last refine window (the feature update after it is
+            # dead, quirk Q5): the forward direction stops at frame U+T-1+hw, the backward one at U-hw, and the refine
+            # block only computes the T supervised windows.  Outputs and gradients are unchanged.
+            last = s == S - 1
+            F_s = U + T + hw if last else F
             ops.fork(2 * Lr)
-            for idx in range(F):
+            for idx in range(F_s):
                 for di, d in enumerate(dirs):
                     k = idx if d == 'forward' else F - 1 - idx
                     prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
@@ -127,24 +132,25 @@ class RefineNetEngine:
             Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
 
             # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
-            nwin = F - 2 * hw
+            w0, nwin = (U - hw, T) if last else (0, F - 2 * hw)     # first window computed, number of windows
             srcs = []
             for j in range(w):
-                srcs += [Src(Hf, img_off=j * N), Src(Hbk, img_off=j * N)]
+                srcs += [Src(Hf, img_off=(w0 + j) * N), Src(Hbk, img_off=(w0 + j) * N)]
                 if P.pos:
-                    srcs.append(Src(P4, img_off=j * N))
+                    srcs.append(Src(P4, img_off=(w0 + j) * N))
             R = ops.empty(nwin * N, H, W, Cl)
             if P.pos:
                 R1 = ops.empty(nwin * N, H, W, P.C1p)
+                lo, hi = w0 * N, (w0 + nwin + w - 1) * N            # the source frames of these windows
                 if P.r1_wino:
                     ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
-                    ops.refine_phase_bias(R1, P4, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
+                    ops.refine_phase_bias(R1, P4[lo:hi], params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
                 else:
                     ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                 if P.xcol:
-                    ops.refine_xcol_fwd([Hf, Hbk, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
+                    ops.refine_xcol_fwd([Hf[lo:hi], Hbk[lo:hi], P4[lo:hi]], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
                 ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
-                st['R1'] = R1 if need_grad else None
+                st['R1'], st['w0'] = (R1 if need_grad else None), w0
             else:
                 ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R, Cl)])
 
@@ -156,13 +162,13 @@ class RefineNetEngine:
             elif skip_up:
                 nb = 1                                        # the fused group only
                 Sb = ops.empty(TN, H, W, C)
-                ops.add(Sb, fc, R[(U - hw) * N:(U - hw + T) * N])
+                ops.add(Sb, fc, R[(U - hw - w0) * N:(U - hw - w0 + T) * N])
             else:
                 nb = 3
                 Sb = ops.empty(3 * TN, H, W, C)
                 ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
                 ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
-                ops.add(Sb[2 * TN:], fc, R[(U - hw) * N:(U - hw + T) * N])
+                ops.add(Sb[2 * TN:], fc, R[(U - hw - w0) * N:(U - hw - w0 + T) * N])
             Oview = O_all[s] if nb == 3 else O_all[s, 2:3]
             cur, h, wd, Ys = (Sb if nb else None), H, W, []
             fused_tail = ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)
@@ -291,7 +297,7 @@ class RefineNetEngine:
                 ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
-                ops.wgrad(P.r2_wgrad, [Src(st['R1'], img_off=(U - hw) * N)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
+                ops.wgrad(P.r2_wgrad, [Src(st['R1'], img_off=(U - hw - st['w0']) * N)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
                           grads[P.r2_wgrad.bkey], accumulate=a)
                 a = acc(k1)
                 acc(b1)
