@@ -44,7 +44,10 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
     lstm_f, lstm_b = w * 589824, 2 * w * 589824                               # fwd, dgrad, wgrad Winograd
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
     ref_f, ref_b = w * r1 + r2, 2 * w * r1 + 2 * r2                           # conv1 Winograd (fwd, dgrad, wgrad), conv2 direct
-    fwd = F * 1152 + S * 2 * F * L * lstm_f + S * (F - 4) * ref_f + 3 * S * T * out_f
+    nfr, nwin = S * F, S * (F - 4)            # ConvLSTM frames per direction and refine windows, all stages
+    if executed:                              # the last stage stops at the last refine window / computes the T supervised windows only
+        nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
+    fwd = F * 1152 + 2 * nfr * L * lstm_f + nwin * ref_f + 3 * S * T * out_f
     bwd = T * 1152 + S * 2 * T * L * lstm_b + S * T * ref_b + 3 * S * T * out_b
     return fwd + bwd
 
