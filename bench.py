@@ -8,9 +8,11 @@ N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 ->
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, weak scaling: 8 samples per rank)
 
 Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
-ranks).  `roofline` prices the dominant kernel (the ConvLSTM cell implicit-GEMM, 45 % of the step's FLOPs) from
-HIP-event timing of that launch on this run; `cpu_baseline` times the CPU oracle (= the reference's computation,
-bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs only).
+ranks).  `roofline` prices the dominant kernel (the ConvLSTM cell forward, a Winograd F(2x2,3x3) convolution with fused
+gates, 342 - 24 launches per step) from HIP-event timing of that launch on this run: `achieved` uses the ALGORITHMIC
+(direct 3x3) FLOPs as SURVEY section 8d defines them, the executed MFMA rate is reported beside it; `cpu_baseline` times
+the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
+only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 """
 import argparse
 import json
