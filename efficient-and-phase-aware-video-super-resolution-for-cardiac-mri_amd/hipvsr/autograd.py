@@ -3,6 +3,7 @@ forward, backward = the engine's hand-written backward) and one for the fused lo
 import torch
 
 from . import lib as L
+from .hip_ops import packed_view
 
 
 class HipOutputs(tuple):
@@ -74,7 +75,7 @@ def fused_losses(outputs, targets, loss_fn):
         return None
     S, three, TN = packed.shape[:3]
     T = len(targets)
-    y = torch.stack(list(targets), 0)                                   # (T, N, C, sH, sW)
+    y = packed_view(list(targets))                                      # (T, N, C, sH, sW)
     if y.shape[2] != 1:
         y = y.permute(0, 1, 3, 4, 2)
     y = y.contiguous().float()

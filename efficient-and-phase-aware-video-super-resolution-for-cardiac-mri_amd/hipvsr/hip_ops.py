@@ -17,6 +17,19 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def packed_view(tensors, device=None):
+    """list[K] of equally shaped tensors -> (K, ...) fp32 tensor on ``device``: without a copy when the list items are
+    consecutive contiguous slices of one buffer (what hipvsr.cine_cache hands over), through torch.stack otherwise."""
+    t0 = tensors[0]
+    dev = torch.device(device) if device is not None else t0.device
+    n = t0.numel() * t0.element_size()
+    if (t0.dtype == torch.float32 and t0.device == dev and n > 0
+            and all(t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device and t.is_contiguous()
+                    and t.data_ptr() == t0.data_ptr() + k * n for k, t in enumerate(tensors))):
+        return t0.as_strided((len(tensors),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
+    return torch.stack([t.to(dev, torch.float32) for t in tensors], dim=0)
+
+
 class HipOps:
     name = 'hip'
 
@@ -93,7 +106,7 @@ class HipOps:
 
     def stack_inputs(self, inputs):
         """list[F] of (N, Cin, H, W) -> (F*N, H, W, Cin) NHWC, frame-major (plumbing: one copy of the LR input)."""
-        x = torch.stack([t.to(self.device, torch.float32) for t in inputs], dim=0)          # (F, N, Cin, H, W)
+        x = packed_view(inputs, self.device)                                                # (F, N, Cin, H, W)
         F, N, Cin, H, W = x.shape
         return x.permute(0, 1, 3, 4, 2).reshape(F * N, H, W, Cin).contiguous()
 

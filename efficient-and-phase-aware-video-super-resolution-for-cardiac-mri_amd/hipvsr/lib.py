@@ -26,7 +26,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
            'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
-           'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad']
+           'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather']
 
 
 class HipKernelError(RuntimeError):
@@ -58,6 +58,12 @@ class WgradArgs(C.Structure):
                 ('nys', C.c_int32), ('ycols_pad', C.c_int32), ('xgrp', C.c_void_p), ('ygrp', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('ntaps', C.c_int32), ('tile', C.c_int32),
                 ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p), ('zero_page', C.c_void_p)]
+
+
+class CineSample(C.Structure):
+    _fields_ = [('lr_off', C.c_int64), ('hr_off', C.c_int64), ('code_off', C.c_int64), ('Tc', C.c_int32), ('Hl', C.c_int32),
+                ('Wl', C.c_int32), ('Hh', C.c_int32), ('Wh', C.c_int32), ('lr_start', C.c_int32), ('hr_start', C.c_int32),
+                ('y0', C.c_int32), ('x0', C.c_int32), ('hflip', C.c_int32), ('vflip', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 _lib = None
@@ -118,6 +124,7 @@ def load():
     lib.rnh_uptail_dgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_wcontract.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_cine_gather.argtypes = [vp, i64, C.POINTER(CineSample), vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]
     lib.rnh_struct_sizes.argtypes = [C.POINTER(C.c_int32 * 4)]
     lib.rnh_struct_sizes.restype = None
     sizes = (C.c_int32 * 4)()

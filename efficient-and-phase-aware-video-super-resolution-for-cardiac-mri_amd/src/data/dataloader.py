@@ -11,6 +11,13 @@ def _seed_worker(worker_id):
 
 
 class Dataloader(DataLoader):
+    def __new__(cls, dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=None, **kwargs):
+        # a dataset that lives in HBM is iterated by the fused gather (one launch per batch), not by worker processes
+        if getattr(dataset, 'cache', None) is not None:
+            from hipvsr.cine_cache import GpuCineLoader
+            return GpuCineLoader(dataset.cache, batch_size=batch_size, shuffle=shuffle, **dataset.loader_kwargs)
+        return super().__new__(cls)
+
     def __init__(self, dataset, batch_size=1, shuffle=False, num_workers=0, collate_fn=None, **kwargs):
         sampler = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

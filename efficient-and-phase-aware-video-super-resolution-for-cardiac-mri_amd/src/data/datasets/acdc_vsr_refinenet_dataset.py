@@ -3,9 +3,10 @@
 F = num_frames + 2*num_updated_frames, frames cut from the cyclically tripled cine and the phase code sliced the
 same way (reference src/data/datasets/acdc_vsr_refinenet_dataset.py:49-89).
 
-The ACDC NIfTI files and nibabel are not available offline, so ``AcdcVSRRefineNetDataset`` accepts the
-reference's constructor kwargs and, when ``data_dir`` holds no data, serves a deterministic synthetic cine with
-the statistics of the normalised data.  Feeding real data at GPU speed is the "next" row f1.
+``AcdcVSRRefineNetDataset`` accepts the reference's constructor kwargs.  Cines found under ``data_dir`` (the
+reference's layout of .nii.gz files) are decoded once and served from HBM (hipvsr/cine_cache.py, row f1); when
+``data_dir`` holds no data (the ACDC files are not part of this offline image) it serves a deterministic synthetic
+cine with the statistics of the normalised data.
 """
 import math
 from pathlib import Path
@@ -60,16 +61,54 @@ class SyntheticCineDataset(Dataset):
 
 
 class AcdcVSRRefineNetDataset(SyntheticCineDataset):
+    """Reference constructor kwargs (dataset :21-36).  With cines on disk (the reference's directory layout) the
+    samples are served from HBM by ``hipvsr.cine_cache`` - ``src.data.dataloader.Dataloader`` turns this dataset into a
+    ``GpuCineLoader`` - and ``transforms`` / ``augments`` are read as parameters of the fused gather: Normalize's
+    means / stds, the two flips, RandomCropPatch's size (ToTensor is implied).  Anything else in those lists is refused
+    rather than ignored."""
+
     def __init__(self, downscale_factor, transforms=None, pos_code_path=None, augments=None, num_frames=5,
-                 num_updated_frames=0, data_dir=None, type='train', **kwargs):
+                 num_updated_frames=0, data_dir=None, type='train', device=None, **kwargs):
         if downscale_factor not in [2, 3, 4]:
             raise ValueError(f'The downscale factor should be 2, 3, 4. Got {downscale_factor}.')
-        size = (32, 32)
+        size, flips, means, stds = (32, 32), [False, False], None, None
         for a in (augments or []):
-            if dict(a).get('name') == 'RandomCropPatch':
-                size = tuple(dict(a).get('kwargs', {}).get('size', size))
-        if data_dir is not None and any(Path(data_dir).glob('**/*2d+1d*.nii.gz')):
-            raise NotImplementedError('NIfTI loading needs nibabel, which is not part of this offline image; '
-                                      'convert the cines to tensors or install nibabel (next-row f1).')
+            a = dict(a)
+            kw = dict(a.get('kwargs') or {})
+            if a.get('name') == 'RandomCropPatch':
+                size = tuple(kw.get('size', size))
+                if kw.get('ratio', downscale_factor) != downscale_factor:
+                    raise ValueError(f"The ratio between the HR images and the LR images should be {kw.get('ratio')}.")
+            elif a.get('name') == 'RandomHorizontalFlip' and not kw:
+                flips[0] = True
+            elif a.get('name') == 'RandomVerticalFlip' and not kw:
+                flips[1] = True
+            else:
+                raise ValueError(f"augmentation {a.get('name')} {kw} is not part of the fused input path")
+        for tr in (transforms or []):
+            tr = dict(tr)
+            kw = dict(tr.get('kwargs') or {})
+            if tr.get('name') == 'Normalize':
+                means, stds = kw.get('means'), kw.get('stds')
+            elif tr.get('name') != 'ToTensor':
+                raise ValueError(f"transform {tr.get('name')} is not part of the fused input path")
+        self.cache = None
+        if data_dir is not None and any(Path(data_dir).glob(f'{type}/**/*2d+1d*.nii.gz')):
+            from hipvsr.cine_cache import CineCache
+            if device is None:
+                raise ValueError('cines on disk are served from HBM: pass device= (src.main does)')
+            self.cache = CineCache.from_dir(data_dir, type, downscale_factor, pos_code_path, device, means, stds)
+            self.loader_kwargs = dict(type=type, num_frames=num_frames, num_updated_frames=num_updated_frames, size=size, flips=tuple(flips))
+            self.type = type
+            self.data = self.cache.train_items() if type == 'train' else [(c, None) for c in range(len(self.cache.table))]
+            return
         super().__init__(downscale_factor=downscale_factor, num_frames=num_frames, num_updated_frames=num_updated_frames,
                          size=size if type == 'train' else (54, 64), length=64 if type == 'train' else 2, type=type)
+
+    def __len__(self):
+        return len(self.data) if self.cache is not None else super().__len__()
+
+    def __getitem__(self, index):
+        if self.cache is not None:
+            raise RuntimeError('this dataset lives in HBM: iterate it through src.data.dataloader.Dataloader (one fused gather per batch)')
+        return super().__getitem__(index)

@@ -289,6 +289,32 @@ int rnh_ew_add(float *out, const float *a, const float *b, const float *c, int64
  * out[(f*N + n)][y][x][0..3] = (pos[n*F + f], 0, 0, 0). */
 int rnh_phase_plane(const float *pos /* [N][F] */, float *out, int N, int F, int H, int W, void *stream);
 
+/* Input feeding.  Replaces, for one batch, the N calls of
+ * AcdcVSRRefineNetDataset.__getitem__ (src/data/datasets/acdc_vsr_refinenet_dataset.py:49-89: nib.load of the LR and
+ * the HR cine, RandomHorizontalFlip / RandomVerticalFlip / RandomCropPatch src/data/transforms.py:321-450, Normalize
+ * :100-168, ToTensor :74-97, the tripled-cycle window :75-89) and the default collate, with the cines resident in
+ * HBM.  pool: fp32, per cine the LR frames (Tc, Hl, Wl), the HR frames (Tc, Hh, Wh) and the phase code (Tc).
+ *   inputs  (F, N, h, w)    [k][n] = norm(flip(LR frame (lr_start + k) mod Tc))[y0 : y0+h, x0 : x0+w]
+ *   targets (T, N, s*h, s*w) [i][n] = norm(flip(HR frame (hr_start + i) mod Tc))[s*y0 : s*(y0+h), s*x0 : s*(x0+w)]
+ *   pos     (N, F)           [n][k] = code[(lr_start + k) mod Tc]
+ * flip: np.flip(img, 1) if hflip, np.flip(img, 0) if vflip, BEFORE the crop (the augments' order in exp1_x4.yaml:17-23);
+ * norm(x) = (x - mean) / stdv in fp32 with IEEE division (stdv = float32(std + 1e-10), transforms.py:166), skipped if
+ * normalize == 0.  Train sample with target frame t: lr_start = t + Tc - T + 1 - U, hr_start = t + Tc - T + 1,
+ * F = T + 2U; whole-cycle (valid / test): lr_start = Tc - U, hr_start = 0, F = Tc + 2U, T = Tc.
+ * samples_host: N descriptors in host memory, validated against pool_floats here and uploaded to samples_dev
+ * (N * sizeof(rnh_cine_sample_t) bytes of device scratch) on the stream. */
+typedef struct rnh_cine_sample {
+    int64_t lr_off, hr_off, code_off; /* float offsets into the pool */
+    int32_t Tc, Hl, Wl, Hh, Wh;       /* frames per cycle, LR and HR frame size */
+    int32_t lr_start, hr_start;       /* first LR / HR frame, taken modulo Tc */
+    int32_t y0, x0;                   /* LR crop origin, in the flipped image's coordinates */
+    int32_t hflip, vflip;
+    int32_t reserved[3];
+} rnh_cine_sample_t;
+int rnh_cine_gather(const float *pool, int64_t pool_floats, const rnh_cine_sample_t *samples_host, rnh_cine_sample_t *samples_dev,
+                    int N, int F, int T, int s, int h, int w, int normalize, float mean, float stdv, float *inputs,
+                    float *targets, float *pos, void *stream);
+
 const char *rnh_last_error(void);
 int rnh_abi_version(void);
 /* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding

@@ -219,10 +219,59 @@ def g5_edges(mods):
     print('g5_edges.pt', {k: v for k, v in rec.items() if k not in ('cycle',)})
 
 
+def g6_input():
+    """Input feeding (row f1): the reference's own RandomHorizontalFlip / RandomVerticalFlip / RandomCropPatch /
+    Normalize / ToTensor (src/data/transforms.py), composed as in exp1_x4.yaml:11-23, on seeded synthetic cines.
+    transforms.py imports SimpleITK at module level (used by RandomElasticDeformation only, which is not exercised):
+    an empty placeholder module lets that import line pass."""
+    import random
+    sys.modules.setdefault('SimpleITK', types.ModuleType('SimpleITK'))
+    for n in ['src.data']:
+        m = types.ModuleType(n)
+        m.__path__ = []
+        sys.modules[n] = m
+    spec = importlib.util.spec_from_file_location('src.data.transforms', REF + 'data/transforms.py')
+    tr = importlib.util.module_from_spec(spec)
+    sys.modules['src.data.transforms'] = tr
+    sys.modules['src.data'].transforms = tr
+    sys.modules['src'].data = sys.modules['src.data']
+    spec.loader.exec_module(tr)
+
+    class Box(dict):
+        __getattr__ = dict.get
+
+    rng = np.random.RandomState(20200526)
+    cases = []
+    for ci, (s, Hl, Wl, Tc, size) in enumerate([(4, 12, 15, 5, (8, 8)), (2, 10, 9, 4, (6, 7)), (3, 9, 8, 6, (9, 8)), (4, 8, 8, 3, (5, 6))]):
+        hr = np.round(rng.rand(Hl * s, Wl * s, 1, Tc) * 255).astype(np.float32)
+        lr = (rng.rand(Hl, Wl, 1, Tc) * 255).astype(np.float32)
+        augments = tr.compose([Box(name='RandomHorizontalFlip'), Box(name='RandomVerticalFlip'),
+                               Box(name='RandomCropPatch', kwargs=dict(size=list(size), ratio=s))])
+        transforms = tr.compose([Box(name='Normalize', kwargs=dict(means=[54.089], stds=[48.084])), Box(name='ToTensor')])
+        code = np.cos(np.linspace(0, np.pi, Tc, endpoint=False))
+        runs = []
+        for seed in range(6):
+            imgs = [lr[..., t] for t in range(Tc)] + [hr[..., t] for t in range(Tc)]
+            random.seed(1000 * ci + seed)
+            aug = augments(*imgs)
+            out = transforms(*aug)
+            out = [o.permute(2, 0, 1).contiguous() for o in out]                      # dataset :62
+            runs.append(dict(seed=1000 * ci + seed, aug=[torch.from_numpy(np.ascontiguousarray(a)) for a in aug], out=out))
+        whole = [o.permute(2, 0, 1).contiguous() for o in transforms(*[lr[..., t] for t in range(Tc)], *[hr[..., t] for t in range(Tc)])]
+        cases.append(dict(s=s, size=size, lr=torch.from_numpy(lr), hr=torch.from_numpy(hr), code=torch.from_numpy(code),
+                          pos_code=transforms(code, normalize_tags=[False]), runs=runs, whole=whole))      # dataset :71
+    torch.save(cases, os.path.join(HERE, 'g6_input.pt'))
+    print('g6_input.pt', len(cases), 'cases,', os.path.getsize(os.path.join(HERE, 'g6_input.pt')), 'bytes')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     mods = _load_reference()
+    if sys.argv[1:] == ['g6']:
+        g6_input()
+        sys.exit(0)
     g1_tiny(mods)
     g3_trainer_g4_losses(mods)
     g5_edges(mods)
     g2_cfg1(mods)
+    g6_input()
