@@ -23,8 +23,11 @@ def packed_view(tensors, device=None):
     t0 = tensors[0]
     dev = torch.device(device) if device is not None else t0.device
     n = t0.numel() * t0.element_size()
+    # the same storage is required as well: two separate allocations may be neighbours in the caching allocator's pool
+    base = t0.untyped_storage().data_ptr()
     if (t0.dtype == torch.float32 and t0.device == dev and n > 0
             and all(t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device and t.is_contiguous()
+                    and t.untyped_storage().data_ptr() == base
                     and t.data_ptr() == t0.data_ptr() + k * n for k, t in enumerate(tensors))):
         return t0.as_strided((len(tensors),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
     return torch.stack([t.to(dev, torch.float32) for t in tensors], dim=0)

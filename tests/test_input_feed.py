@@ -118,6 +118,20 @@ class _FakeCache:
     draw = cc.CineCache.draw
 
 
+def test_packed_view_needs_one_storage():
+    """Adjacent addresses are not enough: separately allocated tensors that happen to be neighbours (the caching
+    allocator does that) must go through a copy; slices of one buffer must not."""
+    from hipvsr.hip_ops import packed_view
+    buf = torch.arange(24, dtype=torch.float32)
+    views = [buf[6 * k:6 * k + 6].view(2, 3) for k in range(4)]
+    assert packed_view(views).data_ptr() == buf.data_ptr()
+    raw = bytearray(buf.numpy().tobytes())
+    apart = [torch.frombuffer(raw, dtype=torch.float32, count=6, offset=24 * k).view(2, 3) for k in range(4)]
+    assert apart[1].data_ptr() == apart[0].data_ptr() + 24
+    got = packed_view(apart)
+    assert got.data_ptr() != apart[0].data_ptr() and torch.equal(got, buf.view(4, 2, 3))
+
+
 def test_loader_shards_like_a_distributed_sampler():
     cache = _FakeCache([5, 7, 4])
     full = cc.GpuCineLoader(cache, 'train', batch_size=4, shuffle=True, seed=3, rank=0, world_size=1)
