@@ -172,7 +172,8 @@ def main():
 
     net = make_net(dev, seed=0)
     dp.broadcast_parameters(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=0)
+    from hipvsr.step_tail import FlatAdam
+    opt = FlatAdam(net.parameters(), lr=1e-4, weight_decay=0)      # exp1_x4.yaml:56-60; one launch per run of parameters
     tr = object.__new__(AcdcVSRRefineNetTrainer)
     tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
     tr.loss_weights = torch.tensor([1.0], device=dev)

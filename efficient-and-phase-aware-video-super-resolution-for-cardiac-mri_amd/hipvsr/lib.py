@@ -26,7 +26,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
            'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
-           'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather']
+           'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
+           'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim']
 
 
 class HipKernelError(RuntimeError):
@@ -125,6 +126,10 @@ def load():
     lib.rnh_uptail_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_wcontract.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_cine_gather.argtypes = [vp, i64, C.POINTER(CineSample), vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]
+    lib.rnh_adam_step.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, vp]
+    lib.rnh_metrics_ws_floats.argtypes = [i32, i32, i32]
+    lib.rnh_metrics_ws_floats.restype = i64
+    lib.rnh_metrics_psnr_ssim.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, f32, C.POINTER(C.c_float), vp, vp, vp]
     lib.rnh_struct_sizes.argtypes = [C.POINTER(C.c_int32 * 4)]
     lib.rnh_struct_sizes.restype = None
     sizes = (C.c_int32 * 4)()

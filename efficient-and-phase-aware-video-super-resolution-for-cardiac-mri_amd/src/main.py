@@ -56,6 +56,17 @@ def _get_instance(module, config, *args):
     return cls(*args, **kwargs) if kwargs else cls(*args)
 
 
+def _get_optimizer(config, params, device):
+    """``torch.optim.<name>(params, **kwargs)`` as the reference does (src/main.py:76); plain Adam on a HIP device is
+    served by the flat single-launch implementation (same constructor, same state_dict format)."""
+    kwargs = dict(config.get('kwargs') or {})
+    plain = not any(kwargs.get(k) for k in ('amsgrad', 'maximize', 'capturable', 'differentiable'))
+    if config.name == 'Adam' and device.type == 'cuda' and plain:
+        from hipvsr.step_tail import FlatAdam
+        return FlatAdam(params, **kwargs)
+    return _get_instance(torch.optim, config, params)
+
+
 def main(args):
     with open(args.config_path) as f:
         config = Cfg(yaml.safe_load(f))
@@ -101,7 +112,7 @@ def main(args):
         loss_fns.append(_get_instance(torch.nn if cl.name in torch_losses else src.model.losses, cl))
         loss_weights.append(cl.weight)
     metric_fns = [_get_instance(src.model.metrics, cm) for cm in config.metrics if hasattr(src.model.metrics, cm.name)]
-    optimizer = _get_instance(torch.optim, config.optimizer, net.parameters())
+    optimizer = _get_optimizer(config.optimizer, net.parameters(), device)
     lr_scheduler = _get_instance(torch.optim.lr_scheduler, config.lr_scheduler, optimizer) if config.get('lr_scheduler') else None
     config.logger.kwargs.update(log_dir=saved_dir / 'log', net=net)
     logger = _get_instance(src.callbacks.loggers, config.logger)

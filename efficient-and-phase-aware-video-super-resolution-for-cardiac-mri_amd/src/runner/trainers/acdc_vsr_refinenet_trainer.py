@@ -4,7 +4,8 @@ only in evaluation, :95-100), zero_grad / backward / step (:41-47), PSNR-style m
 group (:103-120), running-mean log (:122-136).
 
 Differences, all inside this boundary: L1 / Charbonnier over all 3*S*T (output, target) pairs go through ONE
-fused HIP loss+gradient launch instead of 63 loss_fn calls; and under torch.distributed the gradients are
+fused HIP loss+gradient launch instead of 63 loss_fn calls; PSNR / SSIM of all frames of the step, denormalisation
+included, are one launch (src.model.metrics.fused_metrics); and under torch.distributed the gradients are
 averaged with one all-reduce before the optimizer step."""
 import functools
 
@@ -14,6 +15,7 @@ from tqdm import tqdm
 
 from hipvsr import dp
 from hipvsr.autograd import fused_losses
+from src.model.metrics import fused_metrics
 from src.runner.trainers.base_trainer import BaseTrainer
 from src.utils import denormalize
 
@@ -87,6 +89,11 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
         return losses
 
     def _compute_metrics(self, outputs, targets):
+        packed = getattr(outputs, 'packed', None)
+        fused = fused_metrics(outputs[-1], targets, self.metric_fns, 'acdc',
+                              packed_last=packed[-1, -1].detach() if packed is not None else None)
+        if fused is not None:
+            return fused
         outs = [self._denormalize(o) for o in outputs[-1]]
         tgts = [self._denormalize(t) for t in targets]
         return [torch.stack([fn(o, t) for o, t in zip(outs, tgts)]).mean() for fn in self.metric_fns]

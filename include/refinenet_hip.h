@@ -315,6 +315,30 @@ int rnh_cine_gather(const float *pool, int64_t pool_floats, const rnh_cine_sampl
                     int N, int F, int T, int s, int h, int w, int normalize, float mean, float stdv, float *inputs,
                     float *targets, float *pos, void *stream);
 
+/* Optimizer step on flat buffers.  Replaces torch.optim.Adam.step
+ * (src/main.py:76 instantiates it from exp1_x4.yaml:56-60, acdc_vsr_refinenet_trainer.py:47 steps it) over the 25
+ * parameter tensors that receive a gradient with ONE launch over contiguous ranges:
+ *   g += weight_decay * p;  m = m + (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * step is the 1-based count of this update; the four buffers hold n floats each and are congruent modulo 16 bytes
+ * (the same sub-range of four equally laid out flat buffers). */
+int rnh_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t step, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, void *stream);
+
+/* Per-step metrics.  Replaces AcdcVSRRefineNetTrainer._compute_metrics
+ * (acdc_vsr_refinenet_trainer.py:103-120) / the predictor's (acdc_vsr_refinenet_predictor.py:140-160) with
+ * metric_fns = [PSNR, SSIM]: denormalize (src/utils.py:1-20: clamp(round(x * stdv + mean), 0, 255), applied when
+ * denorm != 0), PSNR (src/model/metrics.py:20-36) and SSIM (:86-113, 11x11 window, valid convolution) of P image
+ * pairs of H x W in one pass.  out / tgt: [P][H][W] fp32; cps = planes per sample (the channel count: PSNR averages
+ * the MSE over the planes of a sample, P % cps == 0).  window11_host: the 11 normalised 1-D window weights, in HOST
+ * memory (the reference's 2-D window is their outer product).  c1, c2 = (0.01, 0.03 * value_range)^2.  want_ssim == 0
+ * skips the windowed sums (PSNR only; images smaller than the window are then allowed, the SSIM slots read 0).
+ * ws: rnh_metrics_ws_floats(P, H, W) floats.  result (device, 2 + P/cps + 2P floats): [0] mean over samples of the
+ * PSNR, [1] mean over images of the SSIM-map mean, then PSNR per sample, SSIM per image, MSE per image. */
+int64_t rnh_metrics_ws_floats(int P, int H, int W);
+int rnh_metrics_psnr_ssim(const float *out, const float *tgt, int P, int cps, int H, int W, int denorm, int want_ssim, float mean, float stdv,
+                          float max_value, float value_range, const float *window11_host, float *ws, float *result, void *stream);
+
 const char *rnh_last_error(void);
 int rnh_abi_version(void);
 /* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding

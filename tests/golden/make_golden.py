@@ -264,14 +264,74 @@ def g6_input():
     print('g6_input.pt', len(cases), 'cases,', os.path.getsize(os.path.join(HERE, 'g6_input.pt')), 'bytes')
 
 
+def g7_metrics_adam(mods):
+    """Rows f3 / f4: the reference's SSIM / PSNR / denormalize / trainer._compute_metrics on fixed tensors (random,
+    smooth, image sizes that straddle the kernel's tile borders, the smallest legal 11x11 image), and the trajectory of
+    torch.optim.Adam - the optimizer the reference's YAML instantiates (src/main.py:76) - on fixed gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator('cpu').manual_seed(777)
+    cases = {}
+
+    def smooth(n, h, w):
+        x = torch.randn(n, 1, h + 16, w + 16, generator=g)
+        k = torch.ones(1, 1, 9, 9) / 81.0
+        x = F.conv2d(F.conv2d(x, k), k)
+        return (x / x.std()) * 0.8
+
+    shapes = dict(random=(2, 24, 29, 3), smooth=(2, 40, 37, 3), wide=(1, 35, 150, 2), minimal=(3, 11, 11, 1), tall=(1, 70, 13, 2))
+    for name, (n, h, w, t) in shapes.items():
+        if name == 'random':
+            outs = [torch.randn(n, 1, h, w, generator=g) for _ in range(t)]
+            tgts = [torch.randn(n, 1, h, w, generator=g) for _ in range(t)]
+        else:
+            tgts = [smooth(n, h, w) for _ in range(t)]
+            outs = [y + 0.05 * torch.randn(n, 1, h, w, generator=g) for y in tgts]
+        outputs = tuple([torch.zeros_like(o) for o in outs] for _ in range(8)) + (outs,)
+        tr = _bare_trainer(mods, None, [], [mods.metrics.PSNR(), mods.metrics.SSIM()])
+        m = tr._compute_metrics(outputs, tgts)
+        den_o = [mods.utils.denormalize(o, 'acdc') for o in outs]
+        den_t = [mods.utils.denormalize(y, 'acdc') for y in tgts]
+        cases[name] = dict(outputs_last=outs, targets=tgts, trainer_psnr=m[0].clone(), trainer_ssim=m[1].clone(),
+                           psnr_per_sample=torch.stack([mods.metrics.PSNR(size_average=False)(a, b) for a, b in zip(den_o, den_t)]),
+                           ssim_per_sample=torch.stack([mods.metrics.SSIM(size_average=False)(a, b) for a, b in zip(den_o, den_t)]))
+    o, y = torch.rand(2, 1, 20, 23, generator=g), torch.rand(2, 1, 20, 23, generator=g)
+    cases['unit_range'] = dict(output=o, target=y, psnr=mods.metrics.PSNR(max_value=1)(o, y).clone(),
+                               ssim=mods.metrics.SSIM(value_range=1)(o, y).clone())
+    cases['ssim_weight'] = mods.metrics.SSIM().weight.clone()
+
+    adam = {}
+    for name, kw in dict(yaml=dict(lr=1e-4, weight_decay=0), decay=dict(lr=3e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.01)).items():
+        shapes_p = [(7, 3, 3, 3), (7,), (1,), (5, 4)]
+        p0 = [torch.randn(*s_, generator=g) * 0.1 for s_ in shapes_p]
+        grads = [[(torch.randn(*s_, generator=g) * (10.0 ** (i - 2)) if (k, i) != (1, 2) else torch.zeros(*s_)) for i, s_ in enumerate(shapes_p)]
+                 for k in range(6)]
+        ps = [torch.nn.Parameter(p.clone()) for p in p0]
+        opt = torch.optim.Adam(ps[:2] + ps[2:], **kw)
+        traj = []
+        for gs in grads:
+            for p_, g_ in zip(ps, gs):
+                p_.grad = g_.clone()
+            ps[2].grad = None                       # a parameter that never receives a gradient (quirk Q1)
+            opt.step()
+            traj.append([p_.detach().clone() for p_ in ps])
+        adam[name] = dict(kwargs=kw, p0=p0, grads=grads, trajectory=traj)
+    cases['adam'] = adam
+    torch.save(cases, os.path.join(HERE, 'g7_metrics.pt'))
+    print('g7_metrics.pt', {k: (float(v['trainer_psnr']), float(v['trainer_ssim'])) for k, v in cases.items() if isinstance(v, dict) and 'trainer_psnr' in v})
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     mods = _load_reference()
     if sys.argv[1:] == ['g6']:
         g6_input()
         sys.exit(0)
+    if sys.argv[1:] == ['g7']:
+        g7_metrics_adam(mods)
+        sys.exit(0)
     g1_tiny(mods)
     g3_trainer_g4_losses(mods)
     g5_edges(mods)
     g2_cfg1(mods)
     g6_input()
+    g7_metrics_adam(mods)
