@@ -60,9 +60,10 @@ class FusedLossFn(torch.autograd.Function):
         return None, d_o, None, None, None, None, None
 
 
-def fused_losses(outputs, targets, loss_fn):
+def fused_losses(outputs, targets, loss_fn, last_only=False):
     """Per-(group, frame) loss values [G*T] through the fused kernel, or None if this combination is not
-    served by it (then the caller falls back to calling loss_fn per pair, like the reference does)."""
+    served by it (then the caller falls back to calling loss_fn per pair, like the reference does).
+    last_only: the T values of the last group alone (what the predictor and the evaluation branch consume)."""
     packed = getattr(outputs, 'packed', None)
     if packed is None or not packed.is_cuda:
         return None
@@ -80,4 +81,6 @@ def fused_losses(outputs, targets, loss_fn):
         y = y.permute(0, 1, 3, 4, 2)
     y = y.contiguous().float()
     ops = outputs.ops
+    if last_only:
+        return FusedLossFn.apply(ops, packed[S - 1, three - 1].reshape(T, -1), y.reshape(T, -1), 1, T, kind, eps)
     return FusedLossFn.apply(ops, packed.reshape(S * three * T, -1), y.reshape(T, -1), S * three, T, kind, eps)

@@ -1,0 +1,74 @@
+"""Whole-cycle inference replayed from a HIP graph.
+
+The reference's predictor (src/runner/predictors/acdc_vsr_refinenet_predictor.py:31-109) runs ``net(inputs, pos_codes)``
+under ``torch.no_grad()`` on ONE whole cardiac cycle at a time (batch 1, F = T_cycle + 2U frames of e.g. 54 x 64 pixels):
+about a thousand sub-20-microsecond launches, i.e. bound by the host's launch rate, not by the GPU.  ``GraphedForward``
+captures the engine's forward once per input shape - the layer/frame wavefront of the ConvLSTM on its 2L side streams
+becomes parallel branches of the graph - and replays it with one ``hipGraphLaunch``.
+
+Static buffers: the inputs are copied into the graph's input buffer (one small D2D copy), the outputs are views of the
+graph's output buffer and are overwritten by the next call with the same shape; weights are read (and re-packed) inside
+the graph from the parameters' storage, so ``load_state_dict`` / in-place updates are seen by later replays.
+"""
+import torch
+
+from .hip_ops import packed_view
+
+
+class _Entry:
+    __slots__ = ('graph', 'x', 'pos', 'outputs', 'replays')
+
+
+class GraphedForward:
+    def __init__(self, net, max_graphs=8):
+        self.net, self.max_graphs = net, max_graphs
+        self._entries = {}
+        self._stream = None
+        self._versions = None
+
+    def _param_key(self):
+        # a parameter that was REPLACED (not updated in place) invalidates the captured pointers
+        return tuple(p.data_ptr() for p in self.net.parameters())
+
+    def _capture(self, inputs, pos_codes):
+        dev = inputs[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError(f'GraphedForward needs inputs on a HIP device, got {dev}')
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dev)
+        e = _Entry()
+        e.x = torch.stack([x.detach().to(dev, torch.float32) for x in inputs], dim=0).contiguous()      # (F, N, Cin, H, W)
+        e.pos = pos_codes.detach().to(dev, torch.float32).clone()
+        static_in = [e.x[k] for k in range(e.x.shape[0])]
+        st = self._stream
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st), torch.no_grad():
+            self.net(static_in, e.pos)             # eager run on the capture stream: plans, index maps, workspaces exist afterwards
+        st.synchronize()
+        e.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.graph, stream=st), torch.no_grad():
+            e.outputs = self.net(static_in, e.pos)
+        e.replays = 0
+        return e
+
+    @torch.no_grad()
+    def __call__(self, inputs, pos_codes):
+        net = self.net
+        if net.training:
+            raise RuntimeError('GraphedForward serves evaluation (net.eval()); the training step is not captured')
+        pk = self._param_key()
+        if pk != self._versions:
+            self._entries.clear()
+            self._versions = pk
+        key = (len(inputs), tuple(inputs[0].shape), tuple(pos_codes.shape), bool(getattr(net, 'last_group_only', False)))
+        e = self._entries.get(key)
+        if e is None:
+            if len(self._entries) >= self.max_graphs:
+                self._entries.pop(next(iter(self._entries)))
+            e = self._entries[key] = self._capture(inputs, pos_codes)
+        x = packed_view([t.detach() for t in inputs], e.x.device)
+        e.x.copy_(x.view_as(e.x))
+        e.pos.copy_(pos_codes)
+        e.graph.replay()
+        e.replays += 1
+        return e.outputs

@@ -1,7 +1,7 @@
 """``python -m src.main <config.yaml>``: the reference's CLI and YAML surface for the RefineNet training path
 (reference src/main.py:19-190): every section ``{name, kwargs}`` is instantiated by name from the matching
 namespace; losses are looked up in torch.nn first; ``main.random_seed`` may be a string.  ``python-box`` is not
-in this image, so the YAML is wrapped in a small attribute dict.  Under ``torchrun`` (WORLD_SIZE > 1) one process
+in this image, so the YAML is wrapped in a small attribute dict.  ``--test`` runs the whole-cycle predictor.  Under ``torchrun`` (WORLD_SIZE > 1) one process
 per GPU is used and gradients are all-reduced (hipvsr.dp)."""
 import argparse
 import logging
@@ -67,6 +67,42 @@ def _get_optimizer(config, params, device):
     return _get_instance(torch.optim, config, params)
 
 
+def _losses_metrics(config):
+    loss_fns, loss_weights = [], []
+    torch_losses = [n for n in dir(torch.nn) if 'Loss' in n]
+    for cl in config.losses:
+        loss_fns.append(_get_instance(torch.nn if cl.name in torch_losses else src.model.losses, cl))
+        loss_weights.append(cl.weight)
+    return loss_fns, loss_weights
+
+
+def _test(config):
+    """The --test branch (reference src/main.py:113-160): test split, batch-1 loader, net, losses, ALL configured metrics
+    (Cardiac* included), the predictor named in the ``predictor`` section, checkpoint from ``main.loaded_path``.
+    Whole-cycle inference does not shard: under torchrun every rank would run a replica, so only one process is used."""
+    if 'cuda' in config.predictor.kwargs.device and not torch.cuda.is_available():
+        raise ValueError("The cuda is not available. Please set the device in the predictor section to 'cpu'.")
+    device = torch.device(config.predictor.kwargs.device)
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
+    config.dataset.kwargs.update(data_dir=config.dataset.kwargs.get('data_dir'), type='test', device=device)
+    test_dataset = _get_instance(src.data.datasets, config.dataset)
+    test_loader = _get_instance(src.data.dataloader, config.dataloader, test_dataset)
+    net = _get_instance(src.model.nets, config.net)
+    loss_fns, loss_weights = _losses_metrics(config)
+    metric_fns = [_get_instance(src.model.metrics, cm) for cm in config.metrics]
+    config.predictor.kwargs.update(device=device, test_dataloader=test_loader, net=net, loss_fns=loss_fns,
+                                   loss_weights=loss_weights, metric_fns=metric_fns)
+    predictor = _get_instance(src.runner.predictors, config.predictor)
+    if config.net.name != 'Bicubic':
+        logging.info(f'Load the previous checkpoint from "{config.main.loaded_path}".')
+        predictor.load(Path(config.main.loaded_path))
+    logging.info('Start testing.')
+    log = predictor.predict()
+    logging.info('End testing.')
+    return log
+
+
 def main(args):
     with open(args.config_path) as f:
         config = Cfg(yaml.safe_load(f))
@@ -75,7 +111,7 @@ def main(args):
     with open(saved_dir / 'config.yaml', 'w+') as f:
         yaml.dump(config.to_dict(), f, default_flow_style=False)
     if args.test:
-        raise NotImplementedError('the --test predictor path is the "next" row f2 of SURVEY.md section 8')
+        return _test(config)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -106,11 +142,7 @@ def main(args):
     valid_loader = _get_instance(src.data.dataloader, config.dataloader, valid_dataset)
 
     net = _get_instance(src.model.nets, config.net)
-    loss_fns, loss_weights = [], []
-    torch_losses = [n for n in dir(torch.nn) if 'Loss' in n]
-    for cl in config.losses:
-        loss_fns.append(_get_instance(torch.nn if cl.name in torch_losses else src.model.losses, cl))
-        loss_weights.append(cl.weight)
+    loss_fns, loss_weights = _losses_metrics(config)
     metric_fns = [_get_instance(src.model.metrics, cm) for cm in config.metrics if hasattr(src.model.metrics, cm.name)]
     optimizer = _get_optimizer(config.optimizer, net.parameters(), device)
     lr_scheduler = _get_instance(torch.optim.lr_scheduler, config.lr_scheduler, optimizer) if config.get('lr_scheduler') else None

@@ -1,1 +1,1 @@
-from . import trainers   # noqa: F401
+from . import trainers, predictors   # noqa: F401

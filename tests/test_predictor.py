@@ -1,0 +1,195 @@
+"""Row f2 of SURVEY.md section 8: whole-cycle inference - the predictor mirror, ``python -m src.main <yaml> --test``
+and the HIP-graph replay of the forward.
+
+CPU: host logic (batch-size check, names, PNG writer, config errors).  GPU (-m gpu): graph replay == eager bit for bit
+and == the reference's golden whole-cycle vector (g5, tolerance 1e-4 as for every forward output), per-frame losses /
+metrics of the predictor against the CPU oracle (PSNR 1e-3 dB on outputs that agree to 1e-4, SSIM 1e-4)."""
+import os
+import pickle
+import struct
+import types
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import refinenet_oracle as orc
+from oracle import step_tail_oracle as sto
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+class _Loader(list):
+    batch_size = 1
+    dataset = types.SimpleNamespace(data=[])
+
+
+def test_predictor_host_logic(tmp_path):
+    from src.runner.predictors import AcdcVSRRefineNetPredictor, BasePredictor
+    from src.runner.predictors.acdc_vsr_refinenet_predictor import write_png_gray8
+    bad = _Loader()
+    bad.batch_size = 2
+    net = torch.nn.Identity()
+    with pytest.raises(ValueError, match='The testing batch size should be 1. Got 2.'):
+        AcdcVSRRefineNetPredictor(device=torch.device('cpu'), test_dataloader=bad, net=net, loss_fns=[], loss_weights=[], metric_fns=[])
+    p = AcdcVSRRefineNetPredictor(device=torch.device('cpu'), test_dataloader=_Loader(), net=net, loss_fns=[torch.nn.L1Loss()],
+                                  loss_weights=[1.0], metric_fns=[], graph=False)
+    assert isinstance(p, BasePredictor) and p._init_log() == {'Loss': 0, 'L1Loss': 0}
+    assert p._sample_name(torch.tensor([3])) == 'patient003_2d+1d_sequence01'
+    from pathlib import Path
+    p.test_dataloader.dataset = types.SimpleNamespace(data=[(Path('/d/test/LR/X4/patient101/patient101_2d+1d_sequence07.nii.gz'), None)])
+    assert p._sample_name(0) == 'patient101_2d+1d_sequence07'
+    # PNG writer: decode by hand
+    img = (np.arange(6 * 9).reshape(6, 9) * 4).astype(np.uint8)
+    write_png_gray8(tmp_path / 'a.png', img)
+    raw = (tmp_path / 'a.png').read_bytes()
+    assert raw[:8] == b'\x89PNG\r\n\x1a\n'
+    w, h, depth, ctype = struct.unpack('>IIBB', raw[16:26])
+    assert (w, h, depth, ctype) == (9, 6, 8, 0)
+    n = struct.unpack('>I', raw[33:37])[0]
+    assert raw[37:41] == b'IDAT'
+    rows = zlib.decompress(raw[41:41 + n])
+    assert np.array_equal(np.frombuffer(rows, np.uint8).reshape(6, 10)[:, 1:], img)
+    ck = tmp_path / 'c.pth'
+    torch.save({'net': {}}, ck)
+    p.load(ck)
+
+
+def test_main_test_branch_needs_the_device(tmp_path):
+    import yaml
+    from src import main as M
+    cfg = _test_config(tmp_path, [8, 8], tmp_path / 'none.pth')
+    path = tmp_path / 't.yaml'
+    path.write_text(yaml.safe_dump(cfg))
+    if not torch.cuda.is_available():
+        with pytest.raises(ValueError, match='The cuda is not available'):
+            M.main(types.SimpleNamespace(config_path=path, test=True))
+
+
+def _test_config(tmp_path, nf, ckpt, metrics=None, exported=True):
+    return dict(
+        main=dict(saved_dir=str(tmp_path / 'test'), loaded_path=str(ckpt)),
+        dataset=dict(name='AcdcVSRRefineNetDataset', kwargs=dict(
+            data_dir=None, downscale_factor=4, pos_code_path=None,
+            transforms=[dict(name='Normalize', kwargs=dict(means=[54.089], stds=[48.084])), dict(name='ToTensor')],
+            num_frames=7, num_updated_frames=6)),
+        dataloader=dict(name='Dataloader', kwargs=dict(batch_size=1, shuffle=False, num_workers=0)),
+        net=dict(name='RefineNet', kwargs=dict(in_channels=1, out_channels=1, num_features=nf, upscale_factor=4, num_stages=3,
+                                               update_memory=True, num_updated_frames=6, refine_window_size=5, positional_encoding=True)),
+        losses=[dict(name='L1Loss', weight=1.0)],
+        metrics=metrics or [dict(name='PSNR'), dict(name='SSIM')],
+        predictor=dict(name='AcdcVSRRefineNetPredictor', kwargs=dict(device='cuda:0', saved_dir=str(tmp_path / 'test'), exported=exported)))
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_and_the_reference_cycle():
+    from hipvsr.graph import GraphedForward
+    from src.model.nets import RefineNet
+    r = torch.load(os.path.join(GOLDEN, 'g5_edges.pt'), weights_only=False)['cycle']
+    dev = _dev()
+    net = RefineNet(**r['kwargs'])
+    net.load_state_dict(r['state_dict'])
+    net = net.to(dev).eval()
+    net.last_group_only = True
+    inputs, pos = [x.to(dev) for x in r['inputs']], r['pos_codes'].to(dev)
+    with torch.no_grad():
+        eager = [o.clone() for o in net(inputs, pos)[-1]]
+    gf = GraphedForward(net)
+    out = gf(inputs, pos)
+    assert out[0] is None and len(out[-1]) == 30
+    for a, b, c in zip(out[-1], eager, r['last']):
+        assert torch.equal(a, b)                                                   # same kernels, same order: bit for bit
+        torch.testing.assert_close(a.cpu(), c, atol=1e-4, rtol=1e-4)               # the reference's own output
+    # replay on other data (same shape): one graph, new result
+    g = torch.Generator('cpu').manual_seed(9)
+    inputs2 = [torch.randn(x.shape, generator=g).to(dev) for x in r['inputs']]
+    pos2 = (torch.rand(r['pos_codes'].shape, generator=g) * 2 - 1).to(dev)
+    with torch.no_grad():
+        eager2 = [o.clone() for o in net(inputs2, pos2)[-1]]
+    out2 = gf(inputs2, pos2)
+    assert len(gf._entries) == 1 and next(iter(gf._entries.values())).replays == 2
+    assert all(torch.equal(a, b) for a, b in zip(out2[-1], eager2)) and not torch.equal(out2[-1][0], eager[0])
+    # weights updated in place are seen by the captured graph (it re-packs them from the parameters' storage)
+    with torch.no_grad():
+        net.out_block.conv3.bias.add_(0.25)
+        eager3 = [o.clone() for o in net(inputs2, pos2)[-1]]
+    out3 = gf(inputs2, pos2)
+    assert all(torch.equal(a, b) for a, b in zip(out3[-1], eager3))
+    torch.testing.assert_close(out3[-1][0], eager2[0] + 0.25, atol=1e-5, rtol=0)
+    # another shape -> another graph; training mode is refused
+    gf([x[..., :5, :6].contiguous() for x in inputs2], pos2)
+    assert len(gf._entries) == 2
+    net.train()
+    with pytest.raises(RuntimeError, match='evaluation'):
+        gf(inputs2, pos2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [True, False])
+def test_src_main_test_branch_vs_oracle(tmp_path, graph):
+    """python -m src.main <yaml> --test on the synthetic test split (2 cines of 30 frames, 54x64 -> 216x256): log,
+    results.csv and exported frames against the CPU oracle run on the same samples."""
+    import yaml
+    from src import main as M
+    from src.data.datasets import AcdcVSRRefineNetDataset
+    nf = [8, 8]
+    cfg_net = orc.Config(in_channels=1, out_channels=1, num_features=nf, num_stages=3, refine_window_size=5, upscale_factor=4,
+                         update_memory=True, num_updated_frames=6, positional_encoding=True)
+    sd = orc.init_state_dict(cfg_net, seed=21)
+    ck = tmp_path / 'model_best.pth'
+    torch.save({'net': sd}, ck)
+    coords = tmp_path / 'coordinates.pkl'
+    with open(coords, 'wb') as f:
+        pickle.dump({'patient000': (40, 150, 30, 200), 'patient001': (0, 216, 100, 256)}, f)
+    metrics = [dict(name='PSNR'), dict(name='SSIM'), dict(name='CardiacPSNR', kwargs=dict(coordinates_path=str(coords))),
+               dict(name='CardiacSSIM', kwargs=dict(coordinates_path=str(coords)))]
+    cfg = _test_config(tmp_path, nf, ck, metrics)
+    cfg['predictor']['kwargs']['graph'] = graph
+    path = tmp_path / 't.yaml'
+    path.write_text(yaml.safe_dump(cfg))
+    log = M.main(types.SimpleNamespace(config_path=path, test=True))
+
+    ds = AcdcVSRRefineNetDataset(**{**cfg['dataset']['kwargs'], 'type': 'test'})
+    assert len(ds) == 2
+    torch.set_num_threads(16)
+    want = {k: 0.0 for k in log}
+    rows = []
+    for i in range(len(ds)):
+        smp = ds[i]
+        inputs = [x.unsqueeze(0) for x in smp['lr_imgs']]
+        targets = [x.unsqueeze(0) for x in smp['hr_imgs']]
+        with torch.no_grad():
+            last = orc.forward(sd, cfg_net, inputs, smp['pos_code'].unsqueeze(0))[-1]
+        pm = sto.predictor_metrics(last, targets)                                 # (T, 2)
+        h0, hn, w0, wn = pickle.load(open(coords, 'rb'))[f'patient{i:03d}']
+        den_o, den_t = [sto.denormalize(o) for o in last], [sto.denormalize(t) for t in targets]
+        cp = torch.stack([sto.psnr(o[..., h0:hn, w0:wn], t[..., h0:hn, w0:wn]) for o, t in zip(den_o, den_t)])
+        cs = torch.stack([sto.ssim(o[..., h0:hn, w0:wn], t[..., h0:hn, w0:wn]) for o, t in zip(den_o, den_t)])
+        l1 = torch.stack([orc.l1_loss(o, t) for o, t in zip(last, targets)])
+        T = len(targets)
+        assert T == 30
+        for t in range(T):
+            rows.append([float(pm[t, 0]), float(pm[t, 1]), float(cp[t]), float(cs[t]), float(l1[t])])
+        for k, v in (('Loss', l1.mean()), ('L1Loss', l1.mean()), ('PSNR', pm[:, 0].mean()), ('SSIM', pm[:, 1].mean()),
+                     ('CardiacPSNR', cp.mean()), ('CardiacSSIM', cs.mean())):
+            want[k] += float(v) * T
+    tol = dict(Loss=1e-5, L1Loss=1e-5, PSNR=1e-3, SSIM=1e-4, CardiacPSNR=1e-3, CardiacSSIM=1e-4)
+    for k in log:
+        assert abs(log[k] - want[k] / 60) <= tol[k], (k, log[k], want[k] / 60)
+    import csv
+    got = list(csv.reader(open(tmp_path / 'test' / 'results.csv')))
+    assert got[0] == ['name', 'PSNR', 'SSIM', 'CardiacPSNR', 'CardiacSSIM', 'L1Loss'] and len(got) == 61
+    assert got[1][0] == 'patient000_2d_slice01_frame01' and got[60][0] == 'patient001_2d_slice01_frame30'
+    for g_, w_ in zip(got[1:], rows):
+        for a, b, t_ in zip(g_[1:], w_, (2e-3, 2e-4, 2e-3, 2e-4, 1e-5)):
+            assert abs(float(a) - b) <= t_, (g_[0], a, b)
+    video = np.load(tmp_path / 'test' / 'videos' / 'patient001' / 'sequence01.npy')
+    assert video.shape == (30, 216, 256) and video.dtype == np.uint8
+    # last frame of the last cine is still in den_o: at most a few pixels may round differently (outputs agree to 1e-4)
+    ref_img = den_o[-1][0, 0].numpy().astype(np.uint8)
+    assert (video[-1] != ref_img).mean() < 1e-3 and np.abs(video[-1].astype(int) - ref_img.astype(int)).max() <= 1
+    assert (tmp_path / 'test' / 'imgs' / 'patient000' / 'slice01_frame30.png').exists()
