@@ -1,9 +1,9 @@
 """Input feeding (row f1) at BASELINE config 2: one fused gather per batch from cines resident in HBM, timed with HIP
 events on the launch stream, next to the oracle's per-sample CPU path (the reference's flip / crop / normalise / collate
 on arrays that are ALREADY decoded - the reference additionally gunzips two cines per sample).
-Usage: python tools/feed_bench.py [N T U h]"""
+Usage: python tests/stress/feed_bench.py [N T U h]"""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')
 sys.path[:0] = [ROOT, PKG]
 import numpy as np

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Determinism stress: the same training step many times; every output and gradient must be bit-identical from
-run to run (no atomics anywhere), so any difference is a race.  GPU box only.  python tools/race_check.py [reps] [N T H]"""
+run to run (no atomics anywhere), so any difference is a race.  GPU box only.  python tests/stress/race_check.py [reps] [N T H]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')
 for p in (ROOT, PKG):
     sys.path.insert(0, p)

@@ -351,7 +351,7 @@ def test_phase_plane_sources_many_images_vs_torch():
 
 def test_training_step_is_bitwise_repeatable():
     """No atomics anywhere: the same step must give the same bits.  30 repetitions of BASELINE config 1 caught both
-    races that the asm-scheduled kernels had (tools/race_check.py, tools/race_kernel.py are the long versions)."""
+    races that the asm-scheduled kernels had (tests/stress/race_check.py, tools/race_kernel.py are the long versions)."""
     from src.model.nets import RefineNet
     dev = _dev()
     cfg = orc.exp1_x4_config()
