@@ -6,6 +6,10 @@ missing, and every wrapper raises ``HipKernelError`` on a non-zero return code.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torch's - before the library below is loaded;
+#                            loaded the other way round, the library's own libamdhip64 comes in first and torch's copy
+#                            then reports "no ROCm-capable device")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
 

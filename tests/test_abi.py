@@ -50,3 +50,22 @@ def test_product_has_no_cpu_path():
     net = RefineNet(1, 1, [8, 8], num_stages=2, update_memory=True, num_updated_frames=2, positional_encoding=True)
     with pytest.raises(RuntimeError, match='HIP device'):
         net([torch.zeros(1, 1, 4, 4)] * 6, torch.zeros(1, 6, 1))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """build() loads the library before anything imported torch: the process must still end up with ONE HIP runtime
+    (a second one reports 'no ROCm-capable device' at the first launch).  Run in a child so that the import order is ours."""
+    import subprocess
+    import sys
+    from conftest import PKG
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from hipvsr import lib as L\nL.load()\n"
+            "import torch\nfrom hipvsr.step_tail import psnr_ssim\n"
+            "x = torch.rand(2, 16, 16, device='cuda:0')\n"
+            "r = psnr_ssim(x, x, 2, 1, 16, 16)\ntorch.cuda.synchronize()\nprint('ok', float(r[1]))\n") % (ROOT, PKG)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith('ok 1.0'), out.stderr[-2000:]
