@@ -236,11 +236,27 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args
 }
 
 // stage 1: U[xi][ci][co] = sum over the tile-row ranges, in fixed order (one thread per element: coalesced, 16*Cx*Cy threads)
-__global__ void wino_wgrad_sum_kernel(const float *slab, float *U, int KS, long n) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < KS; ++k) s += slab[(long)k * n + e];
-        U[e] = s;
+// (n is a multiple of 4: 16 * Cx * Cy.)  One float4 column per thread; the partial slabs are fetched eight at a time so
+// that eight 16-byte loads are in flight per lane, and added in slab order - the same sums, element by element, as a
+// plain loop over k.
+__global__ void __launch_bounds__(256) wino_wgrad_sum_kernel(const float *__restrict__ slab, float *__restrict__ U, int KS, long n) {
+    const long n4 = n >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const float *p = slab + 4 * e;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 8 <= KS; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = rnh_ld4(p + (long)(k + j) * n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s.x += v[j].x, s.y += v[j].y, s.z += v[j].z, s.w += v[j].w;
+        }
+        for (; k < KS; ++k) {
+            const float4 v = rnh_ld4(p + (long)k * n);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        rnh_st4(U + 4 * e, s);
     }
 }
 
@@ -359,7 +375,7 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     // the sums go behind the partial slabs in the same workspace (rnh_wino_wgrad_ws_floats sizes it for KS + 1 slabs)
     const long nU = (long)16 * s.Cx * s.Cy;
     float *U = a.slab + (long)s.KS * nU;
-    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(wg_grid_for(nU)), dim3(256), 0, st, a.slab, U, s.KS, nU);
+    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(wg_grid_for(nU / 4)), dim3(256), 0, st, a.slab, U, s.KS, nU);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad(sum)");
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(wg_grid_for((long)s.Cx * s.Cy + s.Cy)), dim3(256), 0, st, U, b.bslab, s.KS, s.Cx, s.Cy,
                        rowmap, colmap, Cin, dw, db, accumulate);

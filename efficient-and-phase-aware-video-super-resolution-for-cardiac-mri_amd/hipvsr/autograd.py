@@ -60,10 +60,11 @@ class FusedLossFn(torch.autograd.Function):
         return None, d_o, None, None, None, None, None
 
 
-def fused_losses(outputs, targets, loss_fn, last_only=False):
+def fused_losses(outputs, targets, loss_fn, last_only=False, per_sample=False):
     """Per-(group, frame) loss values [G*T] through the fused kernel, or None if this combination is not
     served by it (then the caller falls back to calling loss_fn per pair, like the reference does).
-    last_only: the T values of the last group alone (what the predictor and the evaluation branch consume)."""
+    last_only: the T values of the last group alone (what the predictor and the evaluation branch consume);
+    with per_sample the (T, N) values of every sample on its own (a predictor that runs N cines at once)."""
     packed = getattr(outputs, 'packed', None)
     if packed is None or not packed.is_cuda:
         return None
@@ -81,6 +82,9 @@ def fused_losses(outputs, targets, loss_fn, last_only=False):
         y = y.permute(0, 1, 3, 4, 2)
     y = y.contiguous().float()
     ops = outputs.ops
+    if last_only and per_sample:
+        N = TN // T
+        return FusedLossFn.apply(ops, packed[S - 1, three - 1].reshape(TN, -1), y.reshape(TN, -1), 1, TN, kind, eps).view(T, N)
     if last_only:
         return FusedLossFn.apply(ops, packed[S - 1, three - 1].reshape(T, -1), y.reshape(T, -1), 1, T, kind, eps)
     return FusedLossFn.apply(ops, packed.reshape(S * three * T, -1), y.reshape(T, -1), S * three, T, kind, eps)

@@ -103,10 +103,11 @@ class CardiacSSIM(_Cardiac):
         return self.ssim(*self._crop(output, target, name))
 
 
-def fused_metrics(outputs_last, targets, metric_fns, dataset='acdc', packed_last=None, per_frame=False):
+def fused_metrics(outputs_last, targets, metric_fns, dataset='acdc', packed_last=None, per_frame=False, per_sample=False):
     """All frames of a step in ONE launch.  per_frame=False (trainer, acdc_vsr_refinenet_trainer.py:103-120): list of
     0-dim tensors, the mean over the frames of each metric's batch-averaged score.  per_frame=True (predictor,
-    acdc_vsr_refinenet_predictor.py:140-160): the (T, len(metric_fns)) tensor of per-frame scores.  None when this
+    acdc_vsr_refinenet_predictor.py:140-160): the (T, len(metric_fns)) tensor of per-frame scores; per_sample=True: the
+    (T, N, len(metric_fns)) tensor of per-frame, per-sample scores (a predictor that runs N cines at once).  None when this
     combination is not served (then the caller does what the reference does: denormalize + metric_fn per frame).
 
     outputs_last: list[T] of (N, 1, H, W); packed_last: the (T*N, H, W, 1) tensor they are views of, if known."""
@@ -126,7 +127,9 @@ def fused_metrics(outputs_last, targets, metric_fns, dataset='acdc', packed_last
     y = packed_view([t.detach() for t in targets])
     res = step_tail.psnr_ssim(o.contiguous(), y.contiguous(), T * N, 1, H, W, DENORM[dataset], float(ps[0].max_value) if ps else 255.0,
                               float(ss[0].value_range) if ss else 255.0, want_ssim=bool(ss))
-    if not per_frame:
+    if not (per_frame or per_sample):
         return [res[0] if type(f) is PSNR else res[1] for f in fns]          # equal batch sizes: mean of means == overall mean
-    per = {PSNR: res[2:2 + T * N].view(T, N).mean(1), SSIM: res[2 + T * N:2 + 2 * T * N].view(T, N).mean(1)}
-    return torch.stack([per[type(f)] for f in fns], dim=1)
+    per = {PSNR: res[2:2 + T * N].view(T, N), SSIM: res[2 + T * N:2 + 2 * T * N].view(T, N)}
+    if per_sample:
+        return torch.stack([per[type(f)] for f in fns], dim=2)
+    return torch.stack([per[type(f)].mean(1) for f in fns], dim=1)

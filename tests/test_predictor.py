@@ -129,8 +129,8 @@ def test_graph_replay_equals_eager_and_the_reference_cycle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('graph', [True, False])
-def test_src_main_test_branch_vs_oracle(tmp_path, graph):
+@pytest.mark.parametrize('graph,group', [(True, 8), (False, 1), (True, 1), (False, 8)])
+def test_src_main_test_branch_vs_oracle(tmp_path, graph, group):
     """python -m src.main <yaml> --test on the synthetic test split (2 cines of 30 frames, 54x64 -> 216x256): log,
     results.csv and exported frames against the CPU oracle run on the same samples."""
     import yaml
@@ -149,6 +149,7 @@ def test_src_main_test_branch_vs_oracle(tmp_path, graph):
                dict(name='CardiacSSIM', kwargs=dict(coordinates_path=str(coords)))]
     cfg = _test_config(tmp_path, nf, ck, metrics)
     cfg['predictor']['kwargs']['graph'] = graph
+    cfg['predictor']['kwargs']['cines_per_launch'] = group      # 8: both cines of the split go through as one batch of 2
     path = tmp_path / 't.yaml'
     path.write_text(yaml.safe_dump(cfg))
     log = M.main(types.SimpleNamespace(config_path=path, test=True))
@@ -193,3 +194,29 @@ def test_src_main_test_branch_vs_oracle(tmp_path, graph):
     ref_img = den_o[-1][0, 0].numpy().astype(np.uint8)
     assert (video[-1] != ref_img).mean() < 1e-3 and np.abs(video[-1].astype(int) - ref_img.astype(int)).max() <= 1
     assert (tmp_path / 'test' / 'imgs' / 'patient000' / 'slice01_frame30.png').exists()
+
+
+@pytest.mark.gpu
+def test_grouped_cines_equal_one_by_one(tmp_path):
+    """Running the cines of one shape as a batch changes nothing: results.csv and the exported frames are identical to the
+    one-cine-per-forward run (samples of a batch are independent bit for bit; losses and metrics are per sample)."""
+    import yaml
+    from src import main as M
+    nf = [8, 8]
+    cfg_net = orc.Config(in_channels=1, out_channels=1, num_features=nf, num_stages=3, refine_window_size=5, upscale_factor=4,
+                         update_memory=True, num_updated_frames=6, positional_encoding=True)
+    ck = tmp_path / 'm.pth'
+    torch.save({'net': orc.init_state_dict(cfg_net, seed=5)}, ck)
+    out = {}
+    for group in (1, 8):
+        d = tmp_path / f'g{group}'
+        d.mkdir()
+        cfg = _test_config(d, nf, ck)
+        cfg['losses'] = [dict(name='L1Loss', weight=1.0), dict(name='HuberLoss', weight=0.5, kwargs=dict(delta=0.5))]   # Huber: the unfused loss path
+        cfg['predictor']['kwargs']['cines_per_launch'] = group
+        path = d / 't.yaml'
+        path.write_text(yaml.safe_dump(cfg))
+        log = M.main(types.SimpleNamespace(config_path=path, test=True))
+        out[group] = (log, (d / 'test' / 'results.csv').read_text(), np.load(d / 'test' / 'videos' / 'patient001' / 'sequence01.npy'))
+    assert out[1][1] == out[8][1] and np.array_equal(out[1][2], out[8][2])
+    assert out[1][0].keys() == out[8][0].keys() and all(abs(out[1][0][k] - out[8][0][k]) < 1e-9 for k in out[1][0])

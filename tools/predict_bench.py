@@ -40,6 +40,11 @@ def main():
         c = timed(lambda: gf(inputs, pos))
     for name, ms in (('eager, all 9 groups (the reference predictor\'s call)', a), ('eager, last group only', b), ('HIP graph, last group only', c)):
         print(f'{name}: {ms:.2f} ms per cycle = {Tc / ms * 1e3:.0f} frames/s')
+    for K in (2, 4, 8, 16):                               # K cines of one shape as one batch (the predictor's cines_per_launch)
+        inputs, _, pos = synthetic_batch(dev, K, Tc, H, W, seed=1)
+        with torch.no_grad():
+            d = timed(lambda: gf(inputs, pos))
+        print(f'HIP graph, last group only, {K} cines per launch: {d:.2f} ms = {K * Tc / d * 1e3:.0f} frames/s')
 
 
 if __name__ == '__main__':
