@@ -29,10 +29,15 @@ namespace {
 // them 5 times per hidden element, and the libm versions cost 4x the instructions for digits the fp32 GEMM in
 // front of them does not have).  tanh(x) = 1 - 2 / (1 + e^{2x}) is exact at +-inf and loses nothing near 0 that the
 // 1e-7 relative error of the gates would not already hide.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each; __frcp_rn would be a correctly rounded division: two v_div_scale, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup per value) and no branch: both forms of tanh are computed and selected (hipcc turned the
+// ternary around the exp form into an exec-masked branch per value, 64 of them per lane in the gate epilogue).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
-    const float t = ax < 0.04f ? ax * (1.f - 0.33333334f * ax * ax) : 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * ax));
+    const float big = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * ax)), 1.f);
+    const float small = ax * __builtin_fmaf(-0.33333334f * ax, ax, 1.f);      // |x| < 0.04: the exp form cancels
+    const float t = ax < 0.04f ? small : big;
     return copysignf(t, x);
 }
 

@@ -28,10 +28,15 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float w_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each; __frcp_rn would be a correctly rounded division: two v_div_scale, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup per value) and no branch: both forms of tanh are computed and selected (hipcc turned the
+// ternary around the exp form into an exec-masked branch per value, 64 of them per lane in the gate epilogue).
+__device__ __forceinline__ float w_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float w_tanh(float x) {
     const float ax = fabsf(x);
-    const float t = ax < 0.04f ? ax * (1.f - 0.33333334f * ax * ax) : 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * ax));
+    const float big = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * ax)), 1.f);
+    const float small = ax * __builtin_fmaf(-0.33333334f * ax, ax, 1.f);      // |x| < 0.04: the exp form cancels
+    const float t = ax < 0.04f ? small : big;
     return copysignf(t, x);
 }
 
@@ -370,22 +375,27 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             }
         }
         // phase 1: every wave activates its gate (wave 0..3 = i, f, o, g) and parks it in LDS (and in gates_out).
-        // Four accumulator registers at a time: 16 independent exp / rcp chains for the one wave on this SIMD.
+        // GV accumulator registers at a time: 4 GV independent exp / rcp chains for the one wave on this SIMD (measured
+        // per workgroup, gate phase: GV = 1: 25.2k cycles, 2: 21.6k, 4: 18.2k, 8: 17.4k, 16: 16.3k).
+#ifndef RNH_WINO_GV
+#define RNH_WINO_GV 16
+#endif
+        constexpr int GV = RNH_WINO_GV;
         if (full) {
 #pragma unroll
-            for (int v0 = 0; v0 < 16; v0 += 4) {
-                float Y[4][4], g[4][4];
+            for (int v0 = 0; v0 < 16; v0 += GV) {
+                float Y[GV][4], g[GV][4];
 #pragma unroll
-                for (int dv = 0; dv < 4; ++dv) out4(v0 + dv, Y[dv]);
+                for (int dv = 0; dv < GV; ++dv) out4(v0 + dv, Y[dv]);
                 if (wave == 3) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) g[e >> 2][e & 3] = w_tanh(Y[e >> 2][e & 3]);
+                    for (int e = 0; e < 4 * GV; ++e) g[e >> 2][e & 3] = w_tanh(Y[e >> 2][e & 3]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) g[e >> 2][e & 3] = w_sigmoid(Y[e >> 2][e & 3]);
+                    for (int e = 0; e < 4 * GV; ++e) g[e >> 2][e & 3] = w_sigmoid(Y[e >> 2][e & 3]);
                 }
 #pragma unroll
-                for (int dv = 0; dv < 4; ++dv) {
+                for (int dv = 0; dv < GV; ++dv) {
                     const int v = v0 + dv, trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
                     float *gp = P.gates_out ? P.gates_out + (long)tpix[trl] * 4 * hd + wave * hd + hc : nullptr;
 #pragma unroll
@@ -413,7 +423,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
                 }
             }
         }
-        __syncthreads();
+        // the gates are in LDS: wait for the LDS writes only - __syncthreads() would also wait (vmcnt(0)) for the gates_out
+        // stores just issued to be acknowledged by memory
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         WSTAMP(4);
         // phase 2: wave w finishes output pixel w of every tile
         if (full) {

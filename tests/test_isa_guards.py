@@ -5,7 +5,8 @@ an asm statement, so a v_mov it inserts to reconcile two definitions of such a r
 to split a live range) reads the register before the data has landed.  That happened in the Winograd kernel (about
 one workgroup in 10^5 summed stale operands; tools/race_kernel.py found it) and is invisible in the source.  The
 test compiles the kernels to assembly (no GPU needed) and fails on any move out of a register that an asm load of the
-MFMA region writes (moves of ordinary values, e.g. saved lane indices, are fine), and on any scratch access there.
+MFMA region writes (moves and spill stores of ordinary values, e.g. saved lane indices, are fine), and on any other
+scratch access there (reloads, spills of accumulators).
 """
 import os
 import re
@@ -19,6 +20,7 @@ CSRC = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 LOAD_RE = re.compile(r'(?:buffer_load_dwordx2|buffer_load_dword|ds_read_b64)\s+v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
+SPILL_RE = re.compile(r'scratch_store_dword(?:x[234])?\s+off,\s*v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
 MOVE_RE = re.compile(r'v_mov_b(?:32|64)(?:_e32|_e64)?\s+\S+,\s*v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
 
 
@@ -81,6 +83,12 @@ def suspicious_copies(lines):
         if m:
             pool = targets if i >= first_mfma else (seen_vm | seen_lds)
             if any(r in pool and r not in landed for r in _regs(m)):
+                copies.append(ln)
+        elif SPILL_RE.match(ln):
+            # a spill store is a copy out of its source registers: harmless for an ordinary value (it can only make a
+            # counted vmcnt wait stricter, never weaker), a stale-data bug for the target of a load still in flight
+            pool = targets if i >= first_mfma else (seen_vm | seen_lds)
+            if any(r in pool and r not in landed for r in _regs(SPILL_RE.match(ln))):
                 copies.append(ln)
         elif ln.startswith('scratch_') or ln.startswith('v_pk_mov'):
             copies.append(ln)
