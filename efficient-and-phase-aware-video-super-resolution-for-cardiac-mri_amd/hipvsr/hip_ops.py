@@ -45,6 +45,7 @@ class HipOps:
         self._packed = {}      # id(plan) -> (wp, biasp)
         self._ws = {}
         self._side = []
+        self._fork_n = 2
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
         self.direct = (os.environ.get('RNH_DIRECT', '1') != '0') if direct is None else bool(direct)
@@ -73,7 +74,18 @@ class HipOps:
         return torch.tensor(lst, dtype=torch.int32, device=self.device)
 
     # ---- streams: the two LSTM directions run on side streams between fork() and join() ---------------------
+    # The ConvLSTM wavefront asks for 2L logical streams, one per (direction, layer).  RNH_LSTM_STREAMS maps them onto
+    # HIP streams: 'cell' = 2L streams, 'layer' = L streams (both directions of a layer share one: measured best at
+    # BASELINE config 2, where every cell launch fills the chip and cross-stream event waits only cost latency),
+    # 'dir' = 2, 'one' = 1.
+    def _side_index(self, i):
+        mode = os.environ.get('RNH_LSTM_STREAMS', 'layer')
+        half = max(self._fork_n // 2, 1)
+        return {'cell': i, 'layer': i % half, 'dir': i // half, 'one': 0}[mode]
+
     def fork(self, n):
+        self._fork_n = n
+        n = 1 + max(self._side_index(i) for i in range(n))
         while len(self._side) < n:
             self._side.append(torch.cuda.Stream(self.device))
         ev = torch.cuda.Event()
@@ -82,7 +94,7 @@ class HipOps:
             st.wait_event(ev)
 
     def side(self, i):
-        return torch.cuda.stream(self._side[i])
+        return torch.cuda.stream(self._side[self._side_index(i)])
 
     def record(self):
         ev = torch.cuda.Event()
@@ -93,6 +105,7 @@ class HipOps:
         torch.cuda.current_stream(self.device).wait_event(ev)
 
     def join(self, n):
+        n = 1 + max(self._side_index(i) for i in range(n))
         cur = torch.cuda.current_stream(self.device)
         for st in self._side[:n]:
             ev = torch.cuda.Event()
