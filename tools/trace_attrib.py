@@ -2,7 +2,7 @@
 """Wall-time attribution from a rocprofv3 *_kernel_trace.csv: sweep over kernel start / end events; every interval is
 split evenly over the kernels running in it (idle intervals are charged to the kernel that starts next).  Shows what the
 step's wall time - not the sum of kernel durations - is made of when kernels overlap on several streams.
-usage: trace_attrib.py trace.csv [skip_fraction] [nsteps]"""
+usage: trace_attrib.py trace.csv [skip_fraction]"""
 import collections
 import csv
 import sys
@@ -41,8 +41,10 @@ for t, kind, i in ev:
     else:
         active.discard(i)
 span = ev[-1][0] - ev[0][0]
-print(f'span {span / 1e6 / nsteps:.1f} ms per step over {nsteps:g} steps; concurrency histogram (ms per step): ' +
-      ', '.join(f'{k}: {v / 1e6 / nsteps:.1f}' for k, v in sorted(hist.items())))
-print(f'{"kernel":70s} {"share ms/step":>14s} {"alone ms/step":>14s} {"idle before":>12s}')
-for n, v in share.most_common(22):
-    print(f'{n:70s} {v / 1e6 / nsteps:14.2f} {solo[n] / 1e6 / nsteps:14.2f} {idle[n] / 1e6 / nsteps:12.2f}')
+print(f'span {span / 1e6:.1f} ms; kernels running at once (% of span): ' +
+      ', '.join(f'{k}: {100 * v / span:.1f}' for k, v in sorted(hist.items())))
+print(f'{"kernel":70s} {"share %":>9s} {"alone %":>9s} {"idle before %":>14s} {"calls":>7s}')
+calls = collections.Counter(r[2] for r in rows)
+for n, v in share.most_common(24):
+    print(f'{n:70s} {100 * v / span:9.2f} {100 * solo[n] / span:9.2f} {100 * idle[n] / span:14.2f} {calls[n]:7d}')
+print(f'{"(all kernels)":70s} {100 * sum(share.values()) / span:9.2f} {100 * sum(solo.values()) / span:9.2f} {100 * sum(idle.values()) / span:14.2f}')
