@@ -255,3 +255,41 @@ def test_flat_adam_on_the_network_two_launches_and_checkpoint_format():
     sto.adam_step([cpu[k] for k in names], [ref_grads[k] for k in names], [ms[k] for k in names], [vs[k] for k in names], 4, lr=1e-3)
     for k, p in net.named_parameters():
         assert torch.allclose(p.detach().cpu(), cpu[k], rtol=0, atol=3e-5), k
+
+
+@pytest.mark.gpu
+def test_flat_adam_param_groups_and_misaligned_runs():
+    """Two parameter groups with their own hyper-parameters; gradients that are views of one flat buffer (the engine's
+    layout) with odd sizes, so that the run after the gradient-less parameter starts off a 16-byte boundary; a
+    non-contiguous gradient takes the staging copy.  Reference: torch.optim.Adam on the CPU, same inputs."""
+    from hipvsr.step_tail import FlatAdam
+    g = torch.Generator('cpu').manual_seed(5)
+    shapes = [(3,), (5, 1), (1,), (7,), (2, 3)]
+    p0 = [torch.randn(*s, generator=g) for s in shapes]
+    q0 = [torch.randn(4, 6, generator=g), torch.randn(9, generator=g)]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in p0 + q0]
+    ref = torch.optim.Adam([dict(params=ref_p[:5], lr=2e-3), dict(params=ref_p[5:], lr=5e-4, betas=(0.7, 0.9), weight_decay=0.1)])
+    dev_p = [torch.nn.Parameter(p.clone().to(_dev())) for p in p0 + q0]
+    opt = FlatAdam([dict(params=dev_p[:5], lr=2e-3), dict(params=dev_p[5:], lr=5e-4, betas=(0.7, 0.9), weight_decay=0.1)])
+    n = sum(p.numel() for p in p0)
+    for step in range(4):
+        flat = torch.randn(n, generator=g)
+        dflat = flat.to(_dev())
+        off = 0
+        for i, (rp, dp_) in enumerate(zip(ref_p[:5], dev_p[:5])):
+            k = rp.numel()
+            rp.grad = None if i == 2 else flat[off:off + k].view_as(rp).clone()
+            dp_.grad = None if i == 2 else dflat[off:off + k].view_as(dp_)
+            off += k
+        gq = torch.randn(6, 4, generator=g)
+        ref_p[5].grad, dev_p[5].grad = gq.t().clone(), gq.to(_dev()).t()            # non-contiguous on the device
+        g9 = torch.randn(9, generator=g)
+        ref_p[6].grad, dev_p[6].grad = g9.clone(), g9.to(_dev())
+        ref.step()
+        opt.step()
+        assert opt.launches == 3 + (0 if step else 0)          # runs: [p0, p1], [p3, p4], [q0, q1]
+        for rp, dp_ in zip(ref_p, dev_p):
+            assert torch.allclose(dp_.detach().cpu(), rp.detach(), rtol=1e-6, atol=1e-8), step
+    assert torch.equal(dev_p[2].detach().cpu(), p0[2])
+    sd = opt.state_dict()
+    assert [g_['lr'] for g_ in sd['param_groups']] == [2e-3, 5e-4] and len(sd['state']) == 6
