@@ -303,30 +303,47 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             loadb(u0, s + 2);
             wait_vm(u1, K16());
             compute(V1, u1);
-            // step 2
+            // step 2: also the transform of the staged chunk into the other LDS buffer (nobody reads it during this chunk;
+            // its loads are older than the 16 weight loads the wait above leaves in flight): plain code in front of the
+            // MFMAs, so that hipcc interleaves its packed adds and LDS writes with them
             wait_lds(V0);
             loadv(V1, buf, 3);
             loadb(u1, s + 3);
             wait_vm(u0, K16());
+            if constexpr (more) xform_store(buf ^ 1);
             compute(V0, u0);
-        }
-        // last step: the weights of the next chunk's first step and the transform of the staged chunk into the other LDS
-        // buffer (nobody reads it during this chunk): plain code in front of the MFMAs, so that hipcc interleaves its
-        // packed adds and LDS writes with them.  Nothing is prefetched past the end.
-        wait_lds(V1);
-        if constexpr (more) {
-            loadb(u0, s + SPC);
-            wait_vm(u1, K16());
-            xform_store(buf ^ 1);
+            // last step.  The chunk's barrier sits HERE, in front of the last 32 MFMAs, not behind them: every wave has
+            // issued all its reads of this buffer and finished its writes of the other one (lgkmcnt(0)), so after the
+            // barrier the first operands of the next chunk can be fetched from LDS under the cover of this step's MFMAs.
+            // (Behind the MFMAs the barrier's skew and the LDS latency were exposed: 12.5 k of the loop's 96 k cycles.)
+            // Not __syncthreads(): its fence would also wait (vmcnt(0)) for the weight prefetch in flight.
+            wait_lds(V1);
+            asm volatile("s_barrier" ::: "memory");
+            if constexpr (more) {
+                loadv(V0, buf ^ 1, 0);
+                loadb(u0, s + SPC);
+                wait_vm(u1, K16());
+            } else {
+                wait_vm(u1, K0());
+            }
+            compute(V1, u1);
+            s += SPC;
         } else {
-            wait_vm(u1, K0());
+            // two-step chunks (TG = 2): the staging loads were issued one step ago, so the transform stays in the last
+            // step and the barrier behind it.  Nothing is prefetched past the end.
+            wait_lds(V1);
+            if constexpr (more) {
+                loadb(u0, s + SPC);
+                wait_vm(u1, K16());
+                xform_store(buf ^ 1);
+            } else {
+                wait_vm(u1, K0());
+            }
+            compute(V1, u1);
+            s += SPC;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (more) loadv(V0, buf ^ 1, 0);
         }
-        compute(V1, u1);
-        s += SPC;
-        // LDS writes done, then the barrier - not __syncthreads(), whose fence would also wait (vmcnt(0)) for the
-        // weight prefetch that was just issued
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if constexpr (more) loadv(V0, buf ^ 1, 0);
     };
     for (int c = 0; c + 1 < nchunks_total; ++c) chunk(c & 1, std::true_type());
     chunk((nchunks_total - 1) & 1, std::false_type());
