@@ -15,6 +15,7 @@
 // the end (see conv_wino.hip for what goes wrong otherwise; tests/test_isa_guards.py checks the generated code).
 // Partial sums per tile-row range go to a slab; rnh_wino_wgrad's reduction sums them in fixed order and applies G^T . G.
 #include "rnh_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -235,6 +236,218 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args
     }
 }
 
+// ---- variant with the input transform shared through LDS -----------------------------------------------------------
+// The four waves of a workgroup are four column tiles (ct) of the same (tile-row range, row tile): they need the SAME
+// transformed input patches V = B^T d B.  Here each wave loads and transforms one of four consecutive groups (a "quad" =
+// 16 tiles) and parks V in LDS; after a barrier every wave reads all four groups (four ds_read_b128 per tile; lane stride
+// 20 floats: conflict-free) and contributes only its own output-gradient transform.  Per group and wave: 8 + 28 + 2
+// (its quarter of the loads / transform arithmetic / LDS writes) + 8 LDS reads + 8 loads + 24 VALU instead of 32 loads +
+// 112 + 24 VALU next to the 32 MFMAs.  Needs CT % 4 == 0 and G % 4 == 0 (W % 32 == 0); compiler-scheduled loads
+// (raw buffer load builtins), phases pinned by scheduling barriers.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float wg_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+constexpr int WL_STRIDE = 20;                                   // floats per (group, tile, lane) in LDS: 16 + 4 pad
+constexpr int WL_BUF = 4 * 2 * 64 * WL_STRIDE;                  // floats per buffer (4 groups x 2 tiles x 64 lanes)
+
+__global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_args_t P, const float *xp, const int Cx, const int Cy,
+                                                                const int KS, const int rows_per) {
+    __shared__ __attribute__((aligned(16))) float sV[2 * WL_BUF];   // 80 KB
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int RT = Cx >> 5, CT = Cy >> 5;
+    const int item = blockIdx.x * 4 + wave;                     // CT % 4 == 0: the four waves share (ks, rt)
+    const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
+    const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Q = G >> 2, Hp = H + 2, Wp = W + 2;
+    const int rows_total = P.B * TY;
+    const int r0 = ks * rows_per, r1 = min(rows_total, r0 + rows_per);
+
+    int ysrc = 0, cy0 = ct * 32;
+    while (cy0 >= P.ys[ysrc].nch) cy0 -= P.ys[ysrc++].nch;
+    const rnh_src_t &Y = P.ys[ysrc];
+    const int sc = Y.scale, Hs = H * sc, Ws = W * sc;
+    int vx[2][4], vy[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[t][j] = ((2 * (kh + 2 * t) + j) * Cx + rt * 32 + l31) * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
+    }
+    const int xrow = Wp * Cx * 4, xgrp = 8 * Cx * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
+    auto xbase = [&](int r) {
+        const int img = r / TY, ty = r - img * TY;
+        return wg_rsrc(xp + ((long)img * Hp + 2 * ty) * Wp * Cx);
+    };
+    auto ybase = [&](int r) {
+        const int img = r / TY, ty = r - img * TY;
+        return wg_rsrc(Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
+    float bsum = 0.f;
+
+    // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
+    auto load_x = [&](float (&d)[2][16], int r, int q) {
+        const __amdgpu_buffer_rsrc_t xd = xbase(r);
+        const int gx = __builtin_amdgcn_readfirstlane((4 * q + wave) * xgrp);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[t][i * 4 + j] = wg_ld(xd, vx[t][j], gx + i * xrow);
+    };
+    // V = B^T d B of both tiles -> LDS buffer `buf`, slot of this wave's group
+    // (Packing the two tiles into v_pk_add_f32 halves was tried: the register pairing spills next to the 256 accumulators
+    // and the kernel ran 1.5x slower.)
+    auto xform_store = [&](const float (&d)[2][16], int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float tq[16], V[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tq[0 * 4 + j] = d[t][0 * 4 + j] - d[t][2 * 4 + j];
+                tq[1 * 4 + j] = d[t][1 * 4 + j] + d[t][2 * 4 + j];
+                tq[2 * 4 + j] = d[t][2 * 4 + j] - d[t][1 * 4 + j];
+                tq[3 * 4 + j] = d[t][1 * 4 + j] - d[t][3 * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
+                V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
+                V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
+                V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
+            }
+            float *o = sV + buf * WL_BUF + ((wave * 2 + t) * 64 + lane) * WL_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4v *>(o + 4 * i) = f32x4v{V[4 * i], V[4 * i + 1], V[4 * i + 2], V[4 * i + 3]};
+        }
+    };
+    auto read_v = [&](f32x4v (&V)[2][4], int buf, int j) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *o = sV + buf * WL_BUF + ((j * 2 + t) * 64 + lane) * WL_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) V[t][i] = *reinterpret_cast<const f32x4v *>(o + 4 * i);
+        }
+    };
+    auto load_y = [&](float (&y)[2][4], __amdgpu_buffer_rsrc_t yd, int g) {
+        const int gy = __builtin_amdgcn_readfirstlane(g * ygrp);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            y[t][0] = wg_ld(yd, vy[t][0], gy);
+            y[t][1] = wg_ld(yd, vy[t][1], gy);
+            y[t][2] = wg_ld(yd, vy[t][0], gy + yrow);
+            y[t][3] = wg_ld(yd, vy[t][1], gy + yrow);
+        }
+    };
+    auto mfma_group = [&](const f32x4v (&V)[2][4], const float (&y)[2][4]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float tz[8], Z[16];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {                          // Z = A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]
+                tz[0 * 2 + b] = y[t][0 * 2 + b];
+                tz[1 * 2 + b] = y[t][0 * 2 + b] + y[t][1 * 2 + b];
+                tz[2 * 2 + b] = y[t][0 * 2 + b] - y[t][1 * 2 + b];
+                tz[3 * 2 + b] = -y[t][1 * 2 + b];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Z[i * 4 + 0] = tz[i * 2 + 0];
+                Z[i * 4 + 1] = tz[i * 2 + 0] + tz[i * 2 + 1];
+                Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
+                Z[i * 4 + 3] = -tz[i * 2 + 1];
+            }
+            bsum += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[t][xi >> 2][xi & 3], Z[xi], acc[xi], 0, 0, 0);
+        }
+    };
+
+    // ---- quads: NQ = rows * Q, software-pipelined over the quads ---------------------------------------------------
+    // Vector-memory loads return in order, so the ORDER of issue decides what a wait covers: the output gradients of a
+    // group are issued one group ahead of their use and always BEFORE the 32 long-latency patch loads of the next quad
+    // (which are needed only at the end of the iteration); the first group's gradients of quad n + 1 are issued in front
+    // of the last MFMAs of quad n.  Only the LDS reads of a quad's first group (behind the barrier) are exposed.
+    const int NQ = (r1 - r0) * Q;
+    float xn[2][16];
+    f32x4v Va[2][4], Vb[2][4];
+    float ya[2][4], yb[2][4];
+    if (NQ > 0) {
+        load_x(xn, r0, 0);
+        load_y(ya, ybase(r0), 0);
+        xform_store(xn, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int r = r0, q = 0, n = 0;
+    // The body is branch-free (the last quad is peeled off through the same lambda): with an `if (more)` inside, hipcc keeps
+    // the transform of the next quad out of the MFMA stream and merges the wait counts of both paths conservatively.
+    auto quad = [&](auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        const int buf = n & 1;
+        int rn = r, qn = q + 1;
+        if (qn == Q) qn = 0, ++rn;
+        const __amdgpu_buffer_rsrc_t yd = ybase(r);
+        read_v(Va, buf, 0);
+        read_v(Vb, buf, 1);
+        load_y(yb, yd, 4 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) load_x(xn, rn, qn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Va, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(Va, buf, 2);
+        load_y(ya, yd, 4 * q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Vb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(Vb, buf, 3);
+        load_y(yb, yd, 4 * q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Va, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {
+            load_y(ya, ybase(rn), 4 * qn);                        // first group of the next quad
+            __builtin_amdgcn_sched_barrier(0);
+            xform_store(xn, buf ^ 1);                             // in front of the last group's MFMAs: interleaved by hipcc
+        }
+        mfma_group(Vb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        r = rn, q = qn, ++n;
+    };
+    while (n + 1 < NQ) quad(std::true_type());
+    if (NQ > 0) quad(std::false_type());
+
+    float *out = P.slab + (((long)ks * 16) * Cx + rt * 32) * Cy + ct * 32 + l31;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * kh;
+            out[((long)xi * Cx + row) * Cy] = acc[xi][v];
+        }
+    if (P.bslab && rt == 0) {
+        const float b = bsum + __shfl_xor(bsum, 32, 64);
+        if (kh == 0) P.bslab[(long)ks * Cy + ct * 32 + l31] = b;
+    }
+}
+
 // stage 1: U[xi][ci][co] = sum over the tile-row ranges, in fixed order (one thread per element: coalesced, 16*Cx*Cy threads)
 // (n is a multiple of 4: 16 * Cx * Cy.)  One float4 column per thread; the partial slabs are fetched eight at a time so
 // that eight 16-byte loads are in flight per lane, and added in slab order - the same sums, element by element, as a
@@ -370,7 +583,15 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     rnh_wgrad_args_t b = a;
     if (!db) b.bslab = nullptr;
     const int items = s.KS * (s.Cx / 32) * (s.Cy / 32);
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
+    // the LDS-sharing variant needs whole quads of groups per tile row and four column tiles per workgroup
+    // (RNH_WGRAD_LDS=0 keeps the per-lane kernel for A/B measurements; both accumulate the tiles in the same order and
+    // give bit-identical sums)
+    const char *e = getenv("RNH_WGRAD_LDS");
+    const bool use_lds = !(e && e[0] == '0');
+    if (use_lds && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0)
+        hipLaunchKernelGGL(wino_wgrad_lds_kernel, dim3(items / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
+    else
+        hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad");
     // the sums go behind the partial slabs in the same workspace (rnh_wino_wgrad_ws_floats sizes it for KS + 1 slabs)
     const long nU = (long)16 * s.Cx * s.Cy;

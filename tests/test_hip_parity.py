@@ -395,11 +395,14 @@ def test_last_group_only_inference(g1):
     assert all(g is not None for g in out)
 
 
+@pytest.mark.parametrize('W', [32, 16, 64])
 @pytest.mark.parametrize('which', ['lstm', 'up', 'refine'])
-def test_winograd_weight_gradient_vs_pixel_contraction(which):
+def test_winograd_weight_gradient_vs_pixel_contraction(which, W):
     """rnh_wino_wgrad (F(3x3,2x2): padded gather, transforms per lane, G^T.G in the reduction) against rnh_conv_wgrad
     on the same operands: ConvLSTM (two 64-channel sources, 256 columns, bias), PixelShuffle conv (dy gathered from the
-    2x larger tensor, strided column map) and refine conv1's hidden-state rows (ten sources with frame offsets)."""
+    2x larger tensor, strided column map) and refine conv1's hidden-state rows (ten sources with frame offsets).
+    W = 32, 64: the variant that shares the input transform through LDS (quads of groups); W = 16: the per-lane kernel.
+    Both accumulate the tiles in the same order: where both apply they must agree bit for bit."""
     from hipvsr.hip_ops import HipOps
     from hipvsr.plans import NetPlans, Src
     from hipvsr.spec import NetConfig
@@ -409,7 +412,7 @@ def test_winograd_weight_gradient_vs_pixel_contraction(which):
     P = NetPlans(cfg)
     g = torch.Generator('cpu').manual_seed(17)
     R = lambda *s: torch.randn(*s, generator=g).to(dev)                       # noqa: E731
-    B, H, W = 3, 6, 32
+    B, H = 3, 6
     if which == 'lstm':
         plan = P.lstm[('forward', 1)]['wgrad']
         xs = [Src(R(B + 1, H, W, 64), img_off=1), Src(R(B + 1, H, W, 64))]
@@ -430,13 +433,22 @@ def test_winograd_weight_gradient_vs_pixel_contraction(which):
         ys = [Src(R(B, H, W, 132), nch=128)]
         shape, bias = (129, 645, 3, 3), True
     res = []
-    for wino in (True, False):
-        ops = HipOps(dev)
-        ops.wino_wgrad = wino
-        dw, db = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
-        ops.wgrad(plan, xs, ys, B, H, W, dw, db if bias else None)
-        torch.cuda.synchronize()
-        res.append((dw.cpu(), db.cpu()))
+    old = os.environ.get('RNH_WGRAD_LDS')
+    try:
+        for wino, lds in ((True, '1'), (False, '1'), (True, '0')):
+            os.environ['RNH_WGRAD_LDS'] = lds
+            ops = HipOps(dev)
+            ops.wino_wgrad = wino
+            dw, db = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
+            ops.wgrad(plan, xs, ys, B, H, W, dw, db if bias else None)
+            torch.cuda.synchronize()
+            res.append((dw.cpu(), db.cpu()))
+    finally:
+        if old is None:
+            os.environ.pop('RNH_WGRAD_LDS', None)
+        else:
+            os.environ['RNH_WGRAD_LDS'] = old
     _grad_close(res[0][0], res[1][0], 'dw', rel=1e-5)
     _grad_close(res[0][1], res[1][1], 'db', rel=1e-5)
     assert float(res[1][0].abs().max()) > 0
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])      # LDS variant == per-lane variant
