@@ -284,12 +284,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
     }
     const int xrow = Wp * Cx * 4, xgrp = 8 * Cx * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
-    auto xbase = [&](int r) {
-        const int img = r / TY, ty = r - img * TY;
-        return wg_rsrc(xp + ((long)img * Hp + 2 * ty) * Wp * Cx);
-    };
-    auto ybase = [&](int r) {
-        const int img = r / TY, ty = r - img * TY;
+    // (image, tile row) of a row index advance without divisions: the loop only ever steps to the next row
+    auto xbase = [&](int img, int ty) { return wg_rsrc(xp + ((long)img * Hp + 2 * ty) * Wp * Cx); };
+    auto ybase = [&](int img, int ty) {
         return wg_rsrc(Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C);
     };
 
@@ -301,8 +298,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     float bsum = 0.f;
 
     // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
-    auto load_x = [&](float (&d)[2][16], int r, int q) {
-        const __amdgpu_buffer_rsrc_t xd = xbase(r);
+    auto load_x = [&](float (&d)[2][16], int img, int ty, int q) {
+        const __amdgpu_buffer_rsrc_t xd = xbase(img, ty);
         const int gx = __builtin_amdgcn_readfirstlane((4 * q + wave) * xgrp);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -314,28 +311,25 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     // V = B^T d B of both tiles -> LDS buffer `buf`, slot of this wave's group
     // (Packing the two tiles into v_pk_add_f32 halves was tried: the register pairing spills next to the 256 accumulators
     // and the kernel ran 1.5x slower.)
-    auto xform_store = [&](const float (&d)[2][16], int buf) {
+    auto xform_store = [&](const float (&d)[2][16], int buf, int t) {
+        float tq[16], V[16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float tq[16], V[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tq[0 * 4 + j] = d[t][0 * 4 + j] - d[t][2 * 4 + j];
-                tq[1 * 4 + j] = d[t][1 * 4 + j] + d[t][2 * 4 + j];
-                tq[2 * 4 + j] = d[t][2 * 4 + j] - d[t][1 * 4 + j];
-                tq[3 * 4 + j] = d[t][1 * 4 + j] - d[t][3 * 4 + j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
-                V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
-                V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
-                V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
-            }
-            float *o = sV + buf * WL_BUF + ((wave * 2 + t) * 64 + lane) * WL_STRIDE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4v *>(o + 4 * i) = f32x4v{V[4 * i], V[4 * i + 1], V[4 * i + 2], V[4 * i + 3]};
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = d[t][0 * 4 + j] - d[t][2 * 4 + j];
+            tq[1 * 4 + j] = d[t][1 * 4 + j] + d[t][2 * 4 + j];
+            tq[2 * 4 + j] = d[t][2 * 4 + j] - d[t][1 * 4 + j];
+            tq[3 * 4 + j] = d[t][1 * 4 + j] - d[t][3 * 4 + j];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
+            V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
+            V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
+            V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
+        }
+        float *o = sV + buf * WL_BUF + ((wave * 2 + t) * 64 + lane) * WL_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4v *>(o + 4 * i) = f32x4v{V[4 * i], V[4 * i + 1], V[4 * i + 2], V[4 * i + 3]};
     };
     auto read_v = [&](f32x4v (&V)[2][4], int buf, int j) {
 #pragma unroll
@@ -388,26 +382,30 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     float xn[2][16];
     f32x4v Va[2][4], Vb[2][4];
     float ya[2][4], yb[2][4];
+    int img = r0 / TY, ty = r0 - img * TY, q = 0, n = 0;
     if (NQ > 0) {
-        load_x(xn, r0, 0);
-        load_y(ya, ybase(r0), 0);
-        xform_store(xn, 0);
+        load_x(xn, img, ty, 0);
+        load_y(ya, ybase(img, ty), 0);
+        xform_store(xn, 0, 0);
+        xform_store(xn, 0, 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int r = r0, q = 0, n = 0;
     // The body is branch-free (the last quad is peeled off through the same lambda): with an `if (more)` inside, hipcc keeps
     // the transform of the next quad out of the MFMA stream and merges the wait counts of both paths conservatively.
     auto quad = [&](auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         const int buf = n & 1;
-        int rn = r, qn = q + 1;
-        if (qn == Q) qn = 0, ++rn;
-        const __amdgpu_buffer_rsrc_t yd = ybase(r);
+        int imgn = img, tyn = ty, qn = q + 1;
+        if (qn == Q) {
+            qn = 0;
+            if (++tyn == TY) tyn = 0, ++imgn;
+        }
+        const __amdgpu_buffer_rsrc_t yd = ybase(img, ty);
         read_v(Va, buf, 0);
         read_v(Vb, buf, 1);
         load_y(yb, yd, 4 * q + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) load_x(xn, rn, qn);
+        if constexpr (more) load_x(xn, imgn, tyn, qn);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
@@ -419,17 +417,19 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         read_v(Vb, buf, 3);
         load_y(yb, yd, 4 * q + 3);
         __builtin_amdgcn_sched_barrier(0);
+        // the transform of the next quad's patches (loaded two groups ago) is spread over the last two groups' MFMAs
+        if constexpr (more) xform_store(xn, buf ^ 1, 0);
         mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) {
-            load_y(ya, ybase(rn), 4 * qn);                        // first group of the next quad
+            load_y(ya, ybase(imgn, tyn), 4 * qn);                 // first group of the next quad
             __builtin_amdgcn_sched_barrier(0);
-            xform_store(xn, buf ^ 1);                             // in front of the last group's MFMAs: interleaved by hipcc
+            xform_store(xn, buf ^ 1, 1);
         }
         mfma_group(Vb, yb);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        r = rn, q = qn, ++n;
+        img = imgn, ty = tyn, q = qn, ++n;
     };
     while (n + 1 < NQ) quad(std::true_type());
     if (NQ > 0) quad(std::false_type());
