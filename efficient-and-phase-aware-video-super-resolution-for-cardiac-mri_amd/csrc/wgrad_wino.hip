@@ -390,8 +390,12 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         xform_store(xn, 0, 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NQ > 0) read_v(Va, 0, 0);
     // The body is branch-free (the last quad is peeled off through the same lambda): with an `if (more)` inside, hipcc keeps
     // the transform of the next quad out of the MFMA stream and merges the wait counts of both paths conservatively.
+    // The quad's barrier sits in front of its LAST group's MFMAs (as in conv_wino.hip): by then every wave has written the
+    // next quad's V and issued its last reads of this one, so the next quad's first operands are fetched from LDS under
+    // the cover of those MFMAs.  Va enters a quad holding its first group.
     auto quad = [&](auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         const int buf = n & 1;
@@ -401,7 +405,6 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
             if (++tyn == TY) tyn = 0, ++imgn;
         }
         const __amdgpu_buffer_rsrc_t yd = ybase(img, ty);
-        read_v(Va, buf, 0);
         read_v(Vb, buf, 1);
         load_y(yb, yd, 4 * q + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -417,18 +420,20 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         read_v(Vb, buf, 3);
         load_y(yb, yd, 4 * q + 3);
         __builtin_amdgcn_sched_barrier(0);
-        // the transform of the next quad's patches (loaded two groups ago) is spread over the last two groups' MFMAs
-        if constexpr (more) xform_store(xn, buf ^ 1, 0);
-        mfma_group(Va, ya);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) {
-            load_y(ya, ybase(imgn, tyn), 4 * qn);                 // first group of the next quad
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {                                     // the next quad's patches were loaded two groups ago
+            xform_store(xn, buf ^ 1, 0);
             xform_store(xn, buf ^ 1, 1);
         }
-        mfma_group(Vb, yb);
+        mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (more) {
+            load_y(ya, ybase(imgn, tyn), 4 * qn);                 // first group of the next quad
+            read_v(Va, buf ^ 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Vb, yb);
+        __builtin_amdgcn_sched_barrier(0);
         img = imgn, ty = tyn, q = qn, ++n;
     };
     while (n + 1 < NQ) quad(std::true_type());
