@@ -3,7 +3,8 @@ and the HIP-graph replay of the forward.
 
 CPU: host logic (batch-size check, names, PNG writer, config errors).  GPU (-m gpu): graph replay == eager bit for bit
 and == the reference's golden whole-cycle vector (g5, tolerance 1e-4 as for every forward output), per-frame losses /
-metrics of the predictor against the CPU oracle (PSNR 1e-3 dB on outputs that agree to 1e-4, SSIM 1e-4)."""
+metrics of the predictor against the CPU oracle (|delta PSNR| < 0.01 dB - the north star's criterion - and SSIM 1e-3 on
+rounded images whose pixels may flip by one grey level; losses 1e-5)."""
 import os
 import pickle
 import struct
@@ -178,7 +179,11 @@ def test_src_main_test_branch_vs_oracle(tmp_path, graph, group):
         for k, v in (('Loss', l1.mean()), ('L1Loss', l1.mean()), ('PSNR', pm[:, 0].mean()), ('SSIM', pm[:, 1].mean()),
                      ('CardiacPSNR', cp.mean()), ('CardiacSSIM', cs.mean())):
             want[k] += float(v) * T
-    tol = dict(Loss=1e-5, L1Loss=1e-5, PSNR=1e-3, SSIM=1e-4, CardiacPSNR=1e-3, CardiacSSIM=1e-4)
+    # PSNR / SSIM are taken on ROUNDED images: where an output differs from the oracle's by 1e-6 across a rounding
+    # boundary a pixel flips by one grey level, and which pixels do depends on the host CPU's convolution code path (the
+    # oracle runs on the GPU box's host).  Hence the north star's own criterion here (|delta PSNR| < 0.01 dB) and 1e-3
+    # for SSIM; the metric kernels themselves are pinned to 1e-4 dB / 2e-5 on identical inputs (test_step_tail.py).
+    tol = dict(Loss=1e-5, L1Loss=1e-5, PSNR=1e-2, SSIM=1e-3, CardiacPSNR=1e-2, CardiacSSIM=1e-3)
     for k in log:
         assert abs(log[k] - want[k] / 60) <= tol[k], (k, log[k], want[k] / 60)
     import csv
@@ -186,7 +191,7 @@ def test_src_main_test_branch_vs_oracle(tmp_path, graph, group):
     assert got[0] == ['name', 'PSNR', 'SSIM', 'CardiacPSNR', 'CardiacSSIM', 'L1Loss'] and len(got) == 61
     assert got[1][0] == 'patient000_2d_slice01_frame01' and got[60][0] == 'patient001_2d_slice01_frame30'
     for g_, w_ in zip(got[1:], rows):
-        for a, b, t_ in zip(g_[1:], w_, (2e-3, 2e-4, 2e-3, 2e-4, 1e-5)):
+        for a, b, t_ in zip(g_[1:], w_, (1e-2, 1e-3, 1e-2, 1e-3, 1e-5)):
             assert abs(float(a) - b) <= t_, (g_[0], a, b)
     video = np.load(tmp_path / 'test' / 'videos' / 'patient001' / 'sequence01.npy')
     assert video.shape == (30, 216, 256) and video.dtype == np.uint8
