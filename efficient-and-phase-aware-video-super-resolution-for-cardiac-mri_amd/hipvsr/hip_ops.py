@@ -54,6 +54,11 @@ class HipOps:
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, *shape):
+        if os.environ.get('RNH_POISON'):
+            # debugging aid: every buffer starts as NaN, so a kernel that reads an element nobody wrote shows up in the
+            # results instead of depending on what the allocator's block held before
+            return torch.full(shape if not (len(shape) == 1 and isinstance(shape[0], (tuple, list))) else tuple(shape[0]),
+                              float('nan'), dtype=torch.float32, device=self.device)
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
     def zeros(self, *shape):
