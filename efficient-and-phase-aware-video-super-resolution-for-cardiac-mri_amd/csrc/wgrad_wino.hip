@@ -354,18 +354,18 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         for (int t = 0; t < 2; ++t) {
             float tz[8], Z[16];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {                          // Z = A dY A^T,  A = [1 0; 1 1; 1 -1; 0 -1]
+            for (int b = 0; b < 2; ++b) {                          // Z' = A' dY A'^T,  A' = [1 0; 1 1; 1 -1; 0 1]
                 tz[0 * 2 + b] = y[t][0 * 2 + b];
                 tz[1 * 2 + b] = y[t][0 * 2 + b] + y[t][1 * 2 + b];
                 tz[2 * 2 + b] = y[t][0 * 2 + b] - y[t][1 * 2 + b];
-                tz[3 * 2 + b] = -y[t][1 * 2 + b];
+                tz[3 * 2 + b] = y[t][1 * 2 + b];               // sign folded into the reduction
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 Z[i * 4 + 0] = tz[i * 2 + 0];
                 Z[i * 4 + 1] = tz[i * 2 + 0] + tz[i * 2 + 1];
                 Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
-                Z[i * 4 + 3] = -tz[i * 2 + 1];
+                Z[i * 4 + 3] = tz[i * 2 + 1];
             }
             bsum += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256) wino_wgrad_sum_kernel(const float *__rest
 
 // stage 2: dw[(colmap[co]*Cin + rowmap[ci])*9 + 3a + b] (+)= (G^T U G)[a][b];  db[colmap[co]] (+)= sum bslab
 __global__ void wino_wgrad_reduce_kernel(const float *U, const float *bslab, int KS, int Cx, int Cy, const int *rowmap,
-                                         const int *colmap, int Cin, float *dw, float *db, int accumulate) {
+                                         const int *colmap, int Cin, float *dw, float *db, int accumulate, int folded) {
     const long total = (long)Cx * Cy;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Cy; e += (long)gridDim.x * blockDim.x) {
         if (e >= total) {
@@ -497,7 +497,12 @@ __global__ void wino_wgrad_reduce_kernel(const float *U, const float *bslab, int
         if (ci < 0 || co < 0) continue;
         float Uv[16];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) Uv[xi] = U[((long)xi * Cx + i) * Cy + j];
+        // folded: the LDS kernel accumulates with A' = [1 0; 1 1; 1 -1; 0 1] (no negations next to the MFMAs):
+        // Z = s_a s_b Z' with s = (1, 1, 1, -1), applied here, exactly
+        for (int xi = 0; xi < 16; ++xi) {
+            const float u = U[((long)xi * Cx + i) * Cy + j];
+            Uv[xi] = (folded && (((xi >> 2) == 3) != ((xi & 3) == 3))) ? -u : u;
+        }
         // G^T (4x4) G with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
         float T[3][4];
 #pragma unroll
@@ -593,7 +598,8 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     // give bit-identical sums)
     const char *e = getenv("RNH_WGRAD_LDS");
     const bool use_lds = !(e && e[0] == '0');
-    if (use_lds && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0)
+    const bool lds = use_lds && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0;
+    if (lds)
         hipLaunchKernelGGL(wino_wgrad_lds_kernel, dim3(items / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
     else
         hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
@@ -604,7 +610,7 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(wg_grid_for(nU / 4)), dim3(256), 0, st, a.slab, U, s.KS, nU);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad(sum)");
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(wg_grid_for((long)s.Cx * s.Cy + s.Cy)), dim3(256), 0, st, U, b.bslab, s.KS, s.Cx, s.Cy,
-                       rowmap, colmap, Cin, dw, db, accumulate);
+                       rowmap, colmap, Cin, dw, db, accumulate, (int)lds);
     RNH_CHECK_LAUNCH("rnh_wino_wgrad(reduce)");
     return 0;
 }
