@@ -28,10 +28,14 @@ def _regs(m):
     return range(int(m.group(1)), int(m.group(2)) + 1) if m.group(1) else [int(m.group(3))]
 
 
+EXTRA = {'wgrad_wino.hip': ['-fno-slp-vectorize']}          # per-file flags of csrc/build.sh: the guard must see the shipped code
+
+
 def _asm(src, tmp_path):
     out = os.path.join(tmp_path, os.path.basename(src) + '.s')
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
-                    '-S', '--cuda-device-only', '-o', out, src], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] +
+                   EXTRA.get(os.path.basename(src), []) + ['-S', '--cuda-device-only', '-o', out, src], check=True,
+                   stderr=subprocess.DEVNULL)
     return open(out).read()
 
 
