@@ -39,6 +39,10 @@ __device__ __forceinline__ float w_tanh(float x) {
     const float t = ax < 0.04f ? small : big;
     return copysignf(t, x);
 }
+// tanh for the candidate gate g: 2 sigmoid(2x) - 1, the same instruction count as the sigmoid of the other three gate
+// waves (which wait for this one at the barrier).  Absolute error <= 2 ulp of 1 - what c' = f c + i g needs; h = o tanh(c')
+// keeps the form above, which is also relatively accurate near 0.
+__device__ __forceinline__ float w_tanh_gate(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
 
 // U[s][xi][n][q] = (G g G^T)[xi] for input channel kbase[s] + q*kstride and output column n
 __global__ void wino_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kbase, const int *knv,
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
                 for (int dv = 0; dv < GV; ++dv) out4(v0 + dv, Y[dv]);
                 if (wave == 3) {
 #pragma unroll
-                    for (int e = 0; e < 4 * GV; ++e) g[e >> 2][e & 3] = w_tanh(Y[e >> 2][e & 3]);
+                    for (int e = 0; e < 4 * GV; ++e) g[e >> 2][e & 3] = w_tanh_gate(Y[e >> 2][e & 3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4 * GV; ++e) g[e >> 2][e & 3] = w_sigmoid(Y[e >> 2][e & 3]);
