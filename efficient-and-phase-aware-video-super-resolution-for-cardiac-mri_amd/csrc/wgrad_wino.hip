@@ -284,10 +284,12 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
     }
     const int xrow = Wp * Cx * 4, xgrp = 8 * Cx * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
-    // (image, tile row) of a row index advance without divisions: the loop only ever steps to the next row
-    auto xbase = [&](int img, int ty) { return wg_rsrc(xp + ((long)img * Hp + 2 * ty) * Wp * Cx); };
-    auto ybase = [&](int img, int ty) {
-        return wg_rsrc(Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C);
+    // Row pointers advance by constants (no multiplications in the loop): the gradient tensor is dense, so its next tile row
+    // is always 2 source rows on; the padded input skips 2 rows more at an image boundary (Hp = 2 TY + 2).
+    const long xstep = (long)2 * Wp * Cx, ystep = (long)2 * sc * Ws * Y.C;
+    auto xrow_ptr = [&](int img, int ty) { return xp + ((long)img * Hp + 2 * ty) * Wp * Cx; };
+    auto yrow_ptr = [&](int img, int ty) {
+        return Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C;
     };
 
     f32x16 acc[16];
@@ -298,8 +300,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     float bsum = 0.f;
 
     // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
-    auto load_x = [&](float (&d)[2][16], int img, int ty, int q) {
-        const __amdgpu_buffer_rsrc_t xd = xbase(img, ty);
+    auto load_x = [&](float (&d)[2][16], const float *xrow_p, int q) {
+        const __amdgpu_buffer_rsrc_t xd = wg_rsrc(xrow_p);
         const int gx = __builtin_amdgcn_readfirstlane((4 * q + wave) * xgrp);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -382,10 +384,11 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     float xn[2][16];
     f32x4v Va[2][4], Vb[2][4];
     float ya[2][4], yb[2][4];
-    int img = r0 / TY, ty = r0 - img * TY, q = 0, n = 0;
+    int ty = r0 % TY, q = 0, n = 0;
+    const float *px = xrow_ptr(r0 / TY, ty), *py = yrow_ptr(r0 / TY, ty);      // current tile row of the padded input / the gradients
     if (NQ > 0) {
-        load_x(xn, img, ty, 0);
-        load_y(ya, ybase(img, ty), 0);
+        load_x(xn, px, 0);
+        load_y(ya, wg_rsrc(py), 0);
         xform_store(xn, 0, 0);
         xform_store(xn, 0, 1);
     }
@@ -399,16 +402,19 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     auto quad = [&](auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         const int buf = n & 1;
-        int imgn = img, tyn = ty, qn = q + 1;
-        if (qn == Q) {
+        int tyn = ty, qn = q + 1;
+        const float *pxn = px, *pyn = py;
+        if (qn == Q) {                                            // (wave-uniform: scalar selects, no branch)
             qn = 0;
-            if (++tyn == TY) tyn = 0, ++imgn;
+            pyn += ystep;
+            pxn += xstep;
+            if (++tyn == TY) tyn = 0, pxn += xstep;
         }
-        const __amdgpu_buffer_rsrc_t yd = ybase(img, ty);
+        const __amdgpu_buffer_rsrc_t yd = wg_rsrc(py);
         read_v(Vb, buf, 1);
         load_y(yb, yd, 4 * q + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) load_x(xn, imgn, tyn, qn);
+        if constexpr (more) load_x(xn, pxn, qn);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
@@ -428,13 +434,13 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if constexpr (more) {
-            load_y(ya, ybase(imgn, tyn), 4 * qn);                 // first group of the next quad
+            load_y(ya, wg_rsrc(pyn), 4 * qn);                     // first group of the next quad
             read_v(Va, buf ^ 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(Vb, yb);
         __builtin_amdgcn_sched_barrier(0);
-        img = imgn, ty = tyn, q = qn, ++n;
+        px = pxn, py = pyn, ty = tyn, q = qn, ++n;
     };
     while (n + 1 < NQ) quad(std::true_type());
     if (NQ > 0) quad(std::false_type());
