@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args
             Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
             Z[i * 4 + 3] = -tz[i * 2 + 1];
         }
-        bsum += (y[0] + y[1]) + (y[2] + y[3]);
+        bsum += tz[1 * 2 + 0] + tz[1 * 2 + 1];                     // (y0 + y2) + (y1 + y3): the column sums exist already
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi], Z[xi], acc[xi], 0, 0, 0);
     };
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
                 Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
                 Z[i * 4 + 3] = tz[i * 2 + 1];
             }
-            bsum += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
+            bsum += tz[1 * 2 + 0] + tz[1 * 2 + 1];                 // (y0 + y2) + (y1 + y3): the column sums exist already
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[t][xi >> 2][xi & 3], Z[xi], acc[xi], 0, 0, 0);
         }
