@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     const int RT = Cx >> 5, CT = Cy >> 5;
     const int item = blockIdx.x * 4 + wave;                     // CT % 4 == 0: the four waves share (ks, rt)
     const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
-    const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Q = G >> 2, Hp = H + 2, Wp = W + 2;
+    const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Q = G >> 2;
     const int rows_total = P.B * TY;
     const int r0 = ks * rows_per, r1 = min(rows_total, r0 + rows_per);
 
@@ -275,19 +275,28 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     while (cy0 >= P.ys[ysrc].nch) cy0 -= P.ys[ysrc++].nch;
     const rnh_src_t &Y = P.ys[ysrc];
     const int sc = Y.scale, Hs = H * sc, Ws = W * sc;
+    // input source of this row tile (32 channels never straddle two sources: nch % 32 == 0)
+    int xsrc = 0, cx0 = rt * 32;
+    while (cx0 >= P.xs[xsrc].nch) cx0 -= P.xs[xsrc++].nch;
+    const rnh_src_t &X = P.xs[xsrc];
+    const int XC = X.C;
+    // The patches come straight from the unpadded sources (no gathered copy): the descriptor base sits one pixel LEFT of
+    // the image, so column j of tile t is at (2 (kh + 2t) + j) pixels; the one column left of the first group / right of
+    // the last one gets offset 0xFFFFFFFF (hardware range check: zero, no access; the other lane half is in range, so
+    // the load still goes to memory in order); rows above / below the image are clamped and zeroed after the load
+    // (a load with ALL lanes out of range would return ahead of older loads).
     int vx[2][4], vy[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vx[t][j] = ((2 * (kh + 2 * t) + j) * Cx + rt * 32 + l31) * 4;
+        for (int j = 0; j < 4; ++j) vx[t][j] = ((2 * (kh + 2 * t) + j) * XC + l31) * 4;
 #pragma unroll
         for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
     }
-    const int xrow = Wp * Cx * 4, xgrp = 8 * Cx * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
-    // Row pointers advance by constants (no multiplications in the loop): the gradient tensor is dense, so its next tile row
-    // is always 2 source rows on; the padded input skips 2 rows more at an image boundary (Hp = 2 TY + 2).
-    const long xstep = (long)2 * Wp * Cx, ystep = (long)2 * sc * Ws * Y.C;
-    auto xrow_ptr = [&](int img, int ty) { return xp + ((long)img * Hp + 2 * ty) * Wp * Cx; };
+    const int xrow = W * XC * 4, xgrp = 8 * XC * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
+    // Row pointers advance by constants (no multiplications in the loop): both tensors are dense.
+    const long ximg = (long)H * W * XC, ystep = (long)2 * sc * Ws * Y.C;
+    auto ximg_ptr = [&](int img) { return X.ptr + X.c0 + cx0 + ((long)img + X.img_off) * ximg - XC; };
     auto yrow_ptr = [&](int img, int ty) {
         return Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C;
     };
@@ -300,15 +309,35 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     float bsum = 0.f;
 
     // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
-    auto load_x = [&](float (&d)[2][16], const float *xrow_p, int q) {
-        const __amdgpu_buffer_rsrc_t xd = wg_rsrc(xrow_p);
-        const int gx = __builtin_amdgcn_readfirstlane((4 * q + wave) * xgrp);
+    auto load_x = [&](float (&d)[2][16], const float *ximg_p, int ty, int q) {
+        const __amdgpu_buffer_rsrc_t xd = wg_rsrc(ximg_p);
+        const int gq = 4 * q + wave;
+        const int gx = __builtin_amdgcn_readfirstlane(gq * xgrp);
+        int vo[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) vo[t][j] = vx[t][j];
+        if (gq == 0 && kh == 0) vo[0][0] = -1;                    // x = -1
+        if (gq == G - 1 && kh == 1) vo[1][3] = -1;                // x = W
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[t][i * 4 + j] = wg_ld(xd, vx[t][j], gx + i * xrow);
+        for (int i = 0; i < 4; ++i) {
+            const int yi = 2 * ty - 1 + i;
+            const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi);
+            const int so = __builtin_amdgcn_readfirstlane(gx + yc * xrow);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[t][i * 4 + j] = wg_ld(xd, vo[t][j], so);
+        }
+        const bool top = ty == 0, bottom = ty == TY - 1;          // wave-uniform: selects
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[t][0 * 4 + j] = top ? 0.f : d[t][0 * 4 + j];
+                d[t][3 * 4 + j] = bottom ? 0.f : d[t][3 * 4 + j];
+            }
     };
     // V = B^T d B of both tiles -> LDS buffer `buf`, slot of this wave's group
     // (Packing the two tiles into v_pk_add_f32 halves was tried: the register pairing spills next to the 256 accumulators
@@ -385,9 +414,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     f32x4v Va[2][4], Vb[2][4];
     float ya[2][4], yb[2][4];
     int ty = r0 % TY, q = 0, n = 0;
-    const float *px = xrow_ptr(r0 / TY, ty), *py = yrow_ptr(r0 / TY, ty);      // current tile row of the padded input / the gradients
+    const float *px = ximg_ptr(r0 / TY), *py = yrow_ptr(r0 / TY, ty);          // current image of the input / tile row of the gradients
     if (NQ > 0) {
-        load_x(xn, px, 0);
+        load_x(xn, px, ty, 0);
         load_y(ya, wg_rsrc(py), 0);
         xform_store(xn, 0, 0);
         xform_store(xn, 0, 1);
@@ -407,14 +436,13 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         if (qn == Q) {                                            // (wave-uniform: scalar selects, no branch)
             qn = 0;
             pyn += ystep;
-            pxn += xstep;
-            if (++tyn == TY) tyn = 0, pxn += xstep;
+            if (++tyn == TY) tyn = 0, pxn += ximg;
         }
         const __amdgpu_buffer_rsrc_t yd = wg_rsrc(py);
         read_v(Vb, buf, 1);
         load_y(yb, yd, 4 * q + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) load_x(xn, pxn, qn);
+        if constexpr (more) load_x(xn, pxn, tyn, qn);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
@@ -594,8 +622,7 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
         if (int rc = rnh_check_src(a.ys[i], "rnh_wino_wgrad")) return rc;
     if ((long)(a.H + 2) * (a.W + 2) * s.Cx * 4 * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad: image too large for 32-bit row offsets");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wino_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, s.Cx);
-    RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");
+
     rnh_wgrad_args_t b = a;
     if (!db) b.bslab = nullptr;
     const int items = s.KS * (s.Cx / 32) * (s.Cy / 32);
@@ -605,6 +632,10 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     const char *e = getenv("RNH_WGRAD_LDS");
     const bool use_lds = !(e && e[0] == '0');
     const bool lds = use_lds && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0;
+    if (!lds) {                                                  // the per-lane kernel reads the gathered, zero-padded copy
+        hipLaunchKernelGGL(wino_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, s.Cx);
+        RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");
+    }
     if (lds)
         hipLaunchKernelGGL(wino_wgrad_lds_kernel, dim3(items / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
     else
