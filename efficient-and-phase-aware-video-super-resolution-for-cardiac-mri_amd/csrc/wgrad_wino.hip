@@ -592,6 +592,13 @@ bool wino_wgrad_shape(const rnh_wgrad_args_t &a, WinoWgradShape *s) {
     return true;
 }
 
+// The LDS-sharing kernel needs whole quads of groups per tile row and four column tiles per workgroup.  RNH_WGRAD_LDS=0
+// keeps the per-lane kernel for A/B measurements; both accumulate the tiles in the same order: bit-identical sums.
+bool wino_wgrad_uses_lds(const rnh_wgrad_args_t &a, const WinoWgradShape &s) {
+    const char *e = getenv("RNH_WGRAD_LDS");
+    return !(e && e[0] == '0') && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0;
+}
+
 }  // namespace
 
 extern "C" int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args) {
@@ -603,7 +610,8 @@ extern "C" int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args) {
 extern "C" int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t *out3) {
     WinoWgradShape s;
     if (!args || !out3 || !wino_wgrad_shape(*args, &s)) RNH_FAIL(RNH_E_RANGE, "rnh_wino_wgrad_ws_floats: shape not supported");
-    out3[0] = (int64_t)args->B * (args->H + 2) * (args->W + 2) * s.Cx;
+    // the gathered, zero-padded input copy is only needed by the per-lane kernel
+    out3[0] = wino_wgrad_uses_lds(*args, s) ? 4 : (int64_t)args->B * (args->H + 2) * (args->W + 2) * s.Cx;
     out3[1] = (int64_t)(s.KS + 1) * 16 * s.Cx * s.Cy;          // partial slabs + their sum
     out3[2] = (int64_t)s.KS * s.Cy;
     return 0;
@@ -626,12 +634,7 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
     rnh_wgrad_args_t b = a;
     if (!db) b.bslab = nullptr;
     const int items = s.KS * (s.Cx / 32) * (s.Cy / 32);
-    // the LDS-sharing variant needs whole quads of groups per tile row and four column tiles per workgroup
-    // (RNH_WGRAD_LDS=0 keeps the per-lane kernel for A/B measurements; both accumulate the tiles in the same order and
-    // give bit-identical sums)
-    const char *e = getenv("RNH_WGRAD_LDS");
-    const bool use_lds = !(e && e[0] == '0');
-    const bool lds = use_lds && (s.Cy / 32) % 4 == 0 && (a.W % 32) == 0;
+    const bool lds = wino_wgrad_uses_lds(a, s);
     if (!lds) {                                                  // the per-lane kernel reads the gathered, zero-padded copy
         hipLaunchKernelGGL(wino_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, s.Cx);
         RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");

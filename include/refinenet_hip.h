@@ -166,7 +166,8 @@ int rnh_conv_wgrad(const rnh_wgrad_args_t *args /* host */, void *stream);
  * rnh_wgrad_args_t (rows and columns in the natural order of the sources; xgrp, ygrp, tile, nsplit, zero_page unused).
  * Supported (rnh_wino_wgrad_supported): 3x3, H even, W % 16 == 0, every source channel count a multiple of 32, x sources
  * of scale 1, one common scale for the dy sources.  Workspaces: rnh_wino_wgrad_ws_floats -> {xp (zero-padded gathered
- * copy of the inputs), slab, bslab} in floats.  The reduction (fixed order) scatters like rnh_wgrad_reduce:
+ * copy of the inputs; 4 floats when the kernel that shares the input transform through LDS applies - W % 32 == 0, output
+ * channels in multiples of 128 - and reads the sources itself), slab, bslab} in floats.  The reduction (fixed order) scatters like rnh_wgrad_reduce:
  * dw[(colmap[j]*Cin + rowmap[i])*9 + tap], db[colmap[j]]. */
 int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args /* host */);
 int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args /* host */, int64_t *out3 /* host: xp, slab, bslab */);
