@@ -200,21 +200,33 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
                      : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
                        "+v"(stg[8]), "+v"(stg[9]), "+v"(stg[10]), "+v"(stg[11]), "+v"(stg[12]), "+v"(stg[13]), "+v"(stg[14]),
                        "+v"(stg[15]));
+        // a - b in ONE v_pk_add_f32 with negated second operand: hipcc scalarises a packed subtraction into two v_add_f32
+        // (54 of the transform's 64 instructions were scalar; writing it as fma(b, -1, a) is folded back into the same)
+        auto sub = [&](f32x2 a, f32x2 b) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
+        auto add = [&](f32x2 a, f32x2 b) {                 // (packed additions are scalarised as well)
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
         f32x2 tq[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tq[0 * 4 + j] = stg[0 * 4 + j] - stg[2 * 4 + j];
-            tq[1 * 4 + j] = stg[1 * 4 + j] + stg[2 * 4 + j];
-            tq[2 * 4 + j] = stg[2 * 4 + j] - stg[1 * 4 + j];
-            tq[3 * 4 + j] = stg[1 * 4 + j] - stg[3 * 4 + j];
+            tq[0 * 4 + j] = sub(stg[0 * 4 + j], stg[2 * 4 + j]);
+            tq[1 * 4 + j] = add(stg[1 * 4 + j], stg[2 * 4 + j]);
+            tq[2 * 4 + j] = sub(stg[2 * 4 + j], stg[1 * 4 + j]);
+            tq[3 * 4 + j] = sub(stg[1 * 4 + j], stg[3 * 4 + j]);
         }
         float *o = stage + buf * BUF + ts * CHS + 2 * cp;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * TILES * CHS) = tq[i * 4 + 0] - tq[i * 4 + 2];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * TILES * CHS) = tq[i * 4 + 1] + tq[i * 4 + 2];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * TILES * CHS) = tq[i * 4 + 2] - tq[i * 4 + 1];
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * TILES * CHS) = tq[i * 4 + 1] - tq[i * 4 + 3];
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * TILES * CHS) = sub(tq[i * 4 + 0], tq[i * 4 + 2]);
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * TILES * CHS) = add(tq[i * 4 + 1], tq[i * 4 + 2]);
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * TILES * CHS) = sub(tq[i * 4 + 2], tq[i * 4 + 1]);
+            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * TILES * CHS) = sub(tq[i * 4 + 1], tq[i * 4 + 3]);
         }
     };
 
