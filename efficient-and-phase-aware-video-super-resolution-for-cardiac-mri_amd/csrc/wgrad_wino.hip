@@ -370,38 +370,54 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
             for (int i = 0; i < 4; ++i) V[t][i] = *reinterpret_cast<const f32x4v *>(o + 4 * i);
         }
     };
-    auto load_y = [&](float (&y)[2][4], __amdgpu_buffer_rsrc_t yd, int g) {
-        const int gy = __builtin_amdgcn_readfirstlane(g * ygrp);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            y[t][0] = wg_ld(yd, vy[t][0], gy);
-            y[t][1] = wg_ld(yd, vy[t][1], gy);
-            y[t][2] = wg_ld(yd, vy[t][0], gy + yrow);
-            y[t][3] = wg_ld(yd, vy[t][1], gy + yrow);
-        }
+    // The output gradients of a lane's two tiles ride in the halves of packed registers (x = tile a, y = tile b): their
+    // transform is an add / subtract network, one v_pk_add_f32 per pair (written as asm: hipcc scalarises packed adds; the
+    // s_nop covers the VALU-write -> MFMA-read wait states, which hipcc does not add behind an asm statement).
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    auto pk_add = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
     };
-    auto mfma_group = [&](const f32x4v (&V)[2][4], const float (&y)[2][4]) {
+    auto pk_sub = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    auto load_y = [&](f32x2w (&y)[4], __amdgpu_buffer_rsrc_t yd, int g) {
+        const int gy = __builtin_amdgcn_readfirstlane(g * ygrp);
+        y[0].x = wg_ld(yd, vy[0][0], gy);
+        y[1].x = wg_ld(yd, vy[0][1], gy);
+        y[2].x = wg_ld(yd, vy[0][0], gy + yrow);
+        y[3].x = wg_ld(yd, vy[0][1], gy + yrow);
+        y[0].y = wg_ld(yd, vy[1][0], gy);
+        y[1].y = wg_ld(yd, vy[1][1], gy);
+        y[2].y = wg_ld(yd, vy[1][0], gy + yrow);
+        y[3].y = wg_ld(yd, vy[1][1], gy + yrow);
+    };
+    auto mfma_group = [&](const f32x4v (&V)[2][4], const f32x2w (&y)[4]) {
+        f32x2w tz[8], Z[16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float tz[8], Z[16];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {                          // Z' = A' dY A'^T,  A' = [1 0; 1 1; 1 -1; 0 1]
-                tz[0 * 2 + b] = y[t][0 * 2 + b];
-                tz[1 * 2 + b] = y[t][0 * 2 + b] + y[t][1 * 2 + b];
-                tz[2 * 2 + b] = y[t][0 * 2 + b] - y[t][1 * 2 + b];
-                tz[3 * 2 + b] = y[t][1 * 2 + b];               // sign folded into the reduction
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Z[i * 4 + 0] = tz[i * 2 + 0];
-                Z[i * 4 + 1] = tz[i * 2 + 0] + tz[i * 2 + 1];
-                Z[i * 4 + 2] = tz[i * 2 + 0] - tz[i * 2 + 1];
-                Z[i * 4 + 3] = tz[i * 2 + 1];
-            }
-            bsum += tz[1 * 2 + 0] + tz[1 * 2 + 1];                 // (y0 + y2) + (y1 + y3): the column sums exist already
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[t][xi >> 2][xi & 3], Z[xi], acc[xi], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) {                              // Z' = A' dY A'^T,  A' = [1 0; 1 1; 1 -1; 0 1]
+            tz[0 * 2 + b] = y[0 * 2 + b];
+            tz[1 * 2 + b] = pk_add(y[0 * 2 + b], y[1 * 2 + b]);
+            tz[2 * 2 + b] = pk_sub(y[0 * 2 + b], y[1 * 2 + b]);
+            tz[3 * 2 + b] = y[1 * 2 + b];                          // sign folded into the reduction
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Z[i * 4 + 0] = tz[i * 2 + 0];
+            Z[i * 4 + 1] = pk_add(tz[i * 2 + 0], tz[i * 2 + 1]);
+            Z[i * 4 + 2] = pk_sub(tz[i * 2 + 0], tz[i * 2 + 1]);
+            Z[i * 4 + 3] = tz[i * 2 + 1];
+        }
+        const f32x2w bs = pk_add(tz[1 * 2 + 0], tz[1 * 2 + 1]);    // (y0 + y2) + (y1 + y3) of both tiles
+        bsum += bs.x;
+        bsum += bs.y;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][xi >> 2][xi & 3], Z[xi].x, acc[xi], 0, 0, 0);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1][xi >> 2][xi & 3], Z[xi].y, acc[xi], 0, 0, 0);
     };
 
     // ---- quads: NQ = rows * Q, software-pipelined over the quads ---------------------------------------------------
@@ -412,7 +428,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     const int NQ = (r1 - r0) * Q;
     float xn[2][16];
     f32x4v Va[2][4], Vb[2][4];
-    float ya[2][4], yb[2][4];
+    f32x2w ya[4], yb[4];
     int ty = r0 % TY, q = 0, n = 0;
     const float *px = ximg_ptr(r0 / TY), *py = yrow_ptr(r0 / TY, ty);          // current image of the input / tile row of the gradients
     if (NQ > 0) {
