@@ -256,12 +256,12 @@ __device__ __forceinline__ float wg_ld(__amdgpu_buffer_rsrc_t r, int voff, int s
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-constexpr int WL_STRIDE = 20;                                   // floats per (group, tile, lane) in LDS: 16 + 4 pad
-constexpr int WL_BUF = 4 * 2 * 64 * WL_STRIDE;                  // floats per buffer (4 groups x 2 tiles x 64 lanes)
+constexpr int WL_STRIDE = 36;                                   // floats per (group, lane) in LDS: 16 xi x (tile a, tile b) + 4 pad
+constexpr int WL_BUF = 4 * 64 * WL_STRIDE;                      // floats per buffer (4 groups x 64 lanes)
 
 __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_args_t P, const float *xp, const int Cx, const int Cy,
                                                                 const int KS, const int rows_per) {
-    __shared__ __attribute__((aligned(16))) float sV[2 * WL_BUF];   // 80 KB
+    __shared__ __attribute__((aligned(16))) float sV[2 * WL_BUF];   // 72 KB
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int RT = Cx >> 5, CT = Cy >> 5;
@@ -308,8 +308,33 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
     float bsum = 0.f;
 
+    // The output gradients of a lane's two tiles ride in the halves of packed registers (x = tile a, y = tile b): their
+    // transform is an add / subtract network, one v_pk_add_f32 per pair (written as asm: hipcc scalarises packed adds; the
+    // s_nop covers the VALU-write -> MFMA-read wait states, which hipcc does not add behind an asm statement).
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    auto pk_add = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    auto pk_sub = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    // (results that only go to other VALU instructions or to LDS need no pad)
+    auto pk_add0 = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    auto pk_sub0 = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
     // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
-    auto load_x = [&](float (&d)[2][16], const float *ximg_p, int ty, int q) {
+    auto load_x = [&](f32x2w (&d)[16], const float *ximg_p, int ty, int q) {
         const __amdgpu_buffer_rsrc_t xd = wg_rsrc(ximg_p);
         const int gq = 4 * q + wave;
         const int gx = __builtin_amdgcn_readfirstlane(gq * xgrp);
@@ -326,63 +351,42 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
             const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi);
             const int so = __builtin_amdgcn_readfirstlane(gx + yc * xrow);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[t][i * 4 + j] = wg_ld(xd, vo[t][j], so);
+            for (int j = 0; j < 4; ++j) {
+                d[i * 4 + j].x = wg_ld(xd, vo[0][j], so);
+                d[i * 4 + j].y = wg_ld(xd, vo[1][j], so);
+            }
         }
         const bool top = ty == 0, bottom = ty == TY - 1;          // wave-uniform: selects
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d[t][0 * 4 + j] = top ? 0.f : d[t][0 * 4 + j];
-                d[t][3 * 4 + j] = bottom ? 0.f : d[t][3 * 4 + j];
-            }
-    };
-    // V = B^T d B of both tiles -> LDS buffer `buf`, slot of this wave's group
-    // (Packing the two tiles into v_pk_add_f32 halves was tried: the register pairing spills next to the 256 accumulators
-    // and the kernel ran 1.5x slower.)
-    auto xform_store = [&](const float (&d)[2][16], int buf, int t) {
-        float tq[16], V[16];
+        const f32x2w zero = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tq[0 * 4 + j] = d[t][0 * 4 + j] - d[t][2 * 4 + j];
-            tq[1 * 4 + j] = d[t][1 * 4 + j] + d[t][2 * 4 + j];
-            tq[2 * 4 + j] = d[t][2 * 4 + j] - d[t][1 * 4 + j];
-            tq[3 * 4 + j] = d[t][1 * 4 + j] - d[t][3 * 4 + j];
+            d[0 * 4 + j] = top ? zero : d[0 * 4 + j];
+            d[3 * 4 + j] = bottom ? zero : d[3 * 4 + j];
         }
+    };
+    // V = B^T d B of both tiles (packed) -> LDS buffer `buf`, slot of this wave's group: [group][lane][xi][tile]
+    auto xform_store = [&](const f32x2w (&d)[16], int buf) {
+        f32x2w tq[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = pk_sub0(d[0 * 4 + j], d[2 * 4 + j]);
+            tq[1 * 4 + j] = pk_add0(d[1 * 4 + j], d[2 * 4 + j]);
+            tq[2 * 4 + j] = pk_sub0(d[2 * 4 + j], d[1 * 4 + j]);
+            tq[3 * 4 + j] = pk_sub0(d[1 * 4 + j], d[3 * 4 + j]);
+        }
+        float *o = sV + buf * WL_BUF + (wave * 64 + lane) * WL_STRIDE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            V[i * 4 + 0] = tq[i * 4 + 0] - tq[i * 4 + 2];
-            V[i * 4 + 1] = tq[i * 4 + 1] + tq[i * 4 + 2];
-            V[i * 4 + 2] = tq[i * 4 + 2] - tq[i * 4 + 1];
-            V[i * 4 + 3] = tq[i * 4 + 1] - tq[i * 4 + 3];
-        }
-        float *o = sV + buf * WL_BUF + ((wave * 2 + t) * 64 + lane) * WL_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4v *>(o + 4 * i) = f32x4v{V[4 * i], V[4 * i + 1], V[4 * i + 2], V[4 * i + 3]};
-    };
-    auto read_v = [&](f32x4v (&V)[2][4], int buf, int j) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float *o = sV + buf * WL_BUF + ((j * 2 + t) * 64 + lane) * WL_STRIDE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) V[t][i] = *reinterpret_cast<const f32x4v *>(o + 4 * i);
+            const f32x2w v0 = pk_sub0(tq[i * 4 + 0], tq[i * 4 + 2]), v1 = pk_add0(tq[i * 4 + 1], tq[i * 4 + 2]);
+            const f32x2w v2 = pk_sub0(tq[i * 4 + 2], tq[i * 4 + 1]), v3 = pk_sub0(tq[i * 4 + 1], tq[i * 4 + 3]);
+            *reinterpret_cast<f32x4v *>(o + 8 * i) = f32x4v{v0.x, v0.y, v1.x, v1.y};
+            *reinterpret_cast<f32x4v *>(o + 8 * i + 4) = f32x4v{v2.x, v2.y, v3.x, v3.y};
         }
     };
-    // The output gradients of a lane's two tiles ride in the halves of packed registers (x = tile a, y = tile b): their
-    // transform is an add / subtract network, one v_pk_add_f32 per pair (written as asm: hipcc scalarises packed adds; the
-    // s_nop covers the VALU-write -> MFMA-read wait states, which hipcc does not add behind an asm statement).
-    typedef float f32x2w __attribute__((ext_vector_type(2)));
-    auto pk_add = [&](f32x2w p, f32x2w r) {
-        f32x2w o;
-        asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
-        return o;
-    };
-    auto pk_sub = [&](f32x2w p, f32x2w r) {
-        f32x2w o;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
-        return o;
+    auto read_v = [&](f32x4v (&V)[8], int buf, int j) {
+        const float *o = sV + buf * WL_BUF + (j * 64 + lane) * WL_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) V[i] = *reinterpret_cast<const f32x4v *>(o + 4 * i);
     };
     auto load_y = [&](f32x2w (&y)[4], __amdgpu_buffer_rsrc_t yd, int g) {
         const int gy = __builtin_amdgcn_readfirstlane(g * ygrp);
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         y[2].y = wg_ld(yd, vy[1][0], gy + yrow);
         y[3].y = wg_ld(yd, vy[1][1], gy + yrow);
     };
-    auto mfma_group = [&](const f32x4v (&V)[2][4], const f32x2w (&y)[4]) {
+    auto mfma_group = [&](const f32x4v (&V)[8], const f32x2w (&y)[4]) {
         f32x2w tz[8], Z[16];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {                              // Z' = A' dY A'^T,  A' = [1 0; 1 1; 1 -1; 0 1]
@@ -415,9 +419,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         bsum += bs.x;
         bsum += bs.y;
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][xi >> 2][xi & 3], Z[xi].x, acc[xi], 0, 0, 0);
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi >> 1][(xi & 1) * 2], Z[xi].x, acc[xi], 0, 0, 0);
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1][xi >> 2][xi & 3], Z[xi].y, acc[xi], 0, 0, 0);
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi >> 1][(xi & 1) * 2 + 1], Z[xi].y, acc[xi], 0, 0, 0);
     };
 
     // ---- quads: NQ = rows * Q, software-pipelined over the quads ---------------------------------------------------
@@ -426,16 +430,15 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     // (which are needed only at the end of the iteration); the first group's gradients of quad n + 1 are issued in front
     // of the last MFMAs of quad n.  Only the LDS reads of a quad's first group (behind the barrier) are exposed.
     const int NQ = (r1 - r0) * Q;
-    float xn[2][16];
-    f32x4v Va[2][4], Vb[2][4];
+    f32x2w xn[16];
+    f32x4v Va[8], Vb[8];
     f32x2w ya[4], yb[4];
     int ty = r0 % TY, q = 0, n = 0;
     const float *px = ximg_ptr(r0 / TY), *py = yrow_ptr(r0 / TY, ty);          // current image of the input / tile row of the gradients
     if (NQ > 0) {
         load_x(xn, px, ty, 0);
         load_y(ya, wg_rsrc(py), 0);
-        xform_store(xn, 0, 0);
-        xform_store(xn, 0, 1);
+        xform_store(xn, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (NQ > 0) read_v(Va, 0, 0);
@@ -471,8 +474,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
         load_y(yb, yd, 4 * q + 3);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (more) {                                     // the next quad's patches were loaded two groups ago
-            xform_store(xn, buf ^ 1, 0);
-            xform_store(xn, buf ^ 1, 1);
+            xform_store(xn, buf ^ 1);
         }
         mfma_group(Va, ya);
         __builtin_amdgcn_sched_barrier(0);
