@@ -2,8 +2,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof_n
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_n -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_n/bench_line_profiled.json 2> gpurun_out/prof_n/err.log
-find gpurun_out/prof_n -name '*kernel_trace.csv' -delete
-python bench.py > gpurun_out/prof_n/bench_line.json 2> gpurun_out/prof_n/bench_err.log
-tail -c 1500 gpurun_out/prof_n/bench_line.json
+mkdir -p gpurun_out/prof_o
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_o -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_o/bench_line_profiled.json 2> gpurun_out/prof_o/err.log
+find gpurun_out/prof_o -name '*kernel_trace.csv' -delete
+python bench.py > gpurun_out/prof_o/bench_line.json 2> gpurun_out/prof_o/bench_err.log
+tail -c 1500 gpurun_out/prof_o/bench_line.json
