@@ -8,9 +8,14 @@ N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 ->
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, weak scaling: 8 samples per rank)
 
 Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
-ranks).  `roofline` prices the dominant kernel (the ConvLSTM cell forward, a Winograd F(2x2,3x3) convolution with fused
-gates, 342 - 24 launches per step) from HIP-event timing of that launch on this run: `achieved` uses the ALGORITHMIC
-(direct 3x3) FLOPs as SURVEY section 8d defines them, the executed MFMA rate is reported beside it; `cpu_baseline` times
+ranks); `ms_per_step_median` is the median of the per-step HIP-event times of the same steps.  `roofline` prices the
+dominant kernel (the ConvLSTM cell forward, a Winograd F(2x2,3x3) convolution with fused gates, 342 - 24 launches per
+step) from HIP-event timing of that launch on this run: `achieved` / `frac` = the FLOPs the matrix cores EXECUTE
+(16 GEMMs over the 2x2 tiles = 4/9 of the direct form) over the launch time and the fp32 MFMA peak - a fraction of a
+ceiling, <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per
+pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not
+do that work).  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
+only if that file was measured on THIS kernel source (sha256 of csrc/conv_wino.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 """
@@ -103,30 +108,38 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
     # what the matrix cores execute: the Winograd F(2x2,3x3) kernel runs 16 GEMMs over n*h*w/4 tiles = 4/9 of it
     flops_exec = flops * 4.0 / 9.0 if wino else flops
-    achieved = flops / (ms * 1e-3) / 1e12
+    algorithmic = flops / (ms * 1e-3) / 1e12
     executed = flops_exec / (ms * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_src = None, None
     prof = os.path.join(ROOT, 'profiles', 'lstm_kernel_hbm_bytes.json')
     if os.path.exists(prof):
         try:
-            traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+            rec = json.load(open(prof))
+            if rec.get('kernel_source_sha256') == kernel_source_sha256():     # measured on this kernel, not an older revision
+                traffic = rec.get('hbm_bytes_per_launch')
+                traffic_src = {k: rec.get(k) for k in ('commit', 'date', 'command')}
         except Exception:
             traffic = None
     name = 'conv_wino_kernel<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
         'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)'
-    out = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'avg_launch_ms': round(ms, 4),
-           'flop_per_launch': flops, 'executed_mfma_flop_per_launch': flops_exec, 'executed_mfma_tflops': round(executed, 2),
-           'executed_frac_of_peak': round(executed / PEAK_F32_MFMA_TFLOPS, 4)}
-    if wino:
-        out['note'] = ('achieved/frac price the ALGORITHMIC (direct 3x3) FLOPs; the kernel computes the same convolution with 4/9 '
-                       'of the multiplications (Winograd), so frac may exceed 1 - executed_frac_of_peak is the matrix-core utilisation')
+    out = {'bound': 'mfma', 'kernel': name, 'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+           'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops_exec,
+           'algorithmic_flop_per_launch': flops, 'algorithmic_equiv_tflops': round(algorithmic, 2),
+           'algorithmic_equiv_frac': round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
+           'algorithmic_bytes_per_launch': 4 * n * h * w * (cx + 2 * hd + 2 * hd + 4 * hd)}    # x, h, c in; h', c', gates out
     return out
 
 
+def kernel_source_sha256():
+    import hashlib
+    with open(os.path.join(PKG, 'csrc', 'conv_wino.hip'), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def cpu_baseline():
-    """The oracle (bit-exact restatement of the reference) at BASELINE config 1 on the host cores: 1 warm-up + 2 timed
-    steps of forward + discounted L1 loss + backward (about 10-20 s)."""
+    """The oracle (bit-exact restatement of the reference) at BASELINE config 1 on the host cores: 1 warm-up + 10 timed
+    steps of forward + discounted L1 loss + backward (about 10-20 s of CPU work on the GPU box's host)."""
     from oracle import refinenet_oracle as orc
     # 16 threads is the fastest setting on the GPU box's host (2 x EPYC 9575F, 256 hardware threads): 0.88 s/step at
     # 16 threads against 1.37 (8), 1.42 (32), 3.2 (64) and 10.6 (128) - the convolutions of one 64x64 sample are small
@@ -188,11 +201,16 @@ def main():
     for _ in range(args.warmup):
         _, loss, _ = tr.train_step(inputs, targets, pos)
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step times (no host sync inside the region)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         _, loss, _ = tr.train_step(inputs, targets, pos)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,7 +225,7 @@ def main():
         roof = lstm_kernel_roofline(net, dev, args.batch, args.size, args.size)
         out = {
             'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(value, 3), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2), 'ms_per_step_median': round(median_ms, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'RefineNet x4 training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'

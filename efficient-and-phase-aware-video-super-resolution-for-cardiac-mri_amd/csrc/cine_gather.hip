@@ -9,21 +9,33 @@
 // only reverses the lane order inside the row), the sample descriptor is wave-uniform and read through scalar loads.
 // Algorithmic bytes: 8 B per output pixel (4 read + 4 written).
 #include "rnh_common.h"
+#include <string.h>
 
 namespace {
 
-__global__ void __launch_bounds__(256) cine_gather_kernel(const float *__restrict__ pool, const rnh_cine_sample_t *__restrict__ S, int N, int F, int T,
+// The sample descriptors travel BY VALUE in the kernel-argument segment (copied by the runtime when the launch is
+// enqueued), RNH_CINE_CHUNK samples per launch.  An earlier version uploaded them with hipMemcpyAsync from the caller's
+// pageable array: such a copy may read the host memory after the call has returned - the Python binding frees (and the
+// next batch re-fills) that array as soon as rnh_cine_gather returns, so two gathers enqueued back to back could cut
+// the first batch with the second batch's descriptors (tools/pageable_async_probe.hip shows the effect in isolation).
+constexpr int RNH_CINE_CHUNK = 32;
+struct cine_chunk_t {
+    rnh_cine_sample_t s[RNH_CINE_CHUNK];
+};
+
+__global__ void __launch_bounds__(256) cine_gather_kernel(const float *__restrict__ pool, const cine_chunk_t S, int n0, int cnt, int N, int F, int T,
                                                           int s, int h, int w, int normalize, float mean, float stdv,
                                                           float *__restrict__ inputs, float *__restrict__ targets, float *__restrict__ pos) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int sh = s * h, sw = s * w;
     const int rows_lr = F * h, rows_per = rows_lr + T * sh;
-    const long units = (long)N * rows_per;
+    const long units = (long)cnt * rows_per;
     for (long u = (long)blockIdx.x * 4 + wave; u < units; u += (long)gridDim.x * 4) {
-        const int n = (int)(u / rows_per);
-        int r = (int)(u - (long)n * rows_per);
-        const rnh_cine_sample_t c = S[n];                   // wave-uniform index: scalar loads
+        const int nl = (int)(u / rows_per);
+        const int n = n0 + nl;
+        int r = (int)(u - (long)nl * rows_per);
+        const rnh_cine_sample_t c = S.s[nl];                // wave-uniform index into the kernel arguments: scalar loads
         const bool lr = r < rows_lr;
         if (!lr) r -= rows_lr;
         const int rh = lr ? h : sh, rw = lr ? w : sw, k = lr ? 1 : s;
@@ -43,9 +55,9 @@ __global__ void __launch_bounds__(256) cine_gather_kernel(const float *__restric
         }
     }
     // phase codes: pos[n][k] = code[(lr_start + k) mod Tc]  (not normalised: dataset :71)
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)N * F; e += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(e / F), kf = (int)(e - (long)n * F);
-        pos[e] = pool[S[n].code_off + (S[n].lr_start + kf) % S[n].Tc];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)cnt * F; e += (long)gridDim.x * blockDim.x) {
+        const int nl = (int)(e / F), kf = (int)(e - (long)nl * F);
+        pos[(long)n0 * F + e] = pool[S.s[nl].code_off + (S.s[nl].lr_start + kf) % S.s[nl].Tc];
     }
 }
 
@@ -54,7 +66,8 @@ __global__ void __launch_bounds__(256) cine_gather_kernel(const float *__restric
 extern "C" int rnh_cine_gather(const float *pool, int64_t pool_floats, const rnh_cine_sample_t *samples_host, rnh_cine_sample_t *samples_dev,
                                int N, int F, int T, int s, int h, int w, int normalize, float mean, float stdv, float *inputs,
                                float *targets, float *pos, void *stream) {
-    if (!pool || !samples_host || !samples_dev || !inputs || !targets || !pos) RNH_FAIL(RNH_E_ARG, "rnh_cine_gather: null pointer");
+    (void)samples_dev;                                      // kept in the signature (ABI 1); no longer used
+    if (!pool || !samples_host || !inputs || !targets || !pos) RNH_FAIL(RNH_E_ARG, "rnh_cine_gather: null pointer");
     if (N <= 0 || F <= 0 || T <= 0 || s <= 0 || h <= 0 || w <= 0) RNH_FAIL(RNH_E_ARG, "rnh_cine_gather: bad sizes");
     if (normalize && !(stdv != 0.f)) RNH_FAIL(RNH_E_ARG, "rnh_cine_gather: zero standard deviation");
     // every row the kernel will touch must lie inside the pool: checked here, on the host copy of the descriptors
@@ -71,13 +84,17 @@ extern "C" int rnh_cine_gather(const float *pool, int64_t pool_floats, const rnh
             RNH_FAIL(RNH_E_ARG, "rnh_cine_gather: sample %d: cine outside the pool", n);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(samples_dev, samples_host, (size_t)N * sizeof(rnh_cine_sample_t), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) RNH_FAIL((int)e, "rnh_cine_gather: descriptor upload: %s", hipGetErrorString(e));
-    const long units = (long)N * ((long)F * h + (long)T * s * h);
-    long grid = (units + 3) / 4;
-    if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(cine_gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, pool, samples_dev, N, F, T, s, h, w, normalize, mean, stdv,
-                       inputs, targets, pos);
-    RNH_CHECK_LAUNCH("rnh_cine_gather");
+    for (int n0 = 0; n0 < N; n0 += RNH_CINE_CHUNK) {
+        const int cnt = N - n0 < RNH_CINE_CHUNK ? N - n0 : RNH_CINE_CHUNK;
+        cine_chunk_t ch;
+        memset(&ch, 0, sizeof(ch));
+        memcpy(ch.s, samples_host + n0, (size_t)cnt * sizeof(rnh_cine_sample_t));      // read here, on the calling thread
+        const long units = (long)cnt * ((long)F * h + (long)T * s * h);
+        long grid = (units + 3) / 4;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(cine_gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, pool, ch, n0, cnt, N, F, T, s, h, w, normalize, mean, stdv,
+                           inputs, targets, pos);
+        RNH_CHECK_LAUNCH("rnh_cine_gather");
+    }
     return 0;
 }

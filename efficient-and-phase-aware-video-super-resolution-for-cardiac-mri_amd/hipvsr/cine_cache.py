@@ -80,7 +80,6 @@ class CineCache:
         self._host, self.table, self.names = [], [], []
         self._floats = 0
         self.pool = None
-        self._desc = {}
 
     # ---- filling -------------------------------------------------------------------------------------------
     def add_cine(self, lr, hr, code, name=None):
@@ -195,12 +194,9 @@ class CineCache:
         inputs = torch.empty(F, N, 1, h, w, device=self.device, dtype=torch.float32)
         targets = torch.empty(T, N, 1, s * h, s * w, device=self.device, dtype=torch.float32)
         pos = torch.empty(N, F, 1, device=self.device, dtype=torch.float32)
-        ddev = self._desc.get(N)
-        if ddev is None:
-            ddev = self._desc[N] = torch.empty(N * C.sizeof(L.CineSample), device=self.device, dtype=torch.uint8)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            L.check(self.lib.rnh_cine_gather(self.pool.data_ptr(), self.pool.numel(), desc, ddev.data_ptr(), N, F, T, s, h, w,
+            L.check(self.lib.rnh_cine_gather(self.pool.data_ptr(), self.pool.numel(), desc, None, N, F, T, s, h, w,
                                              int(self.normalize), self.mean, self.stdv, inputs.data_ptr(), targets.data_ptr(),
                                              pos.data_ptr(), stream), 'rnh_cine_gather')
         batch = {'lr_imgs': list(inputs.unbind(0)), 'hr_imgs': list(targets.unbind(0)), 'pos_code': pos,
@@ -225,10 +221,15 @@ class GpuCineLoader:
     like ``DistributedSampler`` does."""
 
     def __init__(self, cache, type='train', batch_size=1, shuffle=False, num_frames=5, num_updated_frames=0, size=(32, 32),
-                 flips=(True, True), seed=0, rank=None, world_size=None, drop_last=False):
+                 flips=(True, True), seed=None, rank=None, world_size=None, drop_last=False):
         import torch.distributed as dist
         self.cache, self.type, self.batch_size, self.shuffle = cache, type, batch_size, shuffle
         self.T, self.U, self.size, self.flips = num_frames, num_updated_frames, tuple(size), flips
+        # seed: by default drawn from Python's `random`, which src.main seeds from main.random_seed before it builds the
+        # loaders (reference src/main.py:32-34; the reference's crop / flip draws come from that generator too) - equal on
+        # all ranks and equal again when a run is resumed, so (seed, epoch) fixes the order and the draws
+        if seed is None:
+            seed = random.getrandbits(31)
         self.drop_last, self.seed, self.epoch = drop_last, seed, 0
         on = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank() if on else 0)
@@ -241,10 +242,17 @@ class GpuCineLoader:
             items = [(c, None) for c in range(len(cache.table))]
         self.items = items
         self.dataset = _Items(items, type)
-        self.rng = random.Random(seed * 1000003 + self.rank)        # augmentation draws: per rank, like per-worker states
+        self._reseed()
+
+    def _reseed(self):
+        # augmentation draws: per rank (like per-worker states) and per epoch
+        self.rng = random.Random((self.seed * 1000003 + self.epoch) * 1009 + self.rank)
 
     def set_epoch(self, epoch):
+        """Called by the trainer before every epoch (like DistributedSampler.set_epoch): order and draws of epoch e do not
+        depend on how many epochs this object has iterated, so a resumed run continues the original sequence."""
         self.epoch = epoch
+        self._reseed()
 
     def _order(self):
         n = len(self.items)
@@ -262,7 +270,7 @@ class GpuCineLoader:
 
     def __iter__(self):
         order = self._order()
-        self.epoch += 1
+        self.epoch += 1                                             # stand-alone use: a new permutation next time
         for b in range(0, len(order), self.batch_size):
             idx = order[b:b + self.batch_size]
             if self.drop_last and len(idx) < self.batch_size:

@@ -14,6 +14,23 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_log(log, count, device):
+    """Sum the running log sums and the sample count of an epoch over all ranks (one small collective per epoch), so
+    that ReduceLROnPlateau, Monitor.is_best and the early stop see the same numbers everywhere - a rank that stopped
+    early on its own shard's log would leave the others waiting in the next gradient all-reduce."""
+    if world() == 1:
+        return log, count
+    keys = sorted(log)
+    t = torch.tensor([float(log[k]) for k in keys] + [float(count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    vals = t.tolist()
+    return {k: v for k, v in zip(keys, vals[:-1])}, vals[-1]
+
+
 def broadcast_parameters(module, src=0):
     """Make every rank start from rank ``src``'s weights."""
     if world() == 1:

@@ -9,6 +9,12 @@ becomes parallel branches of the graph - and replays it with one ``hipGraphLaunc
 Static buffers: the inputs are copied into the graph's input buffer (one small D2D copy), the outputs are views of the
 graph's output buffer and are overwritten by the next call with the same shape; weights are read (and re-packed) inside
 the graph from the parameters' storage, so ``load_state_dict`` / in-place updates are seen by later replays.
+
+Every address a graph has baked in stays valid for the graph's life: tensors allocated during the capture live in the
+graph's private pool; the engine's persistent buffers that exist before the capture (packed weight slabs, index maps,
+per-stream scratch: created by the eager warm-up run) are owned by the net's ``HipOps`` and never freed - a scratch buffer
+that a later, larger call outgrows is retired instead (``HipOps._workspace``, ``graph_captures``).  Replays, eager
+forwards and training steps of the same net may therefore interleave freely (tests/test_predictor.py).
 """
 import torch
 
@@ -41,6 +47,7 @@ class GraphedForward:
         e.pos = pos_codes.detach().to(dev, torch.float32).clone()
         static_in = [e.x[k] for k in range(e.x.shape[0])]
         st = self._stream
+        self.net._engine().ops.graph_captures += 1      # from here on the engine retires scratch buffers instead of freeing them
         st.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(st), torch.no_grad():
             self.net(static_in, e.pos)             # eager run on the capture stream: plans, index maps, workspaces exist afterwards

@@ -44,6 +44,8 @@ class HipOps:
         self._maps = {}        # id(plan) -> dict of device int32 arrays
         self._packed = {}      # id(plan) -> (wp, biasp)
         self._ws = {}
+        self._ws_retired = []   # outgrown scratch buffers a captured HIP graph may still address (see _workspace)
+        self.graph_captures = 0
         self._side = []
         self._fork_n = 2
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
@@ -118,9 +120,14 @@ class HipOps:
             cur.wait_event(ev)
 
     def _workspace(self, key, nfloats):
+        """Scratch buffer ``key`` of the current stream, grown on demand.  A HIP graph captured through this object
+        (hipvsr.graph) has the addresses of the buffers it used baked in: once a graph exists an outgrown buffer is
+        retired, not freed, so that no replay can ever write into memory the allocator has handed to someone else."""
         key = (key, torch.cuda.current_stream(self.device).cuda_stream)      # one scratch buffer per stream
         t = self._ws.get(key)
         if t is None or t.numel() < nfloats:
+            if t is not None and self.graph_captures:
+                self._ws_retired.append(t)
             t = self.empty(int(nfloats))
             self._ws[key] = t
         return t

@@ -5,7 +5,7 @@ from pathlib import Path
 
 
 class Monitor:
-    def __init__(self, checkpoints_dir, mode, target, saved_freq, early_stop):
+    def __init__(self, checkpoints_dir, mode, target, saved_freq, early_stop=0):
         self.checkpoints_dir = Path(checkpoints_dir)
         if mode not in ('min', 'max'):
             raise ValueError(f"The mode should be 'min' or 'max'. Got {mode}.")

@@ -106,17 +106,24 @@ def _test(config):
 def main(args):
     with open(args.config_path) as f:
         config = Cfg(yaml.safe_load(f))
-    saved_dir = Path(config.main.saved_dir)
-    saved_dir.mkdir(parents=True, exist_ok=True)
-    with open(saved_dir / 'config.yaml', 'w+') as f:
-        yaml.dump(config.to_dict(), f, default_flow_style=False)
-    if args.test:
-        return _test(config)
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    saved_dir = Path(config.main.saved_dir)
+    if rank == 0:
+        saved_dir.mkdir(parents=True, exist_ok=True)
+        with open(saved_dir / 'config.yaml', 'w+') as f:
+            yaml.dump(config.to_dict(), f, default_flow_style=False)
+    if args.test:
+        # whole-cycle inference does not shard (replicas only): under torchrun one process does the work
+        return _test(config) if rank == 0 else None
+
     if world > 1:
-        torch.distributed.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            torch.distributed.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        else:
+            torch.distributed.init_process_group('gloo')
 
     random.seed(config.main.random_seed)
     torch.manual_seed(random.getstate()[1][1])
@@ -143,11 +150,11 @@ def main(args):
 
     net = _get_instance(src.model.nets, config.net)
     loss_fns, loss_weights = _losses_metrics(config)
-    metric_fns = [_get_instance(src.model.metrics, cm) for cm in config.metrics if hasattr(src.model.metrics, cm.name)]
+    metric_fns = [_get_instance(src.model.metrics, cm) for cm in config.metrics]      # an unknown name raises, as in the reference
     optimizer = _get_optimizer(config.optimizer, net.parameters(), device)
     lr_scheduler = _get_instance(torch.optim.lr_scheduler, config.lr_scheduler, optimizer) if config.get('lr_scheduler') else None
     config.logger.kwargs.update(log_dir=saved_dir / 'log', net=net)
-    logger = _get_instance(src.callbacks.loggers, config.logger)
+    logger = _get_instance(src.callbacks.loggers, config.logger) if rank == 0 else None
     config.monitor.kwargs.update(checkpoints_dir=saved_dir / 'checkpoints')
     monitor = _get_instance(src.callbacks.monitor, config.monitor)
     config.trainer.kwargs.update(device=device, train_dataloader=train_loader, valid_dataloader=valid_loader, net=net,

@@ -62,6 +62,7 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
             self._update_log(log, bs, T, loss, losses, metrics)
             count += bs * T
             bar.set_postfix(**{k: f'{v / count: .3f}' for k, v in log.items()})
+        log, count = dp.allreduce_log(log, count, self.device)     # every rank sees the log of the WHOLE split
         for k in log:
             log[k] /= max(count, 1)
         return log, batch, (outputs[-1] if outputs is not None else None)

@@ -35,6 +35,12 @@ class BaseTrainer:
             self.np_random_seeds = random.sample(range(10000000), k=self.num_epochs)
         while self.epoch <= self.num_epochs:
             np.random.seed(self.np_random_seeds[self.epoch - 1])
+            for loader in (self.train_dataloader, self.valid_dataloader):
+                # a fresh permutation (and fresh augmentation draws) per epoch, a function of the epoch number alone:
+                # the same on every rank, and the same again after a resume
+                tgt = loader if hasattr(loader, 'set_epoch') else getattr(loader, 'sampler', None)
+                if hasattr(tgt, 'set_epoch'):
+                    tgt.set_epoch(self.epoch)
             logging.info(f'Epoch {self.epoch}.')
             train_log, train_batch, train_outputs = self._run_epoch('training')
             logging.info(f'Train log: {train_log}.')
@@ -45,7 +51,9 @@ class BaseTrainer:
                     self.lr_scheduler.step(valid_log['Loss'])
                 else:
                     self.lr_scheduler.step()
-            if self.logger is not None:
+            # (under torch.distributed the logs are all-reduced in _run_epoch, so the scheduler, the best-checkpoint choice and
+            # the early stop below take the same decision on every rank; files are written by rank 0 only)
+            if self.logger is not None and dp.rank() == 0:
                 self.logger.write(self.epoch, train_log, train_batch, train_outputs, valid_log, valid_batch, valid_outputs)
             if self.monitor is not None:
                 path = self.monitor.is_saved(self.epoch)
@@ -58,7 +66,7 @@ class BaseTrainer:
                     logging.info('Early stopped.')
                     break
             self.epoch += 1
-        if self.logger is not None:
+        if self.logger is not None and dp.rank() == 0:
             self.logger.close()
 
     def _allocate_data(self, batch):
@@ -79,7 +87,7 @@ class BaseTrainer:
         return log
 
     def save(self, path):
-        if dp.world() > 1 and torch.distributed.get_rank() != 0:
+        if dp.rank() != 0:
             return
         torch.save({'net': self.net.state_dict(), 'optimizer': self.optimizer.state_dict(),
                     'lr_scheduler': self.lr_scheduler.state_dict() if self.lr_scheduler else None,

@@ -302,8 +302,9 @@ int rnh_phase_plane(const float *pos /* [N][F] */, float *out, int N, int F, int
  * norm(x) = (x - mean) / stdv in fp32 with IEEE division (stdv = float32(std + 1e-10), transforms.py:166), skipped if
  * normalize == 0.  Train sample with target frame t: lr_start = t + Tc - T + 1 - U, hr_start = t + Tc - T + 1,
  * F = T + 2U; whole-cycle (valid / test): lr_start = Tc - U, hr_start = 0, F = Tc + 2U, T = Tc.
- * samples_host: N descriptors in host memory, validated against pool_floats here and uploaded to samples_dev
- * (N * sizeof(rnh_cine_sample_t) bytes of device scratch) on the stream. */
+ * samples_host: N descriptors in host memory, validated against pool_floats and READ COMPLETELY before the call
+ * returns (they travel to the kernel by value, 32 samples per launch), so the caller may free or re-fill the array at
+ * once.  samples_dev is unused (kept for ABI version 1; may be null). */
 typedef struct rnh_cine_sample {
     int64_t lr_off, hr_off, code_off; /* float offsets into the pool */
     int32_t Tc, Hl, Wl, Hh, Wh;       /* frames per cycle, LR and HR frame size */

@@ -79,6 +79,9 @@ def _worker(rank, world, port, case_path, out_path):
     for p, k in zip(net.params, net.names):
         if p.grad is not None:
             assert p.grad.data_ptr() == grads[k].data_ptr()
+    # epoch log: per-rank sums and counts become the whole split's (ReduceLROnPlateau / Monitor / early stop then agree)
+    log, count = dp.allreduce_log({'Loss': 3.0 * (rank + 1), 'PSNR': 10.0 + rank}, 4 + rank, torch.device('cpu'))
+    assert log == {'Loss': 9.0, 'PSNR': 21.0} and count == 9.0 and dp.rank() == rank
     if rank == 0:
         torch.save({k: (p.grad.clone() if p.grad is not None else None) for p, k in zip(net.params, net.names)}, out_path)
     dist.barrier()
@@ -107,3 +110,33 @@ def test_allreduce_rebuilds_buffer_when_views_were_replaced():
     for p in net.parameters():
         p.grad = torch.ones_like(p)
     assert dp.allreduce_gradients(net) == 0                    # single process: nothing to do
+
+
+def test_loader_order_is_a_function_of_seed_and_epoch():
+    """GpuCineLoader (host logic, no GPU): ranks share one permutation per epoch and take disjoint shards of it; set_epoch
+    makes order and augmentation draws a function of (seed, epoch) - a resumed run replays nothing and skips nothing;
+    the default seed comes from Python's `random`, i.e. from main.random_seed."""
+    import random
+    import types
+    from hipvsr.cine_cache import GpuCineLoader
+    cache = types.SimpleNamespace(table=[None] * 3, train_items=lambda: [(c, t) for c in range(3) for t in range(10)])
+    mk = lambda **kw: GpuCineLoader(cache, type='train', batch_size=4, shuffle=True, **kw)       # noqa: E731
+    random.seed('vsr')
+    a = mk(rank=0, world_size=2)
+    random.seed('vsr')
+    b = mk(rank=1, world_size=2)
+    assert a.seed == b.seed
+    random.seed('other')
+    assert mk(rank=0, world_size=2).seed != a.seed
+    for ep in (1, 2):
+        a.set_epoch(ep)
+        b.set_epoch(ep)
+        oa, ob = a._order(), b._order()
+        assert len(oa) == len(ob) == 15 and not set(oa) & set(ob) and set(oa) | set(ob) == set(range(30))
+    a.set_epoch(1)
+    o1, d1 = a._order(), [a.rng.random() for _ in range(4)]
+    a.set_epoch(2)
+    assert a._order() != o1
+    a.set_epoch(1)                                            # "resume": epoch 1 again gives epoch 1's order and draws
+    assert a._order() == o1 and [a.rng.random() for _ in range(4)] == d1
+    assert [b.rng.random() for _ in range(4)] != d1           # ranks draw differently

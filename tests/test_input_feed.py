@@ -209,6 +209,40 @@ def test_gather_matches_oracle_bit_for_bit(s):
 
 
 @pytest.mark.gpu
+def test_back_to_back_gathers_keep_their_own_descriptors():
+    """120 gathers of DIFFERENT samples enqueued back to back behind a busy stream, no synchronisation in between, the
+    host descriptor arrays freed and re-filled as Python pleases; batches of 40 samples span two launches (32 descriptors
+    per launch).  Every batch must equal the oracle's for ITS items.  (Round 1 uploaded the descriptors with an
+    asynchronous copy from the caller's pageable array, which the next gather re-used: the root cause of the rare wrong
+    answer of the whole-cycle predictor when two cines were gathered back to back.)"""
+    dev = torch.device('cuda:0')
+    s = 2
+    rng = np.random.RandomState(77)
+    cines = _cines(rng, s, 6)
+    cache = cc.CineCache(dev, s, [54.089], [48.084])
+    for lr, hr, code in cines:
+        cache.add_cine(lr, hr, code)
+    T, U, size = 2, 2, (16, 16)
+    r = random.Random(9)
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(6):
+        busy = busy @ busy * 1e-3                                            # keeps the stream busy while the host runs ahead
+    rounds = []
+    for k in range(120):
+        n = 40 if k % 10 == 0 else 1 + k % 3
+        items = [(r.randrange(len(cines)), None) for _ in range(n)]
+        items = [(c, r.randrange(cines[c][0].shape[-1])) for c, _ in items]
+        draws = [cache.draw(c, size, r) for c, _ in items]
+        rounds.append((items, draws, cache.gather(items, draws, T, U, size)))
+    torch.cuda.synchronize()
+    for items, draws, batch in rounds:
+        want = io_.collate([io_.get_item(*cines[c], t, T, U, d, size, s, [54.089], [48.084]) for (c, t), d in zip(items, draws)])
+        for got, ref in zip(batch['lr_imgs'] + batch['hr_imgs'], want[0] + want[1]):
+            assert np.array_equal(got.cpu().numpy(), ref)
+        assert np.array_equal(batch['pos_code'].cpu().numpy(), want[2])
+
+
+@pytest.mark.gpu
 def test_loader_feeds_a_training_step_from_nifti_files(tmp_path):
     """Reference directory layout on disk -> CineCache.from_dir -> GpuCineLoader -> RefineNet step."""
     s, rng = 4, np.random.RandomState(1)

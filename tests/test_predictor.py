@@ -130,6 +130,52 @@ def test_graph_replay_equals_eager_and_the_reference_cycle():
 
 
 @pytest.mark.gpu
+def test_graph_replays_interleaved_with_other_shapes_and_training_steps():
+    """One GraphedForward, three cine shapes / group sizes alternating for 240 replays, with eager forwards and
+    full-width-free training steps of the SAME net (they grow the engine's scratch buffers) in between: every replay
+    must equal the eager forward of the same inputs bit for bit.  Guards the graph path's memory contract (hipvsr/graph.py:
+    every address a graph has baked in stays valid for the graph's life; HipOps._workspace retires instead of frees)."""
+    from hipvsr.graph import GraphedForward
+    from src.model.nets import RefineNet
+    dev = _dev()
+    cfg = orc.Config(in_channels=1, out_channels=1, num_features=[16, 16], num_stages=2, refine_window_size=5, upscale_factor=4,
+                     update_memory=True, num_updated_frames=2, positional_encoding=True)
+    net = RefineNet(**cfg)
+    net.load_state_dict(orc.init_state_dict(cfg, seed=3))
+    net = net.to(dev).eval()
+    net.last_group_only = True
+    gf = GraphedForward(net)
+    g = torch.Generator('cpu').manual_seed(4)
+    shapes = [(1, 9, 20, 24), (2, 9, 20, 24), (1, 7, 33, 18)]                  # (N, F, H, W)
+    ops = net._engine().ops
+
+    def batch(n, f, h, w):
+        return [torch.randn(n, 1, h, w, generator=g).to(dev) for _ in range(f)], (torch.rand(n, f, 1, generator=g) * 2 - 1).to(dev)
+
+    def train_step(n, h, w):
+        net.train()
+        xs, pc = batch(n, 6, h, w)
+        outs = net(xs, pc)
+        sum(o.abs().mean() for grp in outs for o in grp).backward()
+        net.zero_grad()
+        net.eval()
+
+    train_step(1, 8, 8)                                                       # small scratch buffers first ...
+    retired0 = len(ops._ws_retired)
+    for it in range(240):
+        n, f, h, w = shapes[it % 3]
+        xs, pc = batch(n, f, h, w)
+        with torch.no_grad():
+            eager = [o.clone() for o in net(xs, pc)[-1]]
+        out = gf(xs, pc)[-1]
+        assert all(torch.equal(a, b) for a, b in zip(out, eager)), it
+        if it in (5, 50):
+            train_step(3, 24 + it, 40)                                        # ... outgrown while graphs that saw the old ones are alive
+    assert len(gf._entries) == 3 and all(e.replays == 80 for e in gf._entries.values())
+    assert ops.graph_captures == 3 and len(ops._ws_retired) > retired0        # buffers were retired, not freed
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('graph,group', [(True, 8), (False, 1), (True, 1), (False, 8)])
 def test_src_main_test_branch_vs_oracle(tmp_path, graph, group):
     """python -m src.main <yaml> --test on the synthetic test split (2 cines of 30 frames, 54x64 -> 216x256): log,

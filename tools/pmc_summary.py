@@ -1,19 +1,71 @@
 #!/usr/bin/env python3
-"""Average rocprofv3 --pmc counters per kernel: pmc_summary.py <dir> [substring]   (never prints kernel names in full)."""
+"""Average rocprofv3 --pmc counters per kernel.
+
+  pmc_summary.py <dir> [substring]                       print the averages (kernel names shortened)
+  pmc_summary.py <dir> --json out.json --hbm hbm.json    also write the per-kernel summary with derived figures and the
+                                                         HBM-bytes record bench.py reads for `roofline.traffic`
+
+Derived (MI355X_MICROARCH.md, "HBM" and "Per-instruction cycle constants"): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE counts 64 B per 128-B request on gfx950; both counters are in KiB); mfma_pipe_busy_frac =
+SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums
+the 8 XCDs) - or from SQ_BUSY_CYCLES where GRBM is missing.
+"""
 import collections
 import csv
 import glob
+import hashlib
+import json
+import os
+import subprocess
 import sys
+import time
+
+args = sys.argv[1:]
+root = args[0]
+jout = args[args.index('--json') + 1] if '--json' in args else None
+hout = args[args.index('--hbm') + 1] if '--hbm' in args else None
+sub = args[1] if len(args) > 1 and not args[1].startswith('--') else None
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(sys.argv[1] + '/**/*_counter_collection.csv', recursive=True):
+for f in glob.glob(root + '/**/*_counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if len(sys.argv) > 2 and sys.argv[2] not in n:
+        if sub and sub not in n:
             continue
-        short = n.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')[:48]
+        short = n.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0][:48]
         agg[short][r['Counter_Name']].append(float(r['Counter_Value']))
+summary = {}
 for k, v in agg.items():
     print(k, 'launches', len(next(iter(v.values()))))
+    rec = {}
     for c, x in sorted(v.items()):
-        print(f'    {c:28s} {sum(x) / len(x):16.1f}')
+        rec[c] = round(sum(x) / len(x), 1)
+        print(f'    {c:28s} {rec[c]:16.1f}')
+    if 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
+        rec['hbm_bytes_per_launch'] = (2 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in rec and rec.get('GRBM_GUI_ACTIVE'):
+        cyc = rec['GRBM_GUI_ACTIVE'] / 8.0
+        rec['kernel_cycles'] = round(cyc, 1)
+        rec['mfma_pipe_busy_frac'] = round(rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc), 4)
+    if rec.get('SQ_INSTS_MFMA') and rec.get('SQ_INSTS_VALU'):
+        rec['valu_insts_per_mfma'] = round((rec['SQ_INSTS_VALU'] - rec['SQ_INSTS_MFMA']) / rec['SQ_INSTS_MFMA'], 3)
+    summary[k] = rec
+if jout:
+    json.dump(summary, open(jout, 'w'), indent=1)
+if hout:
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc', 'conv_wino.hip')
+    key = next((k for k in summary if k.startswith('conv_wino_kernel<2')), None)
+    if key and 'hbm_bytes_per_launch' in summary[key]:
+        try:
+            commit = subprocess.run(['git', '-C', here, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+        except Exception:
+            commit = None
+        json.dump({'kernel': 'conv_wino_kernel<LSTM> at N=8,128x128 (one ConvLSTM cell launch, Winograd F(2x2,3x3))',
+                   'FETCH_SIZE_KB_raw': summary[key]['FETCH_SIZE'], 'WRITE_SIZE_KB': summary[key]['WRITE_SIZE'],
+                   'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact',
+                   'hbm_bytes_per_launch': summary[key]['hbm_bytes_per_launch'], 'algorithmic_bytes_per_launch': 303170560,
+                   'kernel_source_sha256': hashlib.sha256(open(src, 'rb').read()).hexdigest(),
+                   'commit': commit, 'date': time.strftime('%Y-%m-%d'),
+                   'command': 'tools/prof_pmc_wino.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/kbench.py lstm'},
+                  open(hout, 'w'), indent=1)
