@@ -35,6 +35,8 @@ import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CUs x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
+PEAK_HBM_TBS = 8.0
 
 
 def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
@@ -56,6 +58,20 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
         nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
     fwd = F * 1152 + 2 * nfr * L * lstm_f + nwin * ref_f + 3 * S * T * out_f
     bwd = T * 1152 + S * 2 * T * L * lstm_b + S * T * ref_b + 3 * S * T * out_b
+    return fwd + bwd
+
+
+def step_flops_bf16(T, U=6, S=3, L=3):
+    """Executed conv FLOPs per LR pixel per sample of the bf16-storage path (x4): every convolution in direct form, refine
+    conv1 on 192 padded columns and its phase planes as 8-channel sources are NOT counted (only the reference's 129 x 645),
+    the upsampler tail collapsed as in the fp32 path, the dead last-stage work skipped."""
+    F = T + 2 * U
+    lstm = 589824
+    r1, r2 = 645 * 129 * 18, 129 * 64 * 18
+    out_f, out_b = 294912 + 51200, 2 * 294912 + 65536
+    nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
+    fwd = F * 1152 + 2 * nfr * L * lstm + nwin * (r1 + r2) + 3 * S * T * out_f
+    bwd = T * 1152 + S * 2 * T * L * 2 * lstm + S * T * 2 * (r1 + r2) + 3 * S * T * out_b
     return fwd + bwd
 
 
@@ -87,9 +103,10 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     hd, cx = pl['hd'], pl['cx']
     params = {k: p.detach() for k, p in net.named_parameters()}
     ops.pack(pl['full'], params[pl['full'].wkey], params[pl['full'].bkey])
-    x, hp, cp = (torch.randn(n, h, w, c, device=dev) for c in (cx, hd, hd))
-    ho, co = ops.empty(n, h, w, hd), ops.empty(n, h, w, hd)
-    go = ops.empty(n, h, w, 4 * hd)
+    act = eng.act
+    x, hp, cp = torch.randn(n, h, w, cx, device=dev).to(act), torch.randn(n, h, w, hd, device=dev).to(act), torch.randn(n, h, w, hd, device=dev)
+    ho, co = ops.empty(n, h, w, hd, dtype=act), ops.empty(n, h, w, hd)
+    go = ops.empty(n, h, w, 4 * hd, dtype=act)
 
     def launch():
         ops.conv(pl['full'], [Src(x), Src(hp)], n, h, w, lstm=dict(hd=hd, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
@@ -104,6 +121,16 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     wino = bool(getattr(pl['full'], 'wino', False))
+    if eng.bf16:
+        # bf16-storage path: the direct 3x3 form on bf16 MFMA (rnh_conv_bf16); executed == algorithmic FLOPs.  The launch is
+        # priced against both ceilings: the dense bf16 MFMA peak and HBM (bf16 x, h in; fp32 c in / out; bf16 h', gates out)
+        flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
+        byts = n * h * w * (2 * cx + 2 * hd + 4 * hd + 4 * hd + 2 * hd + 2 * 4 * hd)
+        tf, tbs = flops / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': 'conv_bf16_kernel<LSTM,128,9> (ConvLSTM cell 128->256, direct 3x3 on v_mfma_f32_32x32x16_bf16, fused gates)',
+                'achieved': round(tf, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                'traffic': None, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops, 'algorithmic_flop_per_launch': flops,
+                'algorithmic_bytes_per_launch': byts, 'hbm_algorithmic_tbs': round(tbs, 3), 'hbm_frac_of_8tbs': round(tbs / PEAK_HBM_TBS, 4)}
     # ALGORITHMIC work of the launch: 589 824 FLOP per pixel at cx = hd = 64, the direct 3x3 form
     flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
     # what the matrix cores execute: the Winograd F(2x2,3x3) kernel runs 16 GEMMs over n*h*w/4 tiles = 4/9 of it
@@ -169,6 +196,9 @@ def main():
     ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
     ap.add_argument('--size', type=int, default=128, help='LR height = width')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="f32: the headline (BASELINE config 2, the reference's precision); bf16: the bf16-storage path of "
+                         "BASELINE config 3 (a separately labelled line, same synthetic batch per GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -184,6 +214,7 @@ def main():
     from src.runner.trainers import AcdcVSRRefineNetTrainer
 
     net = make_net(dev, seed=0)
+    net.set_compute_dtype(args.dtype)
     dp.broadcast_parameters(net)
     from hipvsr.step_tail import FlatAdam
     opt = FlatAdam(net.parameters(), lr=1e-4, weight_decay=0)      # exp1_x4.yaml:56-60; one launch per run of parameters
@@ -220,22 +251,28 @@ def main():
     value = n_global * args.frames * args.steps / dt
     flop_step = step_flops_per_lr_pixel(args.frames) * args.size * args.size * n_global
     flop_exec = step_flops_per_lr_pixel(args.frames, executed=True) * args.size * args.size * n_global
+    bf = args.dtype == 'bf16'
+    if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
+        flop_exec = step_flops_bf16(args.frames) * args.size * args.size * n_global
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
 
     if rank == 0:
         roof = lstm_kernel_roofline(net, dev, args.batch, args.size, args.size)
         out = {
             'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(value, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2), 'ms_per_step_median': round(median_ms, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'RefineNet x4 training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
-                                   f'{4 * args.size}x{4 * args.size}, fp32, exp1_x4 net (BASELINE config 2)',
+                                   f'{4 * args.size}x{4 * args.size}, {prec}, exp1_x4 net (BASELINE config {3 if bf else 2})',
                        'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
                        'input_frames_per_s': round(n_global * (args.frames + 12) * args.steps / dt, 2),
                        'step_tflop_reference_formulation': round(flop_step / 1e12, 2),
                        'step_tflop_executed': round(flop_exec / 1e12, 2),
                        'executed_tflops_per_gpu': round(flop_exec / world / (dt / args.steps) / 1e12, 2),
-                       'executed_frac_of_f32_mfma_peak': round(flop_exec / world / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       ('executed_frac_of_bf16_mfma_peak' if bf else 'executed_frac_of_f32_mfma_peak'):
+                           round(flop_exec / world / (dt / args.steps) / 1e12 / peak, 4),
                        'final_loss': round(float(loss.detach()), 6),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,

@@ -15,9 +15,10 @@ namespace {
 
 // The sample descriptors travel BY VALUE in the kernel-argument segment (copied by the runtime when the launch is
 // enqueued), RNH_CINE_CHUNK samples per launch.  An earlier version uploaded them with hipMemcpyAsync from the caller's
-// pageable array: such a copy may read the host memory after the call has returned - the Python binding frees (and the
-// next batch re-fills) that array as soon as rnh_cine_gather returns, so two gathers enqueued back to back could cut
-// the first batch with the second batch's descriptors (tools/pageable_async_probe.hip shows the effect in isolation).
+// pageable array, which the Python binding frees (and the next batch re-fills) as soon as rnh_cine_gather returns: correct
+// only as long as the runtime stages pageable copies before returning.  ROCm 7.2 on MI355X does (tools/pageable_async_probe.hip:
+// 0 of 400 copies saw later host writes, profiles/r02_a_pageable_probe.txt), so this was a latent dependence on
+// unspecified behaviour, not an observed fault; by-value arguments remove it and the descriptor buffer.
 constexpr int RNH_CINE_CHUNK = 32;
 struct cine_chunk_t {
     rnh_cine_sample_t s[RNH_CINE_CHUNK];

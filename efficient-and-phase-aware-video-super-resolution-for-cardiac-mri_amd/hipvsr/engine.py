@@ -32,9 +32,20 @@ class Context:
 
 
 class RefineNetEngine:
-    def __init__(self, cfg, ops):
-        self.cfg, self.ops = cfg, ops
-        self.plans = NetPlans(cfg)
+    def __init__(self, cfg, ops, dtype='f32'):
+        """dtype 'f32': everything fp32 (the reference's precision).  dtype 'bf16' (BASELINE.json configs[2]): the bf16-storage
+        path - feature maps, hidden states, saved gates and the activation gradients between the big convolutions live in
+        HBM as bf16 and all 3x3 convolutions run on bf16 MFMA with fp32 accumulators (rnh_conv_bf16 / rnh_wgrad_bf16);
+        the cell state c and its gradient, the upsampler's inner feature map (which the collapsed tail kernels consume),
+        the outputs, the loss and every parameter gradient stay fp32; the state_dict is fp32 either way."""
+        import torch
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self.cfg, self.ops, self.dtype = cfg, ops, dtype
+        self.bf16 = dtype == 'bf16'
+        self.act = torch.bfloat16 if self.bf16 else torch.float32
+        self.f32 = torch.float32
+        self.plans = NetPlans(cfg, bf16=self.bf16)
         self.hw = cfg.refine_window_size // 2
         if (3 if self.plans.pos else 2) * cfg.refine_window_size > L.MAX_SRC:
             raise ValueError(f'refine_window_size {cfg.refine_window_size} needs more than {L.MAX_SRC} conv sources')
@@ -77,9 +88,15 @@ class RefineNetEngine:
         x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
         ctx.x_all = x_all
         self._pack(params, 'fwd')
+        act, f32 = self.act, self.f32
         feat = ops.inconv_fwd(x_all, params['in_block.conv.weight'], params['in_block.conv.bias'],
                               params['in_block.prelu.weight'])
-        P4 = ops.phase_plane(pos_codes, N, F, H, W) if P.pos else None
+        if self.bf16:
+            feat = ops.cast(feat, act)                            # the input block's features cross into bf16 storage here
+        P4 = (ops.phase_plane(pos_codes, N, F, H, W, dtype=act, channels=P.pw) if self.bf16 else
+              ops.phase_plane(pos_codes, N, F, H, W)) if P.pos else None
+        # the tail kernels (csrc/uptail.hip) read their input in fp32: with a single PixelShuffle stage that input is Sb
+        sb_dt = f32 if len(P.up) == 1 else act
         ctx.P4 = P4
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
@@ -92,8 +109,8 @@ class RefineNetEngine:
             # of the layer/frame wavefront run concurrently.
             dirs = ('forward', 'backward')
             for d in dirs:
-                st[d] = dict(H=[ops.empty(F * N, H, W, hd) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
-                             G=[ops.empty(TN, H, W, 4 * hd) for hd in nf] if need_grad else None)
+                st[d] = dict(H=[ops.empty(F * N, H, W, hd, dtype=act) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
+                             G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad else None)
             # In the last stage nothing reads the hidden states past the last refine window (the feature update after it is
             # dead, quirk Q5): the forward direction stops at frame U+T-1+hw, the backward one at U-hw, and the refine
             # block only computes the T supervised windows.  Outputs and gradients are unchanged.
@@ -138,9 +155,9 @@ class RefineNetEngine:
                 srcs += [Src(Hf, img_off=(w0 + j) * N), Src(Hbk, img_off=(w0 + j) * N)]
                 if P.pos:
                     srcs.append(Src(P4, img_off=(w0 + j) * N))
-            R = ops.empty(nwin * N, H, W, Cl)
+            R = ops.empty(nwin * N, H, W, Cl, dtype=act)
             if P.pos:
-                R1 = ops.empty(nwin * N, H, W, P.C1p)
+                R1 = ops.empty(nwin * N, H, W, P.C1p, dtype=act)
                 lo, hi = w0 * N, (w0 + nwin + w - 1) * N            # the source frames of these windows
                 if P.r1_wino:
                     ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
@@ -161,11 +178,11 @@ class RefineNetEngine:
                 nb = 0                                        # no output group of this stage is consumed
             elif skip_up:
                 nb = 1                                        # the fused group only
-                Sb = ops.empty(TN, H, W, C)
+                Sb = ops.empty(TN, H, W, C, dtype=sb_dt)
                 ops.add(Sb, fc, R[(U - hw - w0) * N:(U - hw - w0 + T) * N])
             else:
                 nb = 3
-                Sb = ops.empty(3 * TN, H, W, C)
+                Sb = ops.empty(3 * TN, H, W, C, dtype=sb_dt)
                 ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
                 ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
                 ops.add(Sb[2 * TN:], fc, R[(U - hw - w0) * N:(U - hw - w0 + T) * N])
@@ -194,7 +211,7 @@ class RefineNetEngine:
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
             if S > 1 and s < S - 1:
-                nfeat = ops.empty(F * N, H, W, C)
+                nfeat = ops.empty(F * N, H, W, C, dtype=act)
                 ops.add(nfeat[0:hw * N], feat[0:hw * N], Hf[0:hw * N])
                 ops.add(nfeat[hw * N:(F - hw) * N], feat[hw * N:(F - hw) * N], R)
                 ops.add(nfeat[(F - hw) * N:], feat[(F - hw) * N:], Hbk[(F - hw) * N:])
@@ -211,6 +228,7 @@ class RefineNetEngine:
         N, H, W, F, T = ctx.N, ctx.H, ctx.W, ctx.F, ctx.T
         nf, Lr, C, Cl = P.nf, P.L, P.C, P.Cl
         TN = T * N
+        act = self.act
         self._pack(params, 'bwd')
 
         grads, touched = OrderedDict(), set()
@@ -252,7 +270,7 @@ class RefineNetEngine:
             if ops.uptail_xcorr_supported(C, rt, cfg.out_channels):
                 M, Sd = ops.uptail_xcorr(xin, dO, rt)
             else:
-                D = ops.uptail_expand(dO, rt)
+                D = ops.uptail_expand(dO, rt, P.tail_dc)
                 M = ops.empty(P.tail_m.Cout, C, 3, 3)
                 Sd = ops.empty(P.tail_m.Cout)
                 ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
@@ -273,12 +291,12 @@ class RefineNetEngine:
                 acc(u['wgrad'].bkey)
                 ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
                           accumulate=a)
-                dnext = ops.empty(3 * TN, h_in, w_in, C)
+                dnext = ops.empty(3 * TN, h_in, w_in, C, dtype=act)
                 ops.conv(u['dgrad'], ysrcs, 3 * TN, h_in, w_in, dsts=[Dst(dnext, C)])
                 dcur = dnext
             dS = dcur
             dHf, dHb, dR = dS[0:TN], dS[TN:2 * TN], dS[2 * TN:3 * TN]
-            dfeat = ops.empty(TN, H, W, C)
+            dfeat = ops.empty(TN, H, W, C, dtype=act)
             ops.add(dfeat, dHf, dHb, dR)
             if dfeat_next is not None:                # feat[s+1] = feat[s] + R[s] on the supervised frames
                 ops.add(dfeat, dfeat_next, accumulate=True)
@@ -293,7 +311,7 @@ class RefineNetEngine:
                     xs.append(Src(ctx.P4, img_off=(U - hw + j) * N))
             k1, b1 = P.r1_wgrad.wkey, P.r1_wgrad.bkey
             if P.pos:
-                dR1p = ops.zeros((T + 2 * hw) * N, H, W, P.C1p)
+                dR1p = ops.zeros((T + 2 * hw) * N, H, W, P.C1p, dtype=act)
                 ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
@@ -315,7 +333,7 @@ class RefineNetEngine:
                 gsrc = dR1p
                 st['R1'] = None
             else:
-                gsrc = ops.zeros((T + 2 * hw) * N, H, W, Cl)
+                gsrc = ops.zeros((T + 2 * hw) * N, H, W, Cl, dtype=act)
                 ops.add(gsrc[hw * N:(hw + T) * N], dR)
                 a = acc(k1)
                 acc(b1)
@@ -337,9 +355,9 @@ class RefineNetEngine:
             # streams are allocated here, before the fork.
             dirs = ('forward', 'backward')
             tops = {'forward': dHf, 'backward': dHb}
-            Gd = {d: [ops.empty(TN, H, W, 4 * hd) for hd in nf] for d in dirs}
-            DX = {d: [ops.empty(TN, H, W, P.lstm[(d, l)]['cx']) if l > 0 else None for l in range(Lr)] for d in dirs}
-            dfeat_d = {d: ops.empty(TN, H, W, C) for d in dirs}          # layer-0 input gradients per direction
+            Gd = {d: [ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] for d in dirs}
+            DX = {d: [ops.empty(TN, H, W, P.lstm[(d, l)]['cx'], dtype=act) if l > 0 else None for l in range(Lr)] for d in dirs}
+            dfeat_d = {d: ops.empty(TN, H, W, C, dtype=act) for d in dirs}          # layer-0 input gradients per direction
             dh_next = {d: [None] * Lr for d in dirs}
             dc_next = {d: [None] * Lr for d in dirs}
             ops.fork(2 * Lr)
@@ -370,11 +388,11 @@ class RefineNetEngine:
                             if cfg.memory:
                                 dsts = [Dst(dxbuf, cx)]
                                 if prev_grad:
-                                    dhp = ops.empty(N, H, W, hd)
+                                    dhp = ops.empty(N, H, W, hd, dtype=act)
                                     dsts.append(Dst(dhp, hd))
                                 ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
                             else:
-                                tmp = ops.empty(N, H, W, cx)
+                                tmp = ops.empty(N, H, W, cx, dtype=act)
                                 ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx), Dst(tmp, cx)])
                                 ops.add(dxbuf, tmp, accumulate=True)
                             dh_next[d][l], dc_next[d][l] = dhp, dcp
@@ -402,6 +420,8 @@ class RefineNetEngine:
 
         # ---- input block backward (supervised frames only, refine_net.py:66-67) --------------------------------
         xc = ctx.x_all[U * N:(U + T) * N]
+        if self.bf16:
+            dfeat_next = ops.cast(dfeat_next, self.f32)           # back across the precision boundary of the input block
         ops.inconv_bwd(xc, params['in_block.conv.weight'], params['in_block.conv.bias'], params['in_block.prelu.weight'],
                        dfeat_next, grads['in_block.conv.weight'], grads['in_block.conv.bias'], grads['in_block.prelu.weight'],
                        accumulate=False)

@@ -55,26 +55,28 @@ class HipOps:
         self.wino_wgrad = os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0'
 
     # ---- memory -------------------------------------------------------------------------------------
-    def empty(self, *shape):
+    def empty(self, *shape, dtype=torch.float32):
         if os.environ.get('RNH_POISON'):
             # debugging aid: every buffer starts as NaN, so a kernel that reads an element nobody wrote shows up in the
             # results instead of depending on what the allocator's block held before
             return torch.full(shape if not (len(shape) == 1 and isinstance(shape[0], (tuple, list))) else tuple(shape[0]),
-                              float('nan'), dtype=torch.float32, device=self.device)
-        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+                              float('nan'), dtype=dtype, device=self.device)
+        return torch.empty(*shape, dtype=dtype, device=self.device)
 
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _chk(self, *ts):
+    def _chk(self, *ts, mixed=False):
+        """fp32 (mixed=True: fp32 or bf16 - the entry points of the bf16-storage path), contiguous, on this device."""
         for t in ts:
             if t is None:
                 continue
-            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
-                raise L.HipKernelError(f'expected contiguous fp32 tensors on {self.device}, got {t.dtype} '
+            ok = t.dtype == torch.float32 or (mixed and t.dtype == torch.bfloat16)
+            if not ok or not t.is_contiguous() or t.device != self.device:
+                raise L.HipKernelError(f'expected contiguous {"fp32 / bf16" if mixed else "fp32"} tensors on {self.device}, got {t.dtype} '
                                        f'contiguous={t.is_contiguous()} on {t.device}')
 
     def _i32(self, lst):
@@ -150,6 +152,8 @@ class HipOps:
             else:
                 m = dict(rowmap=self._i32(plan.rowmap), colmap=self._i32(plan.colmap), xgrp=self._i32(plan.xgrp),
                          ygrp=self._i32(plan.ygrp))
+                if plan.bf16:
+                    m.update(rowmap64=self._i32(plan.rowmap64), colmap64=self._i32(plan.colmap64))
             m['_plan'] = plan          # keeps id(plan) unique while cached
             self._maps[id(plan)] = m
         return m
@@ -162,9 +166,18 @@ class HipOps:
         m = self._plan_maps(plan)
         buf = self._packed.get(id(plan))
         if buf is None:
-            buf = (self.empty(plan.wns * 16 * plan.Npad * 4 if plan.wino else plan.nk * plan.Npad * 16), self.empty(plan.Npad))
+            if plan.bf16:
+                buf = (self.empty(plan.nk * plan.Npad * 16, dtype=torch.bfloat16), self.empty(plan.Npad))
+            else:
+                buf = (self.empty(plan.wns * 16 * plan.Npad * 4 if plan.wino else plan.nk * plan.Npad * 16), self.empty(plan.Npad))
             self._packed[id(plan)] = buf
         wp, bp = buf
+        if plan.bf16:
+            L.check(self.lib.rnh_pack_weights_bf16(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['kbase']), _ptr(m['knv']),
+                                                   _ptr(m['ktap']), _ptr(m['kcoff']), _ptr(m['colmap']), plan.nk, plan.Npad,
+                                                   plan.Cout, plan.Cin, plan.ntaps, plan.kstride, int(plan.transposed),
+                                                   self._stream()), f'rnh_pack_weights_bf16({plan.name})')
+            return
         if plan.wino:
             L.check(self.lib.rnh_wino_pack_weights(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['wkbase']), _ptr(m['wknv']),
                                                    _ptr(m['wkcoff']), _ptr(m['colmap']), plan.wns, plan.Npad, plan.Cout, plan.Cin,
@@ -195,6 +208,8 @@ class HipOps:
             raise L.HipKernelError(f'{plan.name}: weights were not packed')
         if len(srcs) != len(plan.ksegs):
             raise L.HipKernelError(f'{plan.name}: {len(srcs)} sources for {len(plan.ksegs)} K segments')
+        if plan.bf16:
+            return self._conv_bf16(plan, srcs, B, H, W, dsts, ps, lstm)
         a = L.ConvArgs()
         for i, (s, sg) in enumerate(zip(srcs, plan.ksegs)):
             self._fill_src(a.src[i], s)
@@ -253,9 +268,106 @@ class HipOps:
         if d.img_off < 0 or d.img_off + B > t.shape[0]:
             raise L.HipKernelError(f'{who}: source image range [{d.img_off}, {d.img_off + B}) outside {t.shape[0]}')
 
+    # ---- bf16-storage path (csrc/conv_bf16.hip, wgrad_bf16.hip, mixed_kernels.hip) ----------------------------------
+    def _fill_msrc(self, dst, s: Src, B, H, W, who):
+        t = s.t
+        self._chk(t, mixed=True)
+        if s.add is not None:
+            raise L.HipKernelError(f'{who}: the bf16 kernels take no second operand')
+        dst.ptr, dst.dtype = t.data_ptr(), L.dt_of(t)
+        dst.C, dst.c0 = t.shape[-1], s.c0
+        dst.nch = t.shape[-1] - s.c0 if s.nch is None else s.nch
+        dst.img_off, dst.scale, dst.sub_y, dst.sub_x = s.img_off, s.scale, s.sub[0], s.sub[1]
+        self._check_src_range(dst, t, B, H, W, who)
+
+    def _conv_bf16(self, plan, srcs, B, H, W, dsts, ps, lstm):
+        a = L.ConvBf16Args()
+        for i, (s, sg) in enumerate(zip(srcs, plan.ksegs)):
+            self._fill_msrc(a.src[i], s, B, H, W, plan.name)
+            if a.src[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: source {i} has {a.src[i].nch} channels, plan wants {sg.nch}')
+        wp, bp = self._packed[id(plan)]
+        a.nsrc, a.B, a.H, a.W, a.ntaps, a.nchunks = len(srcs), B, H, W, plan.ntaps, plan.nchunks
+        a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
+        a.Npad, a.epilogue = plan.Npad, plan.epilogue
+        if plan.epilogue == L.EPI_STORE:
+            a.ndst = len(dsts)
+            tot = 0
+            for i, d in enumerate(dsts):
+                self._chk(d.t, mixed=True)
+                if tuple(d.t.shape[1:3]) != (H, W) or d.img_off < 0 or d.img_off + B > d.t.shape[0] or d.c0 + d.ncols > d.t.shape[-1]:
+                    raise L.HipKernelError(f'{plan.name}: destination {i} geometry')
+                a.dst[i].ptr, a.dst[i].dtype, a.dst[i].C, a.dst[i].c0 = d.t.data_ptr(), L.dt_of(d.t), d.t.shape[-1], d.c0
+                a.dst[i].ncols, a.dst[i].accumulate, a.dst[i].img_off = d.ncols, int(d.accumulate), d.img_off
+                tot += d.ncols
+            if tot > plan.Npad:
+                raise L.HipKernelError(f'{plan.name}: destination columns exceed Npad')
+        elif plan.epilogue == L.EPI_PS:
+            t, r = ps
+            self._chk(t, mixed=True)
+            cq = t.shape[-1]
+            if tuple(t.shape) != (B, H * r, W * r, cq):
+                raise L.HipKernelError(f'{plan.name}: pixel-shuffle destination shape {tuple(t.shape)}')
+            a.ndst = 1
+            a.dst[0].ptr, a.dst[0].dtype, a.dst[0].C, a.dst[0].c0, a.dst[0].ncols = t.data_ptr(), L.dt_of(t), cq, 0, cq
+            a.ps_r, a.ps_cq = r, cq
+        else:
+            hd = lstm['hd']
+            for k in ('c_prev', 'h_out', 'c_out', 'gates_out'):
+                t = lstm.get(k)
+                self._chk(t, mixed=k in ('h_out', 'gates_out'))
+                if t is not None and tuple(t.shape) != (B, H, W, hd * (4 if k == 'gates_out' else 1)):
+                    raise L.HipKernelError(f'{plan.name}: {k} shape {tuple(t.shape)}')
+            a.hd = hd
+            a.c_prev, a.h_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out'])
+            a.c_out, a.gates_out = _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
+            a.h_dtype = L.dt_of(lstm['h_out'])
+            a.gates_dtype = L.dt_of(lstm['gates_out']) if lstm.get('gates_out') is not None else L.DT_F32
+        L.check(self.lib.rnh_conv_bf16(C.byref(a), self._stream()), f'rnh_conv_bf16({plan.name})')
+
+    def _wgrad_bf16(self, plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
+        m = self._plan_maps(plan)
+        a = L.WgradBf16Args()
+        for i, (s, sg) in enumerate(zip(xsrcs, plan.xsegs)):
+            self._fill_msrc(a.xs[i], s, B, H, W, plan.name)
+            if a.xs[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: x source {i} channels')
+        for i, (s, sg) in enumerate(zip(ysrcs, plan.ysegs)):
+            self._fill_msrc(a.ys[i], s, B, H, W, plan.name)
+            if a.ys[i].nch != sg.nch:
+                raise L.HipKernelError(f'{plan.name}: dy source {i} channels')
+        rpi = min(H, 32)
+        nitems = B * (-(-W // 32)) * (-(-H // rpi))
+        nsplit = plan.nsplit_bf16(nitems)
+        a.nxs, a.nys, a.xrows_pad, a.ycols_pad = len(xsrcs), len(ysrcs), plan.xrows_pad64, plan.ycols_pad64
+        a.B, a.H, a.W, a.ntaps, a.nsplit = B, H, W, plan.ntaps, nsplit
+        slab = self._workspace('wgrad_slab', nsplit * plan.ntaps * plan.xrows_pad64 * plan.ycols_pad64)
+        bslab = self._workspace('wgrad_bslab', nsplit * plan.ycols_pad64) if db is not None else None
+        a.slab, a.bslab = slab.data_ptr(), (bslab.data_ptr() if bslab is not None else None)
+        st = self._stream()
+        L.check(self.lib.rnh_wgrad_bf16(C.byref(a), st), f'rnh_wgrad_bf16({plan.name})')
+        L.check(self.lib.rnh_wgrad_reduce(_ptr(slab), _ptr(bslab), nsplit, plan.ntaps, plan.xrows_pad64, plan.ycols_pad64,
+                                          _ptr(m['rowmap64']), _ptr(m['colmap64']), plan.Cin, _ptr(dw), _ptr(db),
+                                          int(accumulate), st), f'rnh_wgrad_reduce({plan.name})')
+
+    def cast(self, t, dtype):
+        """fp32 <-> bf16 copy (rnh_cast); the same tensor if it already has ``dtype``."""
+        if t.dtype == dtype:
+            return t
+        self._chk(t, mixed=True)
+        out = self.empty(*t.shape, dtype=dtype)
+        if t.numel() % 8:
+            raise L.HipKernelError('cast: element count must be a multiple of 8')
+        L.check(self.lib.rnh_cast(_ptr(t), L.dt_of(t), _ptr(out), L.dt_of(out), t.numel(), self._stream()), 'rnh_cast')
+        return out
+
     def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
         m = self._plan_maps(plan)
         self._chk(dw, db)
+        if plan.bf16:
+            if len(xsrcs) != len(plan.xsegs) or len(ysrcs) != len(plan.ysegs):
+                raise L.HipKernelError(f'{plan.name}: source count')
+            return self._wgrad_bf16(plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate)
         if len(xsrcs) != len(plan.xsegs) or len(ysrcs) != len(plan.ysegs):
             raise L.HipKernelError(f'{plan.name}: source count')
         a = L.WgradArgs()
@@ -436,10 +548,10 @@ class HipOps:
                 'rnh_uptail_xcorr')
         return M, S
 
-    def uptail_expand(self, d_o, r):
+    def uptail_expand(self, d_o, r, Dc=None):
         self._chk(d_o)
         B, Hh, Wh, Co = d_o.shape
-        Dc = (Co * (r + 2) * (r + 2) + 3) // 4 * 4
+        Dc = (Co * (r + 2) * (r + 2) + 3) // 4 * 4 if Dc is None else Dc
         D = self.empty(B, Hh // r, Wh // r, Dc)
         L.check(self.lib.rnh_uptail_expand(_ptr(d_o), _ptr(D), B, Hh // r, Wh // r, Co, r, Dc, self._stream()), 'rnh_uptail_expand')
         return D
@@ -452,6 +564,17 @@ class HipOps:
                 'rnh_uptail_wcontract')
 
     def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=None):
+        if any(t is not None and t.dtype != torch.float32 for t in (dh, dh2, gates, dgates)):
+            self._chk(dh, dh2, gates, dgates, mixed=True)
+            self._chk(dc_next, c_prev, c_next, dc_prev)
+            hd = dh.shape[-1]
+            if gates.numel() != 4 * dh.numel() or dgates.numel() != 4 * dh.numel() or any(
+                    t is not None and t.shape != dh.shape for t in (dc_next, c_prev, c_next, dc_prev, dh2)):
+                raise L.HipKernelError('lstm_gates_bwd: shapes')
+            L.check(self.lib.rnh_lstm_gates_bwd_m(_ptr(dh), L.dt_of(dh), _ptr(dh2), L.dt_of(dh2) if dh2 is not None else L.DT_F32,
+                                                  _ptr(dc_next), _ptr(gates), L.dt_of(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates),
+                                                  L.dt_of(dgates), _ptr(dc_prev), dh.numel() // hd, hd, self._stream()), 'rnh_lstm_gates_bwd_m')
+            return
         self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2)
         hd = dh.shape[-1]
         npix = dh.numel() // hd
@@ -464,17 +587,27 @@ class HipOps:
                                             _ptr(dc_prev), npix, hd, self._stream()), 'rnh_lstm_gates_bwd')
 
     def add(self, out, a, b=None, c=None, accumulate=False):
-        self._chk(out, a, b, c)
         n = out.numel()
         for t in (a, b, c):
             if t is not None and t.numel() != n:
                 raise L.HipKernelError('add: size mismatch')
+        if any(t is not None and t.dtype != torch.float32 for t in (out, a, b, c)):
+            self._chk(out, a, b, c, mixed=True)
+            dt = lambda t: L.dt_of(t) if t is not None else L.DT_F32          # noqa: E731
+            L.check(self.lib.rnh_ew_add_m(_ptr(out), dt(out), _ptr(a), dt(a), _ptr(b), dt(b), _ptr(c), dt(c), n, int(accumulate),
+                                          self._stream()), 'rnh_ew_add_m')
+            return out
+        self._chk(out, a, b, c)
         L.check(self.lib.rnh_ew_add(_ptr(out), _ptr(a), _ptr(b), _ptr(c), n, int(accumulate), self._stream()), 'rnh_ew_add')
         return out
 
-    def phase_plane(self, pos, N, F, H, W):
+    def phase_plane(self, pos, N, F, H, W, dtype=torch.float32, channels=4):
         pos = pos.reshape(N, F).contiguous()
         self._chk(pos)
+        if channels == 8:                                     # the bf16-storage path's 8-channel plane (p, 0, ..., 0)
+            out = self.empty(F * N, H, W, 8, dtype=dtype)
+            L.check(self.lib.rnh_phase_plane_m(_ptr(pos), _ptr(out), L.dt_of(out), N, F, H, W, self._stream()), 'rnh_phase_plane_m')
+            return out
         out = self.empty(F * N, H, W, 4)
         L.check(self.lib.rnh_phase_plane(_ptr(pos), _ptr(out), N, F, H, W, self._stream()), 'rnh_phase_plane')
         return out

@@ -31,7 +31,20 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
            'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
            'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
-           'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim']
+           'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
+           # bf16-storage path
+           'rnh_conv_bf16', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
+           'rnh_phase_plane_m', 'rnh_struct_sizes_bf16']
+DT_F32, DT_BF16 = 0, 1
+
+
+def dt_of(t):
+    """RNH_DT_* tag of a tensor (fp32 or bf16; anything else is refused)."""
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise HipKernelError(f'expected an fp32 or bf16 tensor, got {t.dtype}')
 
 
 class HipKernelError(RuntimeError):
@@ -63,6 +76,30 @@ class WgradArgs(C.Structure):
                 ('nys', C.c_int32), ('ycols_pad', C.c_int32), ('xgrp', C.c_void_p), ('ygrp', C.c_void_p),
                 ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('ntaps', C.c_int32), ('tile', C.c_int32),
                 ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p), ('zero_page', C.c_void_p)]
+
+
+class MSrc(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('dtype', C.c_int32), ('C', C.c_int32), ('c0', C.c_int32), ('nch', C.c_int32),
+                ('img_off', C.c_int32), ('scale', C.c_int32), ('sub_y', C.c_int32), ('sub_x', C.c_int32)]
+
+
+class MDst(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('dtype', C.c_int32), ('C', C.c_int32), ('c0', C.c_int32), ('ncols', C.c_int32),
+                ('accumulate', C.c_int32), ('img_off', C.c_int32), ('_pad', C.c_int32)]
+
+
+class ConvBf16Args(C.Structure):
+    _fields_ = [('src', MSrc * MAX_SRC), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('ntaps', C.c_int32), ('nchunks', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p),
+                ('Npad', C.c_int32), ('epilogue', C.c_int32), ('ndst', C.c_int32), ('ps_r', C.c_int32), ('ps_cq', C.c_int32),
+                ('hd', C.c_int32), ('dst', MDst * MAX_DST), ('c_prev', C.c_void_p), ('c_out', C.c_void_p),
+                ('h_out', C.c_void_p), ('gates_out', C.c_void_p), ('h_dtype', C.c_int32), ('gates_dtype', C.c_int32)]
+
+
+class WgradBf16Args(C.Structure):
+    _fields_ = [('xs', MSrc * MAX_SRC), ('nxs', C.c_int32), ('xrows_pad', C.c_int32), ('ys', MSrc * MAX_SRC),
+                ('nys', C.c_int32), ('ycols_pad', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('ntaps', C.c_int32), ('nsplit', C.c_int32), ('slab', C.c_void_p), ('bslab', C.c_void_p)]
 
 
 class CineSample(C.Structure):
@@ -134,6 +171,20 @@ def load():
     lib.rnh_metrics_ws_floats.argtypes = [i32, i32, i32]
     lib.rnh_metrics_ws_floats.restype = i64
     lib.rnh_metrics_psnr_ssim.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, f32, C.POINTER(C.c_float), vp, vp, vp]
+    lib.rnh_conv_bf16.argtypes = [C.POINTER(ConvBf16Args), vp]
+    lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
+    lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
+    lib.rnh_lstm_gates_bwd_m.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, i64, i32, vp]
+    lib.rnh_cast.argtypes = [vp, i32, vp, i32, i64, vp]
+    lib.rnh_phase_plane_m.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_struct_sizes_bf16.argtypes = [C.POINTER(C.c_int32 * 4)]
+    lib.rnh_struct_sizes_bf16.restype = None
+    msz = (C.c_int32 * 4)()
+    lib.rnh_struct_sizes_bf16(C.byref(msz))
+    mine_m = [C.sizeof(MSrc), C.sizeof(MDst), C.sizeof(ConvBf16Args), C.sizeof(WgradBf16Args)]
+    if list(msz) != mine_m:
+        raise HipKernelError(f'bf16 struct layout mismatch between the binding {mine_m} and the library {list(msz)}')
     lib.rnh_struct_sizes.argtypes = [C.POINTER(C.c_int32 * 4)]
     lib.rnh_struct_sizes.restype = None
     sizes = (C.c_int32 * 4)()

@@ -64,14 +64,19 @@ class ConvPlan:
     """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
 
     def __init__(self, name, wkey, bkey, wshape, ksegs: List[KSeg], colmap: List[int], tile=None,
-                 epilogue=L.EPI_STORE, transposed=False, kstride=1, wino=False):
+                 epilogue=L.EPI_STORE, transposed=False, kstride=1, wino=False, bf16=False):
         self.name, self.wkey, self.bkey = name, wkey, bkey
         self.Cout, self.Cin, kh, kw = wshape
         self.ntaps = kh * kw
         assert self.ntaps in (1, 9)
         self.ksegs, self.transposed, self.kstride, self.epilogue = ksegs, transposed, kstride, epilogue
         self.tile = pick_tile(len(colmap)) if tile is None else tile
-        self.Npad = _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        # bf16 = True: a plan of rnh_conv_bf16 (csrc/conv_bf16.hip): same K order (source -> 16-channel chunk -> tap), weights
+        # packed to bf16 in natural k order, columns padded to 64 (column tiles of 128 where that divides, else of 64)
+        self.bf16 = bool(bf16)
+        self.Npad = _pad_to(len(colmap), 64) if self.bf16 else _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        self.nchunks = sum((sg.nch + KC - 1) // KC for sg in ksegs)
+        wino = wino and not self.bf16
         self.colmap = list(colmap) + [-1] * (self.Npad - len(colmap))
         self.kbase, self.knv, self.ktap, self.kcoff = [], [], [], []
         for sg in ksegs:
@@ -126,7 +131,7 @@ def pick_wgrad_tile(nrows, ncols):
 class WgradPlan:
     """Row (forward input channel) / column (output channel) layout of one rnh_conv_wgrad call."""
 
-    def __init__(self, name, wkey, bkey, wshape, xsegs: List[XSeg], ysegs: List[YSeg], tile=None):
+    def __init__(self, name, wkey, bkey, wshape, xsegs: List[XSeg], ysegs: List[YSeg], tile=None, bf16=False):
         self.name, self.wkey, self.bkey = name, wkey, bkey
         self.Cout, self.Cin, kh, kw = wshape
         self.ntaps = kh * kw
@@ -154,6 +159,16 @@ class WgradPlan:
         self.colmap = colmap + [-1] * (self.ycols_pad - len(colmap))
         self.xgrp = xgrp + [-1] * (self.xcols_pad // self.mi - len(xgrp))
         self.ygrp = ygrp + [-1] * (self.ycols_pad // self.ni - len(ygrp))
+        # rnh_wgrad_bf16 (csrc/wgrad_bf16.hip): workgroup tiles of 64 rows x 64 columns
+        self.bf16 = bool(bf16)
+        self.xrows_pad64, self.ycols_pad64 = _pad_to(len(rowmap), 64), _pad_to(len(colmap), 64)
+        self.rowmap64 = rowmap + [-1] * (self.xrows_pad64 - len(rowmap))
+        self.colmap64 = colmap + [-1] * (self.ycols_pad64 - len(colmap))
+
+    def nsplit_bf16(self, nitems):
+        """Pixel-range splits of rnh_wgrad_bf16: enough workgroups (tiles x splits) to fill the 256 CUs about once."""
+        tiles = (self.xrows_pad64 // 64) * (self.ycols_pad64 // 64)
+        return int(max(1, min(nitems, 256, -(-256 // tiles))))
 
     def nsplit(self, npix):
         import os
@@ -208,13 +223,22 @@ def r4(n):
 class NetPlans:
     """All plans of one RefineNet configuration (``cfg`` has the reference constructor kwargs as attributes)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, bf16=False):
+        """bf16 = True: the plans of the bf16-storage path (rnh_conv_bf16 / rnh_wgrad_bf16): no Winograd forms, no side
+        paths (refine conv1 runs with all 2*Cl + 1 columns and the phase planes as 8-channel K sources), channel counts
+        in multiples of 8."""
+        import functools
         self.cfg = cfg
+        self.bf16 = bf = bool(bf16)
+        ConvPlan_ = functools.partial(ConvPlan, bf16=bf)
+        WgradPlan_ = functools.partial(WgradPlan, bf16=bf)
         nf = list(cfg.num_features)
         self.nf, self.C, self.Cl, self.L = nf, nf[0], nf[-1], len(nf)
         for c in nf:
-            if c % 4:
-                raise ValueError('num_features must be multiples of 4 for the HIP path')
+            if c % (8 if bf else 4):
+                raise ValueError(f'num_features must be multiples of {8 if bf else 4} for the HIP path')
+        pw = 8 if bf else 4                       # channels of a phase plane (p, 0, ..., 0)
+        self.pw = pw
         self.lstm = {}
         for d in ('forward', 'backward'):
             for l, hd in enumerate(nf):
@@ -225,14 +249,14 @@ class NetPlans:
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) else lstm_colmap(hd)
-                wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G
-                full = ConvPlan(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
+                wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G and not bf
+                full = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
                                 tile=ltile, epilogue=L.EPI_LSTM, wino=wino)
-                first = ConvPlan(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
+                first = ConvPlan_(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
                                  epilogue=L.EPI_LSTM, wino=wino) if cfg.memory else full
-                dgrad = ConvPlan(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
+                dgrad = ConvPlan_(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
                                  wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
-                wgrad = WgradPlan(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
+                wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
                                   [YSeg(4 * hd, 4 * hd, 0)])
                 self.lstm[(d, l)] = dict(full=full, first=first, dgrad=dgrad, wgrad=wgrad, cx=cx, hd=hd, second=second)
 
@@ -241,20 +265,20 @@ class NetPlans:
         self.xcol = self.r1_wino = False
         if self.pos:
             C1 = 2 * Cl + 1
-            self.C1, self.C1p = C1, r4(C1)
+            self.C1, self.C1p = C1, (_pad_to(C1, 8) if bf else r4(C1))
             ws1, ws2 = (C1, w * C1, 3, 3), (Cl, C1, 3, 3)
             k1, b1 = 'refine_block.body.conv1.weight', 'refine_block.body.conv1.bias'
             k2, b2 = 'refine_block.body.conv2.weight', 'refine_block.body.conv2.bias'
             segs, xsegs = [], []
             for j in range(w):
-                segs += [KSeg(Cl, Cl, j * C1), KSeg(Cl, Cl, j * C1 + Cl), KSeg(4, 1, j * C1 + 2 * Cl)]
-                xsegs += [XSeg(Cl, Cl, j * C1), XSeg(Cl, Cl, j * C1 + Cl), XSeg(4, 1, j * C1 + 2 * Cl)]
+                segs += [KSeg(Cl, Cl, j * C1), KSeg(Cl, Cl, j * C1 + Cl), KSeg(pw, 1, j * C1 + 2 * Cl)]
+                xsegs += [XSeg(Cl, Cl, j * C1), XSeg(Cl, Cl, j * C1 + Cl), XSeg(pw, 1, j * C1 + 2 * Cl)]
             # conv1 writes C1p channels (the pad channels have zero weights and bias => zeros).  C1 = 2*Cl + 1 is one more
             # than a whole number of 32-column MFMA tiles when Cl % 32 == 0: that channel then takes the side path
             # (HipOps.refine_xcol_fwd / _wgrad) and the GEMMs run on r1_cols = 2*Cl columns
-            self.xcol = C1 % 32 == 1 and Cl % 32 == 0 and os.environ.get('RNH_XCOL', '1') != '0'
+            self.xcol = C1 % 32 == 1 and Cl % 32 == 0 and os.environ.get('RNH_XCOL', '1') != '0' and not bf
             self.r1_cols = C1 - 1 if self.xcol else self.C1p
-            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs,
+            self.r1_fwd = ConvPlan_('refine1.fwd', k1, b1, ws1, segs,
                                    list(range(C1 - 1)) if self.xcol else list(range(C1)) + [-1] * (self.C1p - C1))
             # Winograd split of the two big refine convolutions (only together with the side path, which leaves 2*Cl
             # columns / K channels): the hidden-state sources go through rnh_conv_wino, the 4-channel phase planes (forward)
@@ -264,22 +288,22 @@ class NetPlans:
             if self.r1_wino:
                 hsegs = [sg for sg in segs if sg.nch == Cl]
                 psegs = [sg for sg in segs if sg.nch == 4]
-                self.r1_fwd_h = ConvPlan('refine1.fwd.h', k1, b1, ws1, hsegs, list(range(C1 - 1)), wino=True)
-                self.r1_fwd_p = ConvPlan('refine1.fwd.p', k1, None, ws1, psegs, list(range(C1 - 1)))
-                self.r1_wgrad_h = WgradPlan('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
-                self.r1_wgrad_p = WgradPlan('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
-                self.r1_dgrad_h = ConvPlan('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
+                self.r1_fwd_h = ConvPlan_('refine1.fwd.h', k1, b1, ws1, hsegs, list(range(C1 - 1)), wino=True)
+                self.r1_fwd_p = ConvPlan_('refine1.fwd.p', k1, None, ws1, psegs, list(range(C1 - 1)))
+                self.r1_wgrad_h = WgradPlan_('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
+                self.r1_wgrad_p = WgradPlan_('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
+                self.r1_dgrad_h = ConvPlan_('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
                                            list(range(2 * Cl)), transposed=True, wino=True)
-                self.r1_dgrad_x = ConvPlan('refine1.dgrad.x', k1, None, ws1,
+                self.r1_dgrad_x = ConvPlan_('refine1.dgrad.x', k1, None, ws1,
                                            [KSeg(self.C1p - C1 + 1, 1, C1 - 1, kcoff=j * C1) for j in range(w)], list(range(2 * Cl)),
                                            transposed=True)
-            self.r2_fwd = ConvPlan('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
-            self.r2_dgrad = ConvPlan('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
+            self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
+            self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
-            self.r2_wgrad = WgradPlan('refine2.wgrad', k2, b2, ws2, [XSeg(self.C1p, C1, 0)], [YSeg(Cl, Cl, 0)])
-            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs,
+            self.r2_wgrad = WgradPlan_('refine2.wgrad', k2, b2, ws2, [XSeg(self.C1p, C1, 0)], [YSeg(Cl, Cl, 0)])
+            self.r1_wgrad = WgradPlan_('refine1.wgrad', k1, b1, ws1, xsegs,
                                       [YSeg(C1 - 1, C1 - 1, 0)] if self.xcol else [YSeg(self.C1p, C1, 0)])
-            self.r1_dgrad = ConvPlan('refine1.dgrad', k1, None, ws1, [KSeg(self.C1p, C1, 0, kcoff=j * C1) for j in range(w)],
+            self.r1_dgrad = ConvPlan_('refine1.dgrad', k1, None, ws1, [KSeg(self.C1p, C1, 0, kcoff=j * C1) for j in range(w)],
                                      list(range(2 * Cl)), transposed=True)
         else:
             ws1 = (Cl, w * 2 * Cl, 1, 1)
@@ -288,9 +312,9 @@ class NetPlans:
             for j in range(w):
                 segs += [KSeg(Cl, Cl, j * 2 * Cl), KSeg(Cl, Cl, j * 2 * Cl + Cl)]
                 xsegs += [XSeg(Cl, Cl, j * 2 * Cl), XSeg(Cl, Cl, j * 2 * Cl + Cl)]
-            self.r1_fwd = ConvPlan('refine1.fwd', k1, b1, ws1, segs, list(range(Cl)))
-            self.r1_wgrad = WgradPlan('refine1.wgrad', k1, b1, ws1, xsegs, [YSeg(Cl, Cl, 0)])
-            self.r1_dgrad = ConvPlan('refine1.dgrad', k1, None, ws1, [KSeg(Cl, Cl, 0, kcoff=j * 2 * Cl) for j in range(w)],
+            self.r1_fwd = ConvPlan_('refine1.fwd', k1, b1, ws1, segs, list(range(Cl)))
+            self.r1_wgrad = WgradPlan_('refine1.wgrad', k1, b1, ws1, xsegs, [YSeg(Cl, Cl, 0)])
+            self.r1_dgrad = ConvPlan_('refine1.dgrad', k1, None, ws1, [KSeg(Cl, Cl, 0, kcoff=j * 2 * Cl) for j in range(w)],
                                      list(range(2 * Cl)), transposed=True)
 
         # upsampler: [(conv with PixelShuffle r)]* then the small last conv
@@ -303,20 +327,20 @@ class NetPlans:
         for i, r in enumerate(rs):
             wk, bk = f'out_block.conv{i + 1}.weight', f'out_block.conv{i + 1}.bias'
             ws = (r * r * C, C, 3, 3)
-            fwd = ConvPlan(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS,
+            fwd = ConvPlan_(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS,
                            wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
-            dgrad = ConvPlan(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
+            dgrad = ConvPlan_(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
                              transposed=True, kstride=r * r,
                              wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
-            wgrad = WgradPlan(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
+            wgrad = WgradPlan_(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
             self.up.append(dict(r=r, fwd=fwd, dgrad=dgrad, wgrad=wgrad))
         self.last_w, self.last_b = f'out_block.conv{len(rs) + 1}.weight', f'out_block.conv{len(rs) + 1}.bias'
         # collapsed tail backward (csrc/uptail.hip): wgrad of the last PixelShuffle conv's input against the expanded
         # output gradient D, whose (out_channels * (r+2)^2) columns replace the conv's r*r*C
         rt, Co = rs[-1], cfg.out_channels
         nd2 = Co * (rt + 2) * (rt + 2)
-        self.tail_dc = r4(nd2)
-        self.tail_m = WgradPlan('uptail.M', None, None, (nd2, C, 3, 3), [XSeg(C, C, 0)], [YSeg(self.tail_dc, nd2, 0)])
+        self.tail_dc = _pad_to(nd2, 8) if bf else r4(nd2)
+        self.tail_m = WgradPlan_('uptail.M', None, None, (nd2, C, 3, 3), [XSeg(C, C, 0)], [YSeg(self.tail_dc, nd2, 0)])
 
     def conv_plans(self):
         out = []

@@ -7,6 +7,8 @@ under the reference's names and default initialisation; they are never called - 
 ``hipvsr.engine.RefineNetEngine`` through one autograd Function.  There is no PyTorch fallback: on a non-HIP
 device ``forward`` raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -70,16 +72,27 @@ class RefineNet(BaseNet):
         assert got == self._param_names, (got, self._param_names)
         self._eng = None
         self._flat_grad = None
+        # compute precision of the HIP engine: 'f32' (the reference's) or 'bf16' (bf16 storage / bf16 MFMA with fp32
+        # accumulation, BASELINE.json configs[2]).  Not a constructor argument - the reference's constructor is the
+        # boundary - and never visible in state_dict(): parameters and checkpoints are fp32 either way.
+        self.compute_dtype = os.environ.get('RNH_DTYPE', 'f32')
+
+    def set_compute_dtype(self, dtype):
+        """'f32' or 'bf16'; takes effect at the next forward (the engine and its packed weights are rebuilt)."""
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self.compute_dtype = dtype
+        return self
 
     def _engine(self):
         dev = self.in_block.conv.weight.device
-        if self._eng is None or self._eng.ops.device != dev:
+        if self._eng is None or self._eng.ops.device != dev or self._eng.dtype != self.compute_dtype:
             if dev.type != 'cuda':
                 raise RuntimeError(f'RefineNet (HIP) needs its parameters on a HIP device; they are on {dev}. '
                                    'There is no CPU path in this package.')
             from hipvsr.engine import RefineNetEngine
             from hipvsr.hip_ops import HipOps
-            self._eng = RefineNetEngine(self.cfg, HipOps(dev))
+            self._eng = RefineNetEngine(self.cfg, HipOps(dev), dtype=self.compute_dtype)
         return self._eng
 
     def forward(self, inputs, pos_codes):

@@ -9,7 +9,8 @@
  * maintainer would add.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer to fp32 data unless the parameter comment says "host";
+ *   - every pointer is a DEVICE pointer to fp32 data unless the parameter comment says "host" (the bf16-storage entry
+ *     points at the end carry an explicit element type per tensor);
  *   - activations are NHWC: tensor[b][y][x][c], b = frame * N + n ("image" index), c contiguous;
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no allocation, no
  *     synchronisation, graph-capture safe); workspaces are provided by the caller;
@@ -341,11 +342,93 @@ int64_t rnh_metrics_ws_floats(int P, int H, int W);
 int rnh_metrics_psnr_ssim(const float *out, const float *tgt, int P, int cps, int H, int W, int denorm, int want_ssim, float mean, float stdv,
                           float max_value, float value_range, const float *window11_host, float *ws, float *result, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * bf16-storage path (BASELINE.json configs[2]: "bf16, 8xMI355X").  The reference is fp32
+ * throughout (refine_net.py:234-241 are plain nn.Conv2d); this is the build's own mixed-precision form of the same
+ * call sites: activations of the recurrent / refine / upsampler-input tensors in HBM as bf16, weights packed to bf16 per
+ * step from the fp32 state_dict, v_mfma_f32_32x32x16_bf16 with fp32 accumulators, fp32 cell state c, fp32 bias add and
+ * gate math, fp32 weight gradients, fp32 final convolution and loss.  Tensors carry their element type explicitly. */
+#define RNH_DT_F32  0
+#define RNH_DT_BF16 1
+
+typedef struct rnh_msrc {       /* rnh_src_t with an element type; bf16: C, c0, nch multiples of 8; f32: of 4 */
+    const void *ptr;
+    int32_t dtype;              /* RNH_DT_*                                                              */
+    int32_t C, c0, nch, img_off;
+    int32_t scale, sub_y, sub_x; /* one common scale for all sources of a call                           */
+} rnh_msrc_t;
+
+typedef struct rnh_mdst {       /* rnh_dst_t with an element type; C, c0, ncols multiples of 8           */
+    void *ptr;
+    int32_t dtype;
+    int32_t C, c0, ncols, accumulate, img_off;
+    int32_t _pad;
+} rnh_mdst_t;
+
+typedef struct rnh_conv_bf16_args {
+    rnh_msrc_t src[RNH_MAX_SRC];
+    int32_t nsrc;
+    int32_t B, H, W;
+    int32_t ntaps;              /* 9 or 1                                                                */
+    int32_t nchunks;            /* sum_src ceil(nch / 16): 16-channel K chunks                           */
+    const void *wp;             /* bf16 [nchunks * ntaps][Npad][16] from rnh_pack_weights_bf16           */
+    const float *bias;          /* packed fp32 bias [Npad] or 0                                          */
+    int32_t Npad;               /* multiple of 64; column tiles of 128 if Npad % 128 == 0, else of 64    */
+    int32_t epilogue;           /* RNH_EPI_*                                                             */
+    int32_t ndst;
+    int32_t ps_r, ps_cq;        /* RNH_EPI_PS: dst[0] is the (B, rH, rW, cq) tensor; cq % 8 == 0         */
+    int32_t hd;                 /* RNH_EPI_LSTM: hidden channels (multiple of 8), columns as rnh_conv_args_t */
+    rnh_mdst_t dst[RNH_MAX_DST];
+    const float *c_prev;        /* fp32 [B][H][W][hd] or 0                                               */
+    float *c_out;               /* fp32 [B][H][W][hd]                                                    */
+    void *h_out;                /* [B][H][W][hd] of h_dtype                                              */
+    void *gates_out;            /* [B][H][W][4*hd] of gates_dtype or 0                                   */
+    int32_t h_dtype, gates_dtype;
+} rnh_conv_bf16_args_t;
+
+/* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA: one workgroup = 8 x 32 output pixels x 128 (64) columns; per
+ * 16-channel chunk the 10 x 34 pixel halo of the inputs (converted to bf16 if the source is fp32) and the chunk's
+ * packed weights of all taps go through LDS once and serve all 9 taps.  Same call sites as rnh_conv_igemm. */
+int rnh_conv_bf16(const rnh_conv_bf16_args_t *args /* host */, void *stream);
+/* wp[ks][n][kk] (bf16, kk = 0..15 in natural order) with the index conventions of rnh_pack_weights; biasp fp32. */
+int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,
+                          const int32_t *knv, const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk,
+                          int Npad, int Cout, int Cin, int ntaps, int kstride, int transposed, void *stream);
+
+typedef struct rnh_wgrad_bf16_args {
+    rnh_msrc_t xs[RNH_MAX_SRC]; /* forward inputs (rows of dW): scale 1                                  */
+    int32_t nxs;
+    int32_t xrows_pad;          /* padded row count (sum of nch, rounded up to 64)                       */
+    rnh_msrc_t ys[RNH_MAX_SRC]; /* output gradients (columns of dW); one common scale                    */
+    int32_t nys;
+    int32_t ycols_pad;          /* padded column count (rounded up to 64)                                */
+    int32_t B, H, W, ntaps;
+    int32_t nsplit;             /* pixel-row ranges; slab [nsplit][ntaps][xrows_pad][ycols_pad] fp32     */
+    float *slab;
+    float *bslab;               /* [nsplit][ycols_pad] or 0                                              */
+} rnh_wgrad_bf16_args_t;
+/* Weight gradient on bf16 MFMA with the pixel index as the K dimension: image rows are staged channel-major in LDS
+ * (the transpose happens in the staging writes), 3 input rows serve the 9 taps.  Partial slabs per row range in the
+ * layout of rnh_conv_wgrad, to be summed by rnh_wgrad_reduce (fixed order, no atomics). */
+int rnh_wgrad_bf16(const rnh_wgrad_bf16_args_t *args /* host */, void *stream);
+
+/* Mixed-type versions of the small HBM-bound kernels (element types per operand, RNH_DT_*). */
+int rnh_ew_add_m(void *out, int out_dt, const void *a, int a_dt, const void *b, int b_dt, const void *c, int c_dt,
+                 int64_t n, int accumulate, void *stream);                     /* n % 8 == 0 */
+int rnh_lstm_gates_bwd_m(const void *dh, int dh_dt, const void *dh2, int dh2_dt, const float *dc_next, const void *gates, int g_dt,
+                         const float *c_prev, const float *c_next, void *dgates, int dg_dt, float *dc_prev, int64_t npix,
+                         int hd, void *stream);                                /* hd % 8 == 0 */
+int rnh_cast(const void *src, int src_dt, void *dst, int dst_dt, int64_t n, void *stream);   /* n % 8 == 0 */
+/* out[(f*N + n)][y][x][0..8) = (pos[n*F + f], 0, ..., 0): the phase plane as an 8-channel source of either type */
+int rnh_phase_plane_m(const float *pos /* [N][F] */, void *out, int out_dt, int N, int F, int H, int W, void *stream);
+
 const char *rnh_last_error(void);
 int rnh_abi_version(void);
 /* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding
  * check its struct mirrors. */
 void rnh_struct_sizes(int32_t out[4]);
+/* sizeof(rnh_msrc_t), sizeof(rnh_mdst_t), sizeof(rnh_conv_bf16_args_t), sizeof(rnh_wgrad_bf16_args_t) */
+void rnh_struct_sizes_bf16(int32_t out[4]);
 
 #ifdef __cplusplus
 }

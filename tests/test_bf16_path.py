@@ -1,0 +1,451 @@
+"""The bf16-storage path (BASELINE.json configs[2]; SURVEY.md section 8c: "bf16: only the PSNR criterion + loss rtol 1e-2").
+
+The reference is fp32 throughout (reference src/model/nets/refine_net.py:234-241 are plain nn.Conv2d), so parity is layered:
+
+* kernel level (GPU): rnh_conv_bf16 / rnh_wgrad_bf16 / the mixed-type helpers against float64 torch evaluations of the SAME
+  bf16-rounded operands - what is left is fp32 accumulation order (and, for bf16 destinations, one final rounding);
+* engine level (GPU): the HIP engine in bf16 mode against the same engine over the torch double (tests/torch_ops.py), which
+  rounds to bf16 where the kernels do, on a ragged full-width shape;
+* module level (GPU): the bf16 net against the fp32 CPU oracle (== the reference) under the contract's bf16 criterion:
+  |delta PSNR| < 0.01 dB and loss rtol 1e-2, at BASELINE config 1 and at config 2's geometry;
+* CPU: tests/test_engine_cpu.py runs the bf16 plans over the torch double against the reference goldens.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import refinenet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP = 2.0 ** -8          # half a unit in the last place of bf16 (8 significant bits) relative to the value
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _rb(t):
+    """Round to bf16 and back (what a bf16 store or an MFMA operand conversion does)."""
+    return t.float().bfloat16().float()
+
+
+def _close_f32(mine, ref64, name, rel=2e-5):
+    """fp32 result of a bf16-operand contraction against float64 on the same operands: accumulation-order noise only."""
+    a, b = mine.detach().cpu().double(), ref64.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    assert not torch.isnan(a).any(), name
+    err = float((a - b).abs().max())
+    assert err <= rel * float(b.abs().max()) + 1e-7, (name, err, float(b.abs().max()))
+
+
+def _close_bf16(mine, ref64, name):
+    """bf16 result: the fp32 value rounded once - at most one bf16 ulp of the reference away (rounding boundary flips)."""
+    a, b = mine.detach().cpu().double(), ref64.detach().cpu().double()
+    assert mine.dtype == torch.bfloat16 and a.shape == b.shape, (name, mine.dtype, a.shape, b.shape)
+    over = (a - b).abs() - (2 * BF16_ULP * b.abs() + 2e-5 * float(b.abs().max()) + 1e-30)
+    assert float(over.max()) <= 0, (name, float(over.max()), float(b.abs().max()))
+
+
+def _close(mine, ref64, name):
+    (_close_bf16 if mine.dtype == torch.bfloat16 else _close_f32)(mine, ref64, name)
+
+
+def _full_cfg(**over):
+    from hipvsr.spec import NetConfig
+    kw = dict(in_channels=1, out_channels=1, num_features=[64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4,
+              update_memory=True, num_updated_frames=6, positional_encoding=True)
+    kw.update(over)
+    return NetConfig(**kw)
+
+
+def _nchw(t):
+    return t.detach().cpu().double().permute(0, 3, 1, 2)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+SHAPES = [(2, 8, 32), (1, 11, 45), (2, 5, 13), (1, 16, 64), (3, 3, 7)]          # (B, H, W): whole tiles, ragged rows and columns
+
+
+@pytest.mark.parametrize('B,H,W', SHAPES)
+@pytest.mark.parametrize('which', ['lstm', 'lstm_first', 'lstm_dgrad', 'up', 'up_dgrad', 'refine1', 'refine1_dgrad', 'refine2', 'refine2_dgrad',
+                                   'refine_1x1'])
+def test_conv_bf16_kernel_vs_torch_float64(which, B, H, W):
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = _full_cfg(positional_encoding=which != 'refine_1x1')
+    P, ops = NetPlans(cfg, bf16=True), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    g = torch.Generator('cpu').manual_seed(31 * W + H)
+    R = lambda *sh: torch.randn(*sh, generator=g)                           # noqa: E731
+    bf = torch.bfloat16
+    if which in ('lstm', 'lstm_first', 'lstm_dgrad'):
+        pl = P.lstm[('forward', 1)]
+        w, b = R(*spec[pl['full'].wkey]) * 0.03, R(256) * 0.1
+        if which == 'lstm_dgrad':
+            ops.pack(pl['dgrad'], w.to(dev), None)
+            dg = R(B, H, W, 256).to(bf)
+            dx = torch.full((B, H, W, 64), float('nan'), device=dev, dtype=bf)
+            dh = torch.full((B, H, W, 64), float('nan'), device=dev)           # one bf16 and one fp32 destination
+            ops.conv(pl['dgrad'], [Src(dg.to(dev))], B, H, W, dsts=[Dst(dx, 64), Dst(dh, 64)])
+            torch.cuda.synchronize()
+            ref = _nhwc(F.conv_transpose2d(_nchw(dg), _rb(w).double(), padding=1))
+            _close(dx, ref[..., :64], 'dx')
+            _close(dh, ref[..., 64:], 'dh')
+            return
+        first = which == 'lstm_first'
+        plan = pl['first'] if first else pl['full']
+        ops.pack(plan, w.to(dev), b.to(dev))
+        x, h, c = R(B + 1, H, W, 64), R(B + 2, H, W, 64).to(bf), R(B, H, W, 64)   # x fp32 (converted on load), h bf16
+        ho = torch.full((B, H, W, 64), float('nan'), device=dev, dtype=bf)
+        co = torch.full((B, H, W, 64), float('nan'), device=dev)
+        go = torch.full((B, H, W, 256), float('nan'), device=dev, dtype=bf)
+        srcs = [Src(x.to(dev), img_off=1)] + ([] if first else [Src(h.to(dev), img_off=2)])
+        ops.conv(plan, srcs, B, H, W, lstm=dict(hd=64, c_prev=None if first else c.to(dev), h_out=ho, c_out=co, gates_out=go))
+        torch.cuda.synchronize()
+        xin = _nchw(_rb(x[1:])) if first else torch.cat([_nchw(_rb(x[1:])), _nchw(h[2:])], 1)
+        pre = F.conv2d(xin, _rb(w[:, :64] if first else w).double(), b.double(), padding=1)
+        gi, gf, gop, gg = pre.split(64, dim=1)
+        gi, gf, gop, gg = torch.sigmoid(gi), torch.sigmoid(gf), torch.sigmoid(gop), torch.tanh(gg)
+        cn = gi * gg if first else gf * _nchw(c) + gi * gg
+        _close(go, _nhwc(torch.cat([gi, gf, gop, gg], 1)), 'gates')
+        _close_f32(co, _nhwc(cn), 'c', rel=3e-5)
+        _close(ho, _nhwc(gop * torch.tanh(cn)), 'h')
+    elif which in ('up', 'up_dgrad'):
+        u = P.up[0]
+        w, b = R(256, 64, 3, 3) * 0.04, R(256) * 0.1
+        if which == 'up':
+            ops.pack(u['fwd'], w.to(dev), b.to(dev))
+            x = R(B, H, W, 64).to(bf)
+            Y = torch.full((B, 2 * H, 2 * W, 64), float('nan'), device=dev)          # the path keeps this tensor in fp32
+            ops.conv(u['fwd'], [Src(x.to(dev))], B, H, W, ps=(Y, 2))
+            torch.cuda.synchronize()
+            _close(Y, _nhwc(F.pixel_shuffle(F.conv2d(_nchw(x), _rb(w).double(), b.double(), padding=1), 2)), 'Y')
+        else:
+            ops.pack(u['dgrad'], w.to(dev), None)
+            dY = R(B, 2 * H, 2 * W, 64)                                               # fp32 source, pixel-unshuffle gather
+            dYd = dY.to(dev)
+            dx = torch.full((B, H, W, 64), float('nan'), device=dev, dtype=bf)
+            ops.conv(u['dgrad'], [Src(dYd, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)], B, H, W, dsts=[Dst(dx, 64)])
+            torch.cuda.synchronize()
+            _close(dx, _nhwc(F.conv_transpose2d(F.pixel_unshuffle(_nchw(_rb(dY)), 2), _rb(w).double(), padding=1)), 'dx')
+    elif which in ('refine1', 'refine1_dgrad'):
+        w1, b1 = R(129, 645, 3, 3) * 0.02, R(129) * 0.1
+        if which == 'refine1':
+            ops.pack(P.r1_fwd, w1.to(dev), b1.to(dev))
+            Hf, Hb = R(B + 4, H, W, 64).to(bf), R(B + 4, H, W, 64).to(bf)
+            P8 = torch.zeros(B + 4, H, W, 8).to(bf)
+            P8[..., 0] = R(B + 4, 1, 1).to(bf)
+            Hfd, Hbd, P8d = Hf.to(dev), Hb.to(dev), P8.to(dev)
+            srcs = []
+            for j in range(5):
+                srcs += [Src(Hfd, img_off=j), Src(Hbd, img_off=j), Src(P8d, img_off=j)]
+            R1 = torch.full((B, H, W, P.C1p), float('nan'), device=dev, dtype=bf)
+            ops.conv(P.r1_fwd, srcs, B, H, W, dsts=[Dst(R1, P.r1_cols)])
+            torch.cuda.synchronize()
+            xin = torch.cat([torch.cat([_nchw(Hf[j:j + B]), _nchw(Hb[j:j + B]), _nchw(P8[j:j + B, ..., :1])], 1) for j in range(5)], 1)
+            ref = _nhwc(F.conv2d(xin, _rb(w1).double(), b1.double(), padding=1))
+            _close(R1[..., :129], ref, 'R1')
+            assert float(R1[..., 129:].float().abs().max()) == 0.0                # the pad columns are written as zeros
+        else:
+            ops.pack(P.r1_dgrad, w1.to(dev), None)
+            gs = torch.zeros(B + 4, H, W, P.C1p)
+            gs[..., :129] = R(B + 4, H, W, 129)
+            gs = gs.to(bf)
+            base_f, base_b = R(B, H, W, 64).to(bf), R(B, H, W, 64)
+            dHf, dHb = base_f.to(dev), base_b.to(dev)
+            ops.conv(P.r1_dgrad, [Src(gs.to(dev), img_off=4 - j) for j in range(5)], B, H, W,
+                     dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)])
+            torch.cuda.synchronize()
+            tot = 0
+            for j in range(5):
+                tot = tot + F.conv_transpose2d(_nchw(gs[4 - j:4 - j + B, ..., :129]), _rb(w1[:, j * 129:j * 129 + 128]).double(), padding=1)
+            tot = _nhwc(tot)
+            _close(dHf, base_f.double() + tot[..., :64], 'dHf')
+            _close(dHb, base_b.double() + tot[..., 64:], 'dHb')
+    elif which in ('refine2', 'refine2_dgrad'):
+        w2, b2 = R(64, 129, 3, 3) * 0.05, R(64) * 0.1
+        if which == 'refine2':
+            ops.pack(P.r2_fwd, w2.to(dev), b2.to(dev))
+            R1 = torch.zeros(B, H, W, P.C1p)
+            R1[..., :129] = R(B, H, W, 129)
+            R1[..., 129:] = 7.0                                                     # pad channels must not contribute (zero weights)
+            R1 = R1.to(bf)
+            out = torch.full((B, H, W, 64), float('nan'), device=dev, dtype=bf)
+            ops.conv(P.r2_fwd, [Src(R1.to(dev))], B, H, W, dsts=[Dst(out, 64)])
+            torch.cuda.synchronize()
+            _close(out, _nhwc(F.conv2d(_nchw(R1[..., :129]), _rb(w2).double(), b2.double(), padding=1)), 'R')
+        else:
+            ops.pack(P.r2_dgrad, w2.to(dev), None)
+            dR = R(B, H, W, 64).to(bf)
+            out = torch.full((B + 2, H, W, P.C1p), float('nan'), device=dev, dtype=bf)
+            ops.conv(P.r2_dgrad, [Src(dR.to(dev))], B, H, W, dsts=[Dst(out, P.C1p, img_off=1)])
+            torch.cuda.synchronize()
+            ref = _nhwc(F.conv_transpose2d(_nchw(dR), _rb(w2).double(), padding=1))
+            _close(out[1:1 + B, ..., :129], ref, 'dR1')
+            assert float(out[1:1 + B, ..., 129:].float().abs().max()) == 0.0
+            assert bool(torch.isnan(out[0].float()).all()) and bool(torch.isnan(out[-1].float()).all())      # neighbours untouched
+    else:
+        w1, b1 = R(64, 640, 1, 1) * 0.05, R(64) * 0.1
+        ops.pack(P.r1_fwd, w1.to(dev), b1.to(dev))
+        Hf, Hb = R(B + 4, H, W, 64).to(bf), R(B + 4, H, W, 64).to(bf)
+        Hfd, Hbd = Hf.to(dev), Hb.to(dev)
+        srcs = []
+        for j in range(5):
+            srcs += [Src(Hfd, img_off=j), Src(Hbd, img_off=j)]
+        out = torch.full((B, H, W, 64), float('nan'), device=dev, dtype=bf)
+        ops.conv(P.r1_fwd, srcs, B, H, W, dsts=[Dst(out, 64)])
+        torch.cuda.synchronize()
+        xin = torch.cat([torch.cat([_nchw(Hf[j:j + B]), _nchw(Hb[j:j + B])], 1) for j in range(5)], 1)
+        _close(out, _nhwc(F.conv2d(xin, _rb(w1).double(), b1.double())), 'R(1x1)')
+
+
+@pytest.mark.parametrize('B,H,W', [(3, 6, 32), (2, 40, 45), (2, 5, 13), (1, 70, 64)])
+@pytest.mark.parametrize('which', ['lstm', 'up', 'refine1', 'refine2'])
+def test_wgrad_bf16_kernel_vs_torch_float64(which, B, H, W):
+    """rnh_wgrad_bf16 + rnh_wgrad_reduce against float64 autograd of conv2d on the bf16-rounded operands: row strips with
+    several work items per workgroup (H > 32), ragged strips (W % 32 != 0), fp32 and bf16 sources, the pixel-unshuffle
+    gather of the dy operand, padded rows / columns (8-channel phase planes with one real channel, 136 -> 129), bias."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    dev = _dev()
+    P, ops = NetPlans(_full_cfg(), bf16=True), HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(7 + W + H)
+    R = lambda *sh: torch.randn(*sh, generator=g)                           # noqa: E731
+    bf = torch.bfloat16
+
+    def ref_wgrad(x_nchw, dy_nchw, cout, cin):
+        w0 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x_nchw, w0, padding=1).backward(dy_nchw)
+        return w0.grad, dy_nchw.sum(dim=(0, 2, 3))
+
+    if which == 'lstm':
+        plan = P.lstm[('backward', 0)]['wgrad']
+        x, h, dy = R(B + 1, H, W, 64).to(bf), R(B + 1, H, W, 64).to(bf), R(B, H, W, 256).to(bf)
+        xs, ys = [Src(x.to(dev), img_off=1), Src(h.to(dev))], [Src(dy.to(dev))]
+        shape = (256, 128, 3, 3)
+        rw, rb = ref_wgrad(torch.cat([_nchw(x[1:]), _nchw(h[:B])], 1), _nchw(dy), 256, 128)
+    elif which == 'up':
+        plan = P.up[0]['wgrad']
+        x, big = R(B, H, W, 64).to(bf), R(B, 2 * H, 2 * W, 64)                # dy: fp32, gathered from the 2x larger tensor
+        xs = [Src(x.to(dev))]
+        bigd = big.to(dev)
+        ys = [Src(bigd, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
+        shape = (256, 64, 3, 3)
+        rw, rb = ref_wgrad(_nchw(x), F.pixel_unshuffle(_nchw(_rb(big)), 2), 256, 64)
+    elif which == 'refine1':
+        plan = P.r1_wgrad
+        Hf, Hb = R(B + 4, H, W, 64).to(bf), R(B + 4, H, W, 64).to(bf)
+        P8 = torch.zeros(B + 4, H, W, 8)
+        P8[..., 0] = R(B + 4, 1, 1)
+        P8[..., 1:] = 3.0                                                       # pad channels of the plane: rows the plan does not map
+        P8 = P8.to(bf)
+        dy = torch.zeros(B, H, W, P.C1p)
+        dy[..., :129] = R(B, H, W, 129)
+        dy[..., 129:] = 5.0                                                     # pad columns: not mapped either
+        dy = dy.to(bf)
+        Hfd, Hbd, P8d = Hf.to(dev), Hb.to(dev), P8.to(dev)
+        xs = []
+        for j in range(5):
+            xs += [Src(Hfd, img_off=j), Src(Hbd, img_off=j), Src(P8d, img_off=j)]
+        ys = [Src(dy.to(dev), nch=P.r1_cols)]
+        shape = (129, 645, 3, 3)
+        xin = torch.cat([torch.cat([_nchw(Hf[j:j + B]), _nchw(Hb[j:j + B]), _nchw(P8[j:j + B, ..., :1])], 1) for j in range(5)], 1)
+        rw, rb = ref_wgrad(xin, _nchw(dy[..., :129]), 129, 645)
+    else:
+        plan = P.r2_wgrad
+        R1 = torch.zeros(B + 1, H, W, P.C1p)
+        R1[..., :129] = R(B + 1, H, W, 129)
+        R1 = R1.to(bf)
+        dy = R(B, H, W, 64).to(bf)
+        xs, ys = [Src(R1.to(dev), img_off=1)], [Src(dy.to(dev))]
+        shape = (64, 129, 3, 3)
+        rw, rb = ref_wgrad(_nchw(R1[1:, ..., :129]), _nchw(dy), 64, 129)
+    dw, db = torch.full(shape, float('nan'), device=dev), torch.full(shape[:1], float('nan'), device=dev)
+    ops.wgrad(plan, xs, ys, B, H, W, dw, db)
+    torch.cuda.synchronize()
+    _close_f32(dw, rw, f'{which}.dw', rel=3e-5)
+    _close_f32(db, rb, f'{which}.db', rel=3e-5)
+    dw2, db2 = dw.clone(), db.clone()
+    ops.wgrad(plan, xs, ys, B, H, W, dw2, db2, accumulate=True)               # accumulate: exactly twice; and bitwise repeatable
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dw + dw) and torch.equal(db2, db + db)
+
+
+def test_mixed_type_helpers_vs_torch():
+    from hipvsr.hip_ops import HipOps
+    from torch_ops import TorchOps
+    dev = _dev()
+    ops, ref = HipOps(dev), TorchOps('cpu')
+    g = torch.Generator('cpu').manual_seed(3)
+    R = lambda *sh: torch.randn(*sh, generator=g)                           # noqa: E731
+    bf = torch.bfloat16
+    # add: every combination of operand types, store and accumulate
+    a, b, c = R(3, 5, 7, 16), R(3, 5, 7, 16).to(bf), R(3, 5, 7, 16)
+    for odt in (torch.float32, bf):
+        for acc in (False, True):
+            o0 = R(3, 5, 7, 16).to(odt)
+            od = o0.to(dev)
+            ops.add(od, a.to(dev), b.to(dev), c.to(dev), accumulate=acc)
+            want = ref.add(o0.clone(), a, b, c, accumulate=acc)
+            torch.cuda.synchronize()
+            assert torch.equal(od.cpu(), want), (odt, acc)
+    # cast both ways; phase plane
+    x = R(2, 4, 4, 24)
+    assert torch.equal(ops.cast(x.to(dev), bf).cpu(), x.to(bf)) and torch.equal(ops.cast(x.to(bf).to(dev), torch.float32).cpu(), x.to(bf).float())
+    pos = torch.rand(3, 5, 1, generator=g) * 2 - 1
+    pp = ops.phase_plane(pos.to(dev), 3, 5, 4, 6, dtype=bf, channels=8)
+    assert torch.equal(pp.cpu(), ref.phase_plane(pos, 3, 5, 4, 6, dtype=bf, channels=8))
+    # gate backward: bf16 dh / gates / dgates, fp32 cell states; with and without the optional operands
+    hd, npix = 16, 3 * 5 * 7
+    for has in (True, False):
+        dh, dh2 = R(npix, hd).to(bf), (R(npix, hd) if has else None)           # dh2 may have another type than dh
+        gates = torch.sigmoid(R(npix, 4 * hd)).to(bf)
+        cn, cp, dcn = R(npix, hd), (R(npix, hd) if has else None), (R(npix, hd) if has else None)
+        dgd, dcpd = torch.full((npix, 4 * hd), float('nan'), device=dev, dtype=bf), torch.full((npix, hd), float('nan'), device=dev)
+        D = lambda t: None if t is None else t.to(dev)                      # noqa: E731
+        ops.lstm_gates_bwd(D(dh), D(dcn), D(gates), D(cp), D(cn), dgd, dcpd, dh2=D(dh2))
+        dg_ref, dcp_ref = torch.zeros(npix, 4 * hd, dtype=bf), torch.zeros(npix, hd)
+        ref.lstm_gates_bwd(dh, dcn, gates, cp, cn, dg_ref, dcp_ref, dh2=dh2)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(dcpd.cpu(), dcp_ref, atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(dgd.cpu().float(), dg_ref.float(), atol=1e-6, rtol=2 ** -7)   # one rounding boundary at most
+
+
+def test_engine_bf16_vs_torch_double_on_a_ragged_shape():
+    """The whole bf16 engine (every launch of the path: 64-column and 128-column tiles, all three epilogues, multi-source K,
+    accumulating stores, weight gradients) against the same engine over the torch double, which rounds to bf16 at the same
+    places.  What differs is accumulation order - and the occasional bf16 rounding boundary that a 1e-7 difference flips,
+    whose 4e-3 relative step then propagates: hence L2 criteria, not elementwise ones."""
+    from hipvsr.engine import RefineNetEngine
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.spec import NetConfig
+    from torch_ops import TorchOps
+    dev = _dev()
+    kw = dict(in_channels=1, out_channels=1, num_features=[64, 64], num_stages=2, refine_window_size=5, upscale_factor=4,
+              update_memory=True, num_updated_frames=2, positional_encoding=True)
+    cfg = NetConfig(**kw)
+    sd = orc.init_state_dict(orc.Config(**kw), seed=3)
+    inputs, targets, pos = orc.synthetic_batch(orc.Config(**kw), n=2, t=2, h=20, w=13, seed=4)
+    res = {}
+    for name, ops, d in (('hip', HipOps(dev), dev), ('ref', TorchOps('cpu'), torch.device('cpu'))):
+        eng = RefineNetEngine(cfg, ops, dtype='bf16')
+        params = {k: v.to(d) for k, v in sd.items()}
+        O, ctx = eng.forward(params, [x.to(d) for x in inputs], pos.to(d), need_grad=True)
+        g = torch.Generator('cpu').manual_seed(9)
+        dO = (torch.randn(O.shape, generator=g) * 1e-3).to(d)
+        grads = eng.backward(params, ctx, dO)
+        res[name] = (O.cpu(), {k: (v.cpu() if v is not None else None) for k, v in grads.items()})
+    a, b = res['hip'][0].double(), res['ref'][0].double()
+    assert not torch.isnan(a).any()
+    assert float((a - b).norm()) <= 3e-3 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+    for k, v in res['ref'][1].items():
+        if v is None:
+            assert res['hip'][1][k] is None
+            continue
+        mine = res['hip'][1][k].double()
+        assert not torch.isnan(mine).any(), k
+        assert float((mine - v.double()).norm()) <= 1e-2 * float(v.double().norm()) + 1e-9, (k, float((mine - v.double()).norm()), float(v.norm()))
+
+
+def _module_step(kwargs, sd, inputs, targets, pos, dtype):
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    dev = _dev()
+    net = RefineNet(**kwargs)
+    net.load_state_dict(sd)
+    net = net.to(dev).set_compute_dtype(dtype)
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.net, tr.loss_fns, tr.metric_fns = net, [torch.nn.L1Loss()], []
+    net.train()
+    outs = net([x.to(dev) for x in inputs], pos.to(dev))
+    loss = tr._compute_losses(outs, [t.to(dev) for t in targets])[0]
+    net.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    return net, tr, outs, loss
+
+
+def _psnr(tr, outs, targets):
+    import functools
+    from src.model.metrics import PSNR
+    from src.utils import denormalize
+    tr.metric_fns = [PSNR().to(_dev())]
+    tr._denormalize = functools.partial(denormalize, dataset='acdc')
+    return float(tr._compute_metrics(outs, [t.to(_dev()) for t in targets])[0])
+
+
+@pytest.mark.parametrize('name,n,t,h,w', [('BASELINE config 1', 1, 3, 64, 64), ('config 2 / 3 geometry', 2, 7, 128, 128)])
+def test_bf16_module_vs_fp32_oracle(name, n, t, h, w):
+    """The contract's bf16 criterion against the CPU oracle (== the reference) on identical inputs:
+    |delta PSNR| < 0.01 dB and loss rtol 1e-2; gradients (no contract figure for bf16) within 5 % in L2 per tensor.
+    Also: the state_dict is untouched by the dtype switch and the outputs / parameter gradients are fp32."""
+    from oracle import step_tail_oracle as sto
+    cfg = orc.exp1_x4_config()
+    sd = orc.init_state_dict(cfg, seed=77)
+    inputs, targets, pos = orc.synthetic_batch(cfg, n, t, h, w, seed=78)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref_out, ref_loss, ref_grads = orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
+    net, tr, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, 'bf16')
+    assert net._engine().bf16 and all(o.dtype == torch.float32 for grp in outs for o in grp)
+    for k, v in net.state_dict().items():
+        assert v.dtype == torch.float32 and torch.equal(v.cpu(), sd[k]), k
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-2 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    psnr, want = _psnr(tr, outs, targets), float(sto.trainer_metrics(ref_out[-1], targets)[0])
+    assert abs(psnr - want) < 0.01, (psnr, want)
+    worst = 0.0
+    for go, gr in zip(outs, ref_out):
+        for a, b in zip(go, gr):
+            worst = max(worst, float((a.detach().cpu() - b).norm()) / float(b.norm()))
+    assert worst <= 2e-2, worst
+    gw = 0.0
+    for k, p in net.named_parameters():
+        if ref_grads[k] is None:
+            assert p.grad is None
+            continue
+        assert p.grad.dtype == torch.float32
+        rel = float((p.grad.cpu() - ref_grads[k]).norm()) / float(ref_grads[k].norm())
+        gw = max(gw, rel)
+        assert rel <= 5e-2, (k, rel)
+    print(f'bf16 vs fp32 oracle, {name}: loss {float(loss):.6f} vs {float(ref_loss):.6f}, PSNR {psnr:.4f} vs {want:.4f}, '
+          f'worst relative L2 error of an output {worst:.2e}, of a gradient {gw:.2e}')
+
+
+def test_bf16_training_step_is_bitwise_repeatable_and_switchable():
+    """No atomics in the bf16 kernels either (fixed-order slab reduction): the same step gives the same bits; switching the
+    module back to 'f32' rebuilds the engine and reproduces the fp32 result bit for bit."""
+    from src.model.nets import RefineNet
+    dev = _dev()
+    cfg = orc.exp1_x4_config(num_updated_frames=3)
+    net = RefineNet(**cfg)
+    net.load_state_dict(orc.init_state_dict(cfg, seed=1))
+    net = net.to(dev).train()
+    inputs, targets, pos = orc.synthetic_batch(cfg, 2, 2, 40, 45, seed=2)
+    xs, ys, pc = [x.to(dev) for x in inputs], [y.to(dev) for y in targets], pos.to(dev)
+
+    def step():
+        net.zero_grad()
+        outs = net(xs, pc)
+        sum((o - y).abs().mean() for grp in outs for o, y in zip(grp, ys)).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for grp in outs for o in grp] + [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    f32 = step()
+    net.set_compute_dtype('bf16')
+    ref = step()
+    assert not all(torch.equal(a, b) for a, b in zip(ref, f32))
+    for r in range(5):
+        assert all(torch.equal(a, b) for a, b in zip(step(), ref)), r
+    net.set_compute_dtype('f32')
+    assert all(torch.equal(a, b) for a, b in zip(step(), f32))
+    with pytest.raises(ValueError):
+        net.set_compute_dtype('fp8')

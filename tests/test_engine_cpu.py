@@ -22,10 +22,10 @@ def g1(golden_dir):
     return torch.load(os.path.join(golden_dir, 'g1_tiny.pt'), weights_only=False)
 
 
-def run_engine(c, kind=L.LOSS_L1, eps=1e-6):
+def run_engine(c, kind=L.LOSS_L1, eps=1e-6, dtype='f32'):
     cfg = NetConfig(**c['kwargs'])
     ops = TorchOps('cpu')
-    eng = RefineNetEngine(cfg, ops)
+    eng = RefineNetEngine(cfg, ops, dtype=dtype)
     params = {k: v.clone() for k, v in c['state_dict'].items()}
     O_all, ctx = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
     S, T = cfg.num_stages, len(c['targets'])
@@ -63,6 +63,30 @@ def test_engine_matches_reference_golden(g1, case):
         scale = float(gref.abs().max()) + 1e-12
         err = float((grads[k] - gref).abs().max())
         assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_engine_bf16_storage_plans_match_reference_golden(g1, case):
+    """The bf16-storage path's plans (no Winograd, no side paths, 8-channel phase planes, 64-column tiles) and dtype
+    plumbing, over the torch double that rounds to bf16 where the HIP kernels do: same computation as the reference up
+    to bf16 rounding of the stored activations and MFMA operands (8 mantissa bits: relative 4e-3 per rounding)."""
+    c = g1[case]
+    cfg, O_all, total, grads = run_engine(c, dtype='bf16')
+    S, T = cfg.num_stages, len(c['targets'])
+    N = c['inputs'][0].shape[0]
+    assert O_all.dtype == torch.float32
+    for g in range(3 * S):
+        for i in range(T):
+            mine = O_all[g // 3, g % 3, i * N:(i + 1) * N].permute(0, 3, 1, 2)
+            ref = c['outputs'][g][i]
+            assert float((mine - ref).norm()) <= 2e-2 * float(ref.norm()) + 1e-3, (g, i)
+    assert abs(float(total) - float(c['train_loss'])) <= 1e-2 * abs(float(c['train_loss']))
+    for k, gref in c['grads'].items():
+        if gref is None:
+            assert grads[k] is None
+            continue
+        assert grads[k].dtype == torch.float32 and not torch.isnan(grads[k]).any(), k
+        assert float((grads[k] - gref).norm()) <= 6e-2 * float(gref.norm()) + 1e-6, (k, float((grads[k] - gref).norm()), float(gref.norm()))
 
 
 def test_engine_charbonnier(g1):

@@ -213,8 +213,8 @@ def test_back_to_back_gathers_keep_their_own_descriptors():
     """120 gathers of DIFFERENT samples enqueued back to back behind a busy stream, no synchronisation in between, the
     host descriptor arrays freed and re-filled as Python pleases; batches of 40 samples span two launches (32 descriptors
     per launch).  Every batch must equal the oracle's for ITS items.  (Round 1 uploaded the descriptors with an
-    asynchronous copy from the caller's pageable array, which the next gather re-used: the root cause of the rare wrong
-    answer of the whole-cycle predictor when two cines were gathered back to back.)"""
+    asynchronous copy from the caller's pageable array, which the next gather re-used - safe only because the runtime
+    stages such copies before returning; the descriptors now travel as kernel arguments.)"""
     dev = torch.device('cuda:0')
     s = 2
     rng = np.random.RandomState(77)

@@ -67,11 +67,20 @@ class TorchOps:
         import contextlib
         return contextlib.nullcontext()
 
-    def empty(self, *shape):
-        return torch.full(shape, float('nan'), dtype=torch.float32, device=self.device)   # poison: catches unwritten reads
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.full(shape, float('nan'), dtype=dtype, device=self.device)   # poison: catches unwritten reads
 
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    # bf16-storage path: arithmetic in fp32 on operands ROUNDED to bf16 where the HIP kernels round them (the MFMA
+    # operands; every store into a bf16 tensor rounds once more through copy_)
+    @staticmethod
+    def _r(t, on):
+        return t.float().bfloat16().float() if on else t.float()
+
+    def cast(self, t, dtype):
+        return t if t.dtype == dtype else t.to(dtype)
 
     def stack_inputs(self, inputs):
         x = torch.stack([t.to(self.device, torch.float32) for t in inputs], dim=0)
@@ -80,6 +89,8 @@ class TorchOps:
 
     def pack(self, plan, w, b=None):
         weff = effective_weight(plan, w.detach())
+        if getattr(plan, 'bf16', False):
+            weff = weff.bfloat16().float()
         bp = None
         if b is not None and not plan.transposed:
             bp = torch.zeros(plan.Npad, dtype=torch.float32, device=self.device)
@@ -90,7 +101,8 @@ class TorchOps:
 
     def conv(self, plan, srcs, B, H, W, dsts=None, ps=None, lstm=None):
         weff, bp = self._w[id(plan)]
-        x = torch.cat([gather_src(s, B) for s in srcs], dim=-1).permute(0, 3, 1, 2)
+        bf = getattr(plan, 'bf16', False)
+        x = torch.cat([self._r(gather_src(s, B), bf) for s in srcs], dim=-1).permute(0, 3, 1, 2)
         assert x.shape[1] == weff.shape[1], (plan.name, x.shape, weff.shape)
         y = F.conv2d(x, weff, bp if plan.bkey is not None else None, padding=1 if plan.ntaps == 9 else 0)
         y = y.permute(0, 2, 3, 1)                     # (B, H, W, Npad)
@@ -100,7 +112,7 @@ class TorchOps:
                 tgt = d.t[d.img_off:d.img_off + B, ..., d.c0:d.c0 + d.ncols]
                 val = y[..., col:col + d.ncols]
                 if d.accumulate:
-                    tgt += val
+                    tgt.copy_(tgt.float() + val)
                 else:
                     tgt.copy_(val)
                 col += d.ncols
@@ -127,8 +139,9 @@ class TorchOps:
                 lstm['gates_out'].copy_(torch.cat([gi, gf, go, gg], dim=-1))
 
     def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
-        x = torch.cat([gather_src(s, B) for s in xsrcs], dim=-1).permute(0, 3, 1, 2)
-        dy = torch.cat([gather_src(s, B) for s in ysrcs], dim=-1).permute(0, 3, 1, 2)
+        bf = getattr(plan, 'bf16', False)
+        x = torch.cat([self._r(gather_src(s, B), bf) for s in xsrcs], dim=-1).permute(0, 3, 1, 2)
+        dy = torch.cat([self._r(gather_src(s, B), bf) for s in ysrcs], dim=-1).permute(0, 3, 1, 2)
         kh = 3 if plan.ntaps == 9 else 1
         w0 = torch.zeros(dy.shape[1], x.shape[1], kh, kh, dtype=torch.float32, device=self.device, requires_grad=True)
         with torch.enable_grad():
@@ -252,10 +265,10 @@ class TorchOps:
                 M[:, :, ty, tx] = torch.einsum('bhwd,bhwc->dc', D, ypad[:, ty:ty + Hm, tx:tx + Wm])
         return M, D.sum(dim=(0, 1, 2))
 
-    def uptail_expand(self, d_o, r):
+    def uptail_expand(self, d_o, r, Dc=None):
         B, Hh, Wh, Co = d_o.shape
         nd = r + 2
-        dc = (Co * nd * nd + 3) // 4 * 4
+        dc = (Co * nd * nd + 3) // 4 * 4 if Dc is None else Dc
         pad = F.pad(d_o.permute(0, 3, 1, 2), (1, r, 1, r))                                  # index p + 1; zeros outside
         D = torch.zeros(B, Hh // r, Wh // r, dc, device=self.device)
         for co in range(Co):
@@ -290,8 +303,10 @@ class TorchOps:
 
     def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=None):
         hd = dh.shape[-1]
+        dh = dh.float()
         if dh2 is not None:
-            dh = dh + dh2
+            dh = dh + dh2.float()
+        gates = gates.float()
         gi, gf, go, gg = (gates[..., k * hd:(k + 1) * hd] for k in range(4))
         th = torch.tanh(c_next)
         dct = dh * go * (1 - th * th)
@@ -304,20 +319,20 @@ class TorchOps:
             dc_prev.copy_(dct * gf)
 
     def add(self, out, a, b=None, c=None, accumulate=False):
-        v = a.clone()
+        v = a.float().clone()
         if b is not None:
-            v = v + b
+            v = v + b.float()
         if c is not None:
-            v = v + c
+            v = v + c.float()
         if accumulate:
-            out += v
+            out.copy_(out.float() + v)
         else:
             out.copy_(v)
         return out
 
-    def phase_plane(self, pos, N, Fr, H, W):
+    def phase_plane(self, pos, N, Fr, H, W, dtype=torch.float32, channels=4):
         p = pos.reshape(N, Fr).to(self.device).t().reshape(Fr * N, 1, 1, 1).expand(Fr * N, H, W, 1)
-        return torch.cat([p, torch.zeros(Fr * N, H, W, 3, device=self.device)], dim=-1).contiguous()
+        return torch.cat([p, torch.zeros(Fr * N, H, W, channels - 1, device=self.device)], dim=-1).contiguous().to(dtype)
 
     def loss(self, o, y, G, T, kind, eps, gscale=None, want_grad=False):
         per = y.numel() // T
