@@ -3,38 +3,35 @@
 // data gradients; the reference itself is fp32 throughout - BASELINE.json configs[2] asks for this path).
 //
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so this kernel is not MFMA-bound but bound by how fast
-// operands reach the matrix cores; the design therefore moves every input byte as few times as possible:
+// operands reach the matrix cores and by everything that is NOT an MFMA; the design therefore moves every input byte as
+// few times as possible and keeps two workgroups on every CU so that one's non-MFMA phases run under the other's MFMAs:
 //
-//   * one workgroup (4 waves) = TH x TW = 8 x 32 output pixels of one image x NCOLS = 128 (64) output columns;
+//   * one workgroup (4 waves) = 8 x 32 output pixels of one image x NCOLS = 128 (64) output columns;
 //     wave = (pixel half: 4 rows of 32 pixels) x (column half): 4 x NB accumulator tiles of 32 x 32;
-//   * per 16-channel chunk of the K dimension the 10 x 34 pixel HALO of the tile is staged ONCE in LDS (bf16; fp32
-//     sources are converted on the way with v_cvt_pk_bf16_f32) and serves all 9 taps - the A operand of tap (dy, dx)
-//     is the same LDS image read at a shifted address; the chunk's packed weights of all taps (9 x NCOLS x 16) are staged
-//     beside it.  Both images use a 48-byte pitch per pixel / column (32 B of data + 16 B pad): a 16-byte fragment read of
-//     32 consecutive pixels then touches every bank exactly once per 16-lane group (12 i mod 64, i = 0..15, are distinct
-//     multiples of 4);
-//   * two LDS buffers, one barrier per chunk: chunk c+1 is written (from registers loaded a chunk earlier) while chunk c
-//     is being multiplied, chunk c+2 is requested right behind the barrier;
-//   * epilogue through LDS: the waves park their fp32 accumulators (+ bias) as a [256 pixels][NCOLS] tile, then all 256
-//     threads finish 8 columns of a pixel at a time with 16-byte global accesses - STORE (segments, optional accumulate,
-//     fp32 or bf16), PS (PixelShuffle fused into the store) or LSTM (the four gates of 8 hidden channels meet in one
-//     thread: sigmoid / tanh, c' = f c + i g, h' = o tanh c'; c stays fp32).
+//   * A operand: per 16-channel chunk of the K dimension the 10 x 34 pixel HALO of the tile is staged ONCE in LDS (bf16;
+//     fp32 sources are converted on the way with v_cvt_pk_bf16_f32) and serves all 9 taps - the fragment of tap (dy, dx)
+//     is the same LDS image read at a shifted address.  48-byte pitch per pixel (32 B of data + 16 B pad): a 16-byte
+//     fragment read of 32 consecutive pixels touches every bank exactly once per 16-lane group.  Two halo buffers, one
+//     barrier per chunk; the staging loads are raw buffer loads without a branch (out-of-range offset = zero padding);
+//   * B operand: straight from L2 into registers, two taps ahead, in a ring of three fragment sets (see the kernel);
+//   * epilogue through LDS: the fp32 accumulators (+ bias) are parked as a [pixel][column] tile (128 pixels at a time for
+//     128-column tiles), then all 256 threads finish 8 columns of a pixel per step with whole-row 16-byte global accesses -
+//     STORE (segments, optional accumulate, fp32 or bf16), PS (PixelShuffle fused into the store) or LSTM (the four gates
+//     of 8 hidden channels meet in one thread: sigmoid / tanh, c' = f c + i g, h' = o tanh c'; c stays fp32).
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l, r = l & 31, h = l >> 5 holds A[row r][k = 8h + j] and
 // B[k = 8h + j][col r], j = 0..7; C/D: col = l & 31, row = (v & 3) + 8 (v >> 2) + 4 h.  Rows = the 32 pixels of one
 // image-row segment, k = channel inside the chunk.
 #include "rnh_common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TH = 8, TW = 32, HPW = TW + 2, HPH = TH + 2, HP = HPW * HPH;   // halo: 10 x 34 = 340 pixels
+constexpr int TW = 32, HPW = TW + 2;                                         // tile width; halo width
 constexpr int PITCH = 48;                                                    // bytes per halo pixel / weight column
-constexpr int A_BYTES = HP * PITCH;                                          // 16 320
-constexpr int A_PIECES = 2 * HP;                                             // 16-byte pieces (8 channels) per chunk
-constexpr int A_ITERS = (A_PIECES + 255) / 256;                              // 3
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
     const bf16x2 r = {(__bf16)a, (__bf16)b};                                 // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
@@ -78,6 +75,10 @@ __device__ __forceinline__ float b_tanh(float x) {
     return copysignf(ax < 0.04f ? small : big, x);
 }
 
+// tanh as 2 sigmoid(2x) - 1: one exp, one rcp, two FMAs; absolute error <= 2 ulp of 1 (as the candidate gate of
+// conv_wino.hip) - in the bf16-storage path h' = o tanh(c') is rounded to 8 bits anyway
+__device__ __forceinline__ float b_tanh_fast(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
+
 // wp[ks][n][kk] = W[o][i][tap] as bf16, index conventions of rnh_pack_weights (conv_igemm.hip), kk in natural order
 __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned short *wp, float *biasp, const int *kbase, const int *knv,
                                  const int *ktap, const int *kcoff, const int *colmap, int nk, int Npad, int Cout, int Cin, int ntaps,
@@ -101,23 +102,53 @@ __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned sho
     }
 }
 
+// wave-uniform raw-buffer descriptor: base + 2 GiB window; an offset of 0xFFFFFFFF is out of range and reads as 0 -
+// zero padding and absent channels cost no branch (the convention of conv_igemm.hip / conv_wino.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bdesc(const void *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+#ifdef RNH_STAMPS
+__device__ unsigned long long g_bf16_stamps[64];
+#define BSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_bf16_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BSTAMP(i)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The kernel.  ("Variant D" of this round's experiments; variant L staged the weights of a chunk through LDS beside the
+// halo - 143 KB, one workgroup per CU, 125 us for the ConvLSTM cell; as 4 x 32 pixel tiles with two workgroups per CU 115 us;
+// this one 95 us: profiles/README.md, r02_c.)  The B operand never touches LDS.  The packed weights [chunk*tap][Npad][16] are laid out
+// such that the fragment of (chunk, tap, 32-column block) is ONE contiguous kilobyte (lane l reads bytes 32 (l & 31) +
+// 16 (l >> 5) .. +16 of it), the whole weight set (<= 1.3 MB) lives in L2, and a wave needs each fragment exactly once: so
+// every wave streams its fragments with raw buffer loads straight into registers, two taps ahead of their MFMAs, in a
+// ring of three register sets that runs across chunk boundaries and knows nothing of the barriers.  LDS then holds only
+// the halo (16 KB per buffer, double-buffered), the staging phase per chunk shrinks from 12 to 3 16-byte LDS writes per
+// thread, and the epilogue parks 128 pixels at a time for 128-column tiles (two rounds): 68 KB of LDS per workgroup, TWO
+// workgroups of 8 x 32 pixels per CU - one's prologue, barriers and epilogue run under the other's MFMAs.
 template <int NCOLS>
-struct Geo {
-    static constexpr int NB = NCOLS / 64;                       // 32-column MFMA blocks per wave
-    static constexpr int B_BYTES = 9 * NCOLS * PITCH;
-    static constexpr int BUF = A_BYTES + B_BYTES;
-    static constexpr int OPITCH = NCOLS + 4;                    // floats per pixel of the parked output tile
-    static constexpr int OUT_BYTES = TH * TW * OPITCH * 4;
-    static constexpr int SMEM = 2 * BUF > OUT_BYTES ? 2 * BUF : OUT_BYTES;
-    static constexpr int B_PIECES_TAP = NCOLS * 2;              // 16-byte pieces of one tap
+struct GeoD {
+    static constexpr int TH = 8, MB = 4, NB = NCOLS / 64;
+    static constexpr int HPH = TH + 2, HP = HPW * HPH;
+    static constexpr int A_BYTES = HP * PITCH, A_PIECES = 2 * HP, A_ITERS = (A_PIECES + 255) / 256;
+    static constexpr int OPITCH = NCOLS + 4;                    // floats per parked pixel
+    static constexpr int PXR = NCOLS == 128 ? 128 : 256;        // pixels parked per epilogue round
+    static constexpr int OUT_BYTES = PXR * OPITCH * 4;
+    static constexpr int SMEM = 2 * A_BYTES > OUT_BYTES ? 2 * A_BYTES : OUT_BYTES;
+    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
 };
 
 template <int EPI, int NCOLS, int NTAPS>
-__global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const rnh_conv_bf16_args_t P, const int TYn, const int TXn, const int NT) {
-    using G = Geo<NCOLS>;
-    constexpr int NB = G::NB;
-    constexpr int B_ITERS = (NTAPS * G::B_PIECES_TAP + 255) / 256;
-    constexpr bool B_EXACT = (NTAPS * G::B_PIECES_TAP) % 256 == 0;          // every thread has a piece in every iteration
+__global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_args_t P, const int TYn, const int TXn, const int NT) {
+    using G = GeoD<NCOLS>;
+    constexpr int TH = G::TH, NB = G::NB, MB = G::MB, A_BYTES = G::A_BYTES, A_PIECES = G::A_PIECES, A_ITERS = G::A_ITERS;
+    static_assert(NTAPS % 3 == 0 || NTAPS == 1, "the fragment ring has three sets");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
@@ -129,9 +160,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const rnh_conv_bf16_a
     const int H = P.H, W = P.W;
     const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
 
-    // ---- this thread's pieces of the halo (fixed for the whole K loop) --------------------------------------------
-    long apix[A_ITERS];           // source pixel index inside an image (scale applied), -1: zero padding / no piece
-    int alds[A_ITERS], ahalf[A_ITERS];
+    int apix[A_ITERS], alds[A_ITERS], ahalf[A_ITERS];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
         const int p = tid + 256 * i, px = p >> 1, hr = px / HPW, hc = px - hr * HPW;
@@ -139,40 +168,27 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const rnh_conv_bf16_a
         const bool in = p < A_PIECES && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         ahalf[i] = p & 1;
         alds[i] = p < A_PIECES ? px * PITCH + (p & 1) * 16 : -1;
-        apix[i] = in ? (long)(y * sc) * Ws + x * sc : -1;
+        apix[i] = in ? (y * sc) * Ws + x * sc : -1;
     }
 
-    uint4 ra[A_ITERS], rb[B_ITERS];
-    int si = 0, cc = 0;                                         // loader state: source, chunk inside it
-    auto load_chunk = [&](int cg) {
+    uint4 ra[A_ITERS], rh[A_ITERS];
+    int ra_f32 = 0;
+    int si = 0, cc = 0;
+    auto load_chunk = [&]() {
         const rnh_msrc_t &S = P.src[si];
-        const long ibase = ((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x;
+        const int es = S.dtype == RNH_DT_BF16 ? 2 : 4;
+        const char *base = reinterpret_cast<const char *>(S.ptr) +
+                           ((((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x) * S.C + S.c0 + cc * 16) * es;
+        const __amdgpu_buffer_rsrc_t rs = bdesc(base);
+        const int pstride = S.C * es, left = S.nch - cc * 16;
+        ra_f32 = S.dtype != RNH_DT_BF16;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int ch = cc * 16 + ahalf[i] * 8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (apix[i] >= 0 && ch < S.nch) {
-                const long e = (ibase + apix[i]) * S.C + S.c0 + ch;
-                if (S.dtype == RNH_DT_BF16) {
-                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned short *>(S.ptr) + e);
-                } else {
-                    const float *f = reinterpret_cast<const float *>(S.ptr) + e;
-                    const float4 lo = *reinterpret_cast<const float4 *>(f);
-                    const float4 hi = ch + 4 < S.nch ? *reinterpret_cast<const float4 *>(f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v = pack8(lo, hi);
-                }
-            }
-            ra[i] = v;
-        }
-        const unsigned short *wb = reinterpret_cast<const unsigned short *>(P.wp) + ((long)cg * NTAPS * P.Npad + nt * NCOLS) * 16;
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            const int p = tid + 256 * i;
-            rb[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (B_EXACT || p < NTAPS * G::B_PIECES_TAP) {
-                const int tap = p / G::B_PIECES_TAP, rem = p - tap * G::B_PIECES_TAP;
-                rb[i] = *reinterpret_cast<const uint4 *>(wb + (long)tap * P.Npad * 16 + rem * 8);
-            }
+            const int ch = ahalf[i] * 8;
+            const bool ok = apix[i] >= 0 && ch < left;
+            const int off = apix[i] * pstride + ch * es;
+            ra[i] = bld16(rs, ok ? off : -1);
+            rh[i] = bld16(rs, ok && ra_f32 && ch + 4 < left ? off + 16 : -1);
         }
         if (++cc * 16 >= S.nch) {
             cc = 0;
@@ -180,147 +196,195 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const rnh_conv_bf16_a
         }
     };
     auto store_chunk = [&](int buf) {
-        unsigned char *Ab = smem + buf * G::BUF, *Bb = Ab + A_BYTES;
+        unsigned char *Ab = smem + buf * A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i)
-            if (alds[i] >= 0) *reinterpret_cast<uint4 *>(Ab + alds[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            const int p = tid + 256 * i;
-            if (B_EXACT || p < NTAPS * G::B_PIECES_TAP) {
-                const int tap = p / G::B_PIECES_TAP, rem = p - tap * G::B_PIECES_TAP;
-                *reinterpret_cast<uint4 *>(Bb + (tap * NCOLS + (rem >> 1)) * PITCH + (rem & 1) * 16) = rb[i];
-            }
+        for (int i = 0; i < A_ITERS; ++i) {
+            const uint4 v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
+            if (alds[i] >= 0) *reinterpret_cast<uint4 *>(Ab + alds[i]) = v;
         }
     };
 
-    f32x16 acc[4][NB];
+    // weight fragments: descriptor over the packed weights, per-lane offset inside a (chunk, tap) slab, slab stride
+    const __amdgpu_buffer_rsrc_t wrs = bdesc(P.wp);
+    const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
+    const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
+    const int nslabs = P.nchunks * NTAPS;
+    constexpr int RING = NTAPS == 1 ? 1 : 3;
+    uint4 bq[RING][NB];
+    auto bload = [&](int g, int set) {                         // fragments of global tap index g (beyond the end: zeros, unused)
+        const int base = g < nslabs ? g * slab : -1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, g < nslabs ? base + wlane + n * 32 * 32 : -1);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
+    const int nch = P.nchunks;
 
-    auto compute = [&](int buf) {
-        const unsigned char *Ab = smem + buf * G::BUF, *Bb = Ab + A_BYTES;
+    // One chunk.  The halo of chunk c + 1 sits in registers since tap 2 of chunk c - 1 (a whole chunk of MFMAs ago, so the
+    // wait in store_chunk costs nothing); at tap 2 it goes to the other LDS buffer - nobody reads that one before the
+    // barrier at the end of this chunk - and the loads of chunk c + 2 are issued into the same registers.
+    auto compute = [&](int buf, int c) {
+        const unsigned char *Ab = smem + buf * A_BYTES + (MB * ph * HPW + l31) * PITCH + kh * 16;
+        bf16x8 a[2][MB];
+        auto afrags = [&](int tap, int set) {
+            const int dy = NTAPS == 9 ? tap / 3 : 1, dx = NTAPS == 9 ? tap % 3 : 1;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[set][m] = *reinterpret_cast<const bf16x8 *>(Ab + ((m + dy) * HPW + dx) * PITCH);
+        };
+        afrags(0, 0);
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
-            const int dy = NTAPS == 9 ? tap / 3 : 1, dx = NTAPS == 9 ? tap % 3 : 1;
-            bf16x8 a[4], b[NB];
+            if (tap + 1 < NTAPS) afrags(tap + 1, (tap + 1) & 1);
+            if constexpr (NTAPS == 9) bload(c * NTAPS + tap + 2, (tap + 2) % 3);      // two taps ahead; (9 c + tap) % 3 == tap % 3
+            if (tap == (NTAPS == 9 ? 2 : 0)) {
+                if (c + 1 < nch) store_chunk(buf ^ 1);
+                if (c + 2 < nch) load_chunk();
+            }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                a[m] = *reinterpret_cast<const bf16x8 *>(Ab + ((4 * ph + m + dy) * HPW + l31 + dx) * PITCH + kh * 16);
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
-                b[n] = *reinterpret_cast<const bf16x8 *>(Bb + (tap * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31) * PITCH + kh * 16);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NB; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][m], __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? tap % 3 : 0][n]),
+                                                                        acc[m][n], 0, 0, 0);
+            if constexpr (NTAPS == 1) bload(c + 1, 0);
         }
     };
 
-    // ---- K loop -----------------------------------------------------------------------------------------------------
-    const int nch = P.nchunks;
-    load_chunk(0);
+    // ---- K loop: double-buffered halo, one barrier per chunk ------------------------------------------------------------
+    BSTAMP(0);
+    bload(0, 0);
+    if constexpr (NTAPS == 9) bload(1, 1);
+    load_chunk();
     store_chunk(0);
-    if (nch > 1) load_chunk(1);
+    if (nch > 1) load_chunk();
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
-        compute(c & 1);
-        if (c + 1 < nch) store_chunk((c + 1) & 1);              // the registers hold chunk c + 1
+        BSTAMP(8 + 3 * (c & 15));
+        compute(c & 1, c);
+        BSTAMP(9 + 3 * (c & 15));
+        BSTAMP(10 + 3 * (c & 15));
         __syncthreads();
-        if (c + 2 < nch) load_chunk(c + 2);
     }
+    BSTAMP(1);
 
-    // ---- park the accumulators (+ bias) as an fp32 [pixel][column] tile in LDS ------------------------------------------
-    float *ot = reinterpret_cast<float *>(smem);                // every wave is past its last fragment read (barrier above)
+    // ---- epilogue: the accumulators (+ bias) are parked as an fp32 [pixel][column] tile, PXR pixels at a time (128-column
+    // tiles: the two pixel halves in turn, parked by the two waves that own them; 64-column tiles: all 256 at once), and
+    // all 256 threads finish 8 columns of a pixel per step with whole-row 16-byte accesses ------------------------------
+    float *ot = reinterpret_cast<float *>(smem);
+    constexpr int PXR = G::PXR, ROUNDS = TH * TW / PXR;
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        const int col = chalf * (NCOLS / 2) + n * 32 + l31;
-        const float bv = P.bias ? P.bias[nt * NCOLS + col] : 0.f;
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r > 0) __syncthreads();                             // the previous round has been read
+        if (ROUNDS == 1 || ph == r) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int n = 0; n < NB; ++n) {
+                const int col = chalf * (NCOLS / 2) + n * 32 + l31;
+                const float bv = P.bias ? P.bias[nt * NCOLS + col] : 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int px = (4 * ph + m) * TW + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                ot[px * G::OPITCH + col] = acc[m][n][v] + bv;
-            }
-    }
-    __syncthreads();
-
-    // ---- cooperative finish: 8 columns of one pixel per step ------------------------------------------------------------
-    if constexpr (EPI == RNH_EPI_LSTM) {
-        // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap); NCOLS == 128
-        const int hd = P.hd;
-        for (int it = tid; it < TH * TW * 4; it += 256) {
-            const int px = it >> 2, j0 = (it & 3) * 8, hc = nt * 32 + j0;
-            const int y = y0 + px / TW, x = x0 + (px & (TW - 1));
-            if (y >= H || x >= W || hc >= hd) continue;
-            const float *o = ot + px * G::OPITCH + j0;
-            const long pe = ((long)img * H + y) * W + x;
-            float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
-            if (P.c_prev) {
-                load8(P.c_prev, RNH_DT_F32, pe * hd + hc, cp);
-            } else {
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                gi[e] = b_sigmoid(o[e]);
-                gf[e] = b_sigmoid(o[32 + e]);
-                go[e] = b_sigmoid(o[64 + e]);
-                gg[e] = b_tanh(o[96 + e]);
-                cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-                hn[e] = go[e] * b_tanh(cn[e]);
-            }
-            store8(P.c_out, RNH_DT_F32, pe * hd + hc, cn);
-            store8(P.h_out, P.h_dtype, pe * hd + hc, hn);
-            if (P.gates_out) {
-                store8(P.gates_out, P.gates_dtype, pe * 4 * hd + hc, gi);
-                store8(P.gates_out, P.gates_dtype, pe * 4 * hd + hd + hc, gf);
-                store8(P.gates_out, P.gates_dtype, pe * 4 * hd + 2 * hd + hc, go);
-                store8(P.gates_out, P.gates_dtype, pe * 4 * hd + 3 * hd + hc, gg);
+                    for (int v = 0; v < 16; ++v) {
+                        const int px = (ROUNDS == 1 ? MB * ph + m : m) * TW + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                        ot[px * G::OPITCH + col] = acc[m][n][v] + bv;
+                    }
             }
         }
-    } else {
-        constexpr int G8 = NCOLS / 8;
-        for (int it = tid; it < TH * TW * G8; it += 256) {
-            const int px = it / G8, c8 = it - px * G8;
-            const int y = y0 + px / TW, x = x0 + (px & (TW - 1));
-            if (y >= H || x >= W) continue;
-            const int n0 = nt * NCOLS + c8 * 8;
-            const float *o = ot + px * G::OPITCH + c8 * 8;
-            float f[8];
+        __syncthreads();
+        if (r == 0) BSTAMP(2);
+        const int ybase = y0 + r * (PXR / TW);
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap).  A thread's 8 channels
+            // are the same in every step (256 % 4 == 0): everything but the pixel is hoisted out of the loop
+            const int hd = P.hd, j0 = (tid & 3) * 8, hc = nt * 32 + j0;
+            const float *cprev = P.c_prev;
+            float *cout = P.c_out;
+            void *hout = P.h_out, *gout = P.gates_out;
+            const int hdt = P.h_dtype, gdt = P.gates_dtype;
+            if (hc < hd) {
+                for (int px = tid >> 2; px < PXR; px += 64) {
+                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const float *o = ot + px * G::OPITCH + j0;
+                    const long pe = ((long)img * H + y) * W + x;
+                    float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
+                    if (cprev) {
+                        load8(cprev, RNH_DT_F32, pe * hd + hc, cp);
+                    } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = o[e];
+                        for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        gi[e] = b_sigmoid(o[e]);
+                        gf[e] = b_sigmoid(o[32 + e]);
+                        go[e] = b_sigmoid(o[64 + e]);
+                        gg[e] = b_tanh_fast(o[96 + e]);
+                        cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                        hn[e] = go[e] * b_tanh_fast(cn[e]);
+                    }
+                    store8(cout, RNH_DT_F32, pe * hd + hc, cn);
+                    store8(hout, hdt, pe * hd + hc, hn);
+                    if (gout) {
+                        store8(gout, gdt, pe * 4 * hd + hc, gi);
+                        store8(gout, gdt, pe * 4 * hd + hd + hc, gf);
+                        store8(gout, gdt, pe * 4 * hd + 2 * hd + hc, go);
+                        store8(gout, gdt, pe * 4 * hd + 3 * hd + hc, gg);
+                    }
+                }
+            }
+        } else {
+            // a thread's 8 columns are the same in every step (256 % G8 == 0): destination segment / sub-pixel once per thread
+            constexpr int G8 = NCOLS / 8;
+            const int c8 = tid % G8, n0 = nt * NCOLS + c8 * 8;
+            bool live;
+            void *dptr;
+            int ddt, dacc = 0;
+            long dimg = 0, dpix = 0, dch = 0, dC = 0;                // element = ((img' * H + y) * W' + x') * dC + dch with the strides below
+            int ps_r = 1, ps_i = 0, ps_j = 0;
             if constexpr (EPI == RNH_EPI_PS) {
-                const int r = P.ps_r, cq = P.ps_cq;
-                if (n0 >= cq * r * r) continue;
-                const int sub = n0 / cq, c = n0 - sub * cq, pi = sub / r, pj = sub - pi * r;
-                const long e = ((((long)img * H + y) * r + pi) * ((long)W * r) + (long)x * r + pj) * cq + c;
-                store8(P.dst[0].ptr, P.dst[0].dtype, e, f);
+                const int rr = P.ps_r, cq = P.ps_cq;
+                live = n0 < cq * rr * rr;
+                const int sub = n0 / cq;
+                ps_r = rr, ps_i = sub / rr, ps_j = sub - (sub / rr) * rr;
+                dptr = P.dst[0].ptr, ddt = P.dst[0].dtype, dC = cq, dch = n0 - sub * cq, dimg = img;
             } else {
                 int seg = -1, cbase = 0;
                 for (int d = 0; d < P.ndst; ++d) {
                     if (seg < 0 && n0 < cbase + P.dst[d].ncols) seg = d;
                     if (seg < 0) cbase += P.dst[d].ncols;
                 }
-                if (seg < 0) continue;
-                const rnh_mdst_t &D = P.dst[seg];
-                const long e = (((long)(img + D.img_off) * H + y) * W + x) * D.C + D.c0 + (n0 - cbase);
-                if (D.accumulate) {
-                    float old[8];
-                    load8(D.ptr, D.dtype, e, old);
+                live = seg >= 0;
+                const rnh_mdst_t &D = P.dst[live ? seg : 0];
+                dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
+            }
+            (void)dpix;
+            if (live) {
+                for (int px = tid / G8; px < PXR; px += 256 / G8) {
+                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const float *o = ot + px * G::OPITCH + c8 * 8;
+                    float f[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) f[q] += old[q];
+                    for (int e = 0; e < 8; ++e) f[e] = o[e];
+                    const long e = ((dimg * H + y) * ps_r + ps_i) * ((long)W * ps_r) * dC + ((long)x * ps_r + ps_j) * dC + dch;
+                    if (dacc) {
+                        float old[8];
+                        load8(dptr, ddt, e, old);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] += old[q];
+                    }
+                    store8(dptr, ddt, e, f);
                 }
-                store8(D.ptr, D.dtype, e, f);
             }
         }
     }
+    BSTAMP(3);
 }
 
 inline int bgrid_for(long n, int cap = 8192) {
@@ -341,6 +405,12 @@ int check_msrc(const rnh_msrc_t &s, const char *who) {
 }  // namespace
 
 int rnh_check_msrc(const rnh_msrc_t &s, const char *who) { return check_msrc(s, who); }
+
+#ifdef RNH_STAMPS
+extern "C" int rnh_debug_bf16_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_stamps), sizeof(g_bf16_stamps));
+}
+#endif
 
 extern "C" int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase, const int32_t *knv,
                                      const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk, int Npad, int Cout, int Cin,
@@ -370,12 +440,13 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
     if (chunks != a.nchunks) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: nchunks = %d but the sources hold %d chunks of 16 channels", a.nchunks, chunks);
     if ((long)a.B * a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: too many pixels");
     const int ncols = a.Npad % 128 ? 64 : 128;
+    constexpr int TH = 8;
     const int TYn = (a.H + TH - 1) / TH, TXn = (a.W + TW - 1) / TW, NT = a.Npad / ncols;
     const long blocks = (long)a.B * TYn * TXn * NT;
     if (blocks >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(256);
-#define RNH_LAUNCH(EPI, NC, NTP) hipLaunchKernelGGL((conv_bf16_kernel<EPI, NC, NTP>), grid, block, 0, st, a, TYn, TXn, NT)
+#define RNH_LAUNCH(EPI, NC, NTP) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, NTP>), grid, block, 0, st, a, TYn, TXn, NT)
     switch (a.epilogue) {
         case RNH_EPI_STORE:
             if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad destination count");

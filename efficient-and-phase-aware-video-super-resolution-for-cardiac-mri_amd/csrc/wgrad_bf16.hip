@@ -7,7 +7,11 @@
 // is a GEMM whose K dimension is the PIXEL index, while the tensors are NHWC (channel-fastest): both MFMA operands need
 // 8 consecutive pixels of one channel per lane.  The transpose happens in the staging writes: every thread loads 8
 // channels of one pixel (16 bytes) and writes them as eight 2-byte LDS stores into channel-major row images
-// [channel][32 pixels] (80-byte pitch: the 16-byte fragment reads of 32 consecutive channels are bank-conflict free).
+// [channel][32 pixels] (80-byte pitch: the 16-byte fragment reads of 32 consecutive rows are bank-conflict free).
+// Channel c of a 64-channel tile lives in LDS row (c & 7) * 8 + (c >> 3): the eight channel groups a wave writes with
+// one ds_write_b16 then sit in consecutive rows, 20 dwords apart (banks 0, 20, 8, 28, 16, 4, 24, 12 - with the natural
+// order they were 160 dwords apart, i.e. all in ONE bank: an 8-way conflict on every staging write, measured at 19 % of
+// the bf16 MFMA peak); the MFMA rows / columns come out in that order and are un-permuted when the slab is written.
 //
 //   * work item = (image, 32-pixel column strip, range of RPI rows); per image row y one barrier-separated step;
 //   * the x shift of the taps would make the fragment reads of X start at odd 2-byte offsets, so every input row is
@@ -49,27 +53,38 @@ struct Grp {                                 // where the 8 channels of this thr
     int dtype, C, c0, img_off, sub_y, sub_x, ok;
 };
 
-// 8 channels of pixel (y, x) of image b as packed bf16 (zeros outside the image / for a padding group)
-__device__ __forceinline__ uint4 load_piece(const Grp &g, int b, int y, int x, int H, int W, int sc) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (g.ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-        const long e = ((((long)(b + g.img_off) * H * sc + (long)y * sc + g.sub_y) * ((long)W * sc)) + (long)x * sc + g.sub_x) * g.C + g.c0;
-        if (g.dtype == RNH_DT_BF16) {
-            v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned short *>(g.ptr) + e);
-        } else {
-            const float *f = reinterpret_cast<const float *>(g.ptr) + e;
-            const float4 lo = *reinterpret_cast<const float4 *>(f), hi = *reinterpret_cast<const float4 *>(f + 4);
-            v = make_uint4(wpk2(lo.x, lo.y), wpk2(lo.z, lo.w), wpk2(hi.x, hi.y), wpk2(hi.z, hi.w));
-        }
+// One piece in flight: 8 channels of a pixel as raw 16-byte loads (lo: 8 bf16 or 4 fp32; hi: the other 4 fp32).  The loads
+// are global loads of a clamped address (never a branch around a load: hipcc waits vmcnt(0) at the join) and the result
+// is masked / converted only when it is written to LDS, a whole row of MFMAs later.
+struct Piece {
+    uint4 lo, hi;
+    int ok;
+};
+__device__ __forceinline__ Piece load_piece(const Grp &g, int b, int y, int x, int H, int W, int sc) {
+    Piece p;
+    p.ok = g.ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const int yy = p.ok ? y : 0, xx = p.ok ? x : 0;             // a valid address either way
+    const long e = ((((long)(b + g.img_off) * H * sc + (long)yy * sc + g.sub_y) * ((long)W * sc)) + (long)xx * sc + g.sub_x) * g.C + g.c0;
+    const char *q = reinterpret_cast<const char *>(g.ptr) + e * (g.dtype == RNH_DT_BF16 ? 2 : 4);
+    p.lo = *reinterpret_cast<const uint4 *>(q);
+    p.hi = *reinterpret_cast<const uint4 *>(q + (g.dtype == RNH_DT_BF16 ? 0 : 16));
+    return p;
+}
+__device__ __forceinline__ uint4 piece_bf16(const Piece &p, int dtype) {
+    uint4 v = p.lo;
+    if (dtype != RNH_DT_BF16) {
+        const float4 lo = __builtin_bit_cast(float4, p.lo), hi = __builtin_bit_cast(float4, p.hi);
+        v = make_uint4(wpk2(lo.x, lo.y), wpk2(lo.z, lo.w), wpk2(hi.x, hi.y), wpk2(hi.z, hi.w));
     }
-    return v;
+    return p.ok ? v : make_uint4(0u, 0u, 0u, 0u);
 }
 
 __device__ __forceinline__ Grp find_group(const rnh_msrc_t *srcs, int nsrc, int ch) {
     Grp g;
     g.ok = 0;
-    g.ptr = nullptr;
-    g.dtype = g.C = g.c0 = g.img_off = g.sub_y = g.sub_x = 0;
+    g.ptr = srcs[0].ptr;                     // a padding group still issues its (masked) loads: they read the first bytes of source 0
+    g.dtype = srcs[0].dtype;
+    g.C = g.c0 = g.img_off = g.sub_y = g.sub_x = 0;
     int base = 0;
     for (int i = 0; i < nsrc; ++i) {
         if (!g.ok && ch >= base && ch < base + srcs[i].nch) {
@@ -88,7 +103,7 @@ __device__ __forceinline__ Grp find_group(const rnh_msrc_t *srcs, int nsrc, int 
 }
 
 template <int NTAPS>
-__global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const rnh_wgrad_bf16_args_t P, const int RT, const int CT, const int nseg, const int RPI,
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16_args_t P, const int RT, const int CT, const int nseg, const int RPI,
                                                             const int nitems) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     unsigned char *Xs = smem, *Ys = smem + NXS * XS_BYTES;
@@ -122,18 +137,18 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const rnh_wgrad_bf16
         for (int s = 0; s < 3; ++s) {
             const int k = prel + 1 - s;                          // copy s holds X[x0 + k + s - 1] at position k
             if (k >= 0 && k < WT) {
-                unsigned char *base = Xs + slot * XS_BYTES + (s * 64 + c8 * 8) * RP + k * 2;
+                unsigned char *base = Xs + slot * XS_BYTES + (s * 64 + c8) * RP + k * 2;        // channel c8*8 + e -> row e*8 + c8
 #pragma unroll
-                for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short *>(base + e * RP) = h[e];
+                for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short *>(base + e * 8 * RP) = h[e];
             }
         }
     };
     auto write_y = [&](int slot, const uint4 v) {
         const unsigned short h[8] = {(unsigned short)(v.x & 0xffff), (unsigned short)(v.x >> 16), (unsigned short)(v.y & 0xffff), (unsigned short)(v.y >> 16),
                                      (unsigned short)(v.z & 0xffff), (unsigned short)(v.z >> 16), (unsigned short)(v.w & 0xffff), (unsigned short)(v.w >> 16)};
-        unsigned char *base = Ys + slot * YS_BYTES + (c8 * 8) * RP + pxt * 2;
+        unsigned char *base = Ys + slot * YS_BYTES + c8 * RP + pxt * 2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short *>(base + e * RP) = h[e];
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short *>(base + e * 8 * RP) = h[e];
     };
 
     for (int item = split; item < nitems; item += P.nsplit) {
@@ -147,21 +162,19 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const rnh_wgrad_bf16
 #pragma unroll
         for (int r = -1; r <= 1; ++r) {
             const int y = ya + r, slot = (y + 4) & 3;
-            write_x(slot, load_piece(gx, b, y, x0 + pxt - 1, H, W, scx), pxt - 1);
-            if (pxt < 2) write_x(slot, load_piece(gx, b, y, x0 + pxt + 31, H, W, scx), pxt + 31);
+            write_x(slot, piece_bf16(load_piece(gx, b, y, x0 + pxt - 1, H, W, scx), gx.dtype), pxt - 1);
+            if (pxt < 2) write_x(slot, piece_bf16(load_piece(gx, b, y, x0 + pxt + 31, H, W, scx), gx.dtype), pxt + 31);
         }
-        write_y(ya & 1, load_piece(gy, b, ya, x0 + pxt, H, W, scy));
+        write_y(ya & 1, piece_bf16(load_piece(gy, b, ya, x0 + pxt, H, W, scy), gy.dtype));
         __syncthreads();
 
         for (int y = ya; y < yb; ++y) {
             // requests for the next step: input row y + 2, gradient row y + 1
             const bool more = y + 1 < yb;
-            uint4 nx0 = make_uint4(0u, 0u, 0u, 0u), nx1 = nx0, ny = nx0;
-            if (more) {
-                nx0 = load_piece(gx, b, y + 2, x0 + pxt - 1, H, W, scx);
-                if (pxt < 2) nx1 = load_piece(gx, b, y + 2, x0 + pxt + 31, H, W, scx);
-                ny = load_piece(gy, b, y + 1, x0 + pxt, H, W, scy);
-            }
+            // (issued unconditionally: rows beyond the range read as clamped, masked pieces that are never written)
+            const Piece nx0 = load_piece(gx, b, y + 2, x0 + pxt - 1, H, W, scx);
+            const Piece nx1 = load_piece(gx, b, y + 2, x0 + (pxt < 2 ? pxt + 31 : pxt - 1), H, W, scx);
+            const Piece ny = load_piece(gy, b, more ? y + 1 : y, x0 + pxt, H, W, scy);
             // multiply: taps (dy, dx) read input row y + dy - 1, copy dx
             const unsigned char *Yb = Ys + (y & 1) * YS_BYTES + (cb * 32 + l31) * RP + kh * 16;
 #pragma unroll
@@ -187,9 +200,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const rnh_wgrad_bf16
             }
             if (more) {
                 const int slot = (y + 2 + 4) & 3;
-                write_x(slot, nx0, pxt - 1);
-                if (pxt < 2) write_x(slot, nx1, pxt + 31);
-                write_y((y + 1) & 1, ny);
+                write_x(slot, piece_bf16(nx0, gx.dtype), pxt - 1);
+                if (pxt < 2) write_x(slot, piece_bf16(nx1, gx.dtype), pxt + 31);
+                write_y((y + 1) & 1, piece_bf16(ny, gy.dtype));
             }
             __syncthreads();
         }
@@ -198,15 +211,16 @@ __global__ void __launch_bounds__(256, 1) wgrad_bf16_kernel(const rnh_wgrad_bf16
     // ---- partial sums -> slab[split][tap][row][col] ------------------------------------------------------------------
     const long xr = P.xrows_pad, yc = P.ycols_pad;
     float *sl = P.slab + (long)split * NTAPS * xr * yc;
-    const int col = ct * 64 + cb * 32 + l31;
+    auto chan = [](int L) { return (L & 7) * 8 + (L >> 3); };    // LDS row -> channel of the 64-channel tile
+    const int col = ct * 64 + chan(cb * 32 + l31);
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = rt * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh;
+            const int row = rt * 64 + chan(rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh);
             sl[((long)t * xr + row) * yc + col] = acc[t][v];
         }
-    if (want_bias) P.bslab[(long)split * yc + ct * 64 + tid] = bsum;
+    if (want_bias) P.bslab[(long)split * yc + ct * 64 + chan(tid)] = bsum;
 }
 
 }  // namespace

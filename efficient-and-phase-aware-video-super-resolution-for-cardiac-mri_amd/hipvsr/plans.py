@@ -166,9 +166,10 @@ class WgradPlan:
         self.colmap64 = colmap + [-1] * (self.ycols_pad64 - len(colmap))
 
     def nsplit_bf16(self, nitems):
-        """Pixel-range splits of rnh_wgrad_bf16: enough workgroups (tiles x splits) to fill the 256 CUs about once."""
+        """Pixel-range splits of rnh_wgrad_bf16: tiles x splits = about two workgroups per CU (the kernel keeps two resident:
+        one's staging latency hides behind the other's MFMAs)."""
         tiles = (self.xrows_pad64 // 64) * (self.ycols_pad64 // 64)
-        return int(max(1, min(nitems, 256, -(-256 // tiles))))
+        return int(max(1, min(nitems, 256, -(-512 // tiles))))
 
     def nsplit(self, npix):
         import os
