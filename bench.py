@@ -86,8 +86,11 @@ def make_net(dev, seed=0):
 def synthetic_batch(dev, n, t, h, w, seed, u=6, s=4):
     g = torch.Generator(device=dev).manual_seed(seed)
     F = t + 2 * u
-    inputs = [torch.randn(n, 1, h, w, generator=g, device=dev) for _ in range(F)]
-    targets = [torch.randn(n, 1, s * h, s * w, generator=g, device=dev) for _ in range(t)]
+    # frame lists as views of one packed (F, N, 1, h, w) / (T, N, 1, sh, sw) buffer each - what the product's loader
+    # (hipvsr.cine_cache.GpuCineLoader: one gather launch per batch) hands to the trainer, so the engine and the fused
+    # loss take them without a copy; same values as F + T separate randn calls with this generator
+    inputs = list(torch.stack([torch.randn(n, 1, h, w, generator=g, device=dev) for _ in range(F)]).unbind(0))
+    targets = list(torch.stack([torch.randn(n, 1, s * h, s * w, generator=g, device=dev) for _ in range(t)]).unbind(0))
     phi = torch.randint(0, 30, (n, 1), generator=g, device=dev).float()
     k = torch.arange(F, device=dev).float().unsqueeze(0)
     pos = torch.cos(2 * torch.pi * (k + phi) / 30.0).unsqueeze(-1)
