@@ -360,7 +360,13 @@ class RefineNetEngine:
             dfeat_d = {d: ops.empty(TN, H, W, C, dtype=act) for d in dirs}          # layer-0 input gradients per direction
             dh_next = {d: [None] * Lr for d in dirs}
             dc_next = {d: [None] * Lr for d in dirs}
-            ops.fork(2 * Lr)
+            # state gradients handed from a frame to the previous one of the same (direction, layer): two buffers each, used in
+            # turn, allocated HERE on the main stream - an allocation inside a side-stream block would, under HIP-graph
+            # capture, come from the graph's pool on a stream other than the capture's origin (the capture then fails)
+            DCP = {d: [[ops.empty(N, H, W, hd) for _ in range(2)] for hd in nf] for d in dirs}
+            DHP = {d: [[ops.empty(N, H, W, hd, dtype=act) for _ in range(2)] for hd in nf] for d in dirs} if cfg.memory else None
+            TMP = None if cfg.memory else {d: [ops.empty(N, H, W, P.lstm[(d, l)]['cx'], dtype=act) for l in range(Lr)] for d in dirs}
+            ops.fork(2 * Lr, bank=1)
             for idx in range(T):
                 for di, d in enumerate(dirs):
                     step = 1 if d == 'forward' else -1
@@ -380,7 +386,7 @@ class RefineNetEngine:
                             dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
                             c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
                             dg = Gd[d][l][fi * N:(fi + 1) * N]
-                            dcp = ops.empty(N, H, W, hd) if prev_grad else None
+                            dcp = DCP[d][l][idx & 1] if prev_grad else None
                             ops.lstm_gates_bwd(dh, dc_next[d][l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg,
                                                dcp, dh2=dh_next[d][l])
                             dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
@@ -388,11 +394,11 @@ class RefineNetEngine:
                             if cfg.memory:
                                 dsts = [Dst(dxbuf, cx)]
                                 if prev_grad:
-                                    dhp = ops.empty(N, H, W, hd, dtype=act)
+                                    dhp = DHP[d][l][idx & 1]
                                     dsts.append(Dst(dhp, hd))
                                 ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
                             else:
-                                tmp = ops.empty(N, H, W, cx, dtype=act)
+                                tmp = TMP[d][l]
                                 ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx), Dst(tmp, cx)])
                                 ops.add(dxbuf, tmp, accumulate=True)
                             dh_next[d][l], dc_next[d][l] = dhp, dcp

@@ -79,3 +79,96 @@ class GraphedForward:
         e.graph.replay()
         e.replays += 1
         return e.outputs
+
+
+class _StepEntry:
+    __slots__ = ('graph', 'x', 'y', 'pos', 'outputs', 'loss', 'losses', 'grads', 'flat', 'replays')
+
+
+class GraphedTrainStep:
+    """forward + loss + backward of a training step replayed from a HIP graph (SURVEY.md section 8a row A6 "(later)
+    HIP-graph"; reference src/runner/trainers/acdc_vsr_refinenet_trainer.py:41-46: ``net(inputs, pos_codes)``,
+    ``_compute_losses``, ``loss.backward()``).
+
+    At the reference's own training shape (configs/train/refine_net/exp1_x4.yaml:21-33: batch 16, 32 x 32 crops) a step is
+    about 1 500 sub-30-microsecond launches: the host's launch rate, not the GPU, sets the step time.  The whole step up to
+    the gradients is captured once per input shape - the ConvLSTM wavefront's side streams become parallel branches - and
+    replayed with one launch; what stays outside: the copy of the batch into the graph's static input buffers, the
+    gradient all-reduce (one collective), the optimizer step (two launches of the flat Adam whose step count and learning
+    rate are host-side arguments) and metrics / logging.
+
+    Gradients: the capture runs with ``p.grad is None``, so autograd adopts the engine's gradient tensors - views of one
+    flat buffer in the graph's pool - and a replay overwrites them in place; there is no ``zero_grad`` between replays and
+    nothing accumulates.  The same results, bit for bit, as the eager step (tests/test_predictor.py)."""
+
+    def __init__(self, trainer, max_graphs=4):
+        self.tr, self.max_graphs = trainer, max_graphs
+        self._entries = {}
+        self._stream = None
+        self._versions = None
+
+    def _body(self, e):
+        tr = self.tr
+        outputs = tr.net(e.x, e.pos)
+        losses = tr._compute_losses(outputs, e.y)
+        loss = (torch.stack(losses) * tr.loss_weights).sum()
+        loss.backward()
+        return outputs, loss, losses
+
+    def _capture(self, inputs, targets, pos_codes):
+        net = self.tr.net
+        dev = inputs[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError(f'GraphedTrainStep needs inputs on a HIP device, got {dev}')
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dev)
+        e = _StepEntry()
+        xb = torch.stack([x.detach().to(dev, torch.float32) for x in inputs], dim=0).contiguous()
+        yb = torch.stack([y.detach().to(dev, torch.float32) for y in targets], dim=0).contiguous()
+        e.x, e.y = list(xb.unbind(0)), list(yb.unbind(0))
+        e.pos = pos_codes.detach().to(dev, torch.float32).clone()
+        params = list(net.parameters())
+        st = self._stream
+        net._engine().ops.graph_captures += 1      # scratch buffers are retired, not freed, from here on (HipOps._workspace)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            for _ in range(2):                     # eager warm-up on the capture stream: plans, index maps, workspaces, autograd
+                for p in params:
+                    p.grad = None
+                self._body(e)
+        st.synchronize()
+        for p in params:
+            p.grad = None
+        e.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.graph, stream=st):
+            e.outputs, e.loss, e.losses = self._body(e)
+        e.grads = [p.grad for p in params]
+        e.flat = net._flat_grad
+        e.replays = 0
+        return e
+
+    def __call__(self, inputs, targets, pos_codes):
+        net = self.tr.net
+        if not net.training:
+            raise RuntimeError('GraphedTrainStep serves training (net.train())')
+        pk = tuple(p.data_ptr() for p in net.parameters())
+        if pk != self._versions:                   # a parameter was REPLACED (load_state_dict copies in place and keeps them)
+            self._entries.clear()
+            self._versions = pk
+        key = (len(inputs), tuple(inputs[0].shape), len(targets), tuple(targets[0].shape), tuple(pos_codes.shape),
+               getattr(net, 'compute_dtype', 'f32'))
+        e = self._entries.get(key)
+        if e is None:
+            if len(self._entries) >= self.max_graphs:
+                self._entries.pop(next(iter(self._entries)))
+            e = self._entries[key] = self._capture(inputs, targets, pos_codes)
+        xv, yv = packed_view([t.detach() for t in inputs], e.pos.device), packed_view([t.detach() for t in targets], e.pos.device)
+        packed_view(e.x).copy_(xv)
+        packed_view(e.y).copy_(yv)
+        e.pos.copy_(pos_codes)
+        e.graph.replay()
+        e.replays += 1
+        for p, g in zip(net.parameters(), e.grads):   # this shape's gradient tensors (another shape may have run in between)
+            p.grad = g
+        net._flat_grad = e.flat
+        return e.outputs, e.loss, e.losses

@@ -46,7 +46,15 @@ class HipOps:
         self._ws = {}
         self._ws_retired = []   # outgrown scratch buffers a captured HIP graph may still address (see _workspace)
         self.graph_captures = 0
-        self._side = []
+        # side streams of the ConvLSTM wavefront, in two banks: the forward uses bank 0, the backward bank 1.  Under HIP-graph
+        # capture a stream remembers the streams whose events it waited on; hipStreamEndCapture (ROCm 7.2) walks those
+        # references recursively and never returns if two streams reference EACH OTHER.  The forward makes layer l's stream
+        # wait on layer l-1's, the backward layer l's on layer l+1's: on the same streams, a captured training step
+        # (hipvsr.graph.GraphedTrainStep) would form exactly such a cycle (found with rocgdb: 174 000 frames of
+        # hip::Stream::EndCapture).  The 'one' mapping of RNH_LSTM_STREAMS (a stream waiting on its own event) has the
+        # same problem and is for eager measurements only.
+        self._banks = ([], [])
+        self._side = self._banks[0]
         self._fork_n = 2
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
         # RNH_DIRECT=0 selects the LDS-staged variant of rnh_conv_igemm (kept for A/B measurements)
@@ -92,7 +100,8 @@ class HipOps:
         half = max(self._fork_n // 2, 1)
         return {'cell': i, 'layer': i % half, 'dir': i // half, 'one': 0}[mode]
 
-    def fork(self, n):
+    def fork(self, n, bank=0):
+        self._side = self._banks[bank]
         self._fork_n = n
         n = 1 + max(self._side_index(i) for i in range(n))
         while len(self._side) < n:

@@ -21,15 +21,40 @@ from src.utils import denormalize
 
 
 class AcdcVSRRefineNetTrainer(BaseTrainer):
-    def __init__(self, **kwargs):
+    # graph: replay forward + loss + backward of a step from a HIP graph (hipvsr.graph.GraphedTrainStep).  None = automatic:
+    # on for launch-bound steps only (N*H*W of the LR batch <= GRAPH_AUTO_PIXELS).  Measured (tools/train_shape_bench.py,
+    # profiles/r02_e_train_shape.txt): at the reference YAML's 16 crops of 32 x 32 the step is GPU-bound either way (fp32 59.4 ms
+    # eager / 59.5 ms replayed; bf16 25.1 / 27.4), so the automatic choice is eager there and the graph is for smaller batches
+    GRAPH_AUTO_PIXELS = 4096
+
+    def __init__(self, graph=None, **kwargs):
         super().__init__(**kwargs)
         self._denormalize = functools.partial(denormalize, dataset='acdc')
+        self.graph = graph
+        self._graphed = None
 
     def _get_inputs_targets(self, batch):
         return batch['lr_imgs'], batch['hr_imgs'], batch['pos_code']
 
     def train_step(self, inputs, targets, pos_codes):
         """forward + loss + backward (+ gradient all-reduce) + optimizer step; returns (outputs, loss, losses)."""
+        use_graph = getattr(self, 'graph', None)
+        if use_graph is None:
+            use_graph = inputs[0].is_cuda and inputs[0].shape[0] * inputs[0].shape[-2] * inputs[0].shape[-1] <= self.GRAPH_AUTO_PIXELS
+        if use_graph:
+            if getattr(self, '_graphed', None) is None:
+                from hipvsr.graph import GraphedTrainStep
+                self._graphed = GraphedTrainStep(self)
+                # the flat Adam re-homes the parameters into its contiguous buffer on its first step: do that before the
+                # first capture, which bakes their addresses in
+                if hasattr(self.optimizer, '_adopt'):
+                    for gi, group in enumerate(self.optimizer.param_groups):
+                        if group['params']:
+                            self.optimizer._adopt(gi, group)
+            outputs, loss, losses = self._graphed(inputs, targets, pos_codes)      # gradients are overwritten, not accumulated
+            dp.allreduce_gradients(self.net)
+            self.optimizer.step()
+            return outputs, loss, losses
         outputs = self.net(inputs, pos_codes)
         losses = self._compute_losses(outputs, targets)
         loss = (torch.stack(losses) * self.loss_weights).sum()

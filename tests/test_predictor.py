@@ -176,6 +176,49 @@ def test_graph_replays_interleaved_with_other_shapes_and_training_steps():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_graphed_training_steps_equal_eager_bit_for_bit(dtype):
+    """hipvsr.graph.GraphedTrainStep (forward + fused loss + backward replayed from a HIP graph, Adam outside) against the
+    eager trainer step at the reference YAML's kind of shape (a batch of small crops): same weights after every one of 6
+    steps, same losses, bit for bit; two batch shapes alternate (the last batch of an epoch is smaller) and keep their own
+    graphs and gradient buffers."""
+    from hipvsr.step_tail import FlatAdam
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    dev = _dev()
+    cfg = orc.Config(in_channels=1, out_channels=1, num_features=[16, 16], num_stages=2, refine_window_size=5, upscale_factor=4,
+                     update_memory=True, num_updated_frames=2, positional_encoding=True)
+    sd = orc.init_state_dict(cfg, seed=8)
+    g = torch.Generator('cpu').manual_seed(5)
+    batches = []
+    for k in range(6):
+        n = 4 if k % 3 != 2 else 2
+        batches.append(([torch.randn(n, 1, 16, 16, generator=g).to(dev) for _ in range(7)], [torch.randn(n, 1, 64, 64, generator=g).to(dev) for _ in range(3)],
+                        (torch.rand(n, 7, 1, generator=g) * 2 - 1).to(dev)))
+    runs = {}
+    for graph in (False, True):
+        net = RefineNet(**cfg)
+        net.load_state_dict(sd)
+        net = net.to(dev).set_compute_dtype(dtype).train()
+        tr = object.__new__(AcdcVSRRefineNetTrainer)
+        tr.net, tr.loss_fns, tr.metric_fns, tr.graph, tr._graphed = net, [torch.nn.L1Loss()], [], graph, None
+        tr.loss_weights = torch.tensor([1.0], device=dev)
+        tr.optimizer = FlatAdam(net.parameters(), lr=1e-3)
+        hist = []
+        for xs, ys, pc in batches:
+            outs, loss, _ = tr.train_step(xs, ys, pc)
+            torch.cuda.synchronize()
+            hist.append((float(loss), [p.detach().clone() for p in net.parameters()], outs[-1][0].detach().clone()))
+        runs[graph] = hist
+        if graph:
+            assert len(tr._graphed._entries) == 2 and sorted(e.replays for e in tr._graphed._entries.values()) == [2, 4]
+    for (la, pa, oa), (lb, pb, ob) in zip(runs[False], runs[True]):
+        assert la == lb and torch.equal(oa, ob)
+        assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    assert runs[True][0][0] != runs[True][-1][0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('graph,group', [(True, 8), (False, 1), (True, 1), (False, 8)])
 def test_src_main_test_branch_vs_oracle(tmp_path, graph, group):
     """python -m src.main <yaml> --test on the synthetic test split (2 cines of 30 frames, 54x64 -> 216x256): log,
