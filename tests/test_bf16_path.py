@@ -420,6 +420,36 @@ def test_bf16_module_vs_fp32_oracle(name, n, t, h, w):
           f'worst relative L2 error of an output {worst:.2e}, of a gradient {gw:.2e}')
 
 
+G1_CASES = [f'x{s}_pos{p}_mem{m}' for s in (2, 3, 4) for p in (1, 0) for m in (1, 0)] + ['x8_pos1_mem1']
+
+
+@pytest.mark.parametrize('case', G1_CASES)
+def test_bf16_module_on_the_reference_goldens(golden_dir, case):
+    """Every variant of the net the reference's goldens cover - x2 / x3 / x4 / x8 upsamplers (one, two and three PixelShuffle
+    stages: the tail input is Sb or an inner feature map), with / without the phase code (3x3 or 1x1 refine conv1), with /
+    without memory, 8-channel layers (one 8-channel group of a 128-column LSTM tile) - through the bf16 kernels, against the
+    reference's own fp32 outputs, loss and gradients: bf16 criterion (loss rtol 1e-2; L2 2 % on outputs, 6 % on gradients)."""
+    c = torch.load(os.path.join(golden_dir, 'g1_tiny.pt'), weights_only=False)[case]
+    net, tr, outs, loss = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'], 'bf16')
+    assert len(outs) == len(c['outputs'])
+    for go, gr in zip(outs, c['outputs']):
+        for a, b in zip(go, gr):
+            assert a.shape == b.shape and a.dtype == torch.float32
+            assert float((a.detach().cpu() - b).norm()) <= 2e-2 * float(b.norm()) + 1e-3
+    assert abs(float(loss.detach()) - float(c['train_loss'])) <= 1e-2 * abs(float(c['train_loss']))
+    for k, p in net.named_parameters():
+        if c['grads'][k] is None:
+            assert p.grad is None, k
+        else:
+            d = float((p.grad.cpu() - c['grads'][k]).norm())
+            assert d <= 6e-2 * float(c['grads'][k].norm()) + 1e-6, (k, d, float(c['grads'][k].norm()))
+    net.eval()
+    with torch.no_grad():
+        last = net([x.to(_dev()) for x in c['inputs']], c['pos_codes'].to(_dev()))[-1]
+    for a, b in zip(last, c['eval_last']):
+        assert float((a.cpu() - b).norm()) <= 2e-2 * float(b.norm()) + 1e-3
+
+
 def test_bf16_training_step_is_bitwise_repeatable_and_switchable():
     """No atomics in the bf16 kernels either (fixed-order slab reduction): the same step gives the same bits; switching the
     module back to 'f32' rebuilds the engine and reproduces the fp32 result bit for bit."""
