@@ -199,6 +199,9 @@ def main():
     ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
     ap.add_argument('--size', type=int, default=128, help='LR height = width')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
+                    help='replay forward + loss + backward of the step from a HIP graph (hipvsr.graph.GraphedTrainStep); auto = the '
+                         "trainer's own rule (off at this batch size)")
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32: the headline (BASELINE config 2, the reference's precision); bf16: the bf16-storage path of "
                          "BASELINE config 3 (a separately labelled line, same synthetic batch per GPU)")
@@ -224,6 +227,7 @@ def main():
     tr = object.__new__(AcdcVSRRefineNetTrainer)
     tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
     tr.loss_weights = torch.tensor([1.0], device=dev)
+    tr.graph, tr._graphed = {'auto': None, 'on': True, 'off': False}[args.graph], None
     inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + 2 + rank)
 
     def barrier():
@@ -270,6 +274,7 @@ def main():
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
                                    f'{4 * args.size}x{4 * args.size}, {prec}, exp1_x4 net (BASELINE config {3 if bf else 2})',
                        'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
+                       'hip_graph_step': tr._graphed is not None,
                        'input_frames_per_s': round(n_global * (args.frames + 12) * args.steps / dt, 2),
                        'step_tflop_reference_formulation': round(flop_step / 1e12, 2),
                        'step_tflop_executed': round(flop_exec / 1e12, 2),

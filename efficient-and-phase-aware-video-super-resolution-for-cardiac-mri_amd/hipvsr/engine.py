@@ -162,6 +162,9 @@ class RefineNetEngine:
                 if P.r1_wino:
                     ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                     ops.refine_phase_bias(R1, P4[lo:hi], params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
+                elif P.r1_split:
+                    ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 2 * Cl)])
+                    ops.conv(P.r1_fwd_b, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p - 2 * Cl, c0=2 * Cl)])
                 else:
                     ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                 if P.xcol:
@@ -311,8 +314,14 @@ class RefineNetEngine:
                     xs.append(Src(ctx.P4, img_off=(U - hw + j) * N))
             k1, b1 = P.r1_wgrad.wkey, P.r1_wgrad.bkey
             if P.pos:
-                dR1p = ops.zeros((T + 2 * hw) * N, H, W, P.C1p, dtype=act)
-                ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
+                dR1p = ops.empty((T + 2 * hw) * N, H, W, P.C1p, dtype=act)       # the T middle frames are written by conv2's data gradient
+                dR1p[:hw * N].zero_()
+                dR1p[(hw + T) * N:].zero_()
+                if P.r1_split:
+                    ops.conv(P.r2_dgrad_a, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
+                    ops.conv(P.r2_dgrad_b, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])
+                else:
+                    ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
                 ops.wgrad(P.r2_wgrad, [Src(st['R1'], img_off=(U - hw - st['w0']) * N)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],

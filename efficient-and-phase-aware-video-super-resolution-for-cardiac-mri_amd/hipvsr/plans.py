@@ -263,7 +263,7 @@ class NetPlans:
 
         Cl, w = self.Cl, cfg.refine_window_size
         self.pos = bool(cfg.positional_encoding)
-        self.xcol = self.r1_wino = False
+        self.xcol = self.r1_wino = self.r1_split = False
         if self.pos:
             C1 = 2 * Cl + 1
             self.C1, self.C1p = C1, (_pad_to(C1, 8) if bf else r4(C1))
@@ -298,6 +298,15 @@ class NetPlans:
                 self.r1_dgrad_x = ConvPlan_('refine1.dgrad.x', k1, None, ws1,
                                            [KSeg(self.C1p - C1 + 1, 1, C1 - 1, kcoff=j * C1) for j in range(w)], list(range(2 * Cl)),
                                            transposed=True)
+            # bf16 path: the 2*Cl + 1 columns of conv1 (and of conv2's data gradient) as a 2*Cl-column launch (128-column tiles
+            # where 2*Cl % 128 == 0) plus an 8-column launch for the last channel, instead of one launch padded to 192
+            self.r1_split = bf and (2 * Cl) % 64 == 0 and os.environ.get('RNH_R1_SPLIT', '1') != '0'
+            if self.r1_split:
+                tail = [C1 - 1] + [-1] * (self.C1p - C1)
+                self.r1_fwd_a = ConvPlan_('refine1.fwd.a', k1, b1, ws1, segs, list(range(C1 - 1)))
+                self.r1_fwd_b = ConvPlan_('refine1.fwd.b', k1, b1, ws1, segs, tail)
+                self.r2_dgrad_a = ConvPlan_('refine2.dgrad.a', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(C1 - 1)), transposed=True)
+                self.r2_dgrad_b = ConvPlan_('refine2.dgrad.b', k2, None, ws2, [KSeg(Cl, Cl, 0)], tail, transposed=True)
             self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
@@ -348,12 +357,16 @@ class NetPlans:
         for v in self.lstm.values():
             out += [v['full'], v['first'], v['dgrad']]
         out += [self.r1_fwd, self.r1_dgrad]
+        if getattr(self, 'r1_split', False):
+            out += [self.r1_fwd_a, self.r1_fwd_b, self.r2_dgrad_a, self.r2_dgrad_b]
         if self.r1_wino:
             out += [self.r1_fwd_h, self.r1_fwd_p, self.r1_dgrad_h, self.r1_dgrad_x]
         if self.pos:
             out += [self.r2_fwd, self.r2_dgrad]
         for u in self.up:
             out += [u['fwd'], u['dgrad']]
+        if getattr(self, 'r1_split', False):                   # replaced by their .a / .b halves: never launched, not packed
+            out = [p for p in out if p is not self.r1_fwd and p is not self.r2_dgrad]
         seen, uniq = set(), []
         for p in out:
             if id(p) not in seen:

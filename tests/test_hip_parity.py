@@ -277,12 +277,16 @@ def test_linearity_and_batch_independence_at_bench_width():
     assert torch.equal(both[:1], one)
 
 
-def test_src_main_trains_from_yaml(tmp_path):
-    """python -m src.main <yaml>: one epoch of training + validation on the synthetic cines, checkpoint written."""
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_src_main_trains_from_yaml(tmp_path, monkeypatch, dtype):
+    """python -m src.main <yaml>: one epoch of training + validation on the synthetic cines, checkpoint written - in the
+    reference's precision and (RNH_DTYPE=bf16 in the environment, the YAML schema has no such key) on the bf16-storage path;
+    the checkpoint is fp32 with the reference's keys either way."""
     import types
     import yaml
     from conftest import PKG
     from src import main as M
+    monkeypatch.setenv('RNH_DTYPE', dtype)
     cfg = yaml.safe_load(open(os.path.join(PKG, 'configs', 'refine_net_x4_synthetic.yaml')))
     cfg['main']['saved_dir'] = str(tmp_path / 'run')
     cfg['trainer']['kwargs']['num_epochs'] = 1
@@ -294,6 +298,7 @@ def test_src_main_trains_from_yaml(tmp_path):
     ck = torch.load(tmp_path / 'run' / 'checkpoints' / 'model_1.pth', map_location='cpu', weights_only=False)
     assert set(ck) == {'net', 'optimizer', 'lr_scheduler', 'monitor', 'epoch', 'random_state', 'np_random_seeds'}
     assert list(ck['net'].keys()) == list(orc.state_dict_spec(orc.exp1_x4_config()).keys())
+    assert all(v.dtype == torch.float32 for v in ck['net'].values())
     log = (tmp_path / 'run' / 'log' / 'scalars.jsonl').read_text()
     assert '"Loss"' in log and '"PSNR"' in log
 
