@@ -13,7 +13,10 @@
 //   * the input transform B^T d B is computed on the fly: per step of 4 channels a lane loads the 4x4 patch of its
 //     tile as 16 raw 8-byte buffer loads (channels 2kh, 2kh+1 of the step for lane-half kh; lanes outside the image
 //     carry offset 0xFFFFFFFF and the range check returns the zero padding) and spends 32 packed adds;
-//   * the weights arrive pre-transformed from rnh_wino_pack_weights as U[step][xi][n][4] (8 bytes per lane and xi);
+//   * the weights arrive pre-transformed from rnh_wino_pack_weights as U[step][xi / 2][n][lane half][xi & 1][2]: 16 bytes
+//     per lane and PAIR of transform positions, and the staged input transform has the same pairing in LDS - one
+//     buffer_load_dwordx4 / ds_read_b128 feeds four MFMAs (round 1 used 8-byte operands: twice the operand instructions
+//     beside the MFMA stream, each worth about 8 cycles of matrix-core idle time);
 //   * the 4 waves of a workgroup take 4 column groups of the same 32 tiles.  With the ConvLSTM column order
 //     (plans.lstm_colmap) these are the 4 gates of 32 hidden channels: every wave activates its gate, the gates meet
 //     in LDS and each wave finishes one pixel of every tile (c' = f c + i g, h' = o tanh c').
@@ -26,6 +29,7 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each; __frcp_rn would be a correctly rounded division: two v_div_scale, v_rcp, four FMAs,
@@ -44,7 +48,7 @@ __device__ __forceinline__ float w_tanh(float x) {
 // keeps the form above, which is also relatively accurate near 0.
 __device__ __forceinline__ float w_tanh_gate(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
 
-// U[s][xi][n][q] = (G g G^T)[xi] for input channel kbase[s] + q*kstride and output column n
+// U[s][xi / 2][n][kh][xi & 1][c] = (G g G^T)[xi] for input channel kbase[s] + (2 kh + c) * kstride and output column n
 __global__ void wino_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kbase, const int *knv,
                                  const int *kcoff, const int *colmap, int ns, int Npad, int Cout, int Cin, int kstride, int transposed) {
     const long total = (long)ns * 16 * Npad * 4;
@@ -54,7 +58,10 @@ __global__ void wino_pack_kernel(const float *w, const float *bias, float *wp, f
             if (biasp) biasp[n] = (bias && !transposed && colmap[n] >= 0) ? bias[colmap[n]] : 0.f;
             continue;
         }
-        const int q = (int)(e & 3), n = (int)((e >> 2) % Npad), xi = (int)((e / (4 * (long)Npad)) & 15), s = (int)(e / (64 * (long)Npad));
+        // e = ((((s * 8 + pair) * Npad + n) * 2 + kh) * 2 + odd) * 2 + c:  xi = 2 pair + odd, channel q = 2 kh + c of the step
+        const int c = (int)(e & 1), odd = (int)((e >> 1) & 1), kh = (int)((e >> 2) & 1), n = (int)((e >> 3) % Npad);
+        const int pr = (int)((e / (8 * (long)Npad)) & 7), s = (int)(e / (64 * (long)Npad));
+        const int q = 2 * kh + c, xi = 2 * pr + odd;
         const int col = colmap[n];
         float v = 0.f;
         if (col >= 0 && q < knv[s]) {
@@ -106,7 +113,7 @@ __device__ unsigned long long g_wino_stamps[8];
 template <int EPI, int TG>
 __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
     constexpr int TILES = 32 * TG, CPC = 8 / TG, CH = 2 * CPC, SPC = 4 / TG, CG = 4 / TG;   // tiles, channel pairs / channels / steps per chunk, column groups
-    constexpr int CHS = 2 * CPC + 2, BUF = 16 * TILES * CHS;                                // LDS row of one (xi, tile); floats per buffer
+    constexpr int CHS = 4 * CPC + 4, BUF = 8 * TILES * CHS;                                 // LDS row of one (xi pair, tile): [channel pair][xi & 1][2] + 4 pad; floats per buffer
     static_assert(EPI != RNH_EPI_LSTM || TG == 1, "the gate exchange needs the four column groups of one tile group");
     __shared__ __attribute__((aligned(16))) float stage[2 * BUF > 16384 ? 2 * BUF : 16384];   // 73.7 / 81.9 KB; the LSTM gate exchange reuses it
     float *xch = stage;
@@ -127,8 +134,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     // (Lanes of one MFMA row block sit 2 pixels = 512 B apart in memory: loading patches per lane would touch 32 cache
     // lines per instruction; and the four waves of the block need the same transformed patches.)  Thread = (tile ts,
     // channel pair cp of the chunk): 16 8-byte loads (the 8 threads of a tile read 64 contiguous bytes per pixel), the
-    // input transform once per block, 16 8-byte LDS writes.  LDS layout [xi][tile][18]: the 8-byte reads of a
-    // half-wave (32 tiles, stride 18 floats) cover all 64 banks exactly once.
+    // input transform once per block, 8 16-byte LDS writes.  LDS layout [xi / 2][tile][36]: row = 8 channel pairs x
+    // (xi even, xi odd) x 2 channels + 4 floats of pad; the 16-byte reads of 16 consecutive tiles (stride 36 dwords) touch
+    // every bank once.
     const int ts = threadIdx.x / CPC, cp = threadIdx.x % CPC;
     const int t0 = m0 < ntiles ? m0 : 0;
     const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         }
     };
     auto xform_store = [&](int buf) {                       // V = B^T d B on the thread's two channels, to LDS
-        asm volatile("s_waitcnt vmcnt(16)"
+        asm volatile("s_waitcnt vmcnt(8)"
                      : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
                        "+v"(stg[8]), "+v"(stg[9]), "+v"(stg[10]), "+v"(stg[11]), "+v"(stg[12]), "+v"(stg[13]), "+v"(stg[14]),
                        "+v"(stg[15]));
@@ -220,44 +228,53 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
             tq[2 * 4 + j] = sub(stg[2 * 4 + j], stg[1 * 4 + j]);
             tq[3 * 4 + j] = sub(stg[1 * 4 + j], stg[3 * 4 + j]);
         }
-        float *o = stage + buf * BUF + ts * CHS + 2 * cp;
+        float *o = stage + buf * BUF + ts * CHS + 4 * cp;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 0) * TILES * CHS) = sub(tq[i * 4 + 0], tq[i * 4 + 2]);
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 1) * TILES * CHS) = add(tq[i * 4 + 1], tq[i * 4 + 2]);
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 2) * TILES * CHS) = sub(tq[i * 4 + 2], tq[i * 4 + 1]);
-            *reinterpret_cast<f32x2 *>(o + (i * 4 + 3) * TILES * CHS) = sub(tq[i * 4 + 1], tq[i * 4 + 3]);
+            // positions 4i, 4i + 1 and 4i + 2, 4i + 3: two pairs, 16 bytes each (xi even, xi odd)
+            const f32x2 v0 = sub(tq[i * 4 + 0], tq[i * 4 + 2]), v1 = add(tq[i * 4 + 1], tq[i * 4 + 2]);
+            const f32x2 v2 = sub(tq[i * 4 + 2], tq[i * 4 + 1]), v3 = sub(tq[i * 4 + 1], tq[i * 4 + 3]);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 0) * TILES * CHS) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 1) * TILES * CHS) = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
         }
     };
 
-    const i32x4 bdesc = sdesc(P.wp + (long)((nt * CG + cg) * 32) * 4);
-    const int xistride = P.Npad * 16;                       // bytes between two transform positions of one step
-    int boffx[16];                                          // per-lane byte offset of the 16 positions inside a step
+    const i32x4 bdesc = sdesc(P.wp + (long)((nt * CG + cg) * 32) * 8);
+    const int pstride = P.Npad * 32;                        // bytes between two PAIRS of transform positions of one step
+    int boffx[8];                                           // per-lane byte offset of the 8 pairs inside a step
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) boffx[xi] = (l31 * 4 + 2 * kh) * 4 + xi * xistride;
-    auto loadb = [&](f32x2 *u, int sb) {                    // transformed weights of step sb: 16 loads
-        const int soff = __builtin_amdgcn_readfirstlane(sb * 16 * xistride);
-        ld8(u, boffx, bdesc, soff);
-        ld8(u + 8, boffx + 8, bdesc, soff);
+    for (int pr = 0; pr < 8; ++pr) boffx[pr] = (l31 * 2 + kh) * 16 + pr * pstride;
+    auto loadb = [&](f32x4w *u, int sb) {                   // transformed weights of step sb: 8 loads of 16 bytes
+        const int soff = __builtin_amdgcn_readfirstlane(sb * 8 * pstride);
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %8, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %1, %9, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %2, %10, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %3, %11, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %4, %12, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %5, %13, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %6, %14, %16, %17 offen\n\t"
+            "buffer_load_dwordx4 %7, %15, %16, %17 offen"
+            : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+            : "v"(boffx[0]), "v"(boffx[1]), "v"(boffx[2]), "v"(boffx[3]), "v"(boffx[4]), "v"(boffx[5]), "v"(boffx[6]), "v"(boffx[7]), "s"(bdesc),
+              "s"(soff)
+            : "memory");
     };
     const unsigned lds0 = (unsigned)(size_t)stage;          // LDS byte address of the staging area
-    const unsigned vlane = lds0 + ((tg * 32 + l31) * CHS + 2 * kh) * 4;
-    auto loadv = [&](f32x2 *V, int buf, int q) {            // the lane's tile, channels 4q + 2kh, +1 of the staged chunk
-        const unsigned adr = vlane + buf * BUF * 4 + q * 16;
-#define RNH_DSR(xi) asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(V[xi]) : "v"(adr), "i"((xi) * TILES * CHS * 4) : "memory")
+    const unsigned vlane = lds0 + ((tg * 32 + l31) * CHS + 4 * kh) * 4;
+    auto loadv = [&](f32x4w *V, int buf, int q) {           // the lane's tile, channels 4q + 2kh, +1 of the staged chunk, 8 pairs of positions
+        const unsigned adr = vlane + buf * BUF * 4 + q * 32;
+#define RNH_DSR(pr) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(V[pr]) : "v"(adr), "i"((pr) * TILES * CHS * 4) : "memory")
         RNH_DSR(0); RNH_DSR(1); RNH_DSR(2); RNH_DSR(3); RNH_DSR(4); RNH_DSR(5); RNH_DSR(6); RNH_DSR(7);
-        RNH_DSR(8); RNH_DSR(9); RNH_DSR(10); RNH_DSR(11); RNH_DSR(12); RNH_DSR(13); RNH_DSR(14); RNH_DSR(15);
 #undef RNH_DSR
     };
-    auto wait_lds = [&](f32x2 *V) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]),
-                       "+v"(V[9]), "+v"(V[10]), "+v"(V[11]), "+v"(V[12]), "+v"(V[13]), "+v"(V[14]), "+v"(V[15]));
+    auto wait_lds = [&](f32x4w *V) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]));
     };
-    auto wait_vm = [&](f32x2 *u, auto keep) {
-        asm volatile("s_waitcnt vmcnt(%c16)"
-                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]), "+v"(u[8]),
-                       "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15])
+    auto wait_vm = [&](f32x4w *u, auto keep) {
+        asm volatile("s_waitcnt vmcnt(%c8)"
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7])
                      : "i"(decltype(keep)::value));
     };
 
@@ -267,11 +284,13 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
 
-    auto compute = [&](const f32x2 *V, const f32x2 *u) {
+    auto compute = [&](const f32x4w *V, const f32x4w *u) {
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi].x, u[xi].x, acc[xi], 0, 0, 0);
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[xi].y, u[xi].y, acc[xi], 0, 0, 0);
+        for (int pr = 0; pr < 8; ++pr) {
+            acc[2 * pr] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pr].x, u[pr].x, acc[2 * pr], 0, 0, 0);
+            acc[2 * pr] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pr].y, u[pr].y, acc[2 * pr], 0, 0, 0);
+            acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pr].z, u[pr].z, acc[2 * pr + 1], 0, 0, 0);
+            acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pr].w, u[pr].w, acc[2 * pr + 1], 0, 0, 0);
         }
     };
 
@@ -279,7 +298,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     // MFMAs of chunk c and is transformed into the other LDS buffer at its end ---------------------------------------
     int nchunks_total = 0;
     for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch / CH;
-    f32x2 V0[16], V1[16], u0[16], u1[16];
+    f32x4w V0[8], V1[8], u0[8], u1[8];
     if (threadIdx.x < TILES) {
         const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
         const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
@@ -288,13 +307,13 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
     }
     WSTAMP(1);
     gload();
-    loadb(u0, 0);                                            // 16 loads younger than the staging loads: vmcnt(16) in xform_store
+    loadb(u0, 0);                                            // 8 loads younger than the staging loads: vmcnt(8) in xform_store
     xform_store(0);
     __syncthreads();
     WSTAMP(2);
     int s = 0;                                               // global 4-channel step index (weights)
     loadv(V0, 0, 0);
-    using K16 = std::integral_constant<int, 16>;
+    using K16 = std::integral_constant<int, 8>;              // the 8 weight loads of ONE step may stay in flight
     using K0 = std::integral_constant<int, 0>;
     // One chunk = 4 steps.  The loop body (every chunk but the last) has no branch: a register that is the target of an
     // asynchronous asm load must have exactly one definition per iteration, or hipcc reconciles the definitions at the
@@ -400,14 +419,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         const bool full = m0 + 32 <= ntiles && !(H & 1) && !(W & 1) && nt * 32 + 32 <= hd;
         const int p2 = wave, poff2 = (p2 >> 1) * W + (p2 & 1);
         float cpv[16];
-        if (full) {
-            // state of the pixel this lane finishes in phase 2: loaded now, needed after the barrier
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;
-                cpv[v] = P.c_prev ? P.c_prev[((long)tpix[trl] + poff2) * hd + hc] : 0.f;
-            }
-        }
+        // (the previous cell state of the pixels this lane finishes is fetched in phase 2, all 16 values in one batch behind
+        // the barrier: requested here, hipcc sank the loads to the end of phase 1 anyway - no register is free during the
+        // gate math - and their wait then also covered the 64 gate stores in front of them)
         // phase 1: every wave activates its gate (wave 0..3 = i, f, o, g) and parks it in LDS (and in gates_out).
         // GV accumulator registers at a time: 4 GV independent exp / rcp chains for the one wave on this SIMD (measured
         // per workgroup, gate phase: GV = 1: 25.2k cycles, 2: 21.6k, 4: 18.2k, 8: 17.4k, 16: 16.3k).
@@ -459,10 +473,19 @@ __global__ void __launch_bounds__(256, 1) conv_wino_kernel(const rnh_conv_args_t
         }
         // the gates are in LDS: wait for the LDS writes only - __syncthreads() would also wait (vmcnt(0)) for the gates_out
         // stores just issued to be acknowledged by memory
+        WSTAMP(7);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         WSTAMP(4);
         // phase 2: wave w finishes output pixel w of every tile
         if (full) {
+            if (P.c_prev) {
+                const float *cpb = P.c_prev + (long)poff2 * hd + hc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cpv[v] = cpb[(long)tpix[(v & 3) + 8 * (v >> 2) + 4 * kh] * hd];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cpv[v] = 0.f;
+            }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int trl = (v & 3) + 8 * (v >> 2) + 4 * kh;

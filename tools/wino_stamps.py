@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, PKG]
 os.environ['RNH_WINO'] = '1'
 import torch
 from hipvsr import lib as L
-L.LIB_PATH = os.path.join(PKG, 'hipvsr', 'lib_stamps.so')
+L.LIB_PATH = os.path.join(PKG, 'hipvsr', os.environ.get('STAMPS_LIB', 'lib_stamps.so'))
 from hipvsr.hip_ops import HipOps
 from hipvsr.plans import NetPlans, Src
 from hipvsr.spec import NetConfig, state_dict_spec
@@ -20,7 +20,7 @@ N, H, W = 8, 128, 128
 x, hp, cp = (torch.randn(N, H, W, 64, device=dev) for _ in range(3))
 ho, co, go = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256)
 for _ in range(3):
-    ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=(None if os.environ.get('NOGATES') else go)))
+    ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=(None if os.environ.get('NOCPREV') else cp), h_out=ho, c_out=co, gates_out=(None if os.environ.get('NOGATES') else go)))
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8)()
 ops.lib.rnh_debug_wino_stamps.argtypes = [ctypes.c_void_p]
@@ -30,3 +30,5 @@ names = ['start', 'setup done', 'first chunk staged', 'loop done', 'gates exchan
 for i in range(1, 6):
     print(f'{names[i]:22s} +{z[i] - z[i - 1]:8d} cycles (total {z[i] - z[0]})')
 print('inside the loop: staging stores + barrier', z[6], 'cycles')
+if z[7]:
+    print(f'gate phase of wave 0: own work {z[7] - z[3]} cycles, then {z[4] - z[7]} at the barrier (waiting for the other waves)')
