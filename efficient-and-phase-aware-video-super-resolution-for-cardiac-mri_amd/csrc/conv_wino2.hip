@@ -1,0 +1,609 @@
+// 3x3 convolution (padding 1) in Winograd form F(2x2, 3x3) on fp32 MFMA for gfx950, two workgroups per CU - rnh_conv_wino.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 independent GEMMs (one per position xi of the 4x4 transform domain) of [tiles x C] x [C x N].  conv_wino.hip (rounds 1-2)
+// gave one wave all 16 positions of 32 tiles x 32 columns: 256 accumulators + 256 working registers = the whole register
+// file of a SIMD, ONE wave per SIMD, so every cycle that wave spent outside the MFMA stream (set-up, staging transform,
+// barrier skew, the 2 000-instruction gate epilogue, stores) was a cycle of matrix-core idle time: 0.56 of the fp32 peak.
+// Here a wave owns HALF the transform domain (the positions xi = 4 i + j with j in {2h, 2h+1}: 8 of the 16) of 32 tiles x 32
+// columns - 128 accumulators, 256 registers in all - and a workgroup is 2 halves x 2 column groups = 32 tiles x 64 columns:
+// two workgroups are resident per CU, every SIMD holds one wave of each, and whatever one of them does beside its MFMAs
+// hides behind the MFMAs of the other.  The price:
+//   * the output transform needs all four j: the two halves exchange partial 2x2 outputs through LDS (each wave keeps the
+//     tiles of 8 accumulator registers and sends the other 8 to its partner: 8 ds_write_b128 + 8 ds_read_b128 per lane);
+//   * the staged input transform of 32 tiles feeds 64 columns instead of 128 (LDS and L2 traffic per MFMA as before,
+//     staging loads and transform adds per MFMA doubled for convolutions wider than 64 columns - vector work that now
+//     runs under the other workgroup's MFMAs).
+// Operands as in conv_wino.hip: the input transform B^T d B of a 16-channel chunk is computed once per workgroup (thread =
+// (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32
+// packed adds, 8 16-byte LDS writes into [xi / 2][tile][36]), the weights arrive pre-transformed from
+// rnh_wino_pack_weights as U[step][xi / 2][n][lane half][xi & 1][2]: one buffer_load_dwordx4 and one ds_read_b128 feed
+// four MFMAs.  With the ConvLSTM column order plans.lstm_colmap64 a workgroup's 64 columns are the 4 gates of 16 hidden
+// channels: after the exchange every wave activates 2 gates of 16 tiles, the gates meet in LDS and the 256 threads finish
+// (tile, pixel, channel) items (c' = f c + i g, h' = o tanh c').
+//
+// Same operand conventions as rnh_conv_igemm (rnh_conv_args_t: multi-source K without concatenation, destination
+// segments, packed bias, pixel-unshuffled sources of one common scale).  Epilogues: STORE, PS, LSTM.
+#include "rnh_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+// v_exp_f32 / v_rcp_f32 (1 ulp each) and no branch
+__device__ __forceinline__ float h_tanh(float x) {
+    const float ax = fabsf(x);
+    const float big = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __expf(2.f * ax)), 1.f);
+    const float small = ax * __builtin_fmaf(-0.33333334f * ax, ax, 1.f);      // |x| < 0.04: the exp form cancels
+    const float t = ax < 0.04f ? small : big;
+    return copysignf(t, x);
+}
+
+// the buffer descriptor (base + 2 GiB window, raw buffer) as a plain SGPR quadruple for the asm loads
+__device__ __forceinline__ i32x4 hdesc(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+    d[2] = 0x7fffffff;
+    d[3] = 0x00020000;
+    return d;
+}
+
+#ifdef RNH_STAMPS
+__device__ unsigned long long g_wino2_stamps[8];
+__device__ unsigned long long g_wino2_hw[4096 * 3];          // per block: HW_ID, start, end
+#ifndef RNH_STAMP_BLOCK
+#define RNH_STAMP_BLOCK 0
+#endif
+#define HSTAMP(i) do { if (blockIdx.x == RNH_STAMP_BLOCK && threadIdx.x == 0) g_wino2_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HSTAMP(i)
+#endif
+
+constexpr int H_TILES = 32, H_CPC = 8, H_CH = 16, H_CHS = 4 * H_CPC + 4, H_BUF = 8 * H_TILES * H_CHS;   // floats per staging buffer
+constexpr int H_PART = 4 * 8 * 64 * 4;             // floats of the partial-output exchange: [wave][entry][lane][4]
+constexpr int H_TS = 72, H_GS = 32 * H_TS + 16;    // gate exchange [gate][tile][pixel][16 channels]: strides that keep the four
+                                                   // (lane half, gate) groups of a wave's store in four different bank ranges
+static_assert(H_PART + 4 * H_GS <= 2 * H_BUF, "the epilogue's exchange areas live in the staging buffers");
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
+    constexpr int TILES = H_TILES, CPC = H_CPC, CH = H_CH, CHS = H_CHS, BUF = H_BUF;
+    __shared__ __attribute__((aligned(16))) float stage[2 * BUF];   // 73.7 KB: two workgroups per CU
+    __shared__ int tpix[TILES];                               // top-left output pixel of the block's tiles (epilogue)
+    __shared__ int tcoord[TILES];
+#ifdef RNH_WINO_SOLO                                           // experiments: one workgroup per CU
+    __shared__ float solo_pad[5000];
+    if (P.H < 0) solo_pad[threadIdx.x] = 1.f, tpix[0] = (int)solo_pad[threadIdx.x + 1];
+#endif                             // the same as (image << 20 | y << 10 | x), -1: no such tile
+    HSTAMP(0);
+#ifdef RNH_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_wino2_hw[blockIdx.x * 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_wino2_hw[blockIdx.x * 3 + 1] = __builtin_readcyclecounter();
+    }
+#endif
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wave & 1, cg = wave >> 1;                   // half of the transform domain, column group
+    // The two workgroups of a CU start together and - sharing the MFMA pipe while both are in their main loops - stay in
+    // step for the whole launch: set-up, staging latency and epilogues of both coincide and nothing hides them.  The
+    // workgroups that the first round places in the second wave slot of a SIMD (HW_ID.wave_id) start RNH_WINO_SKEW cycles
+    // late; the offset then persists (whoever is alone in its loop runs at full rate).
+#ifndef RNH_WINO_SKEW
+#define RNH_WINO_SKEW 40000
+#endif
+    if (RNH_WINO_SKEW > 0 && blockIdx.x < 512) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);           // HW_REG_HW_ID, all 32 bits
+        if (hw & 1) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < RNH_WINO_SKEW) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    const int bid = rnh_xcd_remap(blockIdx.x, MT * NT);
+    const int mt = bid / NT, nt = bid - mt * NT;
+    const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
+    const int m0 = mt * TILES;
+
+    // ---- staging: thread = (tile ts, channel pair cp of the chunk) ------------------------------------------------
+    const int ts = threadIdx.x / CPC, cp = threadIdx.x % CPC;
+    const int t0 = m0 < ntiles ? m0 : 0;
+    const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
+    const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
+    const int base_pix = (img0 * Hs + (2 * ty0 - 1) * sc) * Ws - sc;   // at or before every pixel the block touches
+    // the thread's 4x4 patch: pixel offset of its top-left corner (relative to base_pix) and a 16-bit mask of the pixels
+    // inside the image (the 16 offsets are rebuilt from these two per source - they would cost 16 registers to keep)
+    int pix00, okmask = 0;
+    {
+        const int t = m0 + ts;
+        const bool tok = t < ntiles;
+        const int tt = tok ? t : t0;
+        const int img = tt / (TY * TX), trem = tt - img * TY * TX, ty = trem / TX, tx = trem - ty * TX;
+        pix00 = (img * Hs + (2 * ty - 1) * sc) * Ws + (2 * tx - 1) * sc - base_pix;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int y = 2 * ty - 1 + (p >> 2), x = 2 * tx - 1 + (p & 3);
+            okmask |= (tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? 1 << p : 0;
+        }
+    }
+    int si = 0, cchunk = 0, nchunk = P.src[0].nch / CH;
+    int voff[16];
+    i32x4 adesc;
+    auto setup_src = [&](int sidx) {
+        const rnh_src_t &S = P.src[sidx];
+        adesc = hdesc(S.ptr + S.c0 + ((long)S.img_off * Hs * Ws + base_pix + S.sub_y * Ws + S.sub_x) * S.C);
+        const int C4 = S.C * 4;
+        // (opaque copy: the 16 pixel offsets are loop invariants that hipcc would hoist out of the chunk loop - and spill)
+        int pb = pix00;
+        asm volatile("" : "+v"(pb));
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int off = __mul24(pb + ((p >> 2) * Ws + (p & 3)) * sc, C4) + cp * 8;      // < 2^24 pixels per block, < 2^24 bytes per pixel
+            const int inside = __builtin_amdgcn_sbfe(okmask, p, 1);                       // -1 inside the image, 0 outside
+            voff[p] = off | ~inside;
+        }
+        nchunk = S.nch / CH;
+    };
+    setup_src(0);
+
+    // All vector-memory and LDS reads of the loop are volatile asm with hand-counted waits (see conv_wino.hip); every wait
+    // names the registers it covers as "+v" operands, which orders their uses behind it.  The s_nop covers the 5 wait
+    // states between an SALU / v_readfirstlane write of an SGPR and a VMEM instruction reading it.
+    auto ld8 = [&](f32x2 *dst, const int *vo, const i32x4 &desc, int soff) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx2 %0, %8, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %1, %9, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %2, %10, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %3, %11, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %4, %12, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %5, %13, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %6, %14, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %7, %15, %16, %17 offen"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7])
+            : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]), "s"(desc), "s"(soff)
+            : "memory");
+    };
+    f32x2 stg[16];
+    auto gload = [&]() {                                   // next chunk of the source list -> registers (16 loads)
+        const int soff = __builtin_amdgcn_readfirstlane(cchunk * CH * 4);
+        ld8(stg, voff, adesc, soff);
+        ld8(stg + 8, voff + 8, adesc, soff);
+        if (++cchunk == nchunk) {
+            cchunk = 0;
+            if (++si < P.nsrc) setup_src(si);
+        }
+    };
+    auto xform_store = [&](int buf) {                       // V = B^T d B on the thread's two channels, to LDS
+        asm volatile("s_waitcnt vmcnt(4)"
+                     : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
+                       "+v"(stg[8]), "+v"(stg[9]), "+v"(stg[10]), "+v"(stg[11]), "+v"(stg[12]), "+v"(stg[13]), "+v"(stg[14]),
+                       "+v"(stg[15]));
+        auto sub = [&](f32x2 a, f32x2 b) {                 // one v_pk_add_f32 (hipcc scalarises packed adds / subtractions)
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
+        auto add = [&](f32x2 a, f32x2 b) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
+        f32x2 tq[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = sub(stg[0 * 4 + j], stg[2 * 4 + j]);
+            tq[1 * 4 + j] = add(stg[1 * 4 + j], stg[2 * 4 + j]);
+            tq[2 * 4 + j] = sub(stg[2 * 4 + j], stg[1 * 4 + j]);
+            tq[3 * 4 + j] = sub(stg[1 * 4 + j], stg[3 * 4 + j]);
+        }
+        float *o = stage + buf * BUF + ts * CHS + 4 * cp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 v0 = sub(tq[i * 4 + 0], tq[i * 4 + 2]), v1 = add(tq[i * 4 + 1], tq[i * 4 + 2]);
+            const f32x2 v2 = sub(tq[i * 4 + 2], tq[i * 4 + 1]), v3 = sub(tq[i * 4 + 1], tq[i * 4 + 3]);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 0) * TILES * CHS) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 1) * TILES * CHS) = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
+        }
+    };
+
+    // this wave's pairs of transform positions: pr = 2 i + h (row i of the 4x4 domain, columns 2h and 2h + 1)
+    const i32x4 bdesc = hdesc(P.wp + (long)((nt * 2 + cg) * 32) * 8);
+    const int pstride = P.Npad * 32;                        // bytes between two PAIRS of transform positions of one step
+    int boffx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) boffx[i] = (l31 * 2 + kh) * 16 + (2 * i + h) * pstride;
+    auto loadb = [&](f32x4w *u, int sb) {                   // transformed weights of step sb: 4 loads of 16 bytes
+#ifdef RNH_X_NOB
+        if (sb > 0) return;
+#endif
+        const int soff = __builtin_amdgcn_readfirstlane(sb * 8 * pstride);
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %4, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %3, %7, %8, %9 offen"
+            : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+            : "v"(boffx[0]), "v"(boffx[1]), "v"(boffx[2]), "v"(boffx[3]), "s"(bdesc), "s"(soff)
+            : "memory");
+    };
+    const unsigned lds0 = (unsigned)(size_t)stage;
+    const unsigned vlane = lds0 + ((h * TILES + l31) * CHS + 4 * kh) * 4;
+    // the lane's tile, channels 4q + 2kh, +1 of the staged chunk, pairs 2a and 2a + 1 of this wave's four (half a step: 8 MFMAs)
+    auto loadv = [&](f32x4w *V, int buf, int q, auto a_tag) {
+        constexpr int a = decltype(a_tag)::value;
+        const unsigned adr = vlane + buf * BUF * 4 + q * 32;
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(V[0]) : "v"(adr), "i"((4 * a) * TILES * CHS * 4) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(V[1]) : "v"(adr), "i"((4 * a + 2) * TILES * CHS * 4) : "memory");
+    };
+    auto wait_lds = [&](f32x4w *V) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1])); };
+    auto wait_vm = [&](f32x4w *u, auto keep) {
+        asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "i"(decltype(keep)::value));
+    };
+
+    f32x16 acc[8];                                          // acc[2 i + odd] = position (row i, column 2h + odd)
+
+    auto compute = [&](const f32x4w *V, const f32x4w *u, auto a_tag) {      // V: the two pairs of half a, u: all four pairs of the step
+        constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * a + j;
+            acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].x, u[i].x, acc[2 * i], 0, 0, 0);
+            acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].y, u[i].y, acc[2 * i], 0, 0, 0);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].z, u[i].z, acc[2 * i + 1], 0, 0, 0);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].w, u[i].w, acc[2 * i + 1], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop over 16-channel chunks (4 steps of 4 channels, 16 MFMAs each); chunk c+1 travels global -> registers
+    // under the MFMAs of chunk c and is transformed into the other LDS buffer in its third step ---------------------------
+    int nchunks_total = 0;
+    for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch / CH;
+    f32x4w Va[2], Vb[2], u0[4], u1[4];                        // staged operands by half steps, weights by steps
+    if (threadIdx.x < TILES) {
+        const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
+        const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
+        tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
+        tcoord[threadIdx.x] = tr < ntiles ? (im << 20) | (2 * yy << 10) | (2 * xx) : -1;
+    }
+    HSTAMP(1);
+    gload();
+    loadb(u0, 0);                                            // 4 loads younger than the staging loads: vmcnt(4) in xform_store
+    xform_store(0);
+    __syncthreads();
+    HSTAMP(2);
+    int s = 0;                                               // global 4-channel step index (weights)
+#pragma unroll
+    for (int a = 0; a < 8; ++a)                              // (zeroed here, behind the prologue's transform: 128 registers)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][v] = 0.f;
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    loadv(Va, 0, 0, A0());
+    using K4 = std::integral_constant<int, 4>;               // the 4 weight loads of ONE step may stay in flight
+    using K0 = std::integral_constant<int, 0>;
+    // The loop body (every chunk but the last) has no branch: a register that is the target of an asynchronous asm load
+    // must have exactly one definition per iteration (tests/test_isa_guards.py); the last chunk is peeled off.
+    // LDS operands run half a step (8 MFMAs) ahead in two register pairs, weights one step (16 MFMAs) ahead.
+    auto chunk = [&](const int buf, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        // step 0: [staging loads of the next chunk] [weights of step 1] | MFMAs of step 0
+        wait_lds(Va);
+        loadv(Vb, buf, 0, A1());
+        // (the staging loads go behind the wait: a staging load whose 64 lanes are all outside the image never goes to
+        // memory and returns ahead of older loads, so it must not be among the loads a counted wait leaves in flight)
+        wait_vm(u0, K0());
+#ifndef RNH_X_NOSTAGE
+        if constexpr (more) gload();
+#endif
+        loadb(u1, s + 1);
+        compute(Va, u0, A0());
+        wait_lds(Vb);
+        loadv(Va, buf, 1, A0());
+        compute(Vb, u0, A1());
+        // step 1
+        wait_lds(Va);
+        loadv(Vb, buf, 1, A1());
+        loadb(u0, s + 2);
+        wait_vm(u1, K4());
+        compute(Va, u1, A0());
+        wait_lds(Vb);
+        loadv(Va, buf, 2, A0());
+        compute(Vb, u1, A1());
+        // step 2: also the transform of the staged chunk into the other LDS buffer (its loads are older than the weight
+        // loads the wait leaves in flight)
+        wait_lds(Va);
+        loadv(Vb, buf, 2, A1());
+        loadb(u1, s + 3);
+        wait_vm(u0, K4());
+#ifndef RNH_X_NOSTAGE
+        if constexpr (more) xform_store(buf ^ 1);
+#endif
+        compute(Va, u0, A0());
+        wait_lds(Vb);
+        loadv(Va, buf, 3, A0());
+        compute(Vb, u0, A1());
+        // last step: the chunk's barrier in front of its last 8 MFMAs (all reads of this buffer issued and landed, all
+        // writes of the other one done), so the first operands of the next chunk are fetched under their cover
+        wait_lds(Va);
+        loadv(Vb, buf, 3, A1());
+        if constexpr (more) {
+            loadb(u0, s + 4);
+            wait_vm(u1, K4());
+        } else {
+            wait_vm(u1, K0());
+        }
+        compute(Va, u1, A0());
+        wait_lds(Vb);
+#ifndef RNH_X_NOBAR
+        asm volatile("s_barrier" ::: "memory");
+#endif
+        if constexpr (more) loadv(Va, buf ^ 1, 0, A0());
+        compute(Vb, u1, A1());
+        s += 4;
+    };
+    for (int c = 0; c + 1 < nchunks_total; ++c) chunk(c & 1, std::true_type());
+    chunk((nchunks_total - 1) & 1, std::false_type());
+    HSTAMP(3);
+
+    // ---- output transform: this half's share of Y = A^T M A, exchange with the partner wave --------------------------
+    // (every wave is past the last chunk's barrier, i.e. nobody reads the staging buffers any more)
+    const int ncol = (nt * 2 + cg) * 32 + l31;
+    // what the epilogue needs from memory is requested here and lands during the exchange: a wait behind the gate / output
+    // stores would be a wait for those stores too (loads and stores share vmcnt and may retire out of order: vmcnt(0))
+    float bv = 0.f;
+    if (P.bias) asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(P.bias + ncol) : "memory");
+    [[maybe_unused]] float cpv[8];
+    [[maybe_unused]] bool lstm_full = false;
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        // phase 2 items of this thread: pixel (lane >> 4) of tiles wave, wave + 4, ..., hidden channel nt * 16 + (lane & 15)
+        lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * 16 + 16 <= P.hd;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cpv[k] = 0.f;
+        if (lstm_full && P.c_prev) {
+            const int p2 = lane >> 4;
+            const float *cpb = P.c_prev + (long)((p2 >> 1) * W + (p2 & 1)) * P.hd + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(cpv[k]) : "v"(cpb + (long)tpix[wave + 4 * k] * P.hd) : "memory");
+        }
+    }
+    f32x4w *px = reinterpret_cast<f32x4w *>(stage);
+    float Yf[8][4];                                             // entries 8h .. 8h + 7: tiles 16h .. 16h + 15 of the block
+    // (the half is a template argument: accumulator registers cannot be indexed at run time)
+    auto exchange = [&](auto h_tag) {
+        constexpr int hh = decltype(h_tag)::value;
+        auto part4 = [&](int v, float *Y) {
+            float s0[2], s1[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                s0[o] = acc[0 + o][v] + acc[2 + o][v] + acc[4 + o][v];
+                s1[o] = acc[2 + o][v] - acc[4 + o][v] - acc[6 + o][v];
+            }
+            if constexpr (hh == 0) {                            // columns 0, 1 of the domain
+                Y[0] = s0[0] + s0[1]; Y[1] = s0[1]; Y[2] = s1[0] + s1[1]; Y[3] = s1[1];
+            } else {                                            // columns 2, 3
+                Y[0] = s0[0]; Y[1] = -s0[0] - s0[1]; Y[2] = s1[0]; Y[3] = -s1[0] - s1[1];
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                           // the partner's entries
+            float Y[4];
+            part4(8 * (1 - hh) + e, Y);
+            const f32x4w y4 = {Y[0], Y[1], Y[2], Y[3]};
+            px[(wave * 8 + e) * 64 + lane] = y4;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part4(8 * hh + e, Yf[e]);
+    };
+    if (h == 0) exchange(std::integral_constant<int, 0>());
+    else exchange(std::integral_constant<int, 1>());
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv), "+v"(cpv[0]), "+v"(cpv[1]), "+v"(cpv[2]), "+v"(cpv[3]), "+v"(cpv[4]), "+v"(cpv[5]), "+v"(cpv[6]), "+v"(cpv[7]));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const f32x4w y4 = px[((wave ^ 1) * 8 + e) * 64 + lane];
+        Yf[e][0] += y4.x + bv; Yf[e][1] += y4.y + bv; Yf[e][2] += y4.z + bv; Yf[e][3] += y4.w + bv;
+    }
+    HSTAMP(4);
+    // tile row (0..31) of entry e of this wave
+    auto trl_of = [&](int e) { const int v = 8 * h + e; return (v & 3) + 8 * (v >> 2) + 4 * kh; };
+
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        const int hd = P.hd;
+        const bool full = lstm_full;
+        float *xg = stage + H_PART;
+        // phase 1: lanes 0..15 / 16..31 of a row block hold gates 2cg / 2cg + 1 (i, f | o, g) of 16 hidden channels;
+        // sigmoid, and tanh as 2 sigmoid(2x) - 1 for the candidate gate, in one form: m rcp(1 + exp(-m x)) + b
+        const int gate = 2 * cg + (l31 >> 4), ch = l31 & 15, hc = nt * 16 + ch;
+        const float gm = gate == 3 ? 2.f : 1.f, gb = gate == 3 ? -1.f : 0.f;
+        float *xw = xg + gate * H_GS + ch;
+        const int ch2 = lane & 15, p2 = lane >> 4, hc2 = nt * 16 + ch2, poff2 = (p2 >> 1) * W + (p2 & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) Yf[e][p] = __builtin_fmaf(gm, __builtin_amdgcn_rcpf(1.f + __expf(-gm * Yf[e][p])), gb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xw[trl_of(e) * H_TS + p * 16] = Yf[e][p];
+        if (P.gates_out) {
+            if (full) {
+                float *gb0 = P.gates_out + gate * hd + hc;
+                const long rowg = (long)W * 4 * hd;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float *gp = gb0 + (long)tpix[trl_of(e)] * 4 * hd;
+#ifdef RNH_NT_GATES
+                    __builtin_nontemporal_store(Yf[e][0], gp); __builtin_nontemporal_store(Yf[e][1], gp + 4 * hd);
+                    __builtin_nontemporal_store(Yf[e][2], gp + rowg); __builtin_nontemporal_store(Yf[e][3], gp + rowg + 4 * hd);
+#else
+                    gp[0] = Yf[e][0]; gp[4 * hd] = Yf[e][1]; gp[rowg] = Yf[e][2]; gp[rowg + 4 * hd] = Yf[e][3];
+#endif
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int trl = trl_of(e), tc = tcoord[trl];
+                    const bool ok = tc >= 0 && hc < hd;
+                    const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (ok && yy + (p >> 1) < H && xx + (p & 1) < W)
+                            P.gates_out[((long)tpix[trl] + (p >> 1) * W + (p & 1)) * 4 * hd + gate * hd + hc] = Yf[e][p];
+                }
+            }
+        }
+        // the gates are in LDS: wait for the LDS writes only (not for the gates_out stores)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        HSTAMP(5);
+        const float *xr = xg + p2 * 16 + ch2;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = wave + 4 * k;
+                const float gi = xr[0 * H_GS + t * H_TS], gf = xr[1 * H_GS + t * H_TS], go = xr[2 * H_GS + t * H_TS], gg = xr[3 * H_GS + t * H_TS];
+                const long o = ((long)tpix[t] + poff2) * hd + hc2;
+                const float cn = gf * cpv[k] + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * h_tanh(cn);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = wave + 4 * k, tc = tcoord[t];
+                if (tc < 0 || hc2 >= hd) continue;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+                if (yy + (p2 >> 1) >= H || xx + (p2 & 1) >= W) continue;
+                const float gi = xr[0 * H_GS + t * H_TS], gf = xr[1 * H_GS + t * H_TS], go = xr[2 * H_GS + t * H_TS], gg = xr[3 * H_GS + t * H_TS];
+                const long o = ((long)tpix[t] + poff2) * hd + hc2;
+                const float cp = P.c_prev ? P.c_prev[o] : 0.f;
+                const float cn = gf * cp + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * h_tanh(cn);
+            }
+        }
+        HSTAMP(6);
+#ifdef RNH_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_wino2_hw[blockIdx.x * 3 + 2] = __builtin_readcyclecounter();
+#endif
+    } else if constexpr (EPI == RNH_EPI_PS) {
+        // column n = (i*r + j)*cq + c  ->  pixel (r*y + i, r*x + j), channel c of the (B, rH, rW, cq) destination
+        const int r = P.ps_r, cq = P.ps_cq;
+        if (ncol >= cq * r * r) return;
+        const int sub = ncol / cq, c = ncol - sub * cq, pi = sub / r, pj = sub - pi * r;
+        float *dp = P.dst[0].ptr + c;
+        const long Wr = (long)W * r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tc = tcoord[trl_of(e)];
+            if (tc < 0) continue;
+            const int im = tc >> 20, yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int y = yy + (p >> 1), x = xx + (p & 1);
+                if (y >= H || x >= W) continue;
+                dp[(((long)im * H + y) * r + pi) * Wr * cq + ((long)x * r + pj) * cq] = Yf[e][p];
+            }
+        }
+    } else {
+        // destination segment of this lane's column
+        int seg = -1, cbase = 0;
+        for (int d = 0; d < P.ndst; ++d) {
+            if (seg < 0 && ncol < cbase + P.dst[d].ncols) seg = d;
+            if (seg < 0) cbase += P.dst[d].ncols;
+        }
+        if (seg < 0) return;
+        const rnh_dst_t &D = P.dst[seg];
+        float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
+        const bool full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1);
+        if (full) {                                          // no per-element predicates
+            const long rowC = (long)W * D.C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float *o = dp + (long)tpix[trl_of(e)] * D.C;
+                if (D.accumulate) {
+                    const float a0 = o[0], a1 = o[D.C], a2 = o[rowC], a3 = o[rowC + D.C];
+                    o[0] = a0 + Yf[e][0]; o[D.C] = a1 + Yf[e][1]; o[rowC] = a2 + Yf[e][2]; o[rowC + D.C] = a3 + Yf[e][3];
+                } else {
+                    o[0] = Yf[e][0]; o[D.C] = Yf[e][1]; o[rowC] = Yf[e][2]; o[rowC + D.C] = Yf[e][3];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int trl = trl_of(e), tc = tcoord[trl];
+                if (tc < 0) continue;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (yy + (p >> 1) >= H || xx + (p & 1) >= W) continue;
+                    float *o = dp + ((long)tpix[trl] + (p >> 1) * W + (p & 1)) * D.C;
+                    *o = D.accumulate ? *o + Yf[e][p] : Yf[e][p];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+#ifdef RNH_STAMPS
+extern "C" int rnh_debug_wino2_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino2_stamps), sizeof(g_wino2_stamps));
+}
+extern "C" int rnh_debug_wino2_hw(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino2_hw), sizeof(g_wino2_hw));
+}
+#endif
+
+extern "C" int rnh_conv_wino2(const rnh_conv_args_t *args, void *stream) {
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: null args");
+    const rnh_conv_args_t &a = *args;
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
+    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
+    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 64");
+    int steps = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
+        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
+        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
+        steps += a.src[i].nch / 4;
+    }
+    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
+    const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
+    const long ntiles = (long)a.B * TY * TX;
+    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: at most 2047 images of 1023 x 1023");
+    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
+    // pixel offsets inside a block (it may straddle two images) go through 24-bit multiplies
+    if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: source images of at most 2^22 pixels");
+    const int MT = (int)((ntiles + H_TILES - 1) / H_TILES), NT = a.Npad / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(MT * NT)), block(256);
+    switch (a.epilogue) {
+        case RNH_EPI_STORE:
+            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
+            for (int d = 0; d < a.ndst; ++d)
+                if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_PS:
+            if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_LSTM:
+            if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
+            if (a.Npad != 64 * ((a.hd + 15) / 16)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (plans.lstm_colmap64)");
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        default:
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+    }
+    RNH_CHECK_LAUNCH("rnh_conv_wino");
+    return 0;
+}

@@ -158,6 +158,7 @@ def load():
     lib.rnh_xcol_combine.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_gather.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_conv_wino.argtypes = [C.POINTER(ConvArgs), vp]
+    lib.rnh_conv_wino2.argtypes = [C.POINTER(ConvArgs), vp]
     lib.rnh_wino_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_phase_bias_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino_wgrad_supported.argtypes = [C.POINTER(WgradArgs)]

@@ -60,6 +60,9 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+WINO_V = int(os.environ.get('RNH_WINO_V', '2'))      # 2: csrc/conv_wino2.hip (two workgroups per CU), 1: csrc/conv_wino.hip
+
+
 class ConvPlan:
     """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
 
@@ -90,8 +93,9 @@ class ConvPlan:
         self.nk = len(self.kbase)
         # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
         # (128-column multiples: 16-channel chunks; other 64-column multiples: the two-tile-group variant, 8-channel chunks)
+        self.wino_v = WINO_V
         self.wino = bool(wino) and self.ntaps == 9 and self.Npad % 64 == 0 and \
-            all(sg.nch % (16 if self.Npad % 128 == 0 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
+            all(sg.nch % (16 if self.Npad % 128 == 0 or self.wino_v == 2 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
         if self.wino:
             self.wkbase, self.wknv, self.wkcoff = [], [], []
             for sg in ksegs:
@@ -249,12 +253,20 @@ class NetPlans:
                 ws = (4 * hd, cin, 3, 3)
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
-                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) else lstm_colmap(hd)
                 wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G and not bf
-                full = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm,
-                                tile=ltile, epilogue=L.EPI_LSTM, wino=wino)
-                first = ConvPlan_(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm, tile=ltile,
-                                 epilogue=L.EPI_LSTM, wino=wino) if cfg.memory else full
+                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and WINO_V == 2) else lstm_colmap(hd)
+                def mk(lcm_, wino_):
+                    full_ = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm_,
+                                     tile=ltile, epilogue=L.EPI_LSTM, wino=wino_)
+                    first_ = ConvPlan_(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm_, tile=ltile,
+                                      epilogue=L.EPI_LSTM, wino=wino_) if cfg.memory else full_
+                    return full_, first_
+                full, first = mk(lcm, wino)
+                if wino and not (full.wino and first.wino):          # not eligible: the implicit-GEMM kernel and its gate layout
+                    wino, lcm = False, lstm_colmap(hd)
+                    full, first = mk(lcm, False)
+                for pl_ in (full, first):                           # hidden channels per column group of the gate layout
+                    pl_.gate_group = 16 if len(lcm) == 64 * ((hd + 15) // 16) and lcm == lstm_colmap64(hd) else 32
                 dgrad = ConvPlan_(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
                                  wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
                 wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],

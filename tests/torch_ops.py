@@ -123,7 +123,7 @@ class TorchOps:
             t.copy_(v.permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, cq))
         else:
             hd = lstm['hd']
-            if plan.tile in (L.TILE_128x128, L.TILE_256x64):        # 64-column gate groups (plans.lstm_colmap64)
+            if plan.gate_group == 16:                               # 64-column gate groups (plans.lstm_colmap64)
                 ng = (hd + 15) // 16
                 v = y[..., :ng * 64].reshape(B, H, W, ng, 4, 16).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, ng * 16)[..., :hd]
             else:
