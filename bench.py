@@ -15,7 +15,7 @@ step) from HIP-event timing of that launch on this run: `achieved` / `frac` = th
 ceiling, <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per
 pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not
 do that work).  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
-only if that file was measured on THIS kernel source (sha256 of csrc/conv_wino.hip), else null.  `cpu_baseline` times
+only if that file was measured on THIS kernel source (sha256 of the Winograd kernel's source file, csrc/conv_wino2.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 """
@@ -150,7 +150,7 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
                 traffic_src = {k: rec.get(k) for k in ('commit', 'date', 'command')}
         except Exception:
             traffic = None
-    name = 'conv_wino_kernel<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
+    name = f'{wino_kernel_name()}<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
         'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)'
     out = {'bound': 'mfma', 'kernel': name, 'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
@@ -161,9 +161,17 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     return out
 
 
+def wino_kernel_name():
+    """The Winograd convolution kernel the plans dispatch to (hipvsr.plans.WINO_V)."""
+    from hipvsr.plans import WINO_V
+    return 'conv_winoh_kernel' if WINO_V == 2 else 'conv_wino_kernel'
+
+
 def kernel_source_sha256():
+    """sha256 of the source file of that kernel: profiles/lstm_kernel_hbm_bytes.json is only quoted while it matches."""
     import hashlib
-    with open(os.path.join(PKG, 'csrc', 'conv_wino.hip'), 'rb') as f:
+    from hipvsr.plans import WINO_V
+    with open(os.path.join(PKG, 'csrc', 'conv_wino2.hip' if WINO_V == 2 else 'conv_wino.hip'), 'rb') as f:
         return hashlib.sha256(f.read()).hexdigest()
 
 

@@ -1,20 +1,35 @@
-// 3x3 convolution (padding 1) in Winograd form F(2x2, 3x3) on fp32 MFMA for gfx950, two workgroups per CU - rnh_conv_wino.
+// 3x3 convolution (padding 1) in Winograd form F(2x2, 3x3) on fp32 MFMA for gfx950, two workgroups per CU - rnh_conv_wino2.
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
 //
-// 16 independent GEMMs (one per position xi of the 4x4 transform domain) of [tiles x C] x [C x N].  conv_wino.hip (rounds 1-2)
+// 16 independent GEMMs (one per position xi of the 4x4 transform domain) of [tiles x C] x [C x N].  conv_wino.hip (round 1)
 // gave one wave all 16 positions of 32 tiles x 32 columns: 256 accumulators + 256 working registers = the whole register
 // file of a SIMD, ONE wave per SIMD, so every cycle that wave spent outside the MFMA stream (set-up, staging transform,
-// barrier skew, the 2 000-instruction gate epilogue, stores) was a cycle of matrix-core idle time: 0.56 of the fp32 peak.
+// barrier skew, the gate epilogue, stores) was a cycle of matrix-core idle time: 0.56 of the fp32 peak.
 // Here a wave owns HALF the transform domain (the positions xi = 4 i + j with j in {2h, 2h+1}: 8 of the 16) of 32 tiles x 32
 // columns - 128 accumulators, 256 registers in all - and a workgroup is 2 halves x 2 column groups = 32 tiles x 64 columns:
-// two workgroups are resident per CU, every SIMD holds one wave of each, and whatever one of them does beside its MFMAs
+// two workgroups are resident per CU, every SIMD holds one wave of each, and part of what one of them does beside its MFMAs
 // hides behind the MFMAs of the other.  The price:
 //   * the output transform needs all four j: the two halves exchange partial 2x2 outputs through LDS (each wave keeps the
 //     tiles of 8 accumulator registers and sends the other 8 to its partner: 8 ds_write_b128 + 8 ds_read_b128 per lane);
 //   * the staged input transform of 32 tiles feeds 64 columns instead of 128 (LDS and L2 traffic per MFMA as before,
-//     staging loads and transform adds per MFMA doubled for convolutions wider than 64 columns - vector work that now
-//     runs under the other workgroup's MFMAs).
+//     staging loads and transform adds per MFMA doubled for convolutions wider than 64 columns).
+// Measured on the ConvLSTM cell (N = 8, 128 x 128, same box): 0.437 -> 0.412 ms, its data gradient 0.351 -> 0.320 ms;
+// MFMA pipe busy 0.55 -> 0.62 / 0.67 -> 0.76 (rocprofv3 PMC); the training step 371 -> 355 ms.
+//
+// What the experiments on this kernel say about the machine (tools/wino_stamps.py, tools/experiments/):
+//   * issue arbitration between the two waves of a SIMD is STRICT, not round-robin: the wave in the lower slot (the
+//     workgroup that arrived first) wins whenever it has an instruction ready; its blocks take ~90 k cycles, the other
+//     workgroup's ~120 k (HWMAP=1 tools/wino_stamps.py; s_setprio on the second workgroup reverses it).  The hardware's
+//     workgroup dispatcher evens that out - a freed slot gets the next block - which is why a PERSISTENT variant of this
+//     kernel (tools/experiments/conv_wino2_persistent.hip: static block lists, the first chunk of the next block staged
+//     under the last chunk of this one) was 7 % slower: the favoured workgroup finishes its list early and the CU runs
+//     half empty at the end;
+//   * a vector instruction of wave B is served about once per MFMA of wave A (34 cycles per instruction measured for a
+//     pure producer wave beside a pure MFMA wave, tools/experiments/conv_wino3_specialised_waves.hip): VALU work does not
+//     run "under" the fp32 MFMAs of the other wave, it interleaves with them, and inside one wave every non-MFMA
+//     instruction costs 8-10 cycles of matrix-core time.  With ~1 500 such instructions per 512 MFMAs of a wave
+//     (operand loads 450, staging 650, epilogue 470) the ceiling of this formulation is about 0.70 of the fp32 peak.
 // Operands as in conv_wino.hip: the input transform B^T d B of a 16-channel chunk is computed once per workgroup (thread =
 // (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32
 // packed adds, 8 16-byte LDS writes into [xi / 2][tile][36]), the weights arrive pre-transformed from
@@ -75,11 +90,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     constexpr int TILES = H_TILES, CPC = H_CPC, CH = H_CH, CHS = H_CHS, BUF = H_BUF;
     __shared__ __attribute__((aligned(16))) float stage[2 * BUF];   // 73.7 KB: two workgroups per CU
     __shared__ int tpix[TILES];                               // top-left output pixel of the block's tiles (epilogue)
-    __shared__ int tcoord[TILES];
-#ifdef RNH_WINO_SOLO                                           // experiments: one workgroup per CU
-    __shared__ float solo_pad[5000];
-    if (P.H < 0) solo_pad[threadIdx.x] = 1.f, tpix[0] = (int)solo_pad[threadIdx.x + 1];
-#endif                             // the same as (image << 20 | y << 10 | x), -1: no such tile
+    __shared__ int tcoord[TILES];                             // the same as (image << 20 | y << 10 | x), -1: no such tile
     HSTAMP(0);
 #ifdef RNH_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -89,20 +100,6 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 #endif
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = wave & 1, cg = wave >> 1;                   // half of the transform domain, column group
-    // The two workgroups of a CU start together and - sharing the MFMA pipe while both are in their main loops - stay in
-    // step for the whole launch: set-up, staging latency and epilogues of both coincide and nothing hides them.  The
-    // workgroups that the first round places in the second wave slot of a SIMD (HW_ID.wave_id) start RNH_WINO_SKEW cycles
-    // late; the offset then persists (whoever is alone in its loop runs at full rate).
-#ifndef RNH_WINO_SKEW
-#define RNH_WINO_SKEW 40000
-#endif
-    if (RNH_WINO_SKEW > 0 && blockIdx.x < 512) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);           // HW_REG_HW_ID, all 32 bits
-        if (hw & 1) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < RNH_WINO_SKEW) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     const int bid = rnh_xcd_remap(blockIdx.x, MT * NT);
     const int mt = bid / NT, nt = bid - mt * NT;
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
@@ -217,9 +214,6 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 #pragma unroll
     for (int i = 0; i < 4; ++i) boffx[i] = (l31 * 2 + kh) * 16 + (2 * i + h) * pstride;
     auto loadb = [&](f32x4w *u, int sb) {                   // transformed weights of step sb: 4 loads of 16 bytes
-#ifdef RNH_X_NOB
-        if (sb > 0) return;
-#endif
         const int soff = __builtin_amdgcn_readfirstlane(sb * 8 * pstride);
         asm volatile(
             "s_nop 4\n\t"
@@ -297,9 +291,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         // (the staging loads go behind the wait: a staging load whose 64 lanes are all outside the image never goes to
         // memory and returns ahead of older loads, so it must not be among the loads a counted wait leaves in flight)
         wait_vm(u0, K0());
-#ifndef RNH_X_NOSTAGE
         if constexpr (more) gload();
-#endif
         loadb(u1, s + 1);
         compute(Va, u0, A0());
         wait_lds(Vb);
@@ -320,9 +312,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         loadv(Vb, buf, 2, A1());
         loadb(u1, s + 3);
         wait_vm(u0, K4());
-#ifndef RNH_X_NOSTAGE
         if constexpr (more) xform_store(buf ^ 1);
-#endif
         compute(Va, u0, A0());
         wait_lds(Vb);
         loadv(Va, buf, 3, A0());
@@ -339,9 +329,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         }
         compute(Va, u1, A0());
         wait_lds(Vb);
-#ifndef RNH_X_NOBAR
         asm volatile("s_barrier" ::: "memory");
-#endif
         if constexpr (more) loadv(Va, buf ^ 1, 0, A0());
         compute(Vb, u1, A1());
         s += 4;
@@ -438,12 +426,9 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float *gp = gb0 + (long)tpix[trl_of(e)] * 4 * hd;
-#ifdef RNH_NT_GATES
+                    // (streaming stores: the gates are read again in the backward pass only and should not push the weights out of L2)
                     __builtin_nontemporal_store(Yf[e][0], gp); __builtin_nontemporal_store(Yf[e][1], gp + 4 * hd);
                     __builtin_nontemporal_store(Yf[e][2], gp + rowg); __builtin_nontemporal_store(Yf[e][3], gp + rowg + 4 * hd);
-#else
-                    gp[0] = Yf[e][0]; gp[4 * hd] = Yf[e][1]; gp[rowg] = Yf[e][2]; gp[rowg + 4 * hd] = Yf[e][3];
-#endif
                 }
             } else {
 #pragma unroll
@@ -562,48 +547,48 @@ extern "C" int rnh_debug_wino2_hw(unsigned long long *out) {
 #endif
 
 extern "C" int rnh_conv_wino2(const rnh_conv_args_t *args, void *stream) {
-    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: null args");
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: null args");
     const rnh_conv_args_t &a = *args;
-    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
-    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
-    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 64");
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: bad arguments");
+    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: 3x3 convolutions only");
+    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: Npad must be a multiple of 64");
     int steps = 0;
     for (int i = 0; i < a.nsrc; ++i) {
-        if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
-        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
-        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
+        if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino2")) return rc;
+        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: one scale for all sources, no second pointer");
+        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino2: source channel counts must be multiples of 16");
         steps += a.src[i].nch / 4;
     }
-    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
+    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
     const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
     const long ntiles = (long)a.B * TY * TX;
-    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: at most 2047 images of 1023 x 1023");
-    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
+    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: at most 2047 images of 1023 x 1023");
+    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: too many pixels for 32-bit offsets");
     // pixel offsets inside a block (it may straddle two images) go through 24-bit multiplies
-    if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: source images of at most 2^22 pixels");
+    if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: source images of at most 2^22 pixels");
     const int MT = (int)((ntiles + H_TILES - 1) / H_TILES), NT = a.Npad / 64;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(MT * NT)), block(256);
     switch (a.epilogue) {
         case RNH_EPI_STORE:
-            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
+            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: bad destination count");
             for (int d = 0; d < a.ndst; ++d)
-                if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
+                if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: bad destination %d", d);
             hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         case RNH_EPI_PS:
             if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
-                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: bad pixel-shuffle destination");
             hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         case RNH_EPI_LSTM:
-            if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
-            if (a.Npad != 64 * ((a.hd + 15) / 16)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (plans.lstm_colmap64)");
+            if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino2: LSTM epilogue needs h_out, c_out, hd, bias");
+            if (a.Npad != 64 * ((a.hd + 15) / 16)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: LSTM column layout (plans.lstm_colmap64)");
             hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY);
             break;
         default:
-            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino2: epilogue %d not available", a.epilogue);
     }
-    RNH_CHECK_LAUNCH("rnh_conv_wino");
+    RNH_CHECK_LAUNCH("rnh_conv_wino2");
     return 0;
 }

@@ -60,7 +60,8 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
-WINO_V = int(os.environ.get('RNH_WINO_V', '2'))      # 2: csrc/conv_wino2.hip (two workgroups per CU), 1: csrc/conv_wino.hip
+# the Winograd convolution kernel: 2 = csrc/conv_wino2.hip (half the transform domain per wave, two workgroups per CU), 1 = csrc/conv_wino.hip
+WINO_V = 1 if os.environ.get('RNH_WINO_V') == '1' else 2
 
 
 class ConvPlan:
@@ -77,9 +78,16 @@ class ConvPlan:
         # bf16 = True: a plan of rnh_conv_bf16 (csrc/conv_bf16.hip): same K order (source -> 16-channel chunk -> tap), weights
         # packed to bf16 in natural k order, columns padded to 64 (column tiles of 128 where that divides, else of 64)
         self.bf16 = bool(bf16)
-        self.Npad = _pad_to(len(colmap), 64) if self.bf16 else _pad_to(len(colmap), L.TILE_COLS[self.tile])
         self.nchunks = sum((sg.nch + KC - 1) // KC for sg in ksegs)
         wino = wino and not self.bf16
+        # rnh_conv_wino (csrc/conv_wino2.hip): K in steps of 4 channels, 16-channel chunks, column blocks of 64
+        # (csrc/conv_wino.hip, RNH_WINO_V=1: column blocks of 128 with 16-channel chunks, other multiples of 64 with 8-channel chunks)
+        self.wino_v = WINO_V
+        npad_tile = _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        self.wino = bool(wino) and self.ntaps == 9 and \
+            all(sg.nch % (16 if self.wino_v == 2 or npad_tile % 128 == 0 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
+        self.Npad = _pad_to(len(colmap), 64) if self.bf16 or (self.wino and self.wino_v == 2) else npad_tile
+        self.wino = self.wino and self.Npad % 64 == 0
         self.colmap = list(colmap) + [-1] * (self.Npad - len(colmap))
         self.kbase, self.knv, self.ktap, self.kcoff = [], [], [], []
         for sg in ksegs:
@@ -91,11 +99,6 @@ class ConvPlan:
                     self.ktap.append(t)
                     self.kcoff.append(sg.kcoff)
         self.nk = len(self.kbase)
-        # Winograd form (rnh_conv_wino): K in steps of 4 channels, columns in groups of 128
-        # (128-column multiples: 16-channel chunks; other 64-column multiples: the two-tile-group variant, 8-channel chunks)
-        self.wino_v = WINO_V
-        self.wino = bool(wino) and self.ntaps == 9 and self.Npad % 64 == 0 and \
-            all(sg.nch % (16 if self.Npad % 128 == 0 or self.wino_v == 2 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
         if self.wino:
             self.wkbase, self.wknv, self.wkcoff = [], [], []
             for sg in ksegs:
@@ -254,7 +257,7 @@ class NetPlans:
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G and not bf
-                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and WINO_V == 2) else lstm_colmap(hd)
+                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and WINO_V >= 2) else lstm_colmap(hd)
                 def mk(lcm_, wino_):
                     full_ = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm_,
                                      tile=ltile, epilogue=L.EPI_LSTM, wino=wino_)

@@ -64,6 +64,13 @@ def suspicious_copies(lines):
         if m:
             targets.update(_regs(m))
     first_mfma = mf[0] - start
+    # hot[i]: line i lies inside a run of MFMAs (gaps of at most 150 lines: one chunk of the pipeline)
+    hot = [False] * len(region)
+    rm = [i - start for i in mf]
+    for a, b in zip(rm, rm[1:]):
+        if b - a <= 150:
+            for j in range(a, b + 1):
+                hot[j] = True
     copies, seen_vm, seen_lds, landed = [], set(), set(), set()
     for i, ln in enumerate(region):
         m = LOAD_RE.match(ln)
@@ -81,7 +88,9 @@ def suspicious_copies(lines):
             # a loop header (target of a later, backward branch): the state along the back edge is unknown.  Forward
             # joins (skipped blocks without loads) keep the state.
             label = ln.split(':')[0]
-            if any(label in later and later.startswith(('s_cbranch', 's_branch')) for later in region[i + 1:]):
+            back = [j for j in range(i + 1, len(region)) if region[j].startswith(('s_cbranch', 's_branch')) and region[j].split()[-1] == label]
+            # (a loop whose body issues no asynchronous load - an epilogue's loop over destinations - cannot bring one in flight)
+            if back and any(LOAD_RE.match(x) for x in region[i:back[-1] + 1]):
                 landed.clear()
             continue
         m = MOVE_RE.match(ln)
@@ -89,11 +98,13 @@ def suspicious_copies(lines):
             pool = targets if i >= first_mfma else (seen_vm | seen_lds)
             if any(r in pool and r not in landed for r in _regs(m)):
                 copies.append(ln)
-        if i < first_mfma:
-            # before the loop nest a vector instruction that overwrites a former load target makes it an ordinary register
-            # again (e.g. the zero that initialises the accumulators lives in a register the prologue's loads used)
-            d = DEST_RE.match(ln)
-            if d:
+        # a vector instruction that overwrites a former load target makes it an ordinary register again: its live range as a
+        # load target ended with its last use, behind the wait (e.g. the zero that initialises the accumulators of the next
+        # block lives in a register the loads of the chunk use)
+        d = DEST_RE.match(ln)
+        if d and not ln.startswith('v_mfma'):
+            landed.update(_regs(d))
+            if i < first_mfma:
                 seen_vm.difference_update(_regs(d))
                 seen_lds.difference_update(_regs(d))
         if m:
@@ -104,7 +115,9 @@ def suspicious_copies(lines):
             pool = targets if i >= first_mfma else (seen_vm | seen_lds)
             if any(r in pool and r not in landed for r in _regs(SPILL_RE.match(ln))):
                 copies.append(ln)
-        elif ln.startswith('scratch_') or ln.startswith('v_pk_mov'):
+        elif (ln.startswith('scratch_') and hot[i]) or ln.startswith('v_pk_mov'):
+            # scratch traffic between the MFMAs of a chunk (accumulator or operand spills); the reloads of loop invariants in
+            # the epilogue of a persistent kernel, which also lies between the first and the last MFMA, are ordinary code
             copies.append(ln)
     return copies
 
