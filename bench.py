@@ -15,7 +15,7 @@ step) from HIP-event timing of that launch on this run: `achieved` / `frac` = th
 ceiling, <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per
 pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not
 do that work).  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
-only if that file was measured on THIS kernel source (sha256 of the Winograd kernel's source file, csrc/conv_wino2.hip), else null.  `cpu_baseline` times
+only if that file was measured on THIS kernel source (sha256 of the Winograd kernel's source file, csrc/conv_wino.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 """
@@ -162,16 +162,14 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
 
 
 def wino_kernel_name():
-    """The Winograd convolution kernel the plans dispatch to (hipvsr.plans.WINO_V)."""
-    from hipvsr.plans import WINO_V
-    return 'conv_winoh_kernel' if WINO_V == 2 else 'conv_wino_kernel'
+    """The Winograd convolution kernel of csrc/conv_wino.hip (rnh_conv_wino)."""
+    return 'conv_winoh_kernel'
 
 
 def kernel_source_sha256():
     """sha256 of the source file of that kernel: profiles/lstm_kernel_hbm_bytes.json is only quoted while it matches."""
     import hashlib
-    from hipvsr.plans import WINO_V
-    with open(os.path.join(PKG, 'csrc', 'conv_wino2.hip' if WINO_V == 2 else 'conv_wino.hip'), 'rb') as f:
+    with open(os.path.join(PKG, 'csrc', 'conv_wino.hip'), 'rb') as f:
         return hashlib.sha256(f.read()).hexdigest()
 
 

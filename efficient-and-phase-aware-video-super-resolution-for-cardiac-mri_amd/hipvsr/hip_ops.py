@@ -265,8 +265,7 @@ class HipOps:
             if any(s_.scale != srcs[0].scale or s_.add is not None for s_ in srcs):
                 raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes sources of one scale, without a second operand')
             a.nk = plan.wns
-            fn = self.lib.rnh_conv_wino2 if plan.wino_v == 2 else self.lib.rnh_conv_wino
-            L.check(fn(C.byref(a), self._stream()), f"rnh_conv_wino{'2' if plan.wino_v == 2 else ''}({plan.name})")
+            L.check(self.lib.rnh_conv_wino(C.byref(a), self._stream()), f'rnh_conv_wino({plan.name})')
             return
         L.check(self.lib.rnh_conv_igemm(C.byref(a), self._stream()), f'rnh_conv_igemm({plan.name})')
 

@@ -29,7 +29,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
-           'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_conv_wino2', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
+           'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
            'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
            'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
            # bf16-storage path
@@ -158,7 +158,6 @@ def load():
     lib.rnh_xcol_combine.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_gather.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_conv_wino.argtypes = [C.POINTER(ConvArgs), vp]
-    lib.rnh_conv_wino2.argtypes = [C.POINTER(ConvArgs), vp]
     lib.rnh_wino_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_phase_bias_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino_wgrad_supported.argtypes = [C.POINTER(WgradArgs)]

@@ -60,10 +60,6 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
-# the Winograd convolution kernel: 2 = csrc/conv_wino2.hip (half the transform domain per wave, two workgroups per CU), 1 = csrc/conv_wino.hip
-WINO_V = 1 if os.environ.get('RNH_WINO_V') == '1' else 2
-
-
 class ConvPlan:
     """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
 
@@ -80,14 +76,9 @@ class ConvPlan:
         self.bf16 = bool(bf16)
         self.nchunks = sum((sg.nch + KC - 1) // KC for sg in ksegs)
         wino = wino and not self.bf16
-        # rnh_conv_wino (csrc/conv_wino2.hip): K in steps of 4 channels, 16-channel chunks, column blocks of 64
-        # (csrc/conv_wino.hip, RNH_WINO_V=1: column blocks of 128 with 16-channel chunks, other multiples of 64 with 8-channel chunks)
-        self.wino_v = WINO_V
-        npad_tile = _pad_to(len(colmap), L.TILE_COLS[self.tile])
-        self.wino = bool(wino) and self.ntaps == 9 and \
-            all(sg.nch % (16 if self.wino_v == 2 or npad_tile % 128 == 0 else 8) == 0 and sg.nvalid == sg.nch for sg in ksegs)
-        self.Npad = _pad_to(len(colmap), 64) if self.bf16 or (self.wino and self.wino_v == 2) else npad_tile
-        self.wino = self.wino and self.Npad % 64 == 0
+        # Winograd form (rnh_conv_wino, csrc/conv_wino.hip): K in steps of 4 channels, 16-channel chunks, column blocks of 64
+        self.wino = bool(wino) and self.ntaps == 9 and all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in ksegs)
+        self.Npad = _pad_to(len(colmap), 64) if self.bf16 or self.wino else _pad_to(len(colmap), L.TILE_COLS[self.tile])
         self.colmap = list(colmap) + [-1] * (self.Npad - len(colmap))
         self.kbase, self.knv, self.ktap, self.kcoff = [], [], [], []
         for sg in ksegs:
@@ -257,7 +248,7 @@ class NetPlans:
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G and not bf
-                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and WINO_V >= 2) else lstm_colmap(hd)
+                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or wino else lstm_colmap(hd)
                 def mk(lcm_, wino_):
                     full_ = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm_,
                                      tile=ltile, epilogue=L.EPI_LSTM, wino=wino_)

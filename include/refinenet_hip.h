@@ -121,19 +121,16 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
                      int transposed, void *stream);
 
 /* The same 3x3 convolution in Winograd form F(2x2, 3x3) (csrc/conv_wino.hip): 16 GEMMs in the transform domain, 2.25x
- * fewer MFMA passes; input and output transforms fused (nothing of the transform domain reaches memory).  Same
- * rnh_conv_args_t, with: ntaps = 9; every source scale 1, ptr2 = 0, nch % 4 == 0; nk = number of 4-channel steps
- * (sum_src nch/4); wp from rnh_wino_pack_weights; Npad a multiple of 64 (column blocks of 128, else two tile groups x 64
- * columns); tile ignored; epilogue RNH_EPI_STORE, RNH_EPI_PS or RNH_EPI_LSTM (column order plans.lstm_colmap).  Results differ from rnh_conv_igemm by fp32 rounding of the transforms only. */
+ * fewer MFMA passes; input and output transforms fused (nothing of the transform domain reaches memory).  A wave owns half
+ * of the transform domain of 32 tiles x 32 columns (128 accumulators), a workgroup computes 32 tiles x 64 columns and two
+ * workgroups share a CU.  Same rnh_conv_args_t, with: ntaps = 9; one scale for all sources, ptr2 = 0, every nch % 16 == 0;
+ * nk = number of 4-channel steps (sum_src nch/4); wp from rnh_wino_pack_weights; Npad a multiple of 64; tile ignored;
+ * source images of at most 2^22 pixels (scale^2 * H * W); epilogue RNH_EPI_STORE, RNH_EPI_PS or RNH_EPI_LSTM.
+ * RNH_EPI_LSTM expects the column order of plans.lstm_colmap64 (a block of 64 columns = gates i, f | o, g of 16 hidden
+ * channels: column block * 64 + (gate >> 1) * 32 + (gate & 1) * 16 + channel) and Npad == 64 * ceil(hd / 16).
+ * Results differ from rnh_conv_igemm by fp32 rounding of the transforms only.  (Replaces the same reference code as
+ * rnh_conv_igemm: src/model/nets/refine_net.py:245-265 ConvLSTMCell.forward and the 3x3 convolutions of :102-133.) */
 int rnh_conv_wino(const rnh_conv_args_t *args /* host */, void *stream);
-/* The same operation, the kernel the plans use (csrc/conv_wino2.hip): a wave owns half of the transform domain of 32 tiles x
- * 32 columns (128 accumulators), a workgroup computes 32 tiles x 64 columns and two workgroups share a CU.  Differences
- * in the contract: every source nch % 16 == 0; Npad a multiple of 64; RNH_EPI_LSTM expects the column order of
- * plans.lstm_colmap64 (a block of 64 columns = gates i, f | o, g of 16 hidden channels: column block * 64 + (gate >> 1) * 32
- * + (gate & 1) * 16 + channel) and Npad == 64 * ceil(hd / 16); source images of at most 2^22 pixels (scale^2 * H * W).
- * RNH_EPI_STORE, RNH_EPI_PS and RNH_EPI_LSTM.  (Replaces the same reference code as rnh_conv_igemm:
- * src/model/nets/refine_net.py:245-265 ConvLSTMCell.forward and the 3x3 convolutions of :102-133.) */
-int rnh_conv_wino2(const rnh_conv_args_t *args /* host */, void *stream);
 /* wp[s][xi][n][q] = (G g G^T)[xi], g = the 3x3 filter of (column n, input channel kbase[s] + q*kstride) - the mapping
  * conventions of rnh_pack_weights with 4-channel steps (q >= knv[s]: zero); biasp[n] as there. */
 int rnh_wino_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kbase,

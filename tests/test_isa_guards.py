@@ -123,7 +123,7 @@ def suspicious_copies(lines):
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
-@pytest.mark.parametrize('src,pattern,nmin', [('conv_wino.hip', 'conv_wino_kernel', 5), ('conv_wino2.hip', 'conv_winoh_kernel', 3), ('wgrad_wino.hip', 'wino_wgrad_kernel', 1)])
+@pytest.mark.parametrize('src,pattern,nmin', [('conv_wino.hip', 'conv_winoh_kernel', 3), ('wgrad_wino.hip', 'wino_wgrad_kernel', 1)])
 def test_no_copies_of_async_load_targets(tmp_path, src, pattern, nmin):
     text = _asm(os.path.join(CSRC, src), str(tmp_path))
     seen = 0

@@ -54,10 +54,9 @@ if jout:
     json.dump(summary, open(jout, 'w'), indent=1)
 if hout:
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the ConvLSTM cell kernel of the run: conv_winoh_kernel<LSTM> (csrc/conv_wino2.hip) or, with RNH_WINO_V=1, conv_wino_kernel<LSTM, 1>
-    key = next((k for k in summary if k.startswith('conv_winoh_kernel<2')), None) or next((k for k in summary if k.startswith('conv_wino_kernel<2')), None)
-    src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc',
-                       'conv_wino2.hip' if key and key.startswith('conv_winoh') else 'conv_wino.hip')
+    # the ConvLSTM cell kernel of the run: conv_winoh_kernel<LSTM> (csrc/conv_wino.hip)
+    key = next((k for k in summary if k.startswith('conv_winoh_kernel<2')), None)
+    src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc', 'conv_wino.hip')
     if key and 'hbm_bytes_per_launch' in summary[key]:
         try:
             commit = subprocess.run(['git', '-C', here, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
