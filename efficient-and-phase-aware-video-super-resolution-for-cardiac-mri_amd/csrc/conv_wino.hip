@@ -311,6 +311,37 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     loadv(Va, 0, 0, A0());
     using K4 = std::integral_constant<int, 4>;               // the 4 weight loads of ONE step may stay in flight
     using K0 = std::integral_constant<int, 0>;
+    // ---- what the epilogue needs from memory: bias of the lane's column and, for the ConvLSTM, the previous cell state of
+    // the thread's two items (tile, pixel, 4 hidden channels) q * 256 + tid - 16 bytes of every gate, of c and of h per
+    // item.  Requested in the LAST chunk right behind its last weight request (vector-memory loads complete in order: any
+    // earlier and the chunk's counted waits for weights would have to sit out these loads first).  The state comes from
+    // HBM behind the gate stores of the whole chip: measured 54 us of a 387 us launch while it was requested behind the
+    // main loop and awaited before the gate math; now it has the last two steps, the exchange and the gate math to arrive.
+    const int ncol = (nt * 2 + cg) * 32 + l31;
+    float bv;
+    [[maybe_unused]] f32x4w cpv[2];
+    [[maybe_unused]] bool lstm_full = false;
+    [[maybe_unused]] long item_o[2];                            // pixel index of the two items
+    [[maybe_unused]] int item_x[2];                             // their float offset in the gate exchange area
+    constexpr int NEPI = EPI == RNH_EPI_LSTM ? 3 : 1;           // loads of the request
+    auto epi_request = [&]() {
+        // (unconditional asm loads from clamped, always valid addresses: a load under an `if` would give its target register
+        // a second definition and hipcc a reason to copy it in flight; no bias / no previous state: zeros behind the wait)
+        asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"((P.bias ? P.bias : P.wp) + ncol) : "memory");
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * 16 + 16 <= P.hd;
+            const float *csrc = P.c_prev ? P.c_prev : P.c_out;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int it = q * 256 + (int)threadIdx.x, t = it >> 4, p = (it >> 2) & 3, c4 = (it & 3) * 4;
+                item_o[q] = (long)tpix[t] + (p >> 1) * W + (p & 1);
+                item_x[q] = t * H_TS + p * 16 + c4;
+                const int hcl = min(nt * 16 + c4, P.hd - 4);    // (the tile list is clamped in tpix, the channel here)
+                const long pl = lstm_full ? item_o[q] : (long)tpix[t];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpv[q]) : "v"(csrc + pl * P.hd + hcl) : "memory");
+            }
+        }
+    };
     // The loop body (every chunk but the last) has no branch: a register that is the target of an asynchronous asm load
     // must have exactly one definition per iteration (tests/test_isa_guards.py); the last chunk is peeled off.
     // LDS operands run half a step (8 MFMAs) ahead in two register pairs, weights one step (16 MFMAs) ahead.
@@ -342,8 +373,13 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         wait_lds(Va);
         loadv(Vb, buf, 2, A1());
         loadb(u1, s + 3);
-        wait_vm(u0, K4());
-        if constexpr (more) xform_store(buf ^ 1);
+        if constexpr (more) {
+            wait_vm(u0, K4());
+            xform_store(buf ^ 1);
+        } else {
+            epi_request();                                  // younger than every weight load: the waits below leave it in flight
+            wait_vm(u0, std::integral_constant<int, 4 + NEPI>());
+        }
         compute(Va, u0, A0());
         wait_lds(Vb);
         loadv(Va, buf, 3, A0());
@@ -356,7 +392,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
             loadb(u0, s + 4);
             wait_vm(u1, K4());
         } else {
-            wait_vm(u1, K0());
+            wait_vm(u1, std::integral_constant<int, NEPI>());
         }
         compute(Va, u1, A0());
         wait_lds(Vb);
@@ -371,26 +407,6 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 
     // ---- output transform: this half's share of Y = A^T M A, exchange with the partner wave --------------------------
     // (every wave is past the last chunk's barrier, i.e. nobody reads the staging buffers any more)
-    const int ncol = (nt * 2 + cg) * 32 + l31;
-    // what the epilogue needs from memory is requested here and lands during the exchange: a wait behind the gate / output
-    // stores would be a wait for those stores too (loads and stores share vmcnt and may retire out of order: vmcnt(0))
-    float bv = 0.f;
-    if (P.bias) asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(P.bias + ncol) : "memory");
-    [[maybe_unused]] float cpv[8];
-    [[maybe_unused]] bool lstm_full = false;
-    if constexpr (EPI == RNH_EPI_LSTM) {
-        // phase 2 items of this thread: pixel (lane >> 4) of tiles wave, wave + 4, ..., hidden channel nt * 16 + (lane & 15)
-        lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * 16 + 16 <= P.hd;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cpv[k] = 0.f;
-        if (lstm_full && P.c_prev) {
-            const int p2 = lane >> 4;
-            const float *cpb = P.c_prev + (long)((p2 >> 1) * W + (p2 & 1)) * P.hd + nt * 16 + (lane & 15);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                asm volatile("global_load_dword %0, %1, off" : "=v"(cpv[k]) : "v"(cpb + (long)tpix[wave + 4 * k] * P.hd) : "memory");
-        }
-    }
     f32x4w *px = reinterpret_cast<f32x4w *>(stage);
     float Yf[8][4];                                             // entries 8h .. 8h + 7: tiles 16h .. 16h + 15 of the block
     // (the half is a template argument: accumulator registers cannot be indexed at run time)
@@ -422,7 +438,8 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     if (h == 0) exchange(std::integral_constant<int, 0>());
     else exchange(std::integral_constant<int, 1>());
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv), "+v"(cpv[0]), "+v"(cpv[1]), "+v"(cpv[2]), "+v"(cpv[3]), "+v"(cpv[4]), "+v"(cpv[5]), "+v"(cpv[6]), "+v"(cpv[7]));
+    asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(bv) : "i"(NEPI - 1));       // the bias has landed, the state may still be on its way
+    if (!P.bias) bv = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const f32x4w y4 = px[((wave ^ 1) * 8 + e) * 64 + lane];
@@ -450,43 +467,48 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         for (int e = 0; e < 8; ++e)
 #pragma unroll
             for (int p = 0; p < 4; ++p) xw[trl_of(e) * H_TS + p * 16] = Yf[e][p];
-        if (P.gates_out) {
-            if (full) {
-                float *gb0 = P.gates_out + gate * hd + hc;
-                const long rowg = (long)W * 4 * hd;
+        if (P.gates_out && !full) {                             // (whole blocks store the gates from LDS in phase 2, 16 bytes per lane)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float *gp = gb0 + (long)tpix[trl_of(e)] * 4 * hd;
-                    // (streaming stores: the gates are read again in the backward pass only and should not push the weights out of L2)
-                    __builtin_nontemporal_store(Yf[e][0], gp); __builtin_nontemporal_store(Yf[e][1], gp + 4 * hd);
-                    __builtin_nontemporal_store(Yf[e][2], gp + rowg); __builtin_nontemporal_store(Yf[e][3], gp + rowg + 4 * hd);
-                }
-            } else {
+            for (int e = 0; e < 8; ++e) {
+                const int trl = trl_of(e), tc = tcoord[trl];
+                const bool ok = tc >= 0 && hc < hd;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int trl = trl_of(e), tc = tcoord[trl];
-                    const bool ok = tc >= 0 && hc < hd;
-                    const int yy = (tc >> 10) & 1023, xx = tc & 1023;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (ok && yy + (p >> 1) < H && xx + (p & 1) < W)
-                            P.gates_out[((long)tpix[trl] + (p >> 1) * W + (p & 1)) * 4 * hd + gate * hd + hc] = Yf[e][p];
-                }
+                for (int p = 0; p < 4; ++p)
+                    if (ok && yy + (p >> 1) < H && xx + (p & 1) < W)
+                        P.gates_out[((long)tpix[trl] + (p >> 1) * W + (p & 1)) * 4 * hd + gate * hd + hc] = Yf[e][p];
             }
         }
         // the gates are in LDS: wait for the LDS writes only (not for the gates_out stores)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         HSTAMP(5);
+        // (on every path: the registers must not be reused while the loads are in flight.  On the partial-block path this is
+        // also a wait for its gate stores.)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpv[0]), "+v"(cpv[1]));
+        if (!P.c_prev) cpv[0] = cpv[1] = f32x4w{0.f, 0.f, 0.f, 0.f};
         const float *xr = xg + p2 * 16 + ch2;
         if (full) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int t = wave + 4 * k;
-                const float gi = xr[0 * H_GS + t * H_TS], gf = xr[1 * H_GS + t * H_TS], go = xr[2 * H_GS + t * H_TS], gg = xr[3 * H_GS + t * H_TS];
-                const long o = ((long)tpix[t] + poff2) * hd + hc2;
-                const float cn = gf * cpv[k] + gi * gg;
-                P.c_out[o] = cn;
-                P.h_out[o] = go * h_tanh(cn);
+            for (int q = 0; q < 2; ++q) {
+                const int c4 = ((q * 256 + (int)threadIdx.x) & 3) * 4;
+                const float *xi = xg + item_x[q];
+                const f32x4w gi = *reinterpret_cast<const f32x4w *>(xi), gf = *reinterpret_cast<const f32x4w *>(xi + H_GS);
+                const f32x4w go = *reinterpret_cast<const f32x4w *>(xi + 2 * H_GS), gg = *reinterpret_cast<const f32x4w *>(xi + 3 * H_GS);
+                if (P.gates_out) {
+                    // (plain stores: with the nt bit, 16-byte pieces of one 128-byte line written by the workgroups of four
+                    // column blocks came out corrupted now and then - tools/debug/lstm_mismatch.py)
+                    f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + item_o[q] * 4 * hd + nt * 16 + c4);
+                    gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
+                }
+                f32x4w cn, hn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cn[j] = gf[j] * cpv[q][j] + gi[j] * gg[j];
+                    hn[j] = go[j] * h_tanh(cn[j]);
+                }
+                const long o = item_o[q] * hd + nt * 16 + c4;
+                *reinterpret_cast<f32x4w *>(P.c_out + o) = cn;
+                *reinterpret_cast<f32x4w *>(P.h_out + o) = hn;
             }
         } else {
 #pragma unroll

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
-LOAD_RE = re.compile(r'(?:buffer_load_dwordx4|buffer_load_dwordx2|buffer_load_dword|ds_read_b128|ds_read_b64)\s+v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
+LOAD_RE = re.compile(r'(?:buffer_load_dwordx4|buffer_load_dwordx2|buffer_load_dword|global_load_dwordx4|global_load_dword|ds_read_b128|ds_read_b64)\s+v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
 SPILL_RE = re.compile(r'scratch_store_dword(?:x[234])?\s+off,\s*v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
 DEST_RE = re.compile(r'v_\w+\s+v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
 MOVE_RE = re.compile(r'v_mov_b(?:32|64)(?:_e32|_e64)?\s+\S+,\s*v(?:\[(\d+):(\d+)\]|(\d+)(?!\d))')
