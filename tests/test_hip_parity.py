@@ -448,7 +448,7 @@ def test_winograd_conv_kernels_vs_torch_float64(which, B, H, W):
     """rnh_conv_wino at full channel width (the 13 reference goldens use num_features [8, 8], which the plans route to the
     implicit GEMM) against float64 torch convolutions of the OIHW weights: ConvLSTM cell with the fused gate epilogue
     (two K sources / the zero-state K = 576 plan; gates_out, c', h'), its data gradient (two destinations), the
-    PixelShuffle convolution (PS epilogue) and its data gradient (TG = 2 variant, pixel-unshuffle fused into the loads),
+    PixelShuffle convolution (PS epilogue) and its data gradient (pixel-unshuffle fused into the staging loads),
     refine conv1 over the ten hidden-state sources and its gather-form data gradient (accumulating stores)."""
     import torch.nn.functional as F
     from hipvsr.hip_ops import HipOps
