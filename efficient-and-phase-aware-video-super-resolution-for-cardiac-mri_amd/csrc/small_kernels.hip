@@ -565,6 +565,24 @@ __global__ void loss_finalize_kernel(const float *ws, float *loss, int GT, long 
     loss[gi] = s / (float)per;
 }
 
+// total = sum_g w[g] * mean_i loss[g*T + i]  (trainer :83-94: the discounted deep-supervision sum), or its gradient
+// dloss[g*T + i] = dtotal * w[g] / T - fixed summation order, one wave
+__global__ void loss_total_kernel(const float *in, const float *w, float *out, int G, int T, int backward) {
+    if (backward) {
+        const float g0 = in[0];
+        for (int e = threadIdx.x; e < G * T; e += blockDim.x) out[e] = g0 * w[e / T] / (float)T;
+        return;
+    }
+    if (threadIdx.x) return;
+    float tot = 0.f;
+    for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+        for (int i = 0; i < T; ++i) s += in[g * T + i];
+        tot += w[g] * (s / (float)T);
+    }
+    out[0] = tot;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // element-wise
 // ---------------------------------------------------------------------------------------------------------
@@ -811,6 +829,13 @@ extern "C" int rnh_loss_fwd_bwd(const float *o, const float *y, float *loss, flo
     RNH_CHECK_LAUNCH("rnh_loss_fwd_bwd");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3((G * T + 63) / 64), dim3(64), 0, st, ws, loss, G * T, (long)per);
     RNH_CHECK_LAUNCH("rnh_loss_fwd_bwd(finalize)");
+    return 0;
+}
+
+extern "C" int rnh_loss_total(const float *in, const float *w, float *out, int G, int T, int backward, void *stream) {
+    if (!in || !w || !out || G < 1 || T < 1) RNH_FAIL(RNH_E_ARG, "rnh_loss_total: bad arguments");
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, w, out, G, T, backward);
+    RNH_CHECK_LAUNCH("rnh_loss_total");
     return 0;
 }
 

@@ -60,6 +60,35 @@ class FusedLossFn(torch.autograd.Function):
         return None, d_o, None, None, None, None, None
 
 
+class LossTotalFn(torch.autograd.Function):
+    """total = sum_g w[g] * mean_i loss[g*T + i]: the trainer's discounted deep-supervision sum in one launch (and one more for
+    its gradient) instead of the ~30 element-wise / reduction kernels per direction that the list arithmetic costs."""
+
+    @staticmethod
+    def forward(ctx, ops, per_pair, w, G, T):
+        ctx.ops, ctx.meta = ops, (G, T)
+        ctx.save_for_backward(w)
+        return ops.loss_total(per_pair.contiguous(), w, G, T).reshape(())
+
+    @staticmethod
+    def backward(ctx, gtot):
+        (w,) = ctx.saved_tensors
+        G, T = ctx.meta
+        return None, ctx.ops.loss_total(gtot.reshape(1).contiguous().float(), w, G, T, backward=True), None, None, None
+
+
+def discounted_total(outputs, per_pair, discounts, T):
+    """The training loss of one loss function from the fused per-pair values (None if they did not come from the HIP path)."""
+    ops = getattr(outputs, 'ops', None)
+    if ops is None or per_pair is None or not per_pair.is_cuda:
+        return None
+    key = ('loss_discounts', tuple(discounts))
+    cache = ops.__dict__.setdefault('_const_cache', {})
+    if key not in cache:
+        cache[key] = torch.tensor(list(discounts), dtype=torch.float32, device=per_pair.device)
+    return LossTotalFn.apply(ops, per_pair, cache[key], len(discounts), T)
+
+
 def fused_losses(outputs, targets, loss_fn, last_only=False, per_sample=False):
     """Per-(group, frame) loss values [G*T] through the fused kernel, or None if this combination is not
     served by it (then the caller falls back to calling loss_fn per pair, like the reference does).

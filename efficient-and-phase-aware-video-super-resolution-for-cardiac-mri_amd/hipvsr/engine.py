@@ -314,9 +314,8 @@ class RefineNetEngine:
                     xs.append(Src(ctx.P4, img_off=(U - hw + j) * N))
             k1, b1 = P.r1_wgrad.wkey, P.r1_wgrad.bkey
             if P.pos:
-                dR1p = ops.empty((T + 2 * hw) * N, H, W, P.C1p, dtype=act)       # the T middle frames are written by conv2's data gradient
-                dR1p[:hw * N].zero_()
-                dR1p[(hw + T) * N:].zero_()
+                # the T middle frames are written by conv2's data gradient, the window halo on both sides stays zero
+                dR1p = ops.halo_buffer('dR1p', ((T + 2 * hw) * N, H, W, P.C1p), act, hw * N, (hw + T) * N)
                 if P.r1_split:
                     ops.conv(P.r2_dgrad_a, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
                     ops.conv(P.r2_dgrad_b, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])

@@ -111,8 +111,11 @@ class GraphedTrainStep:
         tr = self.tr
         outputs = tr.net(e.x, e.pos)
         losses = tr._compute_losses(outputs, e.y)
-        loss = (torch.stack(losses) * tr.loss_weights).sum()
-        loss.backward()
+        loss = tr._total_loss(losses) if hasattr(tr, '_total_loss') else (torch.stack(losses) * tr.loss_weights).sum()
+        if hasattr(tr, '_backward'):
+            tr._backward(loss)                     # (the seed gradient is allocated in the eager warm-up, outside the capture)
+        else:
+            loss.backward()
         return outputs, loss, losses
 
     def _capture(self, inputs, targets, pos_codes):

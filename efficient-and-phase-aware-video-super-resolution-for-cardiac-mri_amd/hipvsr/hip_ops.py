@@ -143,6 +143,18 @@ class HipOps:
             self._ws[key] = t
         return t
 
+    def halo_buffer(self, key, shape, dtype, lo, hi):
+        """A buffer of ``shape`` whose leading-dimension slices outside [lo, hi) are zero and stay zero: allocated and zeroed
+        once per (key, shape, dtype), handed out again on every call - the caller writes [lo, hi) only, and everything that
+        reads it is ordered behind the previous use on the same stream.  (The refine block's gradient planes with their
+        window halo: zeroing the halo of a fresh buffer was six 138 MB fill launches per step.)"""
+        k = ('halo', key, tuple(shape), dtype, lo, hi)
+        t = self._ws.get(k)
+        if t is None:
+            t = self.zeros(*shape, dtype=dtype)
+            self._ws[k] = t
+        return t
+
     def stack_inputs(self, inputs):
         """list[F] of (N, Cin, H, W) -> (F*N, H, W, Cin) NHWC, frame-major (plumbing: one copy of the LR input)."""
         x = packed_view(inputs, self.device)                                                # (F, N, Cin, H, W)
@@ -621,6 +633,15 @@ class HipOps:
             return out
         out = self.empty(F * N, H, W, 4)
         L.check(self.lib.rnh_phase_plane(_ptr(pos), _ptr(out), N, F, H, W, self._stream()), 'rnh_phase_plane')
+        return out
+
+    def loss_total(self, x, w, G, T, backward=False):
+        """sum_g w[g] * mean_i x[g*T + i] (one element), or with backward its gradient [G*T] from the upstream scalar x."""
+        self._chk(x, w)
+        if w.numel() != G or x.numel() != (1 if backward else G * T):
+            raise L.HipKernelError('loss_total: shapes')
+        out = self.empty(G * T if backward else 1)
+        L.check(self.lib.rnh_loss_total(_ptr(x), _ptr(w), _ptr(out), G, T, 1 if backward else 0, self._stream()), 'rnh_loss_total')
         return out
 
     def loss(self, o, y, G, T, kind, eps, gscale=None, want_grad=False):

@@ -25,7 +25,7 @@ LOSS_BLOCKS = 64
 
 EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_reduce', 'rnh_inconv_prelu_fwd',
            'rnh_inconv_prelu_bwd', 'rnh_inconv_bwd_ws_floats', 'rnh_outconv_fwd', 'rnh_outconv_dgrad',
-           'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_ew_add',
+           'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_loss_total', 'rnh_ew_add',
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
@@ -141,6 +141,7 @@ def load():
     lib.rnh_outconv_wgrad_ws_floats.restype = i64
     lib.rnh_lstm_gates_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     lib.rnh_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, f32, vp]
+    lib.rnh_loss_total.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.rnh_ew_add.argtypes = [vp, vp, vp, vp, i64, i32, vp]
     lib.rnh_phase_plane.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.rnh_uptail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

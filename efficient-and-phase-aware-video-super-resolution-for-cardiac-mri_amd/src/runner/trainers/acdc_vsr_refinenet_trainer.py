@@ -14,7 +14,7 @@ import torch
 from tqdm import tqdm
 
 from hipvsr import dp
-from hipvsr.autograd import fused_losses
+from hipvsr.autograd import discounted_total, fused_losses
 from src.model.metrics import fused_metrics
 from src.runner.trainers.base_trainer import BaseTrainer
 from src.utils import denormalize
@@ -32,6 +32,26 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
         self._denormalize = functools.partial(denormalize, dataset='acdc')
         self.graph = graph
         self._graphed = None
+
+    def _total_loss(self, losses):
+        """sum_i weight_i * losses[i] (trainer :45 of the reference).  One loss function of weight 1 - every reference YAML -
+        is that loss itself: no stack / multiply / sum kernels around a scalar."""
+        host = getattr(self, '_loss_weights_host', None)
+        if host is None:                                                   # (read back once: no device sync per step, none in a graph capture)
+            host = self._loss_weights_host = [float(v) for v in self.loss_weights.tolist()]
+        if len(losses) == 1 and host[0] == 1.0:
+            return losses[0]
+        return (torch.stack(losses) * self.loss_weights).sum()
+
+    def _backward(self, loss):
+        """loss.backward() with a cached seed gradient (autograd otherwise fills a fresh ones_like per step)."""
+        if loss.is_cuda:
+            seed = getattr(self, '_seed_grad', None)
+            if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
+                seed = self._seed_grad = torch.ones_like(loss)
+            loss.backward(gradient=seed)
+        else:
+            loss.backward()
 
     def _get_inputs_targets(self, batch):
         return batch['lr_imgs'], batch['hr_imgs'], batch['pos_code']
@@ -57,9 +77,9 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
             return outputs, loss, losses
         outputs = self.net(inputs, pos_codes)
         losses = self._compute_losses(outputs, targets)
-        loss = (torch.stack(losses) * self.loss_weights).sum()
+        loss = self._total_loss(losses)
         self.optimizer.zero_grad()
-        loss.backward()
+        self._backward(loss)
         dp.allreduce_gradients(self.net)
         self.optimizer.step()
         return outputs, loss, losses
@@ -81,7 +101,7 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
                 with torch.no_grad():
                     outputs = self.net(inputs, pos_codes)
                     losses = self._compute_losses(outputs, targets)
-                    loss = (torch.stack(losses) * self.loss_weights).sum()
+                    loss = self._total_loss(losses)
             metrics = self._compute_metrics(outputs, targets)
             bs = loader.batch_size
             self._update_log(log, bs, T, loss, losses, metrics)
@@ -98,6 +118,10 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
         for loss_fn in self.loss_fns:
             per_pair = fused_losses(outputs, targets, loss_fn)            # [G*T] or None
             if self.net.training:
+                fused = discounted_total(outputs, per_pair, [np.power(0.5, (G // 3 - g // 3 - 1)) for g in range(G)], T)
+                if fused is not None:                                      # the whole sum in one launch (hipvsr.autograd.LossTotalFn)
+                    losses.append(fused)
+                    continue
                 terms = []
                 for g in range(G):
                     discount = np.power(0.5, (G // 3 - g // 3 - 1))

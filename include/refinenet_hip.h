@@ -287,6 +287,12 @@ int rnh_lstm_gates_bwd(const float *dh, const float *dh2 /* 0 or a second summan
 #define RNH_LOSS_BLOCKS 64
 int rnh_loss_fwd_bwd(const float *o, const float *y, float *loss, float *d_o, const float *gscale /* device [G*T] */,
                      float *ws, int G, int T, int64_t per, int kind, float eps, void *stream);
+/* The discounted deep-supervision sum of the trainer (acdc_vsr_refinenet_trainer.py:83-94: per group g the mean over the T
+ * frames of loss * 0.5^(S-1-g/3), summed over the groups) as one launch, and its gradient as one more:
+ *   backward = 0: out[0] = sum_g w[g] * mean_i in[g*T + i]          (in = loss[G*T] of rnh_loss_fwd_bwd, w = the discounts)
+ *   backward = 1: out[g*T + i] = in[0] * w[g] / T                   (in = d(total); out = the gscale of rnh_loss_fwd_bwd)
+ * All pointers device memory. */
+int rnh_loss_total(const float *in, const float *w, float *out, int G, int T, int backward, void *stream);
 
 /* out = (accumulate ? out : 0) + a (+ b) (+ c); n floats, n % 4 == 0.  b, c may be 0.
  * Replaces the residual adds of refine_net.py:102,107,112 and the feature update :118-133. */

@@ -73,6 +73,9 @@ class TorchOps:
     def zeros(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
+    def halo_buffer(self, key, shape, dtype, lo, hi):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
     # bf16-storage path: arithmetic in fp32 on operands ROUNDED to bf16 where the HIP kernels round them (the MFMA
     # operands; every store into a bf16 tensor rounds once more through copy_)
     @staticmethod
