@@ -278,6 +278,25 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     // all 256 threads finish 8 columns of a pixel per step with whole-row 16-byte accesses ------------------------------
     float *ot = reinterpret_cast<float *>(smem);
     constexpr int PXR = G::PXR, ROUNDS = TH * TW / PXR;
+    // ConvLSTM: the previous cell state of ALL the thread's items (ROUNDS x PXR / 64 pixels x 8 channels, fp32) is requested
+    // here, before the accumulators are parked, as unconditional asm loads from clamped (always valid) addresses; left to
+    // hipcc each load sat right in front of its use, one exposed memory round trip per item - 10 k of the 16 k cycles of the
+    // finishing phase (tools/bf16_stamps.py).  No previous state: any valid address, zeros behind the wait.
+    constexpr int NIT = EPI == RNH_EPI_LSTM ? ROUNDS * (PXR / 64) : 1;
+    typedef float f32x4q __attribute__((ext_vector_type(4)));       // (a plain vector type: HIP's float4 struct would be passed to the asm through memory)
+    [[maybe_unused]] f32x4q cpq[NIT][2];
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        const int hd = P.hd, hcl = min(nt * 32 + (tid & 3) * 8, hd - 8);
+        const float *csrc = P.c_prev ? P.c_prev : P.c_out;
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+            const int r = q / (PXR / 64), px = (tid >> 2) + 64 * (q % (PXR / 64));
+            const int y = min(y0 + r * (PXR / TW) + px / TW, H - 1), x = min(x0 + (px & (TW - 1)), W - 1);
+            const float *p = csrc + (((long)img * H + y) * W + x) * hd + hcl;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpq[q][0]) : "v"(p) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cpq[q][1]) : "v"(p) : "memory");
+        }
+    }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (r > 0) __syncthreads();                             // the previous round has been read
@@ -297,6 +316,12 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         }
         __syncthreads();
         if (r == 0) BSTAMP(2);
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            if (r == 0) {
+#pragma unroll
+                for (int q = 0; q < NIT; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpq[q][0]), "+v"(cpq[q][1]));
+            }
+        }
         const int ybase = y0 + r * (PXR / TW);
         if constexpr (EPI == RNH_EPI_LSTM) {
             // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap).  A thread's 8 channels
@@ -307,15 +332,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             void *hout = P.h_out, *gout = P.gates_out;
             const int hdt = P.h_dtype, gdt = P.gates_dtype;
             if (hc < hd) {
-                for (int px = tid >> 2; px < PXR; px += 64) {
+#pragma unroll
+                for (int k = 0; k < PXR / 64; ++k) {
+                    const int px = (tid >> 2) + 64 * k;
                     const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
                     if (y >= H || x >= W) continue;
                     const float *o = ot + px * G::OPITCH + j0;
                     const long pe = ((long)img * H + y) * W + x;
                     float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
-                    if (cprev) {
-                        load8(cprev, RNH_DT_F32, pe * hd + hc, cp);
-                    } else {
+                    const f32x4q ca = cpq[r * (PXR / 64) + k][0], cb = cpq[r * (PXR / 64) + k][1];
+                    cp[0] = ca.x; cp[1] = ca.y; cp[2] = ca.z; cp[3] = ca.w; cp[4] = cb.x; cp[5] = cb.y; cp[6] = cb.z; cp[7] = cb.w;
+                    if (!cprev) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) cp[e] = 0.f;
                     }

@@ -88,8 +88,15 @@ srcs = []
 for j in range(5):
     srcs += [Src(Hf, img_off=j * N), Src(Hb, img_off=j * N), Src(P8, img_off=j * N)]
 R1 = ops.empty(nwin * N, H, W, P.C1p, dtype=bf)
-timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9,
-       nwin * N * H * W * (136 * 2 + 136 * 2), 3)
+def r1_fwd():                                               # as the engine runs it (hipvsr/engine.py): columns 0..127 and the rest as two launches
+    if P.r1_split:
+        ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 128)])
+        ops.conv(P.r1_fwd_b, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p - 128, c0=128)])
+    else:
+        ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+
+
+timeit('refine1.fwd', r1_fwd, 2.0 * nwin * N * H * W * 129 * 645 * 9, nwin * N * H * W * (136 * 2 + 136 * 2), 3)
 Rr = ops.empty(nwin * N, H, W, 64, dtype=bf)
 timeit('refine2.fwd', lambda: ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)]), 2.0 * nwin * N * H * W * 64 * 129 * 9,
        nwin * N * H * W * (136 + 64) * 2, 3)
