@@ -130,7 +130,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
     const int rb = wave & 1, cb = wave >> 1;
     const int tiles = RT * CT;
-    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+    // (contiguous block lists per XCD: the RT * CT tiles of one pixel range read the same rows and share them through one L2)
+    const int lb = rnh_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lb / tiles, tile = lb - split * tiles;
     const int rt = tile / CT, ct = tile - rt * CT;
     const int H = P.H, W = P.W;
     const int c8 = tid & 7, pxt = tid >> 3;                      // this thread's channel group and pixel inside a piece round

@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const rnh_wgrad_args
     const int RT = Cx >> 5, CT = Cy >> 5;
     // (the wave index is wave-uniform, but only a readfirstlane tells the compiler so: everything derived from it -
     // tile-row ranges, descriptors - must live in scalar registers)
-    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (contiguous block lists per XCD: the items of one tile-row range share their operands through one L2, see the LDS variant)
+    const int item = rnh_xcd_remap(blockIdx.x, gridDim.x) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= KS * RT * CT) return;                         // whole waves only; no barrier in this kernel
     const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
     const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Hp = H + 2, Wp = W + 2;
@@ -265,7 +266,12 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int RT = Cx >> 5, CT = Cy >> 5;
-    const int item = blockIdx.x * 4 + wave;                     // CT % 4 == 0: the four waves share (ks, rt)
+    // The RT * CT / 4 workgroups of one tile-row range read the same input patches and output gradients: consecutive block
+    // indices go round-robin over the 8 XCDs (8 L2s), so without the remap every L2 fetched every row range once - 5.7 GB
+    // of HBM reads per ConvLSTM weight gradient for 1.4 GB of operands.  Contiguous block lists per XCD (rnh_xcd_remap) keep
+    // the workgroups of a range on one L2.
+    const int lb = rnh_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = lb * 4 + wave;                             // CT % 4 == 0: the four waves share (ks, rt)
     const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
     const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Q = G >> 2;
     const int rows_total = P.B * TY;

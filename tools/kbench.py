@@ -10,6 +10,8 @@ PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-c
 for p in (ROOT, PKG):
     sys.path.insert(0, p)
 import torch                                            # noqa: E402
+from hipvsr import lib as _L                            # noqa: E402
+_L.LIB_PATH = os.path.join(PKG, 'hipvsr', os.environ.get('STAMPS_LIB', 'librefinenet_hip.so'))   # A/B against another build
 from hipvsr.hip_ops import HipOps                       # noqa: E402
 from hipvsr.plans import Dst, NetPlans, Src             # noqa: E402
 from hipvsr.spec import NetConfig, state_dict_spec      # noqa: E402
