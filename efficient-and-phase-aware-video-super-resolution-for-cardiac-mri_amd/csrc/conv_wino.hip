@@ -29,7 +29,10 @@
 //     pure producer wave beside a pure MFMA wave, tools/experiments/conv_wino3_specialised_waves.hip): VALU work does not
 //     run "under" the fp32 MFMAs of the other wave, it interleaves with them, and inside one wave every non-MFMA
 //     instruction costs 8-10 cycles of matrix-core time.  With ~1 500 such instructions per 512 MFMAs of a wave
-//     (operand loads 450, staging 650, epilogue 470) the ceiling of this formulation is about 0.70 of the fp32 peak.
+//     (operand loads 450, staging 650, epilogue 470) the ceiling of this formulation is about 0.70 of the fp32 peak;
+//   * wave priorities do not help either: s_setprio 3 outside the main loop (set-up, first chunk, epilogue) and 0 inside it
+//     - so that a workgroup's short non-MFMA phases are served at once - left both the ConvLSTM cell and its data gradient
+//     where they were (0.404 against 0.398 ms, 0.322 against 0.322 ms).
 // Operands: the input transform B^T d B of a 16-channel chunk is computed once per workgroup (thread =
 // (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32
 // packed adds, 8 16-byte LDS writes into [xi / 2][tile][36]), the weights arrive pre-transformed from

@@ -293,3 +293,32 @@ def test_flat_adam_param_groups_and_misaligned_runs():
     assert torch.equal(dev_p[2].detach().cpu(), p0[2])
     sd = opt.state_dict()
     assert [g_['lr'] for g_ in sd['param_groups']] == [2e-3, 5e-4] and len(sd['state']) == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,T', [(3, 7), (1, 3), (2, 1)])
+def test_loss_total_vs_the_trainers_list_arithmetic(S, T):
+    """rnh_loss_total / hipvsr.autograd.LossTotalFn (the discounted deep-supervision sum in one launch, its gradient in one
+    more) against the reference trainer's own arithmetic (acdc_vsr_refinenet_trainer.py:83-94: per group the mean over the
+    frames of loss * 0.5^(S-1-g/3), summed over the groups) evaluated by ATen in float64: value to 2 ulp-ish (rtol 1e-6),
+    gradient exactly discount / T up to one rounding, upstream gradient honoured."""
+    import numpy as np
+    from hipvsr.autograd import LossTotalFn
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    G = 3 * S
+    g = torch.Generator('cpu').manual_seed(100 * S + T)
+    per = torch.rand(G * T, generator=g) * 3
+    disc = [float(np.power(0.5, (G // 3 - k // 3 - 1))) for k in range(G)]
+    x = per.to(dev).requires_grad_(True)
+    w = torch.tensor(disc, dtype=torch.float32, device=dev)
+    tot = LossTotalFn.apply(ops, x, w, G, T)
+    (tot * 1.75).backward()
+    xr = per.double().requires_grad_(True)
+    ref = torch.stack([(xr[k * T:(k + 1) * T] * disc[k]).mean() for k in range(G)]).sum()
+    (ref * 1.75).backward()
+    assert tot.shape == () and abs(float(tot) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert torch.allclose(x.grad.cpu().double(), xr.grad, rtol=1e-6, atol=0)
+    with pytest.raises(Exception):
+        ops.loss_total(x.detach(), w[:-1], G, T)
