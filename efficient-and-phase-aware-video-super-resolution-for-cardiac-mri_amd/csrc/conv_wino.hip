@@ -141,8 +141,26 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 
     // ---- staging: thread = (tile ts, channel pair cp of the chunk) ------------------------------------------------
     const int ts = threadIdx.x / CPC, cp = threadIdx.x % CPC;
+    // Tile t of the list -> (image, tile row, tile column).  Where the tile grid allows it (TX % 8 == 0, TY % 4 == 0) the
+    // list runs over 8 x 4 blocks of tiles, so that a workgroup's 32 tiles are a 16 x 8 pixel rectangle whose 4x4 patches
+    // cover 18 x 10 input pixels (1.4x the outputs) instead of a 64 x 2 strip that needs 66 x 4 (2.1x): fewer bytes through
+    // the vector cache per chunk and through L2 per launch.
+    const bool blocked = !(TX & 7) && !(TY & 3);
+    auto tile_xy = [&](int t, int &img, int &ty, int &tx) {
+        img = t / (TY * TX);
+        const int rem = t - img * TY * TX;
+        if (blocked) {
+            const int bi = rem >> 5, wi = rem & 31, bpr = TX >> 3, by = bi / bpr, bx = bi - by * bpr;
+            ty = by * 4 + (wi >> 3);
+            tx = bx * 8 + (wi & 7);
+        } else {
+            ty = rem / TX;
+            tx = rem - ty * TX;
+        }
+    };
     const int t0 = m0 < ntiles ? m0 : 0;
-    const int img0 = t0 / (TY * TX), r0 = t0 - img0 * TY * TX, ty0 = r0 / TX;
+    int img0, ty0, tx0_;
+    tile_xy(t0, img0, ty0, tx0_);
     const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
     const int base_pix = (img0 * Hs + (2 * ty0 - 1) * sc) * Ws - sc;   // at or before every pixel the block touches
     // the thread's 4x4 patch: pixel offset of its top-left corner (relative to base_pix) and a 16-bit mask of the pixels
@@ -152,7 +170,8 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         const int t = m0 + ts;
         const bool tok = t < ntiles;
         const int tt = tok ? t : t0;
-        const int img = tt / (TY * TX), trem = tt - img * TY * TX, ty = trem / TX, tx = trem - ty * TX;
+        int img, ty, tx;
+        tile_xy(tt, img, ty, tx);
         pix00 = (img * Hs + (2 * ty - 1) * sc) * Ws + (2 * tx - 1) * sc - base_pix;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -294,7 +313,8 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     f32x4w Va[2], Vb[2], u0[4], u1[4];                        // staged operands by half steps, weights by steps
     if (threadIdx.x < TILES) {
         const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : t0;
-        const int im = tq / (TY * TX), rr = tq - im * TY * TX, yy = rr / TX, xx = rr - yy * TX;
+        int im, yy, xx;
+        tile_xy(tq, im, yy, xx);
         tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
         tcoord[threadIdx.x] = tr < ntiles ? (im << 20) | (2 * yy << 10) | (2 * xx) : -1;
     }
