@@ -439,7 +439,9 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-WINO_SHAPES = [(3, 6, 16), (2, 6, 32), (2, 4, 64), (2, 5, 13), (1, 7, 34)]       # (B, H, W): W = 16 / 32 / 64, odd H and W, tile tails
+# (B, H, W): W = 16 / 32 / 64, odd H and W, tile tails; the last two have tile grids of 8 x 4 / 16 x 8 (the kernel's blocked tile
+# order: a workgroup = an 8 x 4 block of tiles)
+WINO_SHAPES = [(3, 6, 16), (2, 6, 32), (2, 4, 64), (2, 5, 13), (1, 7, 34), (3, 8, 16), (2, 16, 32)]
 
 
 @pytest.mark.parametrize('B,H,W', WINO_SHAPES)
