@@ -113,16 +113,30 @@ __device__ unsigned long long g_wino_hw[4096 * 3];          // per block: HW_ID,
 #define HSTAMP(i)
 #endif
 
-constexpr int H_TILES = 32, H_CPC = 8, H_CH = 16, H_CHS = 4 * H_CPC + 4, H_BUF = 8 * H_TILES * H_CHS;   // floats per staging buffer
-constexpr int H_PART = 4 * 8 * 64 * 4;             // floats of the partial-output exchange: [wave][entry][lane][4]
-constexpr int H_TS = 72, H_GS = 32 * H_TS + 16;    // gate exchange [gate][tile][pixel][16 channels]: strides that keep the four
-                                                   // (lane half, gate) groups of a wave's store in four different bank ranges
-static_assert(H_PART + 4 * H_GS <= 2 * H_BUF, "the epilogue's exchange areas live in the staging buffers");
+constexpr int H_TILES = 32;
+// Geometry of a workgroup of NW waves (2 halves of the transform domain x NW / 2 column groups of 32): NW = 4: 32 tiles x 64
+// columns, 16-channel chunks, two workgroups per CU; NW = 8: 32 tiles x 128 columns, 32-channel chunks, one workgroup per CU
+// (the staged input transform feeds twice the columns: half the staging work per MFMA; both waves of a SIMD are in the same
+// phase, nothing hides set-up and epilogue).  Every thread stages one (tile, channel pair) per chunk either way.
+template <int NW>
+struct WinoGeo {
+    static constexpr int CG = NW / 2;                           // column groups (waves per half)
+    static constexpr int CPC = 2 * NW, CH = 2 * CPC, SPC = CH / 4;   // channel pairs / channels / 4-channel steps per chunk
+    static constexpr int CHS = 4 * CPC + 4;                      // LDS row of one (xi pair, tile): [channel pair][xi & 1][2] + 4 pad
+    static constexpr int BUF = 8 * H_TILES * CHS;                // floats per staging buffer
+    static constexpr int PART = NW * 8 * 64 * 4;                 // floats of the partial-output exchange: [wave][entry][lane][4]
+    static constexpr int CW = 8 * CG;                            // hidden channels of a ConvLSTM block (its 32 * CG columns = 4 gates x CW)
+    // gate exchange [gate][tile][pixel][CW]: strides that keep the lane groups of a wave's store in different bank ranges
+    static constexpr int TS = 4 * CW + 8, GS = 32 * TS + 16;
+    static_assert(PART + 4 * GS <= 2 * BUF, "the epilogue's exchange areas live in the staging buffers");
+};
 
-template <int EPI>
-__global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
-    constexpr int TILES = H_TILES, CPC = H_CPC, CH = H_CH, CHS = H_CHS, BUF = H_BUF;
-    __shared__ __attribute__((aligned(16))) float stage[2 * BUF];   // 73.7 KB: two workgroups per CU
+template <int EPI, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
+    using G = WinoGeo<NW>;
+    constexpr int TILES = H_TILES, CPC = G::CPC, CH = G::CH, CHS = G::CHS, BUF = G::BUF, SPC = G::SPC, CG = G::CG;
+    constexpr int H_PART = G::PART, H_TS = G::TS, H_GS = G::GS, CW = G::CW;
+    __shared__ __attribute__((aligned(16))) float stage[2 * BUF];   // 73.7 KB (two workgroups per CU) / 139 KB
     __shared__ int tpix[TILES];                               // top-left output pixel of the block's tiles (epilogue)
     __shared__ int tcoord[TILES];                             // the same as (image << 20 | y << 10 | x), -1: no such tile
     HSTAMP(0);
@@ -261,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     };
 
     // this wave's pairs of transform positions: pr = 2 i + h (row i of the 4x4 domain, columns 2h and 2h + 1)
-    const i32x4 bdesc = hdesc(P.wp + (long)((nt * 2 + cg) * 32) * 8);
+    const i32x4 bdesc = hdesc(P.wp + (long)((nt * CG + cg) * 32) * 8);
     const int pstride = P.Npad * 32;                        // bytes between two PAIRS of transform positions of one step
     int boffx[4];
 #pragma unroll
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     // earlier and the chunk's counted waits for weights would have to sit out these loads first).  The state comes from
     // HBM behind the gate stores of the whole chip: measured 54 us of a 387 us launch while it was requested behind the
     // main loop and awaited before the gate math; now it has the last two steps, the exchange and the gate math to arrive.
-    const int ncol = (nt * 2 + cg) * 32 + l31;
+    const int ncol = (nt * CG + cg) * 32 + l31;
     float bv;
     [[maybe_unused]] f32x4w cpv[2];
     [[maybe_unused]] bool lstm_full = false;
@@ -352,14 +366,14 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         // a second definition and hipcc a reason to copy it in flight; no bias / no previous state: zeros behind the wait)
         asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"((P.bias ? P.bias : P.wp) + ncol) : "memory");
         if constexpr (EPI == RNH_EPI_LSTM) {
-            lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * 16 + 16 <= P.hd;
+            lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * CW + CW <= P.hd;
             const float *csrc = P.c_prev ? P.c_prev : P.c_out;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int it = q * 256 + (int)threadIdx.x, t = it >> 4, p = (it >> 2) & 3, c4 = (it & 3) * 4;
+                const int it = q * (64 * NW) + (int)threadIdx.x, t = it / CW, p = (it / (CW / 4)) & 3, c4 = (it % (CW / 4)) * 4;
                 item_o[q] = (long)tpix[t] + (p >> 1) * W + (p & 1);
-                item_x[q] = t * H_TS + p * 16 + c4;
-                const int hcl = min(nt * 16 + c4, P.hd - 4);    // (the tile list is clamped in tpix, the channel here)
+                item_x[q] = t * H_TS + p * CW + c4;
+                const int hcl = min(nt * CW + c4, P.hd - 4);    // (the tile list is clamped in tpix, the channel here)
                 const long pl = lstm_full ? item_o[q] : (long)tpix[t];
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpv[q]) : "v"(csrc + pl * P.hd + hcl) : "memory");
             }
@@ -368,61 +382,64 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
     // The loop body (every chunk but the last) has no branch: a register that is the target of an asynchronous asm load
     // must have exactly one definition per iteration (tests/test_isa_guards.py); the last chunk is peeled off.
     // LDS operands run half a step (8 MFMAs) ahead in two register pairs, weights one step (16 MFMAs) ahead.
+    // One chunk = SPC steps of 16 MFMAs.  Step q multiplies out of (Va, Vb) and the weight set of its parity (u0 for even q);
+    // the staging loads of the next chunk go out in step 0, its transform into the other LDS buffer happens in step
+    // SPC - 2, the chunk's barrier sits in front of the last 8 MFMAs of step SPC - 1.
     auto chunk = [&](const int buf, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
-        // step 0: [staging loads of the next chunk] [weights of step 1] | MFMAs of step 0
-        wait_lds(Va);
-        loadv(Vb, buf, 0, A1());
-        // (the staging loads go behind the wait: a staging load whose 64 lanes are all outside the image never goes to
-        // memory and returns ahead of older loads, so it must not be among the loads a counted wait leaves in flight)
-        wait_vm(u0, K0());
-        if constexpr (more) gload();
-        loadb(u1, s + 1);
-        compute(Va, u0, A0());
-        wait_lds(Vb);
-        loadv(Va, buf, 1, A0());
-        compute(Vb, u0, A1());
-        // step 1
-        wait_lds(Va);
-        loadv(Vb, buf, 1, A1());
-        loadb(u0, s + 2);
-        wait_vm(u1, K4());
-        compute(Va, u1, A0());
-        wait_lds(Vb);
-        loadv(Va, buf, 2, A0());
-        compute(Vb, u1, A1());
-        // step 2: also the transform of the staged chunk into the other LDS buffer (its loads are older than the weight
-        // loads the wait leaves in flight)
-        wait_lds(Va);
-        loadv(Vb, buf, 2, A1());
-        loadb(u1, s + 3);
-        if constexpr (more) {
-            wait_vm(u0, K4());
-            xform_store(buf ^ 1);
-        } else {
-            epi_request();                                  // younger than every weight load: the waits below leave it in flight
-            wait_vm(u0, std::integral_constant<int, 4 + NEPI>());
+        auto step = [&](auto q_tag, f32x4w *ucur, f32x4w *unext) {
+            constexpr int q = decltype(q_tag)::value;
+            constexpr bool last = q == SPC - 1;
+            wait_lds(Va);
+            loadv(Vb, buf, q, A1());
+            if constexpr (q == 0) {
+                // (the staging loads go behind the wait: a staging load whose 64 lanes are all outside the image never goes
+                // to memory and returns ahead of older loads, so it must not be among the loads a counted wait leaves in flight)
+                wait_vm(ucur, K0());
+                if constexpr (more) gload();
+                loadb(unext, s + 1);
+            } else if constexpr (!last) {
+                loadb(unext, s + q + 1);
+                if constexpr (q == SPC - 2 && !more) {
+                    epi_request();                          // younger than every weight load: the waits below leave it in flight
+                    wait_vm(ucur, std::integral_constant<int, 4 + NEPI>());
+                } else {
+                    wait_vm(ucur, K4());
+                }
+                // the transform of the staged chunk into the other LDS buffer (its loads are older than the weight loads the
+                // wait leaves in flight)
+                if constexpr (q == SPC - 2 && more) xform_store(buf ^ 1);
+            } else {
+                if constexpr (more) {
+                    loadb(unext, s + SPC);
+                    wait_vm(ucur, K4());
+                } else {
+                    wait_vm(ucur, std::integral_constant<int, NEPI>());
+                }
+            }
+            compute(Va, ucur, A0());
+            wait_lds(Vb);
+            if constexpr (!last) {
+                loadv(Va, buf, q + 1, A0());
+            } else {
+                // the chunk's barrier in front of its last 8 MFMAs (all reads of this buffer issued and landed, all writes of
+                // the other one done), so the first operands of the next chunk are fetched under their cover
+                asm volatile("s_barrier" ::: "memory");
+                if constexpr (more) loadv(Va, buf ^ 1, 0, A0());
+            }
+            compute(Vb, ucur, A1());
+        };
+        step(std::integral_constant<int, 0>(), u0, u1);
+        step(std::integral_constant<int, 1>(), u1, u0);
+        step(std::integral_constant<int, 2>(), u0, u1);
+        step(std::integral_constant<int, 3>(), u1, u0);
+        if constexpr (SPC == 8) {
+            step(std::integral_constant<int, 4>(), u0, u1);
+            step(std::integral_constant<int, 5>(), u1, u0);
+            step(std::integral_constant<int, 6>(), u0, u1);
+            step(std::integral_constant<int, 7>(), u1, u0);
         }
-        compute(Va, u0, A0());
-        wait_lds(Vb);
-        loadv(Va, buf, 3, A0());
-        compute(Vb, u0, A1());
-        // last step: the chunk's barrier in front of its last 8 MFMAs (all reads of this buffer issued and landed, all
-        // writes of the other one done), so the first operands of the next chunk are fetched under their cover
-        wait_lds(Va);
-        loadv(Vb, buf, 3, A1());
-        if constexpr (more) {
-            loadb(u0, s + 4);
-            wait_vm(u1, K4());
-        } else {
-            wait_vm(u1, std::integral_constant<int, NEPI>());
-        }
-        compute(Va, u1, A0());
-        wait_lds(Vb);
-        asm volatile("s_barrier" ::: "memory");
-        if constexpr (more) loadv(Va, buf ^ 1, 0, A0());
-        compute(Vb, u1, A1());
-        s += 4;
+        s += SPC;
     };
     for (int c = 0; c + 1 < nchunks_total; ++c) chunk(c & 1, std::true_type());
     chunk((nchunks_total - 1) & 1, std::false_type());
@@ -478,10 +495,9 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         float *xg = stage + H_PART;
         // phase 1: lanes 0..15 / 16..31 of a row block hold gates 2cg / 2cg + 1 (i, f | o, g) of 16 hidden channels;
         // sigmoid, and tanh as 2 sigmoid(2x) - 1 for the candidate gate, in one form: m rcp(1 + exp(-m x)) + b
-        const int gate = 2 * cg + (l31 >> 4), ch = l31 & 15, hc = nt * 16 + ch;
+        const int gate = (cg * 32 + l31) / CW, ch = (cg * 32 + l31) % CW, hc = nt * CW + ch;
         const float gm = gate == 3 ? 2.f : 1.f, gb = gate == 3 ? -1.f : 0.f;
         float *xw = xg + gate * H_GS + ch;
-        const int ch2 = lane & 15, p2 = lane >> 4, hc2 = nt * 16 + ch2, poff2 = (p2 >> 1) * W + (p2 & 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
@@ -489,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) xw[trl_of(e) * H_TS + p * 16] = Yf[e][p];
+            for (int p = 0; p < 4; ++p) xw[trl_of(e) * H_TS + p * CW] = Yf[e][p];
         if (P.gates_out && !full) {                             // (whole blocks store the gates from LDS in phase 2, 16 bytes per lane)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -509,18 +525,17 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
         // also a wait for its gate stores.)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpv[0]), "+v"(cpv[1]));
         if (!P.c_prev) cpv[0] = cpv[1] = f32x4w{0.f, 0.f, 0.f, 0.f};
-        const float *xr = xg + p2 * 16 + ch2;
         if (full) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int c4 = ((q * 256 + (int)threadIdx.x) & 3) * 4;
+                const int c4 = ((q * (64 * NW) + (int)threadIdx.x) % (CW / 4)) * 4;
                 const float *xi = xg + item_x[q];
                 const f32x4w gi = *reinterpret_cast<const f32x4w *>(xi), gf = *reinterpret_cast<const f32x4w *>(xi + H_GS);
                 const f32x4w go = *reinterpret_cast<const f32x4w *>(xi + 2 * H_GS), gg = *reinterpret_cast<const f32x4w *>(xi + 3 * H_GS);
                 if (P.gates_out) {
                     // (plain stores: with the nt bit, 16-byte pieces of one 128-byte line written by the workgroups of four
                     // column blocks came out corrupted now and then - tools/debug/lstm_mismatch.py)
-                    f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + item_o[q] * 4 * hd + nt * 16 + c4);
+                    f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + item_o[q] * 4 * hd + nt * CW + c4);
                     gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
                 }
                 f32x4w cn, hn;
@@ -529,19 +544,22 @@ __global__ void __launch_bounds__(256, 2) conv_winoh_kernel(const rnh_conv_args_
                     cn[j] = gf[j] * cpv[q][j] + gi[j] * gg[j];
                     hn[j] = go[j] * h_tanh(cn[j]);
                 }
-                const long o = item_o[q] * hd + nt * 16 + c4;
+                const long o = item_o[q] * hd + nt * CW + c4;
                 *reinterpret_cast<f32x4w *>(P.c_out + o) = cn;
                 *reinterpret_cast<f32x4w *>(P.h_out + o) = hn;
             }
         } else {
+            // partial blocks: items (tile, pixel, channel) e = k * threads + tid one by one
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int t = wave + 4 * k, tc = tcoord[t];
+                const int e = k * (64 * NW) + (int)threadIdx.x, ch2 = e % CW, p2 = (e / CW) & 3, t = e / (4 * CW);
+                const int tc = tcoord[t], hc2 = nt * CW + ch2;
                 if (tc < 0 || hc2 >= hd) continue;
                 const int yy = (tc >> 10) & 1023, xx = tc & 1023;
                 if (yy + (p2 >> 1) >= H || xx + (p2 & 1) >= W) continue;
-                const float gi = xr[0 * H_GS + t * H_TS], gf = xr[1 * H_GS + t * H_TS], go = xr[2 * H_GS + t * H_TS], gg = xr[3 * H_GS + t * H_TS];
-                const long o = ((long)tpix[t] + poff2) * hd + hc2;
+                const float *xr = xg + t * H_TS + p2 * CW + ch2;
+                const float gi = xr[0 * H_GS], gf = xr[1 * H_GS], go = xr[2 * H_GS], gg = xr[3 * H_GS];
+                const long o = ((long)tpix[t] + (p2 >> 1) * W + (p2 & 1)) * hd + hc2;
                 const float cp = P.c_prev ? P.c_prev[o] : 0.f;
                 const float cn = gf * cp + gi * gg;
                 P.c_out[o] = cn;
@@ -639,17 +657,41 @@ extern "C" int rnh_wino_pack_weights(const float *w, const float *bias, float *w
     return 0;
 }
 
+template <int NW>
+static int launch_wino(const rnh_conv_args_t &a, int MT, int NT, int TX, int TY, hipStream_t st) {
+    using G = WinoGeo<NW>;
+    const dim3 grid((unsigned)(MT * NT)), block(64 * NW);
+    switch (a.epilogue) {
+        case RNH_EPI_STORE:
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_PS:
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        case RNH_EPI_LSTM:
+            if (a.Npad != 32 * G::CG * ((a.hd + G::CW - 1) / G::CW))
+                RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (%d-column blocks = the four gates of %d hidden channels)", 32 * G::CG, G::CW);
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            break;
+        default:
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+    }
+    return 0;
+}
+
 extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: null args");
     const rnh_conv_args_t &a = *args;
     if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
     if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
-    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of 64");
+    const int wide = a.tile == RNH_WINO_COLS128;                // 128-column blocks (8 waves, 32-channel chunks), else 64-column blocks
+    const int bc = wide ? 128 : 64, cm = wide ? 32 : 16;
+    if (a.Npad < bc || a.Npad % bc) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of %d", bc);
     int steps = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
         if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
-        if (a.src[i].nch & 15) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of 16");
+        if (a.src[i].nch % cm) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of %d", cm);
         steps += a.src[i].nch / 4;
     }
     if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
@@ -659,29 +701,19 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
     // pixel offsets inside a block (it may straddle two images) go through 24-bit multiplies
     if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: source images of at most 2^22 pixels");
-    const int MT = (int)((ntiles + H_TILES - 1) / H_TILES), NT = a.Npad / 64;
+    const int MT = (int)((ntiles + H_TILES - 1) / H_TILES), NT = a.Npad / bc;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(MT * NT)), block(256);
-    switch (a.epilogue) {
-        case RNH_EPI_STORE:
-            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
-            for (int d = 0; d < a.ndst; ++d)
-                if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY);
-            break;
-        case RNH_EPI_PS:
-            if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
-                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY);
-            break;
-        case RNH_EPI_LSTM:
-            if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
-            if (a.Npad != 64 * ((a.hd + 15) / 16)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (plans.lstm_colmap64)");
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY);
-            break;
-        default:
-            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+    if (a.epilogue == RNH_EPI_STORE) {
+        if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
+        for (int d = 0; d < a.ndst; ++d)
+            if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
+    } else if (a.epilogue == RNH_EPI_PS) {
+        if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
+            RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
+    } else if (a.epilogue == RNH_EPI_LSTM) {
+        if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
     }
+    if (int rc = wide ? launch_wino<8>(a, MT, NT, TX, TY, st) : launch_wino<4>(a, MT, NT, TX, TY, st)) return rc;
     RNH_CHECK_LAUNCH("rnh_conv_wino");
     return 0;
 }

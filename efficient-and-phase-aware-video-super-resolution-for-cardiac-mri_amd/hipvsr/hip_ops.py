@@ -277,6 +277,7 @@ class HipOps:
             if any(s_.scale != srcs[0].scale or s_.add is not None for s_ in srcs):
                 raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes sources of one scale, without a second operand')
             a.nk = plan.wns
+            a.tile = plan.wino_cols                             # RNH_WINO_COLS64 / RNH_WINO_COLS128
             L.check(self.lib.rnh_conv_wino(C.byref(a), self._stream()), f'rnh_conv_wino({plan.name})')
             return
         L.check(self.lib.rnh_conv_igemm(C.byref(a), self._stream()), f'rnh_conv_igemm({plan.name})')

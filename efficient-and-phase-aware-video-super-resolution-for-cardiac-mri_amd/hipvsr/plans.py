@@ -64,7 +64,7 @@ class ConvPlan:
     """K / column layout of one rnh_conv_igemm call against the OIHW weight ``wkey``."""
 
     def __init__(self, name, wkey, bkey, wshape, ksegs: List[KSeg], colmap: List[int], tile=None,
-                 epilogue=L.EPI_STORE, transposed=False, kstride=1, wino=False, bf16=False):
+                 epilogue=L.EPI_STORE, transposed=False, kstride=1, wino=False, bf16=False, wino_cols=None):
         self.name, self.wkey, self.bkey = name, wkey, bkey
         self.Cout, self.Cin, kh, kw = wshape
         self.ntaps = kh * kw
@@ -76,9 +76,14 @@ class ConvPlan:
         self.bf16 = bool(bf16)
         self.nchunks = sum((sg.nch + KC - 1) // KC for sg in ksegs)
         wino = wino and not self.bf16
-        # Winograd form (rnh_conv_wino, csrc/conv_wino.hip): K in steps of 4 channels, 16-channel chunks, column blocks of 64
+        # Winograd form (rnh_conv_wino, csrc/conv_wino.hip): K in steps of 4 channels; column blocks of 64 (16-channel chunks, two
+        # workgroups per CU) or of 128 (wino_cols: 32-channel chunks, one 8-wave workgroup per CU - asked for per plan)
         self.wino = bool(wino) and self.ntaps == 9 and all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in ksegs)
-        self.Npad = _pad_to(len(colmap), 64) if self.bf16 or self.wino else _pad_to(len(colmap), L.TILE_COLS[self.tile])
+        if wino_cols is None:                                   # the wider blocks wherever they cost no padding (RNH_WINO_COLS=64: never)
+            wino_cols = 128 if len(colmap) % 128 == 0 and os.environ.get('RNH_WINO_COLS', '128') != '64' else 64
+        self.wino_cols = 128 if self.wino and wino_cols == 128 and all(sg.nch % 32 == 0 for sg in ksegs) else 64
+        self.Npad = _pad_to(len(colmap), self.wino_cols if self.wino else 64) if self.bf16 or self.wino else \
+            _pad_to(len(colmap), L.TILE_COLS[self.tile])
         self.colmap = list(colmap) + [-1] * (self.Npad - len(colmap))
         self.kbase, self.knv, self.ktap, self.kcoff = [], [], [], []
         for sg in ksegs:
@@ -248,12 +253,14 @@ class NetPlans:
                 second = hd if cfg.memory else cx
                 ltile = int(os.environ.get('RNH_LSTM_TILE', L.TILE_128x128_G))       # experiments: 0 = 128x128, 2 = 256x64
                 wino = os.environ.get('RNH_WINO', '1') != '0' and ltile == L.TILE_128x128_G and not bf
-                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or wino else lstm_colmap(hd)
+                # the cell as 128-column blocks (the four gates of 32 hidden channels: gate layout lstm_colmap) where cx, hd % 32 == 0
+                wcols = 128 if wino and os.environ.get('RNH_WINO_COLS', '128') != '64' and cx % 32 == 0 and second % 32 == 0 and hd % 32 == 0 else 64
+                lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and wcols == 64) else lstm_colmap(hd)
                 def mk(lcm_, wino_):
                     full_ = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm_,
-                                     tile=ltile, epilogue=L.EPI_LSTM, wino=wino_)
+                                     tile=ltile, epilogue=L.EPI_LSTM, wino=wino_, wino_cols=wcols)
                     first_ = ConvPlan_(f'{d}{l}.fwd0', wk, bk, ws, [KSeg(cx, cx, 0)], lcm_, tile=ltile,
-                                      epilogue=L.EPI_LSTM, wino=wino_) if cfg.memory else full_
+                                      epilogue=L.EPI_LSTM, wino=wino_, wino_cols=wcols) if cfg.memory else full_
                     return full_, first_
                 full, first = mk(lcm, wino)
                 if wino and not (full.wino and first.wino):          # not eligible: the implicit-GEMM kernel and its gate layout

@@ -76,6 +76,8 @@ typedef struct rnh_dst {
 #define RNH_TILE_256x64  2   /* 4x1 waves of 64x64          */
 #define RNH_TILE_128x160 3   /* 4x1 waves of 32x160         */
 #define RNH_TILE_256x128 6   /* 4x1 waves of 64x128 (rnh_conv_igemm, DIRECT variant only; LSTM-capable) */
+#define RNH_WINO_COLS64  64  /* rnh_conv_wino: workgroups of 32 tiles x 64 columns, two per CU (any other value of `tile` means this) */
+#define RNH_WINO_COLS128 128 /* rnh_conv_wino: workgroups of 32 tiles x 128 columns (8 waves, 32-channel chunks), one per CU */
 #define RNH_TILE_DIRECT  16  /* OR-ed into `tile` for rnh_conv_igemm: fragments straight from global memory, no LDS,
                                 no barrier (same results bit for bit as the LDS-staged variant)                  */
 
