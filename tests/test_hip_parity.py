@@ -445,19 +445,24 @@ WINO_SHAPES = [(3, 6, 16), (2, 6, 32), (2, 4, 64), (2, 5, 13), (1, 7, 34), (3, 8
 
 
 @pytest.mark.parametrize('B,H,W', WINO_SHAPES)
-@pytest.mark.parametrize('which', ['lstm', 'lstm_first', 'lstm_dgrad', 'up', 'up_dgrad', 'refine', 'refine_dgrad'])
-def test_winograd_conv_kernels_vs_torch_float64(which, B, H, W):
+@pytest.mark.parametrize('which', ['lstm', 'lstm_first', 'lstm_dgrad', 'up', 'up_dgrad', 'refine', 'refine_dgrad',
+                                   'lstm@64', 'lstm_first@64', 'lstm_dgrad@64', 'refine@64'])
+def test_winograd_conv_kernels_vs_torch_float64(which, B, H, W, monkeypatch):
     """rnh_conv_wino at full channel width (the 13 reference goldens use num_features [8, 8], which the plans route to the
     implicit GEMM) against float64 torch convolutions of the OIHW weights: ConvLSTM cell with the fused gate epilogue
     (two K sources / the zero-state K = 576 plan; gates_out, c', h'), its data gradient (two destinations), the
     PixelShuffle convolution (PS epilogue) and its data gradient (pixel-unshuffle fused into the staging loads),
-    refine conv1 over the ten hidden-state sources and its gather-form data gradient (accumulating stores)."""
+    refine conv1 over the ten hidden-state sources and its gather-form data gradient (accumulating stores).  The plans give
+    these convolutions the kernel's 128-column geometry (8 waves, one workgroup per CU); '@64' runs them in the 64-column one."""
     import torch.nn.functional as F
     from hipvsr.hip_ops import HipOps
     from hipvsr.plans import Dst, NetPlans, Src
     from hipvsr.spec import state_dict_spec
     dev = _dev()
     cfg = _full_cfg()
+    if which.endswith('@64'):                      # the 64-column geometry (two workgroups per CU) where the plans would pick 128
+        monkeypatch.setenv('RNH_WINO_COLS', '64')
+        which = which[:-3]
     P, ops = NetPlans(cfg), HipOps(dev)
     spec = state_dict_spec(cfg)
     g = torch.Generator('cpu').manual_seed(1000 + 7 * W + H)

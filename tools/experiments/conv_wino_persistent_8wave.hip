@@ -1,3 +1,9 @@
+// EXPERIMENT, not built (round 2): csrc/conv_wino.hip plus conv_winop_kernel, the 8-wave geometry with persistent workgroups
+// (chunk pipeline across blocks: no per-block set-up / first-chunk latency, 8 k of 89 k cycles).  Measured on the data gradient
+// of the ConvLSTM cell: 0.299 ms against 0.301 ms for one workgroup per block - what the pipeline hides, the extra barrier, the
+// wait for the epilogue's stores in front of the next block and the per-block bookkeeping cost again; the ConvLSTM variant also
+// spills (84 registers live across the epilogue) and was left with a parity failure.  Not pursued.
+//
 // 3x3 convolution (padding 1) in Winograd form F(2x2, 3x3) on fp32 MFMA for gfx950, two workgroups per CU - rnh_conv_wino.
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
@@ -16,14 +22,6 @@
 //     staging loads and transform adds per MFMA doubled for convolutions wider than 64 columns).
 // Measured on the ConvLSTM cell (N = 8, 128 x 128, same box): 0.437 -> 0.412 ms, its data gradient 0.351 -> 0.320 ms;
 // MFMA pipe busy 0.55 -> 0.62 / 0.67 -> 0.76 (rocprofv3 PMC); the training step 371 -> 355 ms.
-// The kernel has a second geometry (template argument NW = 8, `tile` = RNH_WINO_COLS128): 8 waves = 2 halves x 4 column
-// groups = 32 tiles x 128 columns, 32-channel chunks (every thread still stages one (tile, channel pair) per chunk), one
-// workgroup per CU in 139 KB of LDS.  The staged input transform then feeds twice the columns - half the staging work per
-// MFMA - and both waves of a SIMD are always in the same phase: the main loop runs at 0.90 of the MFMA rate (73 k cycles for
-// 65.5 k of MFMA per block), but nothing hides set-up (8 k) and epilogue (8 k).  Where the column count is a multiple of 128
-// and every source one of 32 channels (the ConvLSTM cell and its data gradient, refine conv1, the PixelShuffle convolutions)
-// it wins: cell 0.408 -> 0.387 ms, data gradient 0.325 -> 0.304 ms, refine conv1 11.0 -> 10.3 ms, step 355.6 -> 341.8 ms on
-// one box; the plans (hipvsr/plans.py) use it there and the 64-column geometry everywhere else.
 //
 // What the experiments on this kernel say about the machine (tools/wino_stamps.py, tools/experiments/):
 //   * issue arbitration between the two waves of a SIMD is STRICT, not round-robin: the wave in the lower slot (the
@@ -40,9 +38,7 @@
 //     (operand loads 450, staging 650, epilogue 470) the ceiling of this formulation is about 0.70 of the fp32 peak;
 //   * wave priorities do not help either: s_setprio 3 outside the main loop (set-up, first chunk, epilogue) and 0 inside it
 //     - so that a workgroup's short non-MFMA phases are served at once - left both the ConvLSTM cell and its data gradient
-//     where they were (0.404 against 0.398 ms, 0.322 against 0.322 ms);
-//   * persistent workgroups for the 8-wave geometry (one per CU: no partner to be unfair to) did not pay either
-//     (tools/experiments/conv_wino_persistent_8wave.hip: data gradient 0.299 against 0.301 ms).
+//     where they were (0.404 against 0.398 ms, 0.322 against 0.322 ms).
 // Operands: the input transform B^T d B of a 16-channel chunk is computed once per workgroup (thread =
 // (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32
 // packed adds, 8 16-byte LDS writes into [xi / 2][tile][36]), the weights arrive pre-transformed from
@@ -639,6 +635,509 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(co
     }
 }
 
+// ---- persistent form of the 8-wave geometry (one workgroup per CU) ---------------------------------------------------------
+// The launch has one workgroup per CU and each walks over the blocks blockIdx.x, blockIdx.x + gridDim.x, ... of the (tile block,
+// column block) list.  The chunk pipeline runs ACROSS blocks: the last chunk of a block stages the first chunk of the next one
+// (other tile coordinates, other weight columns) like any other next chunk and fetches its first weights, so set-up and the
+// first staging round trip to memory - 8 k of the 89 k cycles of a block with nothing to hide them when the CU holds one
+// workgroup - disappear behind the MFMAs; the epilogue works in the LDS buffer the last chunk has finished reading.  (With two
+// workgroups per CU this form LOST 7 %: the hardware serves the older workgroup first and a static block list cannot even that
+// out - tools/experiments/conv_wino2_persistent.hip; one workgroup per CU has no such partner.)
+template <int EPI>
+__global__ void __launch_bounds__(512, 1) conv_winop_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
+    constexpr int NW = 8;
+    using G = WinoGeo<NW>;
+    constexpr int TILES = H_TILES, CPC = G::CPC, CH = G::CH, CHS = G::CHS, BUF = G::BUF, SPC = G::SPC, CG = G::CG;
+    constexpr int H_PART = G::PART, H_TS = G::TS, CW = G::CW;
+    constexpr int PGS = 32 * H_TS;                              // gate stride (every store instruction of a wave is one gate here)
+    static_assert(H_PART <= BUF && 4 * PGS <= BUF, "the epilogue's exchange areas live in ONE staging buffer (the other holds the next block's first chunk)");
+    __shared__ __attribute__((aligned(16))) float stage[2 * BUF];   // 139 KB
+    __shared__ int tpix[TILES];                               // top-left output pixel of the block's tiles (epilogue)
+    __shared__ int tcoord[TILES];                             // the same as (image << 20 | y << 10 | x), -1: no such tile
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wave & 1, cg = wave >> 1;                   // half of the transform domain, column group
+    const int H = P.H, W = P.W, ntiles = P.B * TY * TX, nblocks = MT * NT;
+    const int my_blocks = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // >= 1: the grid never exceeds the list
+    // block i of this workgroup (i wraps: the pipeline stages one block past the end)
+    auto block_of = [&](int i, int &mt_, int &nt_) {
+        const int bid = rnh_xcd_remap((int)blockIdx.x + (i % my_blocks) * (int)gridDim.x, nblocks);
+        mt_ = bid / NT;
+        nt_ = bid - mt_ * NT;
+    };
+
+    // ---- staging: thread = (tile ts, channel pair cp of the chunk) ------------------------------------------------
+    const int ts = threadIdx.x / CPC, cp = threadIdx.x % CPC;
+    // Tile t of the list -> (image, tile row, tile column).  Where the tile grid allows it (TX % 8 == 0, TY % 4 == 0) the
+    // list runs over 8 x 4 blocks of tiles, so that a workgroup's 32 tiles are a 16 x 8 pixel rectangle whose 4x4 patches
+    // cover 18 x 10 input pixels (1.4x the outputs) instead of a 64 x 2 strip that needs 66 x 4 (2.1x): fewer bytes through
+    // the vector cache per chunk and through L2 per launch.
+    const bool blocked = !(TX & 7) && !(TY & 3);
+    auto tile_xy = [&](int t, int &img, int &ty, int &tx) {
+        img = t / (TY * TX);
+        const int rem = t - img * TY * TX;
+        if (blocked) {
+            const int bi = rem >> 5, wi = rem & 31, bpr = TX >> 3, by = bi / bpr, bx = bi - by * bpr;
+            ty = by * 4 + (wi >> 3);
+            tx = bx * 8 + (wi & 7);
+        } else {
+            ty = rem / TX;
+            tx = rem - ty * TX;
+        }
+    };
+    const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
+    // the block being STAGED (one block ahead of the one being multiplied at block boundaries): base pixel of its descriptor
+    // window, the thread's patch corner relative to it and the 16-bit mask of the patch pixels inside the image
+    int ld_block = 0, base_pix = 0, pix00 = 0, okmask = 0;
+    auto stage_block = [&](int i) {
+        int mt_, nt_;
+        block_of(i, mt_, nt_);
+        const int m0_ = mt_ * TILES, t0 = m0_ < ntiles ? m0_ : 0;
+        int img0, ty0, tx0_;
+        tile_xy(t0, img0, ty0, tx0_);
+        base_pix = (img0 * Hs + (2 * ty0 - 1) * sc) * Ws - sc;  // at or before every pixel the block touches
+        const int t = m0_ + ts;
+        const bool tok = t < ntiles;
+        int img, ty, tx;
+        tile_xy(tok ? t : t0, img, ty, tx);
+        pix00 = (img * Hs + (2 * ty - 1) * sc) * Ws + (2 * tx - 1) * sc - base_pix;
+        okmask = 0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int y = 2 * ty - 1 + (p >> 2), x = 2 * tx - 1 + (p & 3);
+            okmask |= (tok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? 1 << p : 0;
+        }
+    };
+    int si = 0, cchunk = 0, nchunk = P.src[0].nch / CH;
+    int voff[16];
+    i32x4 adesc;
+    auto setup_src = [&](int sidx) {
+        const rnh_src_t &S = P.src[sidx];
+        adesc = hdesc(S.ptr + S.c0 + ((long)S.img_off * Hs * Ws + base_pix + S.sub_y * Ws + S.sub_x) * S.C);
+        const int C4 = S.C * 4;
+        // (opaque copy: the 16 pixel offsets are loop invariants that hipcc would hoist out of the chunk loop - and spill)
+        int pb = pix00;
+        asm volatile("" : "+v"(pb));
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int off = __mul24(pb + ((p >> 2) * Ws + (p & 3)) * sc, C4) + cp * 8;      // < 2^24 pixels per block, < 2^24 bytes per pixel
+            const int inside = __builtin_amdgcn_sbfe(okmask, p, 1);                       // -1 inside the image, 0 outside
+            voff[p] = off | ~inside;
+        }
+        nchunk = S.nch / CH;
+    };
+    stage_block(0);
+    setup_src(0);
+
+    // All vector-memory and LDS reads of the loop are volatile asm with hand-counted waits (hipcc sinks plain loads to their first use and waits for each with a full s_waitcnt between two MFMAs); every wait
+    // names the registers it covers as "+v" operands, which orders their uses behind it.  The s_nop covers the 5 wait
+    // states between an SALU / v_readfirstlane write of an SGPR and a VMEM instruction reading it.
+    auto ld8 = [&](f32x2 *dst, const int *vo, const i32x4 &desc, int soff) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx2 %0, %8, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %1, %9, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %2, %10, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %3, %11, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %4, %12, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %5, %13, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %6, %14, %16, %17 offen\n\t"
+            "buffer_load_dwordx2 %7, %15, %16, %17 offen"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7])
+            : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "v"(vo[5]), "v"(vo[6]), "v"(vo[7]), "s"(desc), "s"(soff)
+            : "memory");
+    };
+    f32x2 stg[16];
+    auto gload = [&]() {                                   // next chunk of the source list -> registers (16 loads)
+        const int soff = __builtin_amdgcn_readfirstlane(cchunk * CH * 4);
+        ld8(stg, voff, adesc, soff);
+        ld8(stg + 8, voff + 8, adesc, soff);
+        if (++cchunk == nchunk) {
+            cchunk = 0;
+            if (++si == P.nsrc) {                           // the source list of the block is through: on to the next block
+                si = 0;
+                stage_block(++ld_block);
+            }
+            setup_src(si);
+        }
+    };
+    auto xform_store = [&](int buf, auto keep) {            // V = B^T d B on the thread's two channels, to LDS
+        asm volatile("s_waitcnt vmcnt(%c16)"
+                     : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]),
+                       "+v"(stg[8]), "+v"(stg[9]), "+v"(stg[10]), "+v"(stg[11]), "+v"(stg[12]), "+v"(stg[13]), "+v"(stg[14]),
+                       "+v"(stg[15])
+                     : "i"(decltype(keep)::value));
+        auto sub = [&](f32x2 a, f32x2 b) {                 // one v_pk_add_f32 (hipcc scalarises packed adds / subtractions)
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
+        auto add = [&](f32x2 a, f32x2 b) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        };
+        f32x2 tq[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = sub(stg[0 * 4 + j], stg[2 * 4 + j]);
+            tq[1 * 4 + j] = add(stg[1 * 4 + j], stg[2 * 4 + j]);
+            tq[2 * 4 + j] = sub(stg[2 * 4 + j], stg[1 * 4 + j]);
+            tq[3 * 4 + j] = sub(stg[1 * 4 + j], stg[3 * 4 + j]);
+        }
+        float *o = stage + buf * BUF + ts * CHS + 4 * cp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 v0 = sub(tq[i * 4 + 0], tq[i * 4 + 2]), v1 = add(tq[i * 4 + 1], tq[i * 4 + 2]);
+            const f32x2 v2 = sub(tq[i * 4 + 2], tq[i * 4 + 1]), v3 = sub(tq[i * 4 + 1], tq[i * 4 + 3]);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 0) * TILES * CHS) = __builtin_shufflevector(v0, v1, 0, 1, 2, 3);
+            *reinterpret_cast<f32x4w *>(o + (i * 2 + 1) * TILES * CHS) = __builtin_shufflevector(v2, v3, 0, 1, 2, 3);
+        }
+    };
+
+    // this wave's pairs of transform positions: pr = 2 i + h (row i of the 4x4 domain, columns 2h and 2h + 1)
+    const int pstride = P.Npad * 32;                        // bytes between two PAIRS of transform positions of one step
+    int boffx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) boffx[i] = (l31 * 2 + kh) * 16 + (2 * i + h) * pstride;
+    auto wdesc_of = [&](int nt_) { return hdesc(P.wp + (long)((nt_ * CG + cg) * 32) * 8); };   // this wave's 32 columns of column block nt_
+    auto loadb = [&](f32x4w *u, const i32x4 &bd, int sb) {   // transformed weights of step sb: 4 loads of 16 bytes
+        const int soff = __builtin_amdgcn_readfirstlane(sb * 8 * pstride);
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %4, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\t"
+            "buffer_load_dwordx4 %3, %7, %8, %9 offen"
+            : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+            : "v"(boffx[0]), "v"(boffx[1]), "v"(boffx[2]), "v"(boffx[3]), "s"(bd), "s"(soff)
+            : "memory");
+    };
+    const unsigned lds0 = (unsigned)(size_t)stage;
+    const unsigned vlane = lds0 + ((h * TILES + l31) * CHS + 4 * kh) * 4;
+    // the lane's tile, channels 4q + 2kh, +1 of the staged chunk, pairs 2a and 2a + 1 of this wave's four (half a step: 8 MFMAs)
+    auto loadv = [&](f32x4w *V, int buf, int q, auto a_tag) {
+        constexpr int a = decltype(a_tag)::value;
+        const unsigned adr = vlane + buf * BUF * 4 + q * 32;
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(V[0]) : "v"(adr), "i"((4 * a) * TILES * CHS * 4) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(V[1]) : "v"(adr), "i"((4 * a + 2) * TILES * CHS * 4) : "memory");
+    };
+    auto wait_lds = [&](f32x4w *V) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1])); };
+    auto wait_vm = [&](f32x4w *u, auto keep) {
+        asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "i"(decltype(keep)::value));
+    };
+
+    f32x16 acc[8];                                          // acc[2 i + odd] = position (row i, column 2h + odd)
+
+    auto compute = [&](const f32x4w *V, const f32x4w *u, auto a_tag) {      // V: the two pairs of half a, u: all four pairs of the step
+        constexpr int a = decltype(a_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * a + j;
+            acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].x, u[i].x, acc[2 * i], 0, 0, 0);
+            acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].y, u[i].y, acc[2 * i], 0, 0, 0);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].z, u[i].z, acc[2 * i + 1], 0, 0, 0);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j].w, u[i].w, acc[2 * i + 1], 0, 0, 0);
+        }
+    };
+
+    int nchunks_block = 0;
+    for (int i = 0; i < P.nsrc; ++i) nchunks_block += P.src[i].nch / CH;
+    f32x4w Va[2], Vb[2], u0[4], u1[4];                        // staged operands by half steps, weights by steps
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    using K4 = std::integral_constant<int, 4>;               // the 4 weight loads of ONE step may stay in flight
+    using K0 = std::integral_constant<int, 0>;
+    int mt, nt, m0, ncol;                                     // the block being multiplied
+    float bv;
+    [[maybe_unused]] f32x4w cpv[2];
+    [[maybe_unused]] bool lstm_full = false;
+    [[maybe_unused]] long item_o[2];                            // pixel index of the thread's two ConvLSTM items
+    [[maybe_unused]] int item_x[2];                             // their float offset in the gate exchange area
+    constexpr int NEPI = EPI == RNH_EPI_LSTM ? 3 : 1;           // loads of the epilogue's request (conv_winoh_kernel)
+    auto epi_request = [&]() {
+        // (unconditional asm loads from clamped, always valid addresses: a load under an `if` would give its target register
+        // a second definition and hipcc a reason to copy it in flight; no bias / no previous state: zeros behind the wait)
+        asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"((P.bias ? P.bias : P.wp) + ncol) : "memory");
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            lstm_full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1) && nt * CW + CW <= P.hd;
+            const float *csrc = P.c_prev ? P.c_prev : P.c_out;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int it = q * (64 * NW) + (int)threadIdx.x, t = it / CW, p = (it / (CW / 4)) & 3, c4 = (it % (CW / 4)) * 4;
+                item_o[q] = (long)tpix[t] + (p >> 1) * W + (p & 1);
+                item_x[q] = t * H_TS + p * CW + c4;
+                const int hcl = min(nt * CW + c4, P.hd - 4);    // (the tile list is clamped in tpix, the channel here)
+                const long pl = lstm_full ? item_o[q] : (long)tpix[t];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpv[q]) : "v"(csrc + pl * P.hd + hcl) : "memory");
+            }
+        }
+    };
+    // One chunk = SPC steps of 16 MFMAs, as in conv_winoh_kernel, but every chunk has a next one: `last` = the last chunk of a
+    // block, whose next chunk is the first of the next block (weights from bd_next) and which carries the epilogue's request.
+    auto chunk = [&](const int buf, const i32x4 &bd, const int s, auto last_tag, const i32x4 &bd_next) {
+        constexpr bool lastc = decltype(last_tag)::value;
+        constexpr int X = lastc ? NEPI : 0;                     // loads of the request in flight behind the weight loads
+        auto step = [&](auto q_tag, f32x4w *ucur, f32x4w *unext) {
+            constexpr int q = decltype(q_tag)::value;
+            constexpr bool last = q == SPC - 1;
+            wait_lds(Va);
+            loadv(Vb, buf, q, A1());
+            if constexpr (q == 0) {
+                wait_vm(ucur, K0());                        // (the staging loads go behind the wait, see conv_winoh_kernel)
+                gload();
+                loadb(unext, bd, s + 1);
+            } else if constexpr (!last) {
+                loadb(unext, bd, s + q + 1);
+                if constexpr (q == SPC - 2) {
+                    if constexpr (lastc) epi_request();     // younger than every weight load: the waits below leave it in flight
+                    wait_vm(ucur, std::integral_constant<int, 4 + X>());
+                    xform_store(buf ^ 1, std::integral_constant<int, 4 + X>());
+                } else {
+                    wait_vm(ucur, K4());
+                }
+            } else {
+                if constexpr (lastc) loadb(unext, bd_next, 0);
+                else loadb(unext, bd, s + SPC);
+                wait_vm(ucur, std::integral_constant<int, 4 + X>());
+            }
+            compute(Va, ucur, A0());
+            wait_lds(Vb);
+            if constexpr (!last) {
+                loadv(Va, buf, q + 1, A0());
+            } else {
+                asm volatile("s_barrier" ::: "memory");
+                loadv(Va, buf ^ 1, 0, A0());
+            }
+            compute(Vb, ucur, A1());
+        };
+        step(std::integral_constant<int, 0>(), u0, u1);
+        step(std::integral_constant<int, 1>(), u1, u0);
+        step(std::integral_constant<int, 2>(), u0, u1);
+        step(std::integral_constant<int, 3>(), u1, u0);
+        step(std::integral_constant<int, 4>(), u0, u1);
+        step(std::integral_constant<int, 5>(), u1, u0);
+        step(std::integral_constant<int, 6>(), u0, u1);
+        step(std::integral_constant<int, 7>(), u1, u0);
+    };
+
+    int mt_n, nt_n;
+    block_of(0, mt, nt);
+    i32x4 bdesc = wdesc_of(nt);
+    gload();
+    loadb(u0, bdesc, 0);                                     // 4 loads younger than the staging loads
+    xform_store(0, K4());
+    __syncthreads();
+    loadv(Va, 0, 0, A0());
+    int g = 0;                                                // chunks done: chunk g lives in LDS buffer g & 1
+    for (int k = 0; k < my_blocks; ++k) {
+        block_of(k + 1, mt_n, nt_n);
+        const i32x4 bdesc_n = wdesc_of(nt_n);
+        m0 = mt * TILES;
+        ncol = (nt * CG + cg) * 32 + l31;
+        if (threadIdx.x < TILES) {                            // (read in the last chunk and the epilogue, behind the chunks' barriers)
+            const int tr = m0 + threadIdx.x, tq = tr < ntiles ? tr : (m0 < ntiles ? m0 : 0);
+            int im, yy, xx;
+            tile_xy(tq, im, yy, xx);
+            tpix[threadIdx.x] = (im * H + 2 * yy) * W + 2 * xx;
+            tcoord[threadIdx.x] = tr < ntiles ? (im << 20) | (2 * yy << 10) | (2 * xx) : -1;
+        }
+        // (an inline constant per register: hipcc zeroes ONE register and copies it 127 times - copies out of a register that is
+        // a load target elsewhere in the loop, which tests/test_isa_guards.py cannot tell from a stale operand)
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) asm volatile("v_mov_b32 %0, 0" : "=v"(acc[a][v]));
+        for (int c = 0; c + 1 < nchunks_block; ++c, ++g) chunk(g & 1, bdesc, SPC * c, std::false_type(), bdesc);
+        chunk(g & 1, bdesc, SPC * (nchunks_block - 1), std::true_type(), bdesc_n);
+        float *const ep = stage + (g & 1) * BUF;              // the epilogue's LDS: the buffer this chunk has finished reading
+        ++g;
+
+    // ---- output transform: this half's share of Y = A^T M A, exchange with the partner wave --------------------------
+    f32x4w *px = reinterpret_cast<f32x4w *>(ep);
+    float Yf[8][4];                                             // entries 8h .. 8h + 7: tiles 16h .. 16h + 15 of the block
+    auto exchange = [&](auto h_tag) {
+        constexpr int hh = decltype(h_tag)::value;
+        auto part4 = [&](int v, float *Y) {
+            float s0[2], s1[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                s0[o] = acc[0 + o][v] + acc[2 + o][v] + acc[4 + o][v];
+                s1[o] = acc[2 + o][v] - acc[4 + o][v] - acc[6 + o][v];
+            }
+            if constexpr (hh == 0) {                            // columns 0, 1 of the domain
+                Y[0] = s0[0] + s0[1]; Y[1] = s0[1]; Y[2] = s1[0] + s1[1]; Y[3] = s1[1];
+            } else {                                            // columns 2, 3
+                Y[0] = s0[0]; Y[1] = -s0[0] - s0[1]; Y[2] = s1[0]; Y[3] = -s1[0] - s1[1];
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                           // the partner's entries
+            float Y[4];
+            part4(8 * (1 - hh) + e, Y);
+            const f32x4w y4 = {Y[0], Y[1], Y[2], Y[3]};
+            px[(wave * 8 + e) * 64 + lane] = y4;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part4(8 * hh + e, Yf[e]);
+    };
+    if (h == 0) exchange(std::integral_constant<int, 0>());
+    else exchange(std::integral_constant<int, 1>());
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the bias has landed; the state and the next block's first weights (the 4 youngest loads) may still be on their way
+    asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(bv) : "i"(NEPI - 1 + 4));
+    if (!P.bias) bv = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const f32x4w y4 = px[((wave ^ 1) * 8 + e) * 64 + lane];
+        Yf[e][0] += y4.x + bv; Yf[e][1] += y4.y + bv; Yf[e][2] += y4.z + bv; Yf[e][3] += y4.w + bv;
+    }
+    // tile row (0..31) of entry e of this wave
+    auto trl_of = [&](int e) { const int v = 8 * h + e; return (v & 3) + 8 * (v >> 2) + 4 * kh; };
+
+    if constexpr (EPI == RNH_EPI_LSTM) {
+        const int hd = P.hd;
+        const bool full = lstm_full;
+        float *xg = ep;                                         // the gates take the place of the partial outputs (one more barrier)
+        // phase 1: lanes 0..15 / 16..31 of a row block hold gates 2cg / 2cg + 1 (i, f | o, g) of 16 hidden channels;
+        // sigmoid, and tanh as 2 sigmoid(2x) - 1 for the candidate gate, in one form: m rcp(1 + exp(-m x)) + b
+        const int gate = (cg * 32 + l31) / CW, ch = (cg * 32 + l31) % CW, hc = nt * CW + ch;
+        const float gm = gate == 3 ? 2.f : 1.f, gb = gate == 3 ? -1.f : 0.f;
+        float *xw = xg + gate * PGS + ch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) Yf[e][p] = __builtin_fmaf(gm, __builtin_amdgcn_rcpf(1.f + __expf(-gm * Yf[e][p])), gb);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its partner's partial outputs
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xw[trl_of(e) * H_TS + p * CW] = Yf[e][p];
+        if (P.gates_out && !full) {                             // (whole blocks store the gates from LDS in phase 2, 16 bytes per lane)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int trl = trl_of(e), tc = tcoord[trl];
+                const bool ok = tc >= 0 && hc < hd;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (ok && yy + (p >> 1) < H && xx + (p & 1) < W)
+                        P.gates_out[((long)tpix[trl] + (p >> 1) * W + (p & 1)) * 4 * hd + gate * hd + hc] = Yf[e][p];
+            }
+        }
+        // the gates are in LDS: wait for the LDS writes only (not for the gates_out stores)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (on every path: the registers must not be reused while the loads are in flight.  On the partial-block path this is
+        // also a wait for its gate stores.)
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(cpv[0]), "+v"(cpv[1]));       // (the 4 youngest: the next block's first weights)
+        if (!P.c_prev) cpv[0] = cpv[1] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c4 = ((q * (64 * NW) + (int)threadIdx.x) % (CW / 4)) * 4;
+                const float *xi = xg + item_x[q];
+                const f32x4w gi = *reinterpret_cast<const f32x4w *>(xi), gf = *reinterpret_cast<const f32x4w *>(xi + PGS);
+                const f32x4w go = *reinterpret_cast<const f32x4w *>(xi + 2 * PGS), gg = *reinterpret_cast<const f32x4w *>(xi + 3 * PGS);
+                if (P.gates_out) {
+                    // (plain stores: with the nt bit, 16-byte pieces of one 128-byte line written by the workgroups of four
+                    // column blocks came out corrupted now and then - tools/debug/lstm_mismatch.py)
+                    f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + item_o[q] * 4 * hd + nt * CW + c4);
+                    gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
+                }
+                f32x4w cn, hn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cn[j] = gf[j] * cpv[q][j] + gi[j] * gg[j];
+                    hn[j] = go[j] * h_tanh(cn[j]);
+                }
+                const long o = item_o[q] * hd + nt * CW + c4;
+                *reinterpret_cast<f32x4w *>(P.c_out + o) = cn;
+                *reinterpret_cast<f32x4w *>(P.h_out + o) = hn;
+            }
+        } else {
+            // partial blocks: items (tile, pixel, channel) e = k * threads + tid one by one
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = k * (64 * NW) + (int)threadIdx.x, ch2 = e % CW, p2 = (e / CW) & 3, t = e / (4 * CW);
+                const int tc = tcoord[t], hc2 = nt * CW + ch2;
+                if (tc < 0 || hc2 >= hd) continue;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+                if (yy + (p2 >> 1) >= H || xx + (p2 & 1) >= W) continue;
+                const float *xr = xg + t * H_TS + p2 * CW + ch2;
+                const float gi = xr[0 * PGS], gf = xr[1 * PGS], go = xr[2 * PGS], gg = xr[3 * PGS];
+                const long o = ((long)tpix[t] + (p2 >> 1) * W + (p2 & 1)) * hd + hc2;
+                const float cp = P.c_prev ? P.c_prev[o] : 0.f;
+                const float cn = gf * cp + gi * gg;
+                P.c_out[o] = cn;
+                P.h_out[o] = go * h_tanh(cn);
+            }
+        }
+    } else if constexpr (EPI == RNH_EPI_PS) {
+        // column n = (i*r + j)*cq + c  ->  pixel (r*y + i, r*x + j), channel c of the (B, rH, rW, cq) destination
+        const int r = P.ps_r, cq = P.ps_cq;
+        const int sub = ncol / cq, c = ncol - sub * cq, pi = sub / r, pj = sub - pi * r;
+        float *dp = P.dst[0].ptr + c;
+        const long Wr = (long)W * r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (ncol >= cq * r * r) continue;
+            const int tc = tcoord[trl_of(e)];
+            if (tc < 0) continue;
+            const int im = tc >> 20, yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int y = yy + (p >> 1), x = xx + (p & 1);
+                if (y >= H || x >= W) continue;
+                dp[(((long)im * H + y) * r + pi) * Wr * cq + ((long)x * r + pj) * cq] = Yf[e][p];
+            }
+        }
+    } else {
+        // destination segment of this lane's column
+        int seg = -1, cbase = 0;
+        for (int d = 0; d < P.ndst; ++d) {
+            if (seg < 0 && ncol < cbase + P.dst[d].ncols) seg = d;
+            if (seg < 0) cbase += P.dst[d].ncols;
+        }
+        const rnh_dst_t &D = P.dst[seg < 0 ? 0 : seg];
+        float *dp = D.ptr + (long)D.img_off * H * W * D.C + D.c0 + (ncol - cbase);
+        const bool full = m0 + TILES <= ntiles && !(H & 1) && !(W & 1);
+        if (seg < 0) {
+        } else if (full) {                                          // no per-element predicates
+            const long rowC = (long)W * D.C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float *o = dp + (long)tpix[trl_of(e)] * D.C;
+                if (D.accumulate) {
+                    const float a0 = o[0], a1 = o[D.C], a2 = o[rowC], a3 = o[rowC + D.C];
+                    o[0] = a0 + Yf[e][0]; o[D.C] = a1 + Yf[e][1]; o[rowC] = a2 + Yf[e][2]; o[rowC + D.C] = a3 + Yf[e][3];
+                } else {
+                    o[0] = Yf[e][0]; o[D.C] = Yf[e][1]; o[rowC] = Yf[e][2]; o[rowC + D.C] = Yf[e][3];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int trl = trl_of(e), tc = tcoord[trl];
+                if (tc < 0) continue;
+                const int yy = (tc >> 10) & 1023, xx = tc & 1023;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (yy + (p >> 1) >= H || xx + (p & 1) >= W) continue;
+                    float *o = dp + ((long)tpix[trl] + (p >> 1) * W + (p & 1)) * D.C;
+                    *o = D.accumulate ? *o + Yf[e][p] : Yf[e][p];
+                }
+            }
+        }
+    }
+        // the next chunk writes this buffer in its next-to-last step and the next block's set-up rewrites tpix / tcoord
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        mt = mt_n;
+        nt = nt_n;
+        bdesc = bdesc_n;
+    }
+    // the pipeline is one chunk ahead: let its loads land before the wave gives its registers back
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 inline int wgrid_for(long n, int cap = 8192) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -694,7 +1193,8 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     const rnh_conv_args_t &a = *args;
     if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
     if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
-    const int wide = a.tile == RNH_WINO_COLS128;                // 128-column blocks (8 waves, 32-channel chunks), else 64-column blocks
+    // 128-column blocks (8 waves, 32-channel chunks; RNH_WINO_COLS128: persistent workgroups, RNH_WINO_COLS128_NP: one per block), else 64-column blocks
+    const int wide = a.tile == RNH_WINO_COLS128 || a.tile == RNH_WINO_COLS128_NP;
     const int bc = wide ? 128 : 64, cm = wide ? 32 : 16;
     if (a.Npad < bc || a.Npad % bc) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of %d", bc);
     int steps = 0;
@@ -723,7 +1223,27 @@ extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     } else if (a.epilogue == RNH_EPI_LSTM) {
         if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
     }
-    if (int rc = wide ? launch_wino<8>(a, MT, NT, TX, TY, st) : launch_wino<4>(a, MT, NT, TX, TY, st)) return rc;
+    if (a.tile == RNH_WINO_COLS128) {
+        // persistent workgroups, one per CU, each takes every gridDim.x-th block of the MT * NT list
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: cannot read the CU count of the device");
+        }
+        const long nblocks = (long)MT * NT;
+        const dim3 grid((unsigned)(nblocks < cus ? nblocks : cus)), block(512);
+        if (a.epilogue == RNH_EPI_LSTM && a.Npad != 128 * ((a.hd + 31) / 32))
+            RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (128-column blocks = the four gates of 32 hidden channels)");
+        switch (a.epilogue) {
+            case RNH_EPI_STORE: hipLaunchKernelGGL((conv_winop_kernel<RNH_EPI_STORE>), grid, block, 0, st, a, MT, NT, TX, TY); break;
+            case RNH_EPI_PS: hipLaunchKernelGGL((conv_winop_kernel<RNH_EPI_PS>), grid, block, 0, st, a, MT, NT, TX, TY); break;
+            case RNH_EPI_LSTM: hipLaunchKernelGGL((conv_winop_kernel<RNH_EPI_LSTM>), grid, block, 0, st, a, MT, NT, TX, TY); break;
+            default: RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
+        }
+    } else if (int rc = wide ? launch_wino<8>(a, MT, NT, TX, TY, st) : launch_wino<4>(a, MT, NT, TX, TY, st)) {
+        return rc;
+    }
     RNH_CHECK_LAUNCH("rnh_conv_wino");
     return 0;
 }
