@@ -125,8 +125,11 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
 /* The same 3x3 convolution in Winograd form F(2x2, 3x3) (csrc/conv_wino.hip): 16 GEMMs in the transform domain, 2.25x
  * fewer MFMA passes; input and output transforms fused (nothing of the transform domain reaches memory).  A wave owns half
  * of the transform domain of 32 tiles x 32 columns (128 accumulators), a workgroup computes 32 tiles x 64 columns and two
- * workgroups share a CU.  Same rnh_conv_args_t, with: ntaps = 9; one scale for all sources, ptr2 = 0, every nch % 16 == 0;
- * nk = number of 4-channel steps (sum_src nch/4); wp from rnh_wino_pack_weights; Npad a multiple of 64; tile ignored;
+ * workgroups share a CU (tile = RNH_WINO_COLS64, or any other value but the next); with tile = RNH_WINO_COLS128 a workgroup is
+ * 8 waves = 32 tiles x 128 columns, one per CU, and every nch % 32 == 0, Npad a multiple of 128, RNH_EPI_LSTM in the column
+ * order plans.lstm_colmap (blocks of 128 = the gates i, f, o, g of 32 hidden channels).  Same rnh_conv_args_t, with: ntaps = 9;
+ * one scale for all sources, ptr2 = 0, every nch % 16 == 0; nk = number of 4-channel steps (sum_src nch/4); wp from
+ * rnh_wino_pack_weights; Npad a multiple of 64;
  * source images of at most 2^22 pixels (scale^2 * H * W); epilogue RNH_EPI_STORE, RNH_EPI_PS or RNH_EPI_LSTM.
  * RNH_EPI_LSTM expects the column order of plans.lstm_colmap64 (a block of 64 columns = gates i, f | o, g of 16 hidden
  * channels: column block * 64 + (gate >> 1) * 32 + (gate & 1) * 16 + channel) and Npad == 64 * ceil(hd / 16).
