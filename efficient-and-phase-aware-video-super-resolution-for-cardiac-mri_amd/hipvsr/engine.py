@@ -169,7 +169,11 @@ class RefineNetEngine:
                     ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                 if P.xcol:
                     ops.refine_xcol_fwd([Hf[lo:hi], Hbk[lo:hi], P4[lo:hi]], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
-                ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
+                if P.r2_wino:
+                    ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nwin * N, H, W, dsts=[Dst(R, Cl)])
+                    ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nwin * N, H, W, dsts=[Dst(R, Cl, accumulate=True)])
+                else:
+                    ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
                 st['R1'], st['w0'] = (R1 if need_grad else None), w0
             else:
                 ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R, Cl)])
@@ -316,7 +320,10 @@ class RefineNetEngine:
             if P.pos:
                 # the T middle frames are written by conv2's data gradient, the window halo on both sides stays zero
                 dR1p = ops.halo_buffer('dR1p', ((T + 2 * hw) * N, H, W, P.C1p), act, hw * N, (hw + T) * N)
-                if P.r1_split:
+                if P.r2_wino:
+                    ops.conv(P.r2_dgrad_h, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
+                    ops.conv(P.r2_dgrad_x, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])
+                elif P.r1_split:
                     ops.conv(P.r2_dgrad_a, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
                     ops.conv(P.r2_dgrad_b, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])
                 else:

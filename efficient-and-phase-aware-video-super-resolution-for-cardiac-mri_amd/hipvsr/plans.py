@@ -276,7 +276,7 @@ class NetPlans:
 
         Cl, w = self.Cl, cfg.refine_window_size
         self.pos = bool(cfg.positional_encoding)
-        self.xcol = self.r1_wino = self.r1_split = False
+        self.xcol = self.r1_wino = self.r1_split = self.r2_wino = False
         if self.pos:
             C1 = 2 * Cl + 1
             self.C1, self.C1p = C1, (_pad_to(C1, 8) if bf else r4(C1))
@@ -320,6 +320,16 @@ class NetPlans:
                 self.r1_fwd_b = ConvPlan_('refine1.fwd.b', k1, b1, ws1, segs, tail)
                 self.r2_dgrad_a = ConvPlan_('refine2.dgrad.a', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(C1 - 1)), transposed=True)
                 self.r2_dgrad_b = ConvPlan_('refine2.dgrad.b', k2, None, ws2, [KSeg(Cl, Cl, 0)], tail, transposed=True)
+            # conv2 (C1 -> Cl channels) the same way: its 2*Cl hidden-state input channels in Winograd form, the phase channel (and
+            # the pad channels behind it) through the implicit GEMM, accumulating; its data gradient as a 2*Cl-column Winograd
+            # launch plus a launch for the columns of the last channel
+            self.r2_wino = self.r1_wino and os.environ.get('RNH_WINO_REFINE2', '1') != '0'
+            if self.r2_wino:
+                self.r2_fwd_h = ConvPlan_('refine2.fwd.h', k2, b2, ws2, [KSeg(2 * Cl, 2 * Cl, 0)], list(range(Cl)), wino=True)
+                self.r2_fwd_x = ConvPlan_('refine2.fwd.x', k2, None, ws2, [KSeg(self.C1p - 2 * Cl, C1 - 2 * Cl, 2 * Cl)], list(range(Cl)))
+                self.r2_dgrad_h = ConvPlan_('refine2.dgrad.h', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(2 * Cl)), transposed=True, wino=True)
+                self.r2_dgrad_x = ConvPlan_('refine2.dgrad.x', k2, None, ws2, [KSeg(Cl, Cl, 0)],
+                                           list(range(2 * Cl, C1)) + [-1] * (self.C1p - C1), transposed=True)
             self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)
@@ -375,7 +385,7 @@ class NetPlans:
         if self.r1_wino:
             out += [self.r1_fwd_h, self.r1_fwd_p, self.r1_dgrad_h, self.r1_dgrad_x]
         if self.pos:
-            out += [self.r2_fwd, self.r2_dgrad]
+            out += [self.r2_fwd_h, self.r2_fwd_x, self.r2_dgrad_h, self.r2_dgrad_x] if self.r2_wino else [self.r2_fwd, self.r2_dgrad]
         for u in self.up:
             out += [u['fwd'], u['dgrad']]
         if getattr(self, 'r1_split', False):                   # replaced by their .a / .b halves: never launched, not packed
