@@ -43,7 +43,8 @@
 //     where they were (0.404 against 0.398 ms, 0.322 against 0.322 ms);
 //   * persistent workgroups for the 8-wave geometry (one per CU: no partner to be unfair to) did not pay either
 //     (tools/experiments/conv_wino_persistent_8wave.hip: data gradient 0.299 against 0.301 ms).
-// Operands: the input transform B^T d B of a 16-channel chunk is computed once per workgroup (thread =
+// Operands (64-column geometry; the 8-wave one below doubles chunk and columns): the input transform B^T d B of a 16-channel
+// chunk is computed once per workgroup (thread =
 // (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32
 // packed adds, 8 16-byte LDS writes into [xi / 2][tile][36]), the weights arrive pre-transformed from
 // rnh_wino_pack_weights as U[step][xi / 2][n][lane half][xi & 1][2]: one buffer_load_dwordx4 and one ds_read_b128 feed
@@ -330,8 +331,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(co
         }
     };
 
-    // ---- main loop over 16-channel chunks (4 steps of 4 channels, 16 MFMAs each); chunk c+1 travels global -> registers
-    // under the MFMAs of chunk c and is transformed into the other LDS buffer in its third step ---------------------------
+    // ---- main loop over chunks of CH channels (SPC steps of 4 channels, 16 MFMAs each); chunk c+1 travels global -> registers
+    // under the MFMAs of chunk c and is transformed into the other LDS buffer in its next-to-last step -------------------
     int nchunks_total = 0;
     for (int i = 0; i < P.nsrc; ++i) nchunks_total += P.src[i].nch / CH;
     f32x4w Va[2], Vb[2], u0[4], u1[4];                        // staged operands by half steps, weights by steps
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(co
     using K4 = std::integral_constant<int, 4>;               // the 4 weight loads of ONE step may stay in flight
     using K0 = std::integral_constant<int, 0>;
     // ---- what the epilogue needs from memory: bias of the lane's column and, for the ConvLSTM, the previous cell state of
-    // the thread's two items (tile, pixel, 4 hidden channels) q * 256 + tid - 16 bytes of every gate, of c and of h per
+    // the thread's two items (tile, pixel, 4 hidden channels) q * threads + tid - 16 bytes of every gate, of c and of h per
     // item.  Requested in the LAST chunk right behind its last weight request (vector-memory loads complete in order: any
     // earlier and the chunk's counted waits for weights would have to sit out these loads first).  The state comes from
     // HBM behind the gate stores of the whole chip: measured 54 us of a 387 us launch while it was requested behind the
