@@ -167,3 +167,36 @@ def test_engine_last_group_only(g1):
     full, _ = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=False)
     last, _ = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=False, last_only=True)
     assert torch.equal(last[-1, 2], full[-1, 2])
+
+
+def test_winograd_geometry_choice_of_the_plans(monkeypatch):
+    """Which geometry of rnh_conv_wino the plans ask for (hipvsr/plans.py ConvPlan.wino_cols): 128-column blocks (8 waves, one
+    workgroup per CU) exactly where they cost no padding - column count a multiple of 128, every source a multiple of 32
+    channels - and the matching ConvLSTM gate layout; 64-column blocks elsewhere; RNH_WINO_COLS=64 turns the wide geometry off;
+    16-channel layers stay Winograd in the 64-column geometry; 8-channel layers fall back to the implicit GEMM and its layout."""
+    from hipvsr.plans import NetPlans, lstm_colmap, lstm_colmap64
+    from hipvsr.spec import NetConfig
+
+    def cfg(nf):
+        return NetConfig(1, 1, nf, num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True, num_updated_frames=6,
+                         positional_encoding=True)
+    P = NetPlans(cfg([64, 64, 64]))
+    pl = P.lstm[('forward', 1)]
+    assert pl['full'].wino and pl['full'].wino_cols == 128 and pl['full'].Npad == 256 and pl['full'].gate_group == 32
+    assert pl['full'].colmap[:256] == lstm_colmap(64) and pl['first'].wino_cols == 128
+    assert pl['dgrad'].wino and pl['dgrad'].wino_cols == 128 and pl['dgrad'].Npad == 128
+    assert P.r1_wino and P.r1_fwd_h.wino_cols == 128 and P.r1_dgrad_h.wino_cols == 128
+    assert P.r2_wino and P.r2_fwd_h.wino and P.r2_fwd_h.wino_cols == 64 and P.r2_dgrad_h.wino_cols == 128
+    assert P.up[0]['fwd'].wino_cols == 128 and P.up[0]['dgrad'].wino and P.up[0]['dgrad'].wino_cols == 64   # 64 output columns
+    monkeypatch.setenv('RNH_WINO_COLS', '64')
+    P64 = NetPlans(cfg([64, 64, 64]))
+    pl = P64.lstm[('forward', 1)]
+    assert pl['full'].wino and pl['full'].wino_cols == 64 and pl['full'].gate_group == 16 and pl['full'].colmap[:256] == lstm_colmap64(64)
+    assert P64.r1_fwd_h.wino_cols == 64 and P64.up[0]['fwd'].wino_cols == 64
+    monkeypatch.delenv('RNH_WINO_COLS')
+    P16 = NetPlans(cfg([16, 16]))
+    pl = P16.lstm[('backward', 0)]
+    assert pl['full'].wino and pl['full'].wino_cols == 64 and pl['full'].Npad == 64 and pl['full'].gate_group == 16
+    P8 = NetPlans(cfg([8, 8]))
+    pl = P8.lstm[('forward', 0)]
+    assert not pl['full'].wino and pl['full'].gate_group == 32 and pl['full'].colmap[:len(lstm_colmap(8))] == lstm_colmap(8)
