@@ -14,7 +14,10 @@ step) from HIP-event timing of that launch on this run: `achieved` / `frac` = th
 (16 GEMMs over the 2x2 tiles = 4/9 of the direct form) over the launch time and the fp32 MFMA peak - a fraction of a
 ceiling, <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per
 pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not
-do that work).  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
+do that work).  `secondary` carries the SAME step in the bf16-storage path (BASELINE config 3 per GPU: same N, T,
+size, steps and warm-up, timed the same way in the same process right after the headline) with its own `ms_per_step`, `value`,
+`roofline` (conv_bf16d_kernel<LSTM> against the dense bf16 MFMA peak; executed = algorithmic there) and `dtype: "bf16"`;
+`--no-secondary` skips it, `--dtype bf16` makes it the only line as before.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
 only if that file was measured on THIS kernel source (sha256 of the Winograd kernel's source file, csrc/conv_wino.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
@@ -52,7 +55,10 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
         out_f, out_b = w * 294912 + 51200, 2 * w * 294912 + 65536             # first PixelShuffle conv: fwd, dgrad, wgrad Winograd; tail collapsed
     lstm_f, lstm_b = w * 589824, 2 * w * 589824                               # fwd, dgrad, wgrad Winograd
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
-    ref_f, ref_b = w * r1 + r2, 2 * w * r1 + 2 * r2                           # conv1 Winograd (fwd, dgrad, wgrad), conv2 direct
+    r2h, r2x = 128 * 64 * 18, 1 * 64 * 18                                     # conv2: the 128 hidden-state channels / channel 128
+    # conv1 in Winograd form (fwd, dgrad, wgrad); conv2 forward and data gradient in Winograd form over its 128 hidden-state
+    # channels (channel 128 through the implicit GEMM), its weight gradient as pixel-contraction GEMM (direct)
+    ref_f, ref_b = w * r1 + w * r2h + r2x, 2 * w * r1 + (w * r2h + r2x) + r2
     nfr, nwin = S * F, S * (F - 4)            # ConvLSTM frames per direction and refine windows, all stages
     if executed:                              # the last stage stops at the last refine window / computes the T supervised windows only
         nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
@@ -98,8 +104,8 @@ def synthetic_batch(dev, n, t, h, w, seed, u=6, s=4):
 
 
 def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
-    """Average duration of ONE ConvLSTM-cell launch (rnh_conv_igemm, LSTM epilogue) at the benchmark shape, by HIP
-    events on the stream the kernels run on (torch's current stream)."""
+    """Average duration of ONE ConvLSTM-cell launch (rnh_conv_wino with the LSTM epilogue in the fp32 path, rnh_conv_bf16 in the
+    bf16-storage path) at the benchmark shape, by HIP events on the stream the kernels run on (torch's current stream)."""
     from hipvsr.plans import Src
     eng = net._engine()
     ops, pl = eng.ops, eng.plans.lstm[('forward', 1)]
@@ -196,44 +202,20 @@ def cpu_baseline():
             'tflops': round(step_flops_per_lr_pixel(3) * 64 * 64 / dt / 1e12, 3)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
-    ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
-    ap.add_argument('--size', type=int, default=128, help='LR height = width')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='replay forward + loss + backward of the step from a HIP graph (hipvsr.graph.GraphedTrainStep); auto = the '
-                         "trainer's own rule (off at this batch size)")
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help="f32: the headline (BASELINE config 2, the reference's precision); bf16: the bf16-storage path of "
-                         "BASELINE config 3 (a separately labelled line, same synthetic batch per GPU)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    dev = torch.device(f'cuda:{local}')
-    torch.cuda.set_device(dev)
-    if 'RANK' in os.environ:                      # launched by torchrun (also with one rank): RCCL process group
-        dist.init_process_group('nccl', device_id=dev)
+def run_case(args, dtype, dev, world, rank):
+    """W warm-up steps, then exactly K timed steps of the training step in `dtype`, bracketed by barrier + synchronize on both
+    sides; the step time is the max over ranks.  Returns the fields of the JSON line that belong to this case."""
     from hipvsr import dp
-    from src.runner.trainers import AcdcVSRRefineNetTrainer
-
-    net = make_net(dev, seed=0)
-    net.set_compute_dtype(args.dtype)
-    dp.broadcast_parameters(net)
     from hipvsr.step_tail import FlatAdam
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    net = make_net(dev, seed=0)
+    net.set_compute_dtype(dtype)
+    dp.broadcast_parameters(net)
     opt = FlatAdam(net.parameters(), lr=1e-4, weight_decay=0)      # exp1_x4.yaml:56-60; one launch per run of parameters
     tr = object.__new__(AcdcVSRRefineNetTrainer)
     tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
     tr.loss_weights = torch.tensor([1.0], device=dev)
-    tr.graph, tr._graphed = {'auto': None, 'on': True, 'off': False}[args.graph], None
+    tr.graph, tr._graphed = args.graph == 'on', None
     inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + 2 + rank)
 
     def barrier():
@@ -241,6 +223,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.reset_peak_memory_stats(dev)
     loss = None
     for _ in range(args.warmup):
         _, loss, _ = tr.train_step(inputs, targets, pos)
@@ -259,27 +242,27 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
-    ms_per_step = dt / args.steps * 1e3
     n_global = args.batch * world
-    value = n_global * args.frames * args.steps / dt
+    bf = dtype == 'bf16'
     flop_step = step_flops_per_lr_pixel(args.frames) * args.size * args.size * n_global
     flop_exec = step_flops_per_lr_pixel(args.frames, executed=True) * args.size * args.size * n_global
-    bf = args.dtype == 'bf16'
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames) * args.size * args.size * n_global
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
-
+    out = None
     if rank == 0:
         roof = lstm_kernel_roofline(net, dev, args.batch, args.size, args.size)
         out = {
-            'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(value, 3), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2), 'ms_per_step_median': round(median_ms, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(n_global * args.frames * args.steps / dt, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+            'ms_per_step_median': round(median_ms, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': f'RefineNet x4 training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
                                    f'{4 * args.size}x{4 * args.size}, {prec}, exp1_x4 net (BASELINE config {3 if bf else 2})',
                        'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
+                       'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
                        'hip_graph_step': tr._graphed is not None,
                        'input_frames_per_s': round(n_global * (args.frames + 12) * args.steps / dt, 2),
                        'step_tflop_reference_formulation': round(flop_step / 1e12, 2),
@@ -291,6 +274,51 @@ def main():
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,
         }
+        if bf:      # the whole step against the dense bf16 MFMA peak in the reference's (= this path's, up to the collapsed tail) formulation
+            out['config']['algorithmic_frac_of_bf16_mfma_peak'] = round(flop_step / world / (dt / args.steps) / 1e12 / peak, 4)
+    del tr, opt, net, inputs, targets, pos
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
+    ap.add_argument('--size', type=int, default=128, help='LR height = width')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the bf16-storage run that rides along as `secondary`')
+    ap.add_argument('--graph', choices=['on', 'off'], default='off',
+                    help='replay forward + loss + backward of the step from a HIP graph (hipvsr.graph.GraphedTrainStep, opt-in: no '
+                         'measured gain at any benchmarked shape, profiles/r02_l_train_shape.txt)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="f32: the headline (BASELINE config 2, the reference's precision) with the bf16-storage step of BASELINE "
+                         "config 3 as `secondary` in the same line; bf16: that bf16 step alone as the line")
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    dev = torch.device(f'cuda:{local}')
+    torch.cuda.set_device(dev)
+    if 'RANK' in os.environ:                      # launched by torchrun (also with one rank): RCCL process group
+        dist.init_process_group('nccl', device_id=dev)
+
+    out = run_case(args, args.dtype, dev, world, rank)
+    sec = None
+    if args.dtype == 'f32' and not args.no_secondary:
+        sec = run_case(args, 'bf16', dev, world, rank)
+    if rank == 0:
+        if sec is not None:
+            out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median',
+                                                    'dtype', 'data', 'config', 'roofline')}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

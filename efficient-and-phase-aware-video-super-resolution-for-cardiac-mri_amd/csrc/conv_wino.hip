@@ -25,16 +25,17 @@
 // it wins: cell 0.408 -> 0.387 ms, data gradient 0.325 -> 0.304 ms, refine conv1 11.0 -> 10.3 ms, step 355.6 -> 341.8 ms on
 // one box; the plans (hipvsr/plans.py) use it there and the 64-column geometry everywhere else.
 //
-// What the experiments on this kernel say about the machine (tools/wino_stamps.py, tools/experiments/):
+// What the experiments on this kernel say about the machine (tools/wino_stamps.py; the three shelved kernels live in the
+// history only: `git show 6671234:tools/experiments/<file>`):
 //   * issue arbitration between the two waves of a SIMD is STRICT, not round-robin: the wave in the lower slot (the
 //     workgroup that arrived first) wins whenever it has an instruction ready; its blocks take ~90 k cycles, the other
 //     workgroup's ~120 k (HWMAP=1 tools/wino_stamps.py; s_setprio on the second workgroup reverses it).  The hardware's
 //     workgroup dispatcher evens that out - a freed slot gets the next block - which is why a PERSISTENT variant of this
-//     kernel (tools/experiments/conv_wino2_persistent.hip: static block lists, the first chunk of the next block staged
+//     kernel (conv_wino2_persistent.hip: static block lists, the first chunk of the next block staged
 //     under the last chunk of this one) was 7 % slower: the favoured workgroup finishes its list early and the CU runs
 //     half empty at the end;
 //   * a vector instruction of wave B is served about once per MFMA of wave A (34 cycles per instruction measured for a
-//     pure producer wave beside a pure MFMA wave, tools/experiments/conv_wino3_specialised_waves.hip): VALU work does not
+//     pure producer wave beside a pure MFMA wave, conv_wino3_specialised_waves.hip): VALU work does not
 //     run "under" the fp32 MFMAs of the other wave, it interleaves with them, and inside one wave every non-MFMA
 //     instruction costs 8-10 cycles of matrix-core time.  With ~1 500 such instructions per 512 MFMAs of a wave
 //     (operand loads 450, staging 650, epilogue 470) the ceiling of this formulation is about 0.70 of the fp32 peak;
@@ -42,7 +43,7 @@
 //     - so that a workgroup's short non-MFMA phases are served at once - left both the ConvLSTM cell and its data gradient
 //     where they were (0.404 against 0.398 ms, 0.322 against 0.322 ms);
 //   * persistent workgroups for the 8-wave geometry (one per CU: no partner to be unfair to) did not pay either
-//     (tools/experiments/conv_wino_persistent_8wave.hip: data gradient 0.299 against 0.301 ms).
+//     (conv_wino_persistent_8wave.hip: data gradient 0.299 against 0.301 ms).
 // Operands (64-column geometry; the 8-wave one below doubles chunk and columns): the input transform B^T d B of a 16-channel
 // chunk is computed once per workgroup (thread =
 // (tile, channel pair): 16 raw 8-byte buffer loads - out-of-image lanes carry offset -1 and read the zero padding - 32

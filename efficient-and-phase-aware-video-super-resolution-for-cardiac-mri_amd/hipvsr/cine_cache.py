@@ -225,11 +225,13 @@ class GpuCineLoader:
         import torch.distributed as dist
         self.cache, self.type, self.batch_size, self.shuffle = cache, type, batch_size, shuffle
         self.T, self.U, self.size, self.flips = num_frames, num_updated_frames, tuple(size), flips
-        # seed: by default drawn from Python's `random`, which src.main seeds from main.random_seed before it builds the
-        # loaders (reference src/main.py:32-34; the reference's crop / flip draws come from that generator too) - equal on
-        # all ranks and equal again when a run is resumed, so (seed, epoch) fixes the order and the draws
+        # seed: src.main passes one derived from main.random_seed and the split (dataset kwarg ``loader_seed``).  Without one it is a
+        # digest of the CURRENT state of Python's `random` - equal on all ranks and after a resume when the callers seeded alike -
+        # read WITHOUT drawing from it: the reference's BaseTrainer takes its per-epoch numpy seeds from that generator
+        # (base_trainer.py:49-54), and a draw here would shift them
         if seed is None:
-            seed = random.getrandbits(31)
+            import zlib
+            seed = zlib.crc32(repr((random.getstate()[1][:16], type)).encode()) & 0x7fffffff
         self.drop_last, self.seed, self.epoch = drop_last, seed, 0
         on = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank() if on else 0)

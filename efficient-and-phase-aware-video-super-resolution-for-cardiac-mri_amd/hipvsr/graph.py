@@ -90,16 +90,20 @@ class GraphedTrainStep:
     HIP-graph"; reference src/runner/trainers/acdc_vsr_refinenet_trainer.py:41-46: ``net(inputs, pos_codes)``,
     ``_compute_losses``, ``loss.backward()``).
 
-    At the reference's own training shape (configs/train/refine_net/exp1_x4.yaml:21-33: batch 16, 32 x 32 crops) a step is
-    about 1 500 sub-30-microsecond launches: the host's launch rate, not the GPU, sets the step time.  The whole step up to
-    the gradients is captured once per input shape - the ConvLSTM wavefront's side streams become parallel branches - and
-    replayed with one launch; what stays outside: the copy of the batch into the graph's static input buffers, the
-    gradient all-reduce (one collective), the optimizer step (two launches of the flat Adam whose step count and learning
-    rate are host-side arguments) and metrics / logging.
+    Measured (profiles/r02_e_train_shape.txt, r02_l_train_shape.txt): at the reference's own training shape
+    (configs/train/refine_net/exp1_x4.yaml:21-33: batch 16, 32 x 32 crops) the step is GPU-bound, not launch-bound - fp32 50.9 ms
+    eager against 51.3 ms replayed, bf16 24.2 against 27.0 (slower) - so the trainer does NOT use this class unless asked to
+    (trainer kwarg ``graph: true``); it is kept for smaller batches, where a step is ~1 500 launches of a few microseconds each.
+    The whole step up to the gradients is captured once per input shape - the ConvLSTM wavefront's side streams become parallel
+    branches - and replayed with one launch; what stays outside: the copy of the batch into the graph's static input buffers,
+    the gradient all-reduce (one collective; single rank only, the trainer refuses the combination), the optimizer step (two
+    launches of the flat Adam whose step count and learning rate are host-side arguments) and metrics / logging.
 
     Gradients: the capture runs with ``p.grad is None``, so autograd adopts the engine's gradient tensors - views of one
     flat buffer in the graph's pool - and a replay overwrites them in place; there is no ``zero_grad`` between replays and
-    nothing accumulates.  The same results, bit for bit, as the eager step (tests/test_predictor.py)."""
+    nothing accumulates.  Replay and eager step launch the same kernels with the same arguments (both take the fused
+    loss-total launch, hipvsr.autograd.LossTotalFn), which is why tests/test_predictor.py can ask for bit-identical results;
+    a loss function outside the fused path would make the two differ in summation order."""
 
     def __init__(self, trainer, max_graphs=4):
         self.tr, self.max_graphs = trainer, max_graphs

@@ -46,6 +46,7 @@ class HipOps:
         self._ws = {}
         self._ws_retired = []   # outgrown scratch buffers a captured HIP graph may still address (see _workspace)
         self.graph_captures = 0
+        self._check_halo = os.environ.get('RNH_CHECK_HALO', '0') == '1'
         # side streams of the ConvLSTM wavefront, in two banks: the forward uses bank 0, the backward bank 1.  Under HIP-graph
         # capture a stream remembers the streams whose events it waited on; hipStreamEndCapture (ROCm 7.2) walks those
         # references recursively and never returns if two streams reference EACH OTHER.  The forward makes layer l's stream
@@ -147,13 +148,25 @@ class HipOps:
         """A buffer of ``shape`` whose leading-dimension slices outside [lo, hi) are zero and stay zero: allocated and zeroed
         once per (key, shape, dtype), handed out again on every call - the caller writes [lo, hi) only, and everything that
         reads it is ordered behind the previous use on the same stream.  (The refine block's gradient planes with their
-        window halo: zeroing the halo of a fresh buffer was six 138 MB fill launches per step.)"""
-        k = ('halo', key, tuple(shape), dtype, lo, hi)
-        t = self._ws.get(k)
-        if t is None:
-            t = self.zeros(*shape, dtype=dtype)
-            self._ws[k] = t
-        return t
+        window halo: zeroing the halo of a fresh buffer was six 138 MB fill launches per step.)
+        One buffer per key: a call with another shape (a partial last batch, another crop size) REPLACES the previous one
+        instead of pinning both for the life of the process - unless a HIP graph has been captured through this object,
+        whose replays still address the old buffer: then it is retired, not freed.  RNH_CHECK_HALO=1 (debug): every reuse
+        first checks that the halo is still all zero (a device sync per call)."""
+        k, sig = ('halo', key), (tuple(shape), dtype, lo, hi)
+        ent = self._ws.get(k)
+        if ent is not None and ent[0] != sig:
+            if self.graph_captures:
+                self._ws_retired.append(ent[1])
+            ent = None
+        if ent is None:
+            ent = (sig, self.zeros(*shape, dtype=dtype))
+            self._ws[k] = ent
+        elif self._check_halo:
+            t = ent[1]
+            if bool(t[:lo].any()) or bool(t[hi:].any()):
+                raise RuntimeError(f'halo_buffer {key!r}: the zero halo outside [{lo}, {hi}) has been written to')
+        return ent[1]
 
     def stack_inputs(self, inputs):
         """list[F] of (N, Cin, H, W) -> (F*N, H, W, Cin) NHWC, frame-major (plumbing: one copy of the LR input)."""

@@ -68,7 +68,7 @@ class AcdcVSRRefineNetDataset(SyntheticCineDataset):
     rather than ignored."""
 
     def __init__(self, downscale_factor, transforms=None, pos_code_path=None, augments=None, num_frames=5,
-                 num_updated_frames=0, data_dir=None, type='train', device=None, **kwargs):
+                 num_updated_frames=0, data_dir=None, type='train', device=None, loader_seed=None, **kwargs):
         if downscale_factor not in [2, 3, 4]:
             raise ValueError(f'The downscale factor should be 2, 3, 4. Got {downscale_factor}.')
         size, flips, means, stds = (32, 32), [False, False], None, None
@@ -99,6 +99,9 @@ class AcdcVSRRefineNetDataset(SyntheticCineDataset):
                 raise ValueError('cines on disk are served from HBM: pass device= (src.main does)')
             self.cache = CineCache.from_dir(data_dir, type, downscale_factor, pos_code_path, device, means, stds)
             self.loader_kwargs = dict(type=type, num_frames=num_frames, num_updated_frames=num_updated_frames, size=size, flips=tuple(flips))
+            if loader_seed is not None:      # src.main derives it from main.random_seed: the loaders draw nothing from the global RNG
+                import zlib
+                self.loader_kwargs['seed'] = zlib.crc32(f'{loader_seed}:{type}'.encode()) & 0x7fffffff
             self.type = type
             self.data = self.cache.train_items() if type == 'train' else [(c, None) for c in range(len(self.cache.table))]
             return

@@ -137,7 +137,7 @@ def main(args):
         torch.cuda.set_device(device)
 
     data_dir = config.dataset.kwargs.get('data_dir')
-    config.dataset.kwargs.update(data_dir=data_dir, type='train', device=device)
+    config.dataset.kwargs.update(data_dir=data_dir, type='train', device=device, loader_seed=str(config.main.random_seed))
     train_dataset = _get_instance(src.data.datasets, config.dataset)
     config.dataset.kwargs.update(type='valid')
     valid_dataset = _get_instance(src.data.datasets, config.dataset)

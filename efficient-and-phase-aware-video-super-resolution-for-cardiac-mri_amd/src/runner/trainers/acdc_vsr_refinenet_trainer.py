@@ -8,6 +8,7 @@ fused HIP loss+gradient launch instead of 63 loss_fn calls; PSNR / SSIM of all f
 included, are one launch (src.model.metrics.fused_metrics); and under torch.distributed the gradients are
 averaged with one all-reduce before the optimizer step."""
 import functools
+import logging
 
 import numpy as np
 import torch
@@ -21,16 +22,17 @@ from src.utils import denormalize
 
 
 class AcdcVSRRefineNetTrainer(BaseTrainer):
-    # graph: replay forward + loss + backward of a step from a HIP graph (hipvsr.graph.GraphedTrainStep).  None = automatic:
-    # on for launch-bound steps only (N*H*W of the LR batch <= GRAPH_AUTO_PIXELS).  Measured (tools/train_shape_bench.py,
-    # profiles/r02_e_train_shape.txt): at the reference YAML's 16 crops of 32 x 32 the step is GPU-bound either way (fp32 59.4 ms
-    # eager / 59.5 ms replayed; bf16 25.1 / 27.4), so the automatic choice is eager there and the graph is for smaller batches
-    GRAPH_AUTO_PIXELS = 4096
+    # graph: replay forward + loss + backward of a step from a HIP graph (hipvsr.graph.GraphedTrainStep).  OFF unless asked for
+    # (trainer kwarg ``graph: true`` in the YAML, ``bench.py --graph on``): no measured shape gains from it - at the reference
+    # YAML's 16 crops of 32 x 32 the step is GPU-bound either way (fp32 59.4 ms eager / 59.5 ms replayed, bf16 25.1 / 27.4:
+    # tools/train_shape_bench.py, profiles/r02_e_train_shape.txt, r02_l_train_shape.txt) - and the graphed step behaves
+    # differently (static gradient tensors, no zero_grad, one capture per batch shape).  Under torch.distributed with more than
+    # one rank the request is refused: a capture next to a live RCCL communicator is not covered by any test.
 
-    def __init__(self, graph=None, **kwargs):
+    def __init__(self, graph=False, **kwargs):
         super().__init__(**kwargs)
         self._denormalize = functools.partial(denormalize, dataset='acdc')
-        self.graph = graph
+        self.graph = bool(graph)
         self._graphed = None
 
     def _total_loss(self, losses):
@@ -58,13 +60,15 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
 
     def train_step(self, inputs, targets, pos_codes):
         """forward + loss + backward (+ gradient all-reduce) + optimizer step; returns (outputs, loss, losses)."""
-        use_graph = getattr(self, 'graph', None)
-        if use_graph is None:
-            use_graph = inputs[0].is_cuda and inputs[0].shape[0] * inputs[0].shape[-2] * inputs[0].shape[-1] <= self.GRAPH_AUTO_PIXELS
+        use_graph = bool(getattr(self, 'graph', False))
+        if use_graph and dp.world() > 1:
+            raise RuntimeError('graph=True (HIP-graph replay of the training step) is single-rank only; drop the trainer kwarg '
+                               'or run one process')
         if use_graph:
             if getattr(self, '_graphed', None) is None:
                 from hipvsr.graph import GraphedTrainStep
                 self._graphed = GraphedTrainStep(self)
+                logging.getLogger(__name__).info('training step replayed from a HIP graph (trainer kwarg graph=True)')
                 # the flat Adam re-homes the parameters into its contiguous buffer on its first step: do that before the
                 # first capture, which bakes their addresses in
                 if hasattr(self.optimizer, '_adopt'):

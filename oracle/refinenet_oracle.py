@@ -354,6 +354,48 @@ def synthetic_batch(cfg, n, t, h, w, seed, dtype=torch.float32):
     return inputs, targets, pos
 
 
+
+def structured_cine(cfg, n, t, h, w, seed, dtype=torch.float32):
+    """The parity / PSNR inputs of SURVEY.md section 8(d): an HR cine = Gaussian-blurred (sigma = 3 px) noise field, slowly
+    rotating between two such fields over the cycle, plus a disc whose radius varies sinusoidally in time (the "ventricle"),
+    scaled into [0, 255]; LR = avg_pool(scale) of HR; both normalised like the reference's ACDC config ((x - 54.089) / 48.084,
+    configs/train/refine_net/exp1_x4.yaml:12-15); phase codes as in synthetic_batch.  Returns (inputs[F], targets[T], pos)."""
+    g = torch.Generator('cpu').manual_seed(int(seed))
+    U, s = cfg.num_updated_frames, cfg.upscale_factor
+    nfr, Hh, Wh = t + 2 * U, s * h, s * w
+    r = torch.arange(-9, 10, dtype=torch.float64)
+    k1 = torch.exp(-r * r / (2 * 3.0 ** 2))
+    k1 = (k1 / k1.sum()).view(1, 1, 1, -1)
+
+    def blurred():
+        z = torch.randn(n, 1, Hh, Wh, generator=g, dtype=torch.float64)
+        z = F.conv2d(F.pad(z, (9, 9, 0, 0), mode='reflect'), k1)
+        z = F.conv2d(F.pad(z, (0, 0, 9, 9), mode='reflect'), k1.transpose(2, 3))
+        return (z - z.mean(dim=(2, 3), keepdim=True)) / z.std(dim=(2, 3), keepdim=True)
+
+    f0, f1 = blurred(), blurred()
+    phi = torch.randint(0, 30, (n, 1), generator=g)
+    cy = (0.35 + 0.3 * torch.rand(n, generator=g, dtype=torch.float64)) * Hh
+    cx = (0.35 + 0.3 * torch.rand(n, generator=g, dtype=torch.float64)) * Wh
+    r0 = 0.18 * min(Hh, Wh)
+    yy = torch.arange(Hh, dtype=torch.float64).view(1, Hh, 1)
+    xx = torch.arange(Wh, dtype=torch.float64).view(1, 1, Wh)
+    dist = torch.sqrt((yy - cy.view(n, 1, 1)) ** 2 + (xx - cx.view(n, 1, 1)) ** 2)
+    hr = []
+    for k in range(nfr):
+        th = 2 * math.pi * (k + phi.to(torch.float64)) / 30.0                                  # (n, 1)
+        field = torch.cos(0.5 * th).view(n, 1, 1, 1) * f0 + torch.sin(0.5 * th).view(n, 1, 1, 1) * f1
+        rad = r0 * (1.0 + 0.25 * torch.sin(th)).view(n, 1, 1)
+        disc = torch.sigmoid((rad - dist) / 1.5).unsqueeze(1)
+        hr.append((100.0 + 35.0 * field + 90.0 * disc).clamp(0, 255))
+    norm = lambda x: ((x - 54.089) / 48.084).to(dtype)                                        # noqa: E731
+    inputs = [norm(F.avg_pool2d(x, s)) for x in hr]
+    targets = [norm(x) for x in hr[U:U + t]]
+    kk = torch.arange(nfr, dtype=dtype).unsqueeze(0)
+    pos = torch.cos(2 * math.pi * (kk + phi.to(dtype)) / 30.0).unsqueeze(-1)
+    return inputs, targets, pos
+
+
 def step(sd, cfg, inputs, targets, pos_codes, loss_fn=l1_loss):
     """One forward + training loss + backward on CPU.  Returns (outputs, loss, grads dict; None where unused)."""
     p = as_leaf_params(sd)
