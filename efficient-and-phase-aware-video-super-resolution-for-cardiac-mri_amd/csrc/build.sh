@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OBJ="$(mktemp -d "${TMPDIR:-/tmp}/rnh_build.XXXXXX")"
 trap 'rm -rf "$OBJ"' EXIT
 mkdir -p "$(dirname "$OUT")"
-SRCS=(conv_igemm conv_wino conv_wgrad wgrad_wino small_kernels uptail cine_gather step_tail conv_bf16 wgrad_bf16 mixed_kernels)
+SRCS=(conv_igemm conv_wino conv_wgrad wgrad_wino small_kernels uptail uptail_bf16 cine_gather step_tail conv_bf16 wgrad_bf16 mixed_kernels)
 pids=()
 for s in "${SRCS[@]}"; do
     extra=()

@@ -44,3 +44,11 @@ __device__ __forceinline__ int rnh_xcd_remap(int bid, int n) {
 
 __device__ __forceinline__ float4 rnh_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void rnh_st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// csrc/uptail.hip internals shared with csrc/uptail_bf16.hip (C++ linkage; not part of the C ABI of include/refinenet_hip.h)
+int rnh_uptail_fwd_compose_(const float *w2, const float *b2, const float *w3, float *ws, int C1, int Cq, int r, int Co, hipStream_t st);
+int rnh_uptail_fwd_border_bf16_(const void *y1, const float *ws, float *out, int B, int Hm, int Wm, int C1, int r, int Co, hipStream_t st);
+int rnh_uptail_dgrad_border_bf16_(const float *d_o, const float *G, void *dy1, int B, int Hm, int Wm, int C1, int r, hipStream_t st);
+void rnh_uptail_xcorr_shape_(int B, int Hm, int Wm, int r, int *TX, int *TY, int *nblk, int *nchunk, int *NT);
+int rnh_uptail_xcorr_finish_bf16_(const void *y1, const float *d_o, float *M, float *S, float *ws, int B, int Hm, int Wm, int C1, int r,
+                                  hipStream_t st);

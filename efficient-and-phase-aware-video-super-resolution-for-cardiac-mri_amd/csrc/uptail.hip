@@ -21,6 +21,22 @@
 
 namespace {
 
+// 4 consecutive elements of a tensor stored as fp32 or bf16 (the bf16-storage path keeps the tail's input in bf16:
+// csrc/uptail_bf16.hip; the border kernels below are shared)
+__device__ __forceinline__ float4 ld4t(const float *p) { return rnh_ld4(p); }
+__device__ __forceinline__ float4 ld4t(const unsigned short *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld1t(const float *p) { return *p; }
+__device__ __forceinline__ float ld1t(const unsigned short *p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void st1t(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1t(unsigned short *p, float v) {
+    const __bf16 b = (__bf16)v;
+    *p = __builtin_bit_cast(unsigned short, b);
+}
+
 // G[co][t2][dl][c1], dl = (dy+1)*ND + (dx+1)
 __global__ void uptail_compose_kernel(const float *w2, const float *w3, float *G, int C1, int Cq, int r, int Co) {
     const int ND = r + 2, r2 = r * r;
@@ -273,7 +289,8 @@ __global__ void __launch_bounds__(256) uptail_fwd_kernel(const float *__restrict
 // The composed 5x5 kernel sums every (t3, t2) path; for an output pixel ON the border of the r-times larger image the
 // paths whose intermediate pixel p + t3 lies outside it do not exist (zero padding of the PixelShuffle output, not of
 // y1).  One wave per border pixel subtracts exactly those paths: lanes split (t3, t2, 4-channel group), wave-reduce.
-__global__ void __launch_bounds__(256) uptail_border_kernel(const float *y1, const float *Gf, const float *beta, float *out, int B, int Hm,
+template <typename T>
+__global__ void __launch_bounds__(256) uptail_border_kernel(const T *y1, const float *Gf, const float *beta, float *out, int B, int Hm,
                                                             int Wm, int C1, int r, int Co) {
     const int Hh = Hm * r, Wh = Wm * r, r2 = r * r, C4 = C1 >> 2;
     const int nper = 2 * Wh + 2 * (Hh - 2);
@@ -294,7 +311,7 @@ __global__ void __launch_bounds__(256) uptail_border_kernel(const float *y1, con
             const int sy = floordiv(ppy, r), sx = floordiv(ppx, r), ij = (ppy - sy * r) * r + (ppx - sx * r);
             const int yy = sy + t2 / 3 - 1, xx = sx + t2 % 3 - 1;
             if ((unsigned)yy >= (unsigned)Hm || (unsigned)xx >= (unsigned)Wm) continue;
-            const float4 a = rnh_ld4(y1 + (((long)b * Hm + yy) * Wm + xx) * C1 + c4 * 4);
+            const float4 a = ld4t(y1 + (((long)b * Hm + yy) * Wm + xx) * C1 + c4 * 4);
             const float4 g = rnh_ld4(Gf + ((((long)co * 9 + t2) * r2 + ij) * 9 + t3) * C1 + c4 * 4);
             s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
         }
@@ -389,7 +406,8 @@ __global__ void __launch_bounds__(256) uptail_dgrad_tile_kernel(const float *__r
 }
 
 // one wave per border pixel q: subtract the (t2, delta) paths whose q - t2 lies outside the image
-__global__ void __launch_bounds__(256) uptail_dgrad_border_kernel(const float *dO, const float *G, float *dY1, int B, int Hm, int Wm,
+template <typename T>
+__global__ void __launch_bounds__(256) uptail_dgrad_border_kernel(const float *dO, const float *G, T *dY1, int B, int Hm, int Wm,
                                                                   int C1, int r) {
     const int ND = r + 2, Hh = Hm * r, Wh = Wm * r, nper = 2 * (Hm + Wm);
     const int lane = threadIdx.x & 63;
@@ -409,7 +427,8 @@ __global__ void __launch_bounds__(256) uptail_dgrad_border_kernel(const float *d
                 s += dO[((long)b * Hh + py) * Wh + px] * G[((long)t2 * ND * ND + dl) * C1 + c1];
             }
         }
-        dY1[(((long)b * Hm + qy) * Wm + qx) * C1 + c1] -= s;
+        T *o = dY1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c1;
+        st1t(o, ld1t(o) - s);
     }
 }
 
@@ -505,7 +524,8 @@ __global__ void __launch_bounds__(256) uptail_xcorr_kernel(const float *__restri
 }
 
 // Cs[chunk][t2][dl][c1] = sum over the chunk's border pixels q' with q' - t2 outside of Y1[q'][c1] * dO[r*(q' - t2) + delta]
-__global__ void __launch_bounds__(256) uptail_mborder_kernel(const float *y1, const float *dO, float *Cs, int B, int Hm, int Wm, int C1,
+template <typename T>
+__global__ void __launch_bounds__(256) uptail_mborder_kernel(const T *y1, const float *dO, float *Cs, int B, int Hm, int Wm, int C1,
                                                              int r, int ipc) {
     const int ND = r + 2, Hh = Hm * r, Wh = Wm * r, nper = 2 * (Hm + Wm), C4 = C1 >> 2;
     const int chunk = blockIdx.x, t2 = blockIdx.y, o = blockIdx.z * 256 + threadIdx.x;
@@ -523,7 +543,7 @@ __global__ void __launch_bounds__(256) uptail_mborder_kernel(const float *y1, co
                 const int py = sy * r + ddy, px = sx * r + ddx;
                 if ((unsigned)py >= (unsigned)Hh || (unsigned)px >= (unsigned)Wh) continue;
                 const float d = dO[((long)b * Hh + py) * Wh + px];
-                const float4 a = rnh_ld4(y1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c4 * 4);
+                const float4 a = ld4t(y1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c4 * 4);
                 acc.x += d * a.x; acc.y += d * a.y; acc.z += d * a.z; acc.w += d * a.w;
             }
     rnh_st4(Cs + (((long)chunk * 9 + t2) * ND * ND + dl) * C1 + c4 * 4, acc);
@@ -596,12 +616,7 @@ extern "C" int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2,
     const int r2 = r * r, C1p = (C1 + 15) & ~15, NOP = (r2 + 1) & ~1;
     float *Gf = ws, *beta = Gf + (long)9 * r2 * 9 * C1, *Kf = beta + r2 * 9, *bsum = Kf + (long)25 * C1p * NOP;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(uptail_compose_fwd1_kernel, dim3(grid_for((long)9 * r2 * 9 * C1 + r2 * 9)), dim3(256), 0, st, w2, b2, w3, Gf, beta, C1,
-                       Cq, r, Co);
-    RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 1)");
-    hipLaunchKernelGGL(uptail_compose_fwd2_kernel, dim3(grid_for((long)25 * C1p * NOP + r2)), dim3(256), 0, st, Gf, beta, Kf, bsum, C1, C1p, r,
-                       NOP);
-    RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 2)");
+    if (int rc = rnh_uptail_fwd_compose_(w2, b2, w3, ws, C1, Cq, r, Co, st)) return rc;
     const int TX = (Wm + UT - 1) / UT, TY = (Hm + UT - 1) / UT;
     const size_t shm = (size_t)UH * UH * UROW * sizeof(float);
     const dim3 grid((unsigned)(B * TX * TY)), block(256);
@@ -609,7 +624,7 @@ extern "C" int rnh_uptail_fwd(const float *y1, const float *w2, const float *b2,
     else hipLaunchKernelGGL((uptail_fwd_kernel<3>), grid, block, shm, st, y1, Kf, bsum, b3, out, B, Hm, Wm, C1, C1p, TX, TY);
     RNH_CHECK_LAUNCH("rnh_uptail_fwd");
     const long nborder = (long)B * (2 * Wm * r + 2 * (Hm * r - 2));
-    hipLaunchKernelGGL(uptail_border_kernel, dim3((unsigned)((nborder + 3) / 4)), dim3(256), 0, st, y1, Gf, beta, out, B, Hm, Wm, C1, r, Co);
+    hipLaunchKernelGGL(uptail_border_kernel<float>, dim3((unsigned)((nborder + 3) / 4)), dim3(256), 0, st, y1, Gf, beta, out, B, Hm, Wm, C1, r, Co);
     RNH_CHECK_LAUNCH("rnh_uptail_fwd(border)");
     return 0;
 }
@@ -630,7 +645,7 @@ extern "C" int rnh_uptail_dgrad(const float *d_o, const float *G, float *dy1, in
                                C1, r, TX, TY);
         RNH_CHECK_LAUNCH("rnh_uptail_dgrad(tile)");
         const long nb = (long)B * 2 * (Hm + Wm);
-        hipLaunchKernelGGL(uptail_dgrad_border_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, d_o, G, dy1, B, Hm, Wm, C1, r);
+        hipLaunchKernelGGL(uptail_dgrad_border_kernel<float>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, d_o, G, dy1, B, Hm, Wm, C1, r);
         RNH_CHECK_LAUNCH("rnh_uptail_dgrad(border)");
         return 0;
     }
@@ -696,11 +711,67 @@ extern "C" int rnh_uptail_xcorr(const float *y1, const float *d_o, float *M, flo
     if (r == 2) hipLaunchKernelGGL((uptail_xcorr_kernel<2>), dim3(nblk, ncg), dim3(256), shm, st, y1, d_o, Xs, B, Hm, Wm, C1, TX, TY);
     else hipLaunchKernelGGL((uptail_xcorr_kernel<3>), dim3(nblk, ncg), dim3(256), shm, st, y1, d_o, Xs, B, Hm, Wm, C1, TX, TY);
     RNH_CHECK_LAUNCH("rnh_uptail_xcorr");
-    hipLaunchKernelGGL(uptail_mborder_kernel, dim3(nchunk, 9, (ND * ND * (C1 / 4) + 255) / 256), dim3(256), 0, st, y1, d_o, Cs, B, Hm, Wm, C1,
+    hipLaunchKernelGGL(uptail_mborder_kernel<float>, dim3(nchunk, 9, (ND * ND * (C1 / 4) + 255) / 256), dim3(256), 0, st, y1, d_o, Cs, B, Hm, Wm, C1,
                        r, ipc);
     RNH_CHECK_LAUNCH("rnh_uptail_xcorr(border)");
     hipLaunchKernelGGL(uptail_mfinish_kernel, dim3(grid_for((long)ND * ND * 9 * C1 + ND * ND)), dim3(256), 0, st, Xs, Cs, M, S, nblk, ncg,
                        nchunk, C1, r, NT);
     RNH_CHECK_LAUNCH("rnh_uptail_xcorr(finish)");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Internals shared with csrc/uptail_bf16.hip (declared in rnh_common.h; C++ linkage, not part of the C ABI): the bf16-storage
+// tail reuses the fp32 composition of the weights, the three border corrections (typed on the tail input) and the fixed-order
+// reduction of the cross-correlation slabs.
+// ---------------------------------------------------------------------------------------------------------
+int rnh_uptail_fwd_compose_(const float *w2, const float *b2, const float *w3, float *ws, int C1, int Cq, int r, int Co, hipStream_t st) {
+    const int r2 = r * r, C1p = (C1 + 15) & ~15, NOP = (r2 + 1) & ~1;
+    float *Gf = ws, *beta = Gf + (long)9 * r2 * 9 * C1, *Kf = beta + r2 * 9, *bsum = Kf + (long)25 * C1p * NOP;
+    hipLaunchKernelGGL(uptail_compose_fwd1_kernel, dim3(grid_for((long)9 * r2 * 9 * C1 + r2 * 9)), dim3(256), 0, st, w2, b2, w3, Gf, beta, C1,
+                       Cq, r, Co);
+    RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 1)");
+    hipLaunchKernelGGL(uptail_compose_fwd2_kernel, dim3(grid_for((long)25 * C1p * NOP + r2)), dim3(256), 0, st, Gf, beta, Kf, bsum, C1, C1p, r,
+                       NOP);
+    RNH_CHECK_LAUNCH("rnh_uptail_fwd(compose 2)");
+    return 0;
+}
+
+int rnh_uptail_fwd_border_bf16_(const void *y1, const float *ws, float *out, int B, int Hm, int Wm, int C1, int r, int Co, hipStream_t st) {
+    const int r2 = r * r;
+    const float *Gf = ws, *beta = Gf + (long)9 * r2 * 9 * C1;
+    const long nborder = (long)B * (2 * Wm * r + 2 * (Hm * r - 2));
+    hipLaunchKernelGGL(uptail_border_kernel<unsigned short>, dim3((unsigned)((nborder + 3) / 4)), dim3(256), 0, st,
+                       (const unsigned short *)y1, Gf, beta, out, B, Hm, Wm, C1, r, Co);
+    RNH_CHECK_LAUNCH("rnh_uptail_fwd_bf16(border)");
+    return 0;
+}
+
+int rnh_uptail_dgrad_border_bf16_(const float *d_o, const float *G, void *dy1, int B, int Hm, int Wm, int C1, int r, hipStream_t st) {
+    const long nb = (long)B * 2 * (Hm + Wm);
+    hipLaunchKernelGGL(uptail_dgrad_border_kernel<unsigned short>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, d_o, G,
+                       (unsigned short *)dy1, B, Hm, Wm, C1, r);
+    RNH_CHECK_LAUNCH("rnh_uptail_dgrad_bf16(border)");
+    return 0;
+}
+
+void rnh_uptail_xcorr_shape_(int B, int Hm, int Wm, int r, int *TX, int *TY, int *nblk, int *nchunk, int *NT) {
+    xcorr_shape(B, Hm, Wm, r, TX, TY, nblk, nchunk, NT);
+}
+
+// border terms + fixed-order reduction of the slabs Xs (written by uptail_xcorr_bf16_kernel in the layout of uptail_xcorr_kernel)
+int rnh_uptail_xcorr_finish_bf16_(const void *y1, const float *d_o, float *M, float *S, float *ws, int B, int Hm, int Wm, int C1, int r,
+                                  hipStream_t st) {
+    int TX, TY, nblk, nchunk, NT;
+    xcorr_shape(B, Hm, Wm, r, &TX, &TY, &nblk, &nchunk, &NT);
+    const int ncg = C1 / 64, ND = r + 2, ipc = (B + nchunk - 1) / nchunk;
+    nchunk = (B + ipc - 1) / ipc;
+    float *Xs = ws, *Cs = ws + (long)nblk * ncg * (NT * 32 * 64 + NT * 32);
+    hipLaunchKernelGGL(uptail_mborder_kernel<unsigned short>, dim3(nchunk, 9, (ND * ND * (C1 / 4) + 255) / 256), dim3(256), 0, st,
+                       (const unsigned short *)y1, d_o, Cs, B, Hm, Wm, C1, r, ipc);
+    RNH_CHECK_LAUNCH("rnh_uptail_xcorr_bf16(border)");
+    hipLaunchKernelGGL(uptail_mfinish_kernel, dim3(grid_for((long)ND * ND * 9 * C1 + ND * ND)), dim3(256), 0, st, Xs, Cs, M, S, nblk, ncg,
+                       nchunk, C1, r, NT);
+    RNH_CHECK_LAUNCH("rnh_uptail_xcorr_bf16(finish)");
     return 0;
 }

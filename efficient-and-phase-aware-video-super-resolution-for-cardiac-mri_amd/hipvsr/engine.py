@@ -24,7 +24,7 @@ from .plans import Dst, NetPlans, Src
 
 class Context:
     """What the forward keeps for the backward."""
-    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad')
+    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad', 'tail_bf16')
 
     def __init__(self):
         self.stages = []
@@ -95,7 +95,11 @@ class RefineNetEngine:
             feat = ops.cast(feat, act)                            # the input block's features cross into bf16 storage here
         P4 = (ops.phase_plane(pos_codes, N, F, H, W, dtype=act, channels=P.pw) if self.bf16 else
               ops.phase_plane(pos_codes, N, F, H, W)) if P.pos else None
-        # the tail kernels (csrc/uptail.hip) read their input in fp32: with a single PixelShuffle stage that input is Sb
+        # the tail kernels read their input in fp32 (csrc/uptail.hip) or, for the x4 / x8 nets' r = 2 tail, in bf16
+        # (csrc/uptail_bf16.hip): then every inner feature map of the upsampler and its gradient are bf16 too.  With a single
+        # PixelShuffle stage the tail's input is Sb, kept fp32
+        tail_bf16 = self.bf16 and len(P.up) > 1 and ops.uptail_bf16_supported(C, P.up[-1]['r'], cfg.out_channels)
+        ctx.tail_bf16 = tail_bf16
         sb_dt = f32 if len(P.up) == 1 else act
         ctx.P4 = P4
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
@@ -205,7 +209,7 @@ class RefineNetEngine:
                                    Oview.reshape(nb * TN, h * r, wd * r, cfg.out_channels))
                     cur = None
                     break
-                Y = ops.empty(nb * TN, h * r, wd * r, C)
+                Y = ops.empty(nb * TN, h * r, wd * r, C, dtype=act if tail_bf16 else f32)
                 ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, r))
                 Ys.append(Y)
                 cur, h, wd = Y, h * r, wd * r
@@ -287,7 +291,7 @@ class RefineNetEngine:
             acc(P.last_b)
             ops.uptail_wcontract(M, Sd, w2, b2, w3, grads[ut['wgrad'].wkey], grads[ut['wgrad'].bkey], grads[P.last_w],
                                  grads[P.last_b], rt, a2, a3)
-            dcur = ops.uptail_dgrad(dO, G, C, rt)
+            dcur = ops.uptail_dgrad(dO, G, C, rt, dtype=act) if ctx.tail_bf16 else ops.uptail_dgrad(dO, G, C, rt)
             for ui in range(len(P.up) - 2, -1, -1):
                 u = P.up[ui]
                 r = u['r']

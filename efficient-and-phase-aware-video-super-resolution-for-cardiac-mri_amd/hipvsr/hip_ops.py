@@ -535,15 +535,25 @@ class HipOps:
 
     # ---- collapsed backward of the upsampler tail (csrc/uptail.hip) -----------------------------------------
     def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
-        self._chk(y1, w2, b2, w3, b3, out)
+        self._chk(w2, b2, w3, b3, out)
+        self._chk(y1, mixed=True)
         B, Hm, Wm, C1 = y1.shape
         Co, Cq = w3.shape[0], w3.shape[1]
         if tuple(out.shape) != (B, Hm * r, Wm * r, Co) or tuple(w2.shape) != (Cq * r * r, C1, 3, 3):
             raise L.HipKernelError('uptail_fwd: shapes')
+        if y1.dtype == torch.bfloat16:                         # bf16-storage path: the tail on bf16 MFMA (csrc/uptail_bf16.hip)
+            ws = self._workspace('uptail_fwd_bf16', self.lib.rnh_uptail_fwd_bf16_ws_floats(C1, Cq, r, Co))
+            L.check(self.lib.rnh_uptail_fwd_bf16(_ptr(y1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(ws), B, Hm, Wm, C1, Cq,
+                                                 r, Co, self._stream()), 'rnh_uptail_fwd_bf16')
+            return out
         ws = self._workspace('uptail_fwd', self.lib.rnh_uptail_fwd_ws_floats(C1, Cq, r, Co))
         L.check(self.lib.rnh_uptail_fwd(_ptr(y1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(out), _ptr(ws), B, Hm, Wm, C1, Cq, r, Co,
                                         self._stream()), 'rnh_uptail_fwd')
         return out
+
+    def uptail_bf16_supported(self, C1, r, Co):
+        """The tail's input / input gradient may live in bf16 (rnh_uptail_*_bf16): r == 2, C1 == 64, out_channels == 1."""
+        return bool(self.lib.rnh_uptail_bf16_supported(C1, r, Co))
 
     @staticmethod
     def uptail_fwd_supported(r, Co):
@@ -557,12 +567,17 @@ class HipOps:
         L.check(self.lib.rnh_uptail_compose(_ptr(w2), _ptr(w3), _ptr(G), C1, Cq, r, Co, self._stream()), 'rnh_uptail_compose')
         return G
 
-    def uptail_dgrad(self, d_o, G, C1, r):
+    def uptail_dgrad(self, d_o, G, C1, r, dtype=torch.float32):
         self._chk(d_o, G)
         B, Hh, Wh, Co = d_o.shape
         if Hh % r or Wh % r:
             raise L.HipKernelError('uptail_dgrad: output size not a multiple of r')
-        dy1 = self.empty(B, Hh // r, Wh // r, C1)
+        dy1 = self.empty(B, Hh // r, Wh // r, C1, dtype=dtype)
+        if dtype == torch.bfloat16:
+            ws = self._workspace('uptail_dgrad_bf16', self.lib.rnh_uptail_dgrad_bf16_ws_floats())
+            L.check(self.lib.rnh_uptail_dgrad_bf16(_ptr(d_o), _ptr(G), _ptr(dy1), _ptr(ws), B, Hh // r, Wh // r, C1, Co, r, self._stream()),
+                    'rnh_uptail_dgrad_bf16')
+            return dy1
         L.check(self.lib.rnh_uptail_dgrad(_ptr(d_o), _ptr(G), _ptr(dy1), B, Hh // r, Wh // r, C1, Co, r, self._stream()),
                 'rnh_uptail_dgrad')
         return dy1
@@ -572,15 +587,17 @@ class HipOps:
 
     def uptail_xcorr(self, y1, d_o, r):
         """M (ND*ND, C1, 3, 3) and S (ND*ND) of the collapsed tail straight from the conv input and d_o (Co == 1)."""
-        self._chk(y1, d_o)
+        self._chk(d_o)
+        self._chk(y1, mixed=True)
         B, Hm, Wm, C1 = y1.shape
         if tuple(d_o.shape) != (B, Hm * r, Wm * r, 1):
             raise L.HipKernelError('uptail_xcorr: shapes')
         nd2 = (r + 2) * (r + 2)
         M, S = self.empty(nd2, C1, 3, 3), self.empty(nd2)
         ws = self._workspace('uptail_xcorr', self.lib.rnh_uptail_xcorr_ws_floats(B, Hm, Wm, C1, r))
-        L.check(self.lib.rnh_uptail_xcorr(_ptr(y1), _ptr(d_o), _ptr(M), _ptr(S), _ptr(ws), B, Hm, Wm, C1, r, self._stream()),
-                'rnh_uptail_xcorr')
+        fn, name = (self.lib.rnh_uptail_xcorr_bf16, 'rnh_uptail_xcorr_bf16') if y1.dtype == torch.bfloat16 else \
+            (self.lib.rnh_uptail_xcorr, 'rnh_uptail_xcorr')
+        L.check(fn(_ptr(y1), _ptr(d_o), _ptr(M), _ptr(S), _ptr(ws), B, Hm, Wm, C1, r, self._stream()), name)
         return M, S
 
     def uptail_expand(self, d_o, r, Dc=None):

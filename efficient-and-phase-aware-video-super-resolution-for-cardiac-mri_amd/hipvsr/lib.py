@@ -29,6 +29,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
+           'rnh_uptail_bf16_supported', 'rnh_uptail_fwd_bf16_ws_floats', 'rnh_uptail_fwd_bf16', 'rnh_uptail_dgrad_bf16_ws_floats',
+           'rnh_uptail_dgrad_bf16', 'rnh_uptail_xcorr_bf16',
            'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
            'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
            'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
@@ -154,6 +156,14 @@ def load():
     lib.rnh_uptail_xcorr_ws_floats.argtypes = [i32, i32, i32, i32, i32]
     lib.rnh_uptail_xcorr_ws_floats.restype = i64
     lib.rnh_uptail_xcorr.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_uptail_bf16_supported.argtypes = [i32, i32, i32]
+    lib.rnh_uptail_fwd_bf16_ws_floats.argtypes = [i32, i32, i32, i32]
+    lib.rnh_uptail_fwd_bf16_ws_floats.restype = i64
+    lib.rnh_uptail_fwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_uptail_dgrad_bf16_ws_floats.argtypes = []
+    lib.rnh_uptail_dgrad_bf16_ws_floats.restype = i64
+    lib.rnh_uptail_dgrad_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_uptail_xcorr_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_unpack.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_combine.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]

@@ -275,6 +275,22 @@ int rnh_uptail_wcontract(const float *M, const float *S, const float *w2, const 
                          float *db2, float *dw3, float *db3, int C1, int Cq, int r, int Co, int accumulate2,
                          int accumulate3, void *stream);
 
+/* The same tail in the bf16-storage path (BASELINE.json configs[2]; csrc/uptail_bf16.hip): the tail's input y1 (B, Hm, Wm, C1)
+ * and the gradient dy1 that leaves it are bf16 in HBM, the contractions run on v_mfma_f32_16x16x32_bf16 with fp32 accumulators
+ * (d_o enters as a bf16 hi + lo pair, the composed weights as bf16); out, d_o, M, S stay fp32.  Same call sites as rnh_uptail_fwd /
+ * rnh_uptail_dgrad / rnh_uptail_xcorr (refine_net.py:199-205 and its backward).  Built for r == 2, C1 == 64, Co == 1
+ * (rnh_uptail_bf16_supported); G from rnh_uptail_compose.  ws: rnh_uptail_fwd_bf16_ws_floats(C1, Cq, r, Co) /
+ * rnh_uptail_dgrad_bf16_ws_floats() / rnh_uptail_xcorr_ws_floats(B, Hm, Wm, C1, r) floats. */
+int rnh_uptail_bf16_supported(int C1, int r, int Co);
+int64_t rnh_uptail_fwd_bf16_ws_floats(int C1, int Cq, int r, int Co);
+int rnh_uptail_fwd_bf16(const void *y1, const float *w2, const float *b2, const float *w3, const float *b3, float *out, float *ws,
+                        int B, int Hm, int Wm, int C1, int Cq, int r, int Co, void *stream);
+int64_t rnh_uptail_dgrad_bf16_ws_floats(void);
+int rnh_uptail_dgrad_bf16(const float *d_o, const float *G, void *dy1, float *ws, int B, int Hm, int Wm, int C1, int Co, int r,
+                          void *stream);
+int rnh_uptail_xcorr_bf16(const void *y1, const float *d_o, float *M, float *S, float *ws, int B, int Hm, int Wm, int C1, int r,
+                          void *stream);
+
 /* Backward of the ConvLSTM gate math (refine_net.py:258-265): from dh', dc' and the saved post-activation
  * gates, c_prev and c_next produce the pre-activation gate gradients [..][4*hd] (channel = gate*hd + ch,
  * order i,f,o,g) and dc_prev.  dc_next / c_prev may be 0 (zero).  n = B*H*W pixels. */

@@ -479,3 +479,76 @@ def test_bf16_training_step_is_bitwise_repeatable_and_switchable():
     assert all(torch.equal(a, b) for a, b in zip(step(), f32))
     with pytest.raises(ValueError):
         net.set_compute_dtype('fp8')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the collapsed upsampler tail with bf16 input / input gradient (csrc/uptail_bf16.hip; round 3)
+# ---------------------------------------------------------------------------------------------------------------------
+_TAIL_SHAPES = [(2, 1, 1), (1, 1, 7), (1, 5, 1), (3, 19, 37), (1, 16, 32), (2, 33, 16), (1, 8, 100), (2, 64, 64)]
+
+
+def _tail_inputs(B, Hm, Wm, seed):
+    g = torch.Generator('cpu').manual_seed(seed)
+    Cq = 64
+    y1 = torch.randn(B, Hm, Wm, 64, generator=g).bfloat16()                 # what the PixelShuffle epilogue stores
+    w2 = torch.randn(Cq * 4, 64, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(Cq * 4, generator=g) * 0.1
+    w3 = torch.randn(1, Cq, 3, 3, generator=g) * 0.05
+    b3 = torch.randn(1, generator=g)
+    d_o = torch.randn(B, 2 * Hm, 2 * Wm, 1, generator=g)
+    return y1, w2, b2, w3, b3, d_o
+
+
+@pytest.mark.parametrize('B,Hm,Wm', _TAIL_SHAPES)
+def test_bf16_tail_forward_vs_float64(B, Hm, Wm):
+    """rnh_uptail_fwd_bf16 (composed 5x5 convolution on v_mfma_f32_16x16x32_bf16, four output rows per accumulator tile,
+    border paths subtracted) against conv2d -> pixel_shuffle -> conv2d in float64 on the SAME bf16 input (reference
+    refine_net.py:199-205): single-row / single-column images, tile tails in both directions, several tiles per workgroup.
+    What is left is the rounding of the composed weights to bf16 (2^-9 relative per weight, 1600 terms): 4e-3 of the
+    output's largest magnitude; and against the fp32 tail kernel on the same input, likewise."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    y1, w2, b2, w3, b3, _ = _tail_inputs(B, Hm, Wm, 100 + Hm)
+    ref = F.conv2d(F.pixel_shuffle(F.conv2d(y1.double().permute(0, 3, 1, 2), w2.double(), b2.double(), padding=1), 2),
+                   w3.double(), b3.double(), padding=1).permute(0, 2, 3, 1)
+    out = torch.full((B, 2 * Hm, 2 * Wm, 1), float('nan'), device=dev)
+    ops.uptail_fwd(y1.to(dev), w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), 2, out)
+    out32 = torch.full((B, 2 * Hm, 2 * Wm, 1), float('nan'), device=dev)
+    ops.uptail_fwd(y1.float().to(dev), w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), 2, out32)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    scale = float(ref.abs().max())
+    err = float((out.cpu().double() - ref).abs().max())
+    l2 = float((out.cpu().double() - ref).norm()) / float(ref.norm())
+    assert err <= 4e-3 * scale and l2 <= 2e-3, (err, scale, l2)
+    assert float((out32.cpu().double() - ref).abs().max()) <= 1e-4 * scale           # (the fp32 kernel on the same input)
+
+
+@pytest.mark.parametrize('B,Hm,Wm', _TAIL_SHAPES)
+def test_bf16_tail_backward_kernels_vs_float64(B, Hm, Wm):
+    """rnh_uptail_dgrad_bf16 (dY1 in bf16) and rnh_uptail_xcorr_bf16 (M, S from a bf16 Y1) against the layer-by-layer
+    float64 backward (autograd of reference refine_net.py:199-205).  d_o enters as a bf16 hi + lo pair (16 bits), Y1 is exact
+    (it IS bf16): M and S are limited by fp32 accumulation only; dY1 by the bf16 rounding of the composed weights and of the
+    stored result (2 x 2^-9)."""
+    from hipvsr.hip_ops import HipOps
+    from torch_ops import TorchOps
+    dev = _dev()
+    ops, ref = HipOps(dev), TorchOps('cpu')
+    y1, w2, _, w3, _, d_o = _tail_inputs(B, Hm, Wm, 200 + Wm)
+    G = ops.uptail_compose(w2.to(dev), w3.to(dev), 2)
+    dy1 = ops.uptail_dgrad(d_o.to(dev), G, 64, 2, dtype=torch.bfloat16)
+    M, S = ops.uptail_xcorr(y1.to(dev), d_o.to(dev), 2)
+    torch.cuda.synchronize()
+    assert dy1.dtype == torch.bfloat16 and not torch.isnan(dy1.float()).any()
+    want = ref.uptail_dgrad(d_o.double(), dict(w2=w2.double(), w3=w3.double(), r=2), 64, 2)
+    scale = float(want.abs().max())
+    err = float((dy1.cpu().double() - want).abs().max())
+    l2 = float((dy1.cpu().double() - want).norm()) / float(want.norm())
+    assert err <= 8e-3 * scale and l2 <= 4e-3, ('dY1', err, scale, l2)
+    ref64 = TorchOps('cpu')
+    Mr, Sr = ref64.uptail_xcorr(y1.double(), d_o.double(), 2)
+    for nm, mine, r_ in (('M', M, Mr), ('S', S, Sr)):
+        e = float((mine.cpu().double() - r_.double()).abs().max())
+        assert e <= 3e-5 * float(r_.abs().max()) + 1e-6, (nm, e, float(r_.abs().max()))

@@ -238,7 +238,7 @@ class TorchOps:
             db1[co] = b0.grad[0]
 
     def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
-        z = F.pixel_shuffle(F.conv2d(y1.permute(0, 3, 1, 2), w2, b2, padding=1), r)
+        z = F.pixel_shuffle(F.conv2d(y1.float().permute(0, 3, 1, 2), w2, b2, padding=1), r)
         out.copy_(F.conv2d(z, w3, b3, padding=1).permute(0, 2, 3, 1))
         return out
 
@@ -249,10 +249,13 @@ class TorchOps:
     def uptail_compose(self, w2, w3, r):
         return dict(w2=w2, w3=w3, r=r)
 
-    def uptail_dgrad(self, d_o, G, C1, r):
+    def uptail_bf16_supported(self, C1, r, Co):
+        return C1 == 64 and r == 2 and Co == 1
+
+    def uptail_dgrad(self, d_o, G, C1, r, dtype=torch.float32):
         dy2 = F.conv_transpose2d(d_o.permute(0, 3, 1, 2), G['w3'], padding=1)             # (B, Cq, rH, rW)
         dz = F.pixel_unshuffle(dy2, r)                                                      # channel c*r*r + i*r + j
-        return F.conv_transpose2d(dz, G['w2'], padding=1).permute(0, 2, 3, 1).contiguous()
+        return F.conv_transpose2d(dz, G['w2'], padding=1).permute(0, 2, 3, 1).contiguous().to(dtype)
 
     def uptail_xcorr_supported(self, C1, r, Co):
         return Co == 1 and r in (2, 3) and C1 % 64 == 0
@@ -260,7 +263,7 @@ class TorchOps:
     def uptail_xcorr(self, y1, d_o, r):
         nd2 = (r + 2) * (r + 2)
         D = self.uptail_expand(d_o, r)[..., :nd2]                                        # (B, Hm, Wm, ND*ND)
-        ypad = F.pad(y1, (0, 0, 1, 1, 1, 1))
+        ypad = F.pad(y1.float(), (0, 0, 1, 1, 1, 1))
         Hm, Wm = y1.shape[1], y1.shape[2]
         M = torch.zeros(nd2, y1.shape[3], 3, 3, device=self.device)
         for ty in range(3):
