@@ -114,6 +114,18 @@ __device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 
+// Diagnostic ablations (tools/bf16_ablate.sh; never defined in the product build): -DRNH_EXP=<mask> removes one cost of the main
+// loop at a time - results are WRONG, only the launch time is of interest.  1: weight fragments loaded once, 2: halo fragments read
+// once per chunk, 4: no halo staging after the prologue, 8: no barrier in the loop, 16: epilogue skipped; 32 / 64 / 128 keep the
+// results: column-tile-major block order, second workgroup of a CU delayed by ~6 / ~12 us
+#ifndef RNH_EXP
+#define RNH_EXP 0
+#endif
+
+#ifndef RNH_SCHED
+#define RNH_SCHED 2
+#endif
+
 #ifdef RNH_STAMPS
 __device__ unsigned long long g_bf16_stamps[64];
 #define BSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_bf16_stamps[i] = __builtin_readcyclecounter(); } while (0)
@@ -154,7 +166,11 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
     const int ph = wave & 1, chalf = wave >> 1;
     const int bid = rnh_xcd_remap(blockIdx.x, P.B * TYn * TXn * NT);
-    const int nt = bid % NT, mt = bid / NT;
+    // (RNH_EXP & 32, experiment: column-tile-major block order - the workgroups that run together stream the SAME weight fragments)
+    const int nt = (RNH_EXP & 32) ? bid / (P.B * TYn * TXn) : bid % NT, mt = (RNH_EXP & 32) ? bid % (P.B * TYn * TXn) : bid / NT;
+    if ((RNH_EXP & (64 | 128)) && blockIdx.x >= 256 && blockIdx.x < 512) {      // experiment: the second workgroup of every CU starts late
+        for (int i = 0; i < ((RNH_EXP & 64) ? 2 : 0) + ((RNH_EXP & 128) ? 4 : 0); ++i) __builtin_amdgcn_s_sleep(100);
+    }
     const int img = mt / (TYn * TXn), trem = mt - img * (TYn * TXn), ty = trem / TXn, tx = trem - ty * TXn;
     const int y0 = ty * TH, x0 = tx * TW;
     const int H = P.H, W = P.W;
@@ -240,9 +256,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         afrags(0, 0);
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
-            if (tap + 1 < NTAPS) afrags(tap + 1, (tap + 1) & 1);
-            if constexpr (NTAPS == 9) bload(c * NTAPS + tap + 2, (tap + 2) % 3);      // two taps ahead; (9 c + tap) % 3 == tap % 3
-            if (tap == (NTAPS == 9 ? 2 : 0)) {
+            if (tap + 1 < NTAPS && !(RNH_EXP & 2)) afrags(tap + 1, (tap + 1) & 1);
+            if constexpr (NTAPS == 9 && !(RNH_EXP & 1)) bload(c * NTAPS + tap + 2, (tap + 2) % 3);      // two taps ahead; (9 c + tap) % 3 == tap % 3
+            if (tap == (NTAPS == 9 ? 2 : 0) && !(RNH_EXP & 4)) {
                 if (c + 1 < nch) store_chunk(buf ^ 1);
                 if (c + 2 < nch) load_chunk();
             }
@@ -250,9 +266,35 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][m], __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? tap % 3 : 0][n]),
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (tap & 1)][m], __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? tap % 3 : 0][n]),
                                                                         acc[m][n], 0, 0, 0);
             if constexpr (NTAPS == 1) bload(c + 1, 0);
+            if constexpr (NTAPS == 9 && RNH_SCHED == 1 && MB * NB - NB - MB >= 0) {
+                // pin the issue order hipcc would otherwise undo (it sinks the weight loads to their first use, two taps later, and
+                // waits for them with vmcnt(0) between two MFMAs): the next tap's four halo fragment reads and the two weight loads
+                // of the tap after next are spread over this tap's first six MFMAs
+                if (tap + 1 < NTAPS) {
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MB * NB - NB - MB, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MB * NB - NB, 0);
+                }
+            }
+            if constexpr (NTAPS == 9 && RNH_SCHED == 2) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -269,9 +311,20 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         compute(c & 1, c);
         BSTAMP(9 + 3 * (c & 15));
         BSTAMP(10 + 3 * (c & 15));
-        __syncthreads();
+        if (!(RNH_EXP & 8)) __syncthreads();
     }
     BSTAMP(1);
+    if (RNH_EXP & 16) {                                         // keep the accumulators alive, skip the epilogue
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s += acc[m][n][v];
+        if (s == 1.2345e-30f) reinterpret_cast<float *>(smem)[tid] = s;
+        return;
+    }
 
     // ---- epilogue: the accumulators (+ bias) are parked as an fp32 [pixel][column] tile, PXR pixels at a time (128-column
     // tiles: the two pixel halves in turn, parked by the two waves that own them; 64-column tiles: all 256 at once), and

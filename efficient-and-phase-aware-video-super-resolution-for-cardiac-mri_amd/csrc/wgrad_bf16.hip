@@ -5,30 +5,35 @@
 //   dW[tap][ci][co] = sum_pixels X[p + off(tap)][ci] * dY[p][co]
 //
 // is a GEMM whose K dimension is the PIXEL index, while the tensors are NHWC (channel-fastest): both MFMA operands need
-// 8 consecutive pixels of one channel per lane.  The transpose happens in the staging writes: every thread loads 8
-// channels of one pixel (16 bytes) and writes them as eight 2-byte LDS stores into channel-major row images
-// [channel][pixels] (80 / 112-byte pitch: the 16-byte fragment reads of 32 consecutive rows are bank-conflict free).
-// Channel c of a 64-channel tile lives in LDS row (c & 7) * 8 + (c >> 3): the eight channel groups a wave writes with
-// one ds_write_b16 then sit in consecutive rows, 20 (28) dwords apart (distinct banks - with the natural
-// order they were 160 dwords apart, i.e. all in ONE bank: an 8-way conflict on every staging write, measured at 19 % of
-// the bf16 MFMA peak); the MFMA rows / columns come out in that order and are un-permuted when the slab is written.
+// 8 consecutive pixels of one channel per lane.  Since round 3 the transpose happens in the LDS READ path: rows are staged
+// as they lie in memory - one 16-byte ds_write_b128 per (pixel, 8 channels) into [pixel][64 channels] row images - and the
+// fragments are fetched with ds_read_b64_tr_b16, which hands every lane 4 consecutive pixels of its channel (two reads per
+// fragment).  (Rounds 1-2 transposed in the staging WRITES: eight ds_write_b16 per piece into [channel][pixels] images and
+// 16-byte fragment reads; PMC of that version at the ConvLSTM shape: 38 % of its LDS cycles were bank conflicts, 4.8 vector
+// instructions per MFMA, LDS busy ~80 % of the MFMA time - 0.31 of the bf16 peak.)
 //
 //   * work item = (image, 32-pixel column strip, range of RPI rows); per image row y one barrier-separated step;
-//   * the x shift of the taps would make the fragment reads of X start at odd 2-byte offsets; instead every lane reads
-//     the five ALIGNED 16-byte pieces around its pixels once per input row and builds the dx = -1 / +1 fragments with four
-//     v_alignbit_b32 each (the first version wrote every row three times, pre-shifted: 3x the LDS writes and LDS space);
-//     the y shift is a choice of row slot: a step takes TWO output rows (36 MFMAs per wave between two barriers), input
-//     rows live in a ring of 6 slots, rows y + 3, y + 4 are loaded while rows y, y + 1 are being multiplied, so each
-//     input row is staged once per strip and serves the three dy taps of three output rows;
+//   * the x shift of a tap is a shift of the pixel ROW address of the transposed read - free, no alignment constraint, no
+//     funnel shifts; the y shift is a choice of row slot: a step takes TWO output rows (36 MFMAs per wave between two
+//     barriers), input rows live in a ring of 6 slots, rows y + 3, y + 4 are loaded while rows y, y + 1 are being multiplied, so
+//     each input row is staged once per strip and serves the three dy taps of three output rows;
+//   * image layout: pixel row pitch 128 B = four 32-byte chunks of 16 channels; chunk c of pixel row r sits at c ^ (r & 2): the
+//     four pixel rows x two chunks one 32-lane half of a transposed read touches then cover all 64 banks exactly once, for
+//     every x shift;
 //   * one workgroup = 64 input channels x 64 output channels x all taps (wave = 32 x 32 x 9 taps = 144 accumulator
 //     registers), looping over its share of the work items (item = split, split + nsplit, ...); the partial sums go to
 //     a slab [nsplit][ntaps][rows][cols] in the layout of rnh_conv_wgrad and are summed in fixed order by
 //     rnh_wgrad_reduce (no atomics: bitwise repeatable);
-//   * the bias gradient (column sums of dY) is taken from the staged dY rows by the row-tile-0 workgroups.
+//   * the bias gradient (column sums of dY) comes off the matrix cores too: the row-tile-0 workgroups multiply the staged dY
+//     fragments with an all-ones operand (4 extra MFMAs per step in two of the four waves).
 //
 // MFMA operand maps: lane l, r = l & 31, h = l >> 5 holds A[row r][k = 8h + j], B[k = 8h + j][col r]; rows = input
-// channels, columns = output channels, k = pixel inside the 16-pixel K step.
+// channels, columns = output channels, k = pixel inside the 16-pixel K step.  ds_read_b64_tr_b16 (cdna_hip_programming.md
+// T10): per 16-lane group a block of 4 rows x 16 columns of 16-bit elements; lane 4q + p of the group supplies the address of
+// row q, columns 4p .. 4p + 3; lane i receives column i of the four rows.  The four 16-lane groups of a wave are (channels
+// 0-15, h = 0), (16-31, h = 0), (0-15, h = 1), (16-31, h = 1): block rows = pixels 8h + 4s .. + 3 for the two reads s = 0, 1.
 #include "rnh_common.h"
+#include <stdlib.h>
 
 int rnh_check_msrc(const rnh_msrc_t &s, const char *who);      // conv_bf16.hip
 
@@ -38,11 +43,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WT = 32;                       // pixels per strip row: two K steps of 16
-constexpr int XR = 112;                      // bytes per channel row of an input-row image: pixels -8 .. 39 (96 B) + 16 B pad
-constexpr int YR = 80;                       // bytes per channel row of a gradient-row image: 32 pixels + 16 B pad
-constexpr int XS_BYTES = 64 * XR, YS_BYTES = 64 * YR;
+constexpr int XPX = WT + 2;                  // pixels x0 - 1 .. x0 + 32 of an input row
+constexpr int XS_BYTES = XPX * 128, YS_BYTES = WT * 128;       // [pixel][64 channels] bf16, 32-byte chunks swizzled by (pixel & 2)
 constexpr int NXS = 6, NYS = 4;              // ring slots: input rows y-1 .. y+4, gradient rows y .. y+3
-constexpr int SMEM = NXS * XS_BYTES + NYS * YS_BYTES;          // 63 488 B: two workgroups per CU
+constexpr int SMEM = NXS * XS_BYTES + NYS * YS_BYTES;          // 42 496 B
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ unsigned wpk2(float a, float b) {
     const bf16x2 r = {(__bf16)a, (__bf16)b};
@@ -66,6 +73,12 @@ struct Piece<false> {
     uint4 lo;
     int ok;
 };
+
+// Diagnostic ablations (never defined in the product build): -DRNH_WEXP=<mask>; results are wrong, only the time is of interest.
+// 1: no global loads in the row loop, 2: no staging writes in the row loop, 4: fragments read once per step
+#ifndef RNH_WEXP
+#define RNH_WEXP 0
+#endif
 
 template <bool F32>
 __device__ __forceinline__ Piece<F32> load_piece(const Grp &g, int b, int y, int x, int H, int W) {
@@ -110,17 +123,6 @@ __device__ __forceinline__ Grp find_group(const rnh_msrc_t *srcs, int nsrc, int 
     return g;
 }
 
-// v_alignbit_b32: the 32 bits starting `sh` bits into the 64-bit value {hi, lo}
-__device__ __forceinline__ unsigned alignbit(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-// 8 pixels starting one pixel BEFORE piece c (needs the last pixel of the previous piece p)
-__device__ __forceinline__ uint4 shift_m1(const uint4 p, const uint4 c) {
-    return make_uint4(alignbit(c.x, p.w, 16), alignbit(c.y, c.x, 16), alignbit(c.z, c.y, 16), alignbit(c.w, c.z, 16));
-}
-// 8 pixels starting one pixel AFTER the start of piece c (needs the first pixel of the next piece n)
-__device__ __forceinline__ uint4 shift_p1(const uint4 c, const uint4 n) {
-    return make_uint4(alignbit(c.y, c.x, 16), alignbit(c.z, c.y, 16), alignbit(c.w, c.z, 16), alignbit(n.x, c.w, 16));
-}
-
 template <int NTAPS, bool XF32, bool YF32>
 __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16_args_t P, const int RT, const int CT, const int nseg, const int RPI,
                                                             const int nitems) {
@@ -145,25 +147,49 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    float bsum = 0.f;
-    const bool want_bias = P.bslab != nullptr && rt == 0 && tid < 64;
-
-    // channel c8 * 8 + e of the tile -> LDS row e * 8 + c8 (conflict-free transposing writes, see above); pixel j of the
-    // strip (-8 .. 39) sits at byte (j + 8) * 2 of an input row, pixel j (0 .. 31) at byte 2 j of a gradient row
-    auto write8 = [&](unsigned char *base, const uint4 v, int pitch) {
-        const unsigned short h[8] = {(unsigned short)(v.x & 0xffff), (unsigned short)(v.x >> 16), (unsigned short)(v.y & 0xffff), (unsigned short)(v.y >> 16),
-                                     (unsigned short)(v.z & 0xffff), (unsigned short)(v.z >> 16), (unsigned short)(v.w & 0xffff), (unsigned short)(v.w >> 16)};
+    // bias gradient (column sums of dY), row-tile-0 workgroups only: every thread sums the 8 channels of the pieces it stages
+    // (each gradient pixel is staged exactly once per item); the 32 pixel columns are added in fixed order at the end
+    const bool want_bias = P.bslab != nullptr && rt == 0;
+    float bs[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short *>(base + e * 8 * pitch) = h[e];
-    };
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+    // staging: the 16-byte piece (pixel row prow, channels 8 c8 .. + 7) of a row image
+    auto piece_off = [&](int prow) { return prow * 128 + 32 * ((c8 >> 1) ^ (prow & 2)) + 16 * (c8 & 1); };
     auto xslot = [&](int r) { return Xs + ((r + 6) % 6) * XS_BYTES; };
     auto yslot = [&](int r) { return Ys + (r & 3) * YS_BYTES; };
-    auto write_x = [&](int r, const Piece<XF32> &p0, const Piece<XF32> &p1) {      // input row r: pixels pxt - 1 and (pxt < 2) pxt + 31
-        unsigned char *row = xslot(r) + c8 * XR;
-        write8(row + (pxt + 7) * 2, piece_bf16<XF32>(p0), XR);
-        if (pxt < 2) write8(row + (pxt + 39) * 2, piece_bf16<XF32>(p1), XR);
+    auto write_x = [&](int r, const Piece<XF32> &p0, const Piece<XF32> &p1) {      // input row r: pixels x0 + pxt - 1 and (pxt < 2) x0 + pxt + 31
+        unsigned char *img = xslot(r);
+        *reinterpret_cast<uint4 *>(img + piece_off(pxt)) = piece_bf16<XF32>(p0);
+        if (pxt < 2) *reinterpret_cast<uint4 *>(img + piece_off(pxt + 32)) = piece_bf16<XF32>(p1);
     };
-    auto write_y = [&](int r, const Piece<YF32> &p) { write8(yslot(r) + c8 * YR + pxt * 2, piece_bf16<YF32>(p), YR); };
+    auto write_y = [&](int r, const Piece<YF32> &p) {
+        const uint4 v = piece_bf16<YF32>(p);
+        *reinterpret_cast<uint4 *>(yslot(r) + piece_off(pxt)) = v;
+        if (want_bias) {
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bs[2 * e] += __builtin_bit_cast(float, w4[e] << 16);
+                bs[2 * e + 1] += __builtin_bit_cast(float, w4[e] & 0xffff0000u);
+            }
+        }
+    };
+
+    // transposed fragment reads: this lane's 16-lane group covers channels 16 gq .. + 15 of the wave's 32 (gq = (lane >> 4) & 1) and
+    // pixels 8 kh + 4 s + q (q = (lane >> 2) & 3), 8 bytes p = lane & 3 of the 32-byte chunk
+    const int gq = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+    auto frag = [&](const unsigned char *img, int blk, int prow0) {               // 32-channel block blk (0, 1), pixel rows prow0 + 8 kh + ...
+        const int ch = 2 * blk + gq;
+        uint2 v[2];
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr) {
+            const int prow = prow0 + 8 * kh + 4 * sr + tq;
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(img + prow * 128 + 32 * (ch ^ (prow & 2)) + 8 * tp));
+            v[sr] = __builtin_bit_cast(uint2, t);
+        }
+        return __builtin_bit_cast(bf16x8, make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
+    };
 
     const int nrg = (H + RPI - 1) / RPI;
     for (int item = split; item < nitems; item += P.nsplit) {
@@ -191,58 +217,47 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
         for (int y = ya; y < yb; y += 2) {
             // requests for the next step (two output rows further): input rows y + 3, y + 4, gradient rows y + 2, y + 3
             Piece<XF32> n0a, n0b, n1a, n1b;
-            ldx(y + 3, n0a, n0b);
-            ldx(y + 4, n1a, n1b);
-            const Piece<YF32> m0 = ldy(y + 2), m1 = ldy(y + 3);
+            Piece<YF32> m0, m1;
+            if constexpr (RNH_WEXP & 1) {
+                n0a.lo = n0b.lo = n1a.lo = n1b.lo = m0.lo = m1.lo = make_uint4(y, y, y, y);
+                n0a.ok = n0b.ok = n1a.ok = n1b.ok = m0.ok = m1.ok = 1;
+            } else {
+                ldx(y + 3, n0a, n0b);
+                ldx(y + 4, n1a, n1b);
+                m0 = ldy(y + 2), m1 = ldy(y + 3);
+            }
 
             // gradient fragments of the two output rows: [row][k step]
             bf16x8 bfr[2][2];
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    bfr[o][ks] = *reinterpret_cast<const bf16x8 *>(yslot(y + o) + (cb * 32 + l31) * YR + kh * 16 + ks * 32);
-            // input rows y - 1 .. y + 2: five aligned pieces per lane, the x shifts of the taps by funnel shifts in registers
+                for (int ks = 0; ks < 2; ++ks) bfr[o][ks] = frag(yslot(y + o), cb, 16 * ks);
+            // input rows y - 1 .. y + 2; the tap's x shift dx - 1 moves the pixel rows of the read (image row 0 is pixel x0 - 1)
 #pragma unroll
             for (int ri = 0; ri < (NTAPS == 9 ? 4 : 2); ++ri) {
                 const int r = NTAPS == 9 ? y - 1 + ri : y + ri;
-                const unsigned char *row = xslot(r) + (rb * 32 + l31) * XR + kh * 16;
-                uint4 pc[5];
-#pragma unroll
-                for (int q = 0; q < 5; ++q) pc[q] = *reinterpret_cast<const uint4 *>(row + q * 16);      // pieces kh .. kh + 4
+                const unsigned char *img = xslot(r);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    // centre piece of (ks, kh) is piece 1 + 2 ks + kh = pc[1 + 2 ks]
-                    const uint4 f0 = shift_m1(pc[2 * ks], pc[2 * ks + 1]), f1 = pc[2 * ks + 1], f2 = shift_p1(pc[2 * ks + 1], pc[2 * ks + 2]);
+                    if constexpr (NTAPS == 9) {
+                        const bf16x8 f0 = (RNH_WEXP & 4) ? bfr[0][ks] : frag(img, rb, 16 * ks), f1 = (RNH_WEXP & 4) ? bfr[1][ks] : frag(img, rb, 16 * ks + 1),
+                                     f2 = (RNH_WEXP & 4) ? bfr[0][ks ^ 1] : frag(img, rb, 16 * ks + 2);
 #pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        if constexpr (NTAPS == 9) {
+                        for (int o = 0; o < 2; ++o) {
                             const int dy = ri - o;                       // input row y - 1 + ri feeds output row y + o through tap row dy
                             if (dy < 0 || dy > 2) continue;
-                            acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0), bfr[o][ks], acc[dy * 3 + 0], 0, 0, 0);
-                            acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1), bfr[o][ks], acc[dy * 3 + 1], 0, 0, 0);
-                            acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f2), bfr[o][ks], acc[dy * 3 + 2], 0, 0, 0);
-                        } else {
-                            if (o != ri) continue;                       // 1x1: input row y + o feeds output row y + o
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1), bfr[o][ks], acc[0], 0, 0, 0);
+                            acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, bfr[o][ks], acc[dy * 3 + 0], 0, 0, 0);
+                            acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, bfr[o][ks], acc[dy * 3 + 1], 0, 0, 0);
+                            acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, bfr[o][ks], acc[dy * 3 + 2], 0, 0, 0);
                         }
+                    } else {
+                        const bf16x8 f1 = frag(img, rb, 16 * ks + 1);       // 1x1: input row y + ri feeds output row y + ri
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, bfr[ri][ks], acc[0], 0, 0, 0);
                     }
                 }
             }
-            if (want_bias) {                                     // column sums of dY: thread = LDS row, 2 x 32 pixels
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const unsigned char *yr = yslot(y + o) + tid * YR;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint4 u = *reinterpret_cast<const uint4 *>(yr + q * 16);
-                        const unsigned w4[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bsum += __builtin_bit_cast(float, w4[e] << 16) + __builtin_bit_cast(float, w4[e] & 0xffff0000u);
-                    }
-                }
-            }
-            if (y + 2 < yb) {
+            if (y + 2 < yb && !(RNH_WEXP & 2)) {
                 write_x(y + 3, n0a, n0b);
                 write_x(y + 4, n1a, n1b);
                 write_y(y + 2, m0);
@@ -255,17 +270,237 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
     // ---- partial sums -> slab[split][tap][row][col] ------------------------------------------------------------------
     const long xr = P.xrows_pad, yc = P.ycols_pad;
     float *sl = P.slab + (long)split * NTAPS * xr * yc;
-    auto chan = [](int L) { return (L & 7) * 8 + (L >> 3); };    // LDS row -> channel of the 64-channel tile
-    const int col = ct * 64 + chan(cb * 32 + l31);
+    const int col = ct * 64 + cb * 32 + l31;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = rt * 64 + chan(rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh);
+            const int row = rt * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh;
             sl[((long)t * xr + row) * yc + col] = acc[t][v];
         }
-    if (want_bias) P.bslab[(long)split * yc + ct * 64 + chan(tid)] = bsum;
+    if (want_bias) {                                             // (block-uniform)
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);            // [pixel column 32][channel 64]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[pxt * 64 + c8 * 8 + e] = bs[e];
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+            for (int q = 0; q < 32; ++q) t += red[q * 64 + tid];
+            P.bslab[(long)split * yc + ct * 64 + tid] = t;
+        }
+    }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel for bf16 sources with the rows brought in by LDS-DMA (global_load_lds_dwordx4), three steps ahead.
+//
+// Ablation of the register-staged kernel above at the ConvLSTM shape (tools/r03_run8.sh): 715 us per launch, 467 us without its
+// global loads, 430 us with MFMAs only - the pieces requested at the top of a step are needed at its end, one step (~1 us)
+// later, which is less than the latency of an HBM / Infinity-Cache read under load: SQ_WAIT_ANY was 47 % of the wave cycles.
+// Here nothing passes through registers: every thread's 16-byte piece (pixel tid >> 3, channels 8 (tid & 7)) goes straight
+// from global memory to its place in the row image - the LDS destination of a wave is linear (base + 16 lane), so the image's
+// chunk swizzle is applied to the SOURCE channel group instead - pixels outside the image and gradient rows of other items
+// are fetched from a zero page (every wave issues the same number of DMAs whatever the position: the counted waits stay
+// valid).  Rows for step s + 3 are requested at the top of step s (10 input-row and 8 gradient-row slots, 76 KB: two workgroups
+// per CU); s_waitcnt vmcnt(N) with N = the requests of the two younger steps + a raw s_barrier publish a step's rows.  hipcc
+// drains ALL outstanding LDS-DMA (vmcnt(0)) in front of any LDS read it knows of, so the transposed fragment reads are inline asm
+// with hand-counted lgkmcnt waits (cdna_hip_programming.md 5.7 form (ii)): one group of six reads (three x-shifted fragments)
+// stays in flight under the previous group's MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];      // zero-initialised: the source of every masked piece
+
+constexpr int DNX = 10, DNY = 8;
+constexpr int DSMEM = DNX * XS_BYTES + DNY * YS_BYTES;                    // 76 288 B
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));        // (a native vector: HIP's uint2 is a struct and cannot be an asm operand on the host pass)
+
+#define RNH_TR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_bf16_args_t P, const int RT, const int CT, const int nseg,
+                                                                const int RPI, const int nitems) {
+    constexpr int NTAPS = 9;                                     // (the 1x1 case stays on the register-staged kernel)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DSMEM];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave & 1, cb = wave >> 1;
+    const int tiles = RT * CT;
+    const int lb = rnh_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lb / tiles, tile = lb - split * tiles;
+    const int rt = tile / CT, ct = tile - rt * CT;
+    const int H = P.H, W = P.W;
+    const int c8 = tid & 7, pxt = tid >> 3;
+    const int c8s = c8 ^ ((pxt & 2) << 1);                       // the channel group that belongs at linear position c8 of pixel row pxt
+    const Grp gx = find_group(P.xs, P.nxs, rt * 64 + c8s * 8, H, W);
+    const Grp gy = find_group(P.ys, P.nys, ct * 64 + c8s * 8, H, W);
+
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    f32x16 bacc;                                                 // bias gradient: ones x dY (all 32 rows equal)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) bacc[v] = 0.f;
+    const bool want_bias = P.bslab != nullptr && rt == 0 && rb == 0;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+
+    // ---- DMA: one piece per thread into the row image at byte 16 tid (+ pixels 32, 33 of an input row by the first 16 lanes of wave 0)
+    auto piece_src = [&](const Grp &g, int b, int y, int x) -> gptr_t {
+        const bool ok = g.ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const char *q = g.ptr + (long)(b + g.img_off) * g.img_stride + (long)(ok ? y : 0) * g.row_stride + (long)(ok ? x : 0) * g.pix_stride;
+        return (gptr_t)(ok ? q : reinterpret_cast<const char *>(g_zero_page));
+    };
+    auto xs_off = [&](int r) { return ((r + 11) % DNX) * XS_BYTES; };          // input row r >= -1
+    auto ys_off = [&](int r) { return DNX * XS_BYTES + (r & (DNY - 1)) * YS_BYTES; };
+    int b = 0, x0 = 0, yb = 0;
+    auto dma_x = [&](int r) {
+        __builtin_amdgcn_global_load_lds(piece_src(gx, b, r, x0 + pxt - 1), (lptr_t)(smem + xs_off(r) + wave * 1024), 16, 0, 0);
+        if (wave == 0) {
+            if (lane < 16) __builtin_amdgcn_global_load_lds(piece_src(gx, b, r, x0 + 31 + pxt), (lptr_t)(smem + xs_off(r) + 32 * 128), 16, 0, 0);
+        }
+    };
+    auto dma_y = [&](int r) {
+        __builtin_amdgcn_global_load_lds(piece_src(gy, b, r < yb ? r : -1, x0 + pxt), (lptr_t)(smem + ys_off(r) + wave * 1024), 16, 0, 0);
+    };
+    auto group = [&](int y) {                                    // what step y needs beyond step y - 2: 6 requests in wave 0, 4 elsewhere
+        dma_x(y + 1);
+        dma_x(y + 2);
+        dma_y(y);
+        dma_y(y + 1);
+    };
+
+    // ---- transposed fragment reads (see the register-staged kernel): per-lane byte offsets inside a row image for the three x shifts
+    const int gq = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+    int xo[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int prow = 8 * kh + tq + dx;                       // (+ 16 ks + 4 sr: multiples of 4 leave bit 1 alone)
+        xo[dx] = prow * 128 + 32 * ((2 * rb + gq) ^ (prow & 2)) + 8 * tp;
+    }
+    const int yo = (8 * kh + tq) * 128 + 32 * ((2 * cb + gq) ^ (tq & 2)) + 8 * tp;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // Work of this workgroup: a CONTIGUOUS range of steps (= pairs of output rows) in the order (image, strip, row pair), cut into
+    // runs that stay inside one strip: a run needs one prologue, and consecutive row pairs of a strip continue the pipeline - with
+    // 64 splits the ConvLSTM call has ~5 runs per workgroup instead of 14 items of 32 rows, each of which exposed a memory round trip
+    // (RPI / nitems, the register-staged kernel's partition, are not used here)
+    (void)RPI;
+    (void)nitems;
+    const int spr = (H + 1) >> 1;                                // steps per strip
+    const long total = (long)P.B * nseg * spr;
+    const long s0 = total * split / P.nsplit, s1 = total * (split + 1) / P.nsplit;
+    for (long sc = s0; sc < s1;) {
+        const long strip = sc / spr;
+        const int st0 = (int)(sc - strip * spr);
+        const int nst = (int)((s1 - sc) < (long)(spr - st0) ? (s1 - sc) : (long)(spr - st0));
+        sc += nst;
+        b = (int)(strip / nseg);
+        x0 = (int)(strip - (long)b * nseg) * WT;
+        const int ya = 2 * st0;
+        yb = ya + 2 * nst < H ? ya + 2 * nst : H;
+        // everything the previous item left in flight has landed and has been read before its slots are requested again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma_x(ya - 1);
+        dma_x(ya);
+        group(ya);
+        group(ya + 2);
+        group(ya + 4);
+        for (int y = ya; y < yb; y += 2) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                        // step y's rows are in LDS for every wave; step y - 2 has been read by all
+            group(y + 6);                                        // into the slots of input rows y - 3, y - 2 / gradient rows y - 2, y - 1
+
+            // gradient fragments of the two output rows [row][k step]: 8 reads
+            u32x2 yb4[2][2][2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const unsigned ya_ = lds0 + ys_off(y + o) + yo;
+                RNH_TR(yb4[o][0][0], ya_, 0);
+                RNH_TR(yb4[o][0][1], ya_, 512);
+                RNH_TR(yb4[o][1][0], ya_, 2048);
+                RNH_TR(yb4[o][1][1], ya_, 2560);
+            }
+            // input fragments: group g = (input row ri, k step ks), three x shifts x two reads; group g + 1 is requested before
+            // group g is multiplied
+            u32x2 xf[2][3][2];
+            auto xreads = [&](int set, int ri, int ks) {
+                const unsigned base = lds0 + xs_off(y - 1 + ri);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const unsigned a_ = base + xo[dx];
+                    if (ks == 0) {
+                        RNH_TR(xf[set][dx][0], a_, 0);
+                        RNH_TR(xf[set][dx][1], a_, 512);
+                    } else {
+                        RNH_TR(xf[set][dx][0], a_, 2048);
+                        RNH_TR(xf[set][dx][1], a_, 2560);
+                    }
+                }
+            };
+            xreads(0, 0, 0);
+            bf16x8 bfr[2][2];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int ri = g >> 1, ks = g & 1, set = g & 1;
+                if (g + 1 < 8) {
+                    xreads(set ^ 1, (g + 1) >> 1, (g + 1) & 1);
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xf[set][0][0]), "+v"(xf[set][0][1]), "+v"(xf[set][1][0]), "+v"(xf[set][1][1]),
+                                 "+v"(xf[set][2][0]), "+v"(xf[set][2][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0][0]), "+v"(xf[set][0][1]), "+v"(xf[set][1][0]), "+v"(xf[set][1][1]),
+                                 "+v"(xf[set][2][0]), "+v"(xf[set][2][1]));
+                }
+                if (g == 0) {                                    // (the gradient reads are older than group 0's: they have landed too)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            asm volatile("" : "+v"(yb4[o][k2][0]), "+v"(yb4[o][k2][1]));
+                            bfr[o][k2] = __builtin_bit_cast(bf16x8, make_uint4(yb4[o][k2][0].x, yb4[o][k2][0].y, yb4[o][k2][1].x, yb4[o][k2][1].y));
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g < 2 && want_bias) {
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[o][g], bacc, 0, 0, 0);
+                }
+                bf16x8 f[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    f[dx] = __builtin_bit_cast(bf16x8, make_uint4(xf[set][dx][0].x, xf[set][dx][0].y, xf[set][dx][1].x, xf[set][dx][1].y));
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int dy = ri - o;                       // input row y - 1 + ri feeds output row y + o through tap row dy
+                    if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[dx], bfr[o][ks], acc[dy * 3 + dx], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the workgroup has gone
+
+    // ---- partial sums -> slab[split][tap][row][col] ------------------------------------------------------------------
+    const long xr = P.xrows_pad, yc = P.ycols_pad;
+    float *sl = P.slab + (long)split * NTAPS * xr * yc;
+    const int col = ct * 64 + cb * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = rt * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh;
+            sl[((long)t * xr + row) * yc + col] = acc[t][v];
+        }
+    if (want_bias && kh == 0) P.bslab[(long)split * yc + col] = bacc[0];       // row 0 of the ones product: lanes 0 .. 31
+}
+#undef RNH_TR
 
 }  // namespace
 
@@ -304,7 +539,10 @@ extern "C" int rnh_wgrad_bf16(const rnh_wgrad_bf16_args_t *args, void *stream) {
         else if (yf) hipLaunchKernelGGL((wgrad_bf16_kernel<NTP, false, true>), grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);     \
         else hipLaunchKernelGGL((wgrad_bf16_kernel<NTP, false, false>), grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);            \
     } while (0)
-    if (a.ntaps == 9) RNH_WG(9);
+    static const bool use_dma = !(getenv("RNH_WGRAD_DMA") && getenv("RNH_WGRAD_DMA")[0] == '0');
+    if (a.ntaps == 9 && !xf && !yf && use_dma)
+        hipLaunchKernelGGL(wgrad_bf16_dma_kernel, grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);
+    else if (a.ntaps == 9) RNH_WG(9);
     else RNH_WG(1);
 #undef RNH_WG
     RNH_CHECK_LAUNCH("rnh_wgrad_bf16");

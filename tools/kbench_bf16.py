@@ -10,6 +10,9 @@ PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-c
 for p in (ROOT, PKG):
     sys.path.insert(0, p)
 import torch                                            # noqa: E402
+from hipvsr import lib as _L                            # noqa: E402
+if os.environ.get('RNH_LIB'):                           # a diagnostic build of the library (tools/bf16_ablate.sh)
+    _L.LIB_PATH = os.environ['RNH_LIB']
 from hipvsr.hip_ops import HipOps                       # noqa: E402
 from hipvsr.plans import Dst, NetPlans, Src             # noqa: E402
 from hipvsr.spec import NetConfig, state_dict_spec      # noqa: E402
@@ -69,12 +72,12 @@ dgo, dcp = ops.empty(N, H, W, 256, dtype=bf), ops.empty(N, H, W, 64)
 timeit('lstm.gates_bwd', lambda: ops.lstm_gates_bwd(dgs[0], cst[0], dgs[2], cst[1], cst[2], dgo, dcp, dh2=dgs[1]), 0.0,
        px * (64 * 2 * 2 + 64 * 4 * 4 + 256 * 2 * 2), 20)
 
-# upsampler conv1 at 128x128 (3 branches x T frames), fp32 output (the tail kernels read it)
+# upsampler conv1 at 128x128 (3 branches x T frames), bf16 output (the bf16 tail kernels read it, csrc/uptail_bf16.hip)
 B3 = 3 * TN
 u = P.up[0]
 sb = R(B3, H, W, 64)
-y1 = ops.empty(B3, 2 * H, 2 * W, 64)
-timeit('up1.fwd(ps)', lambda: ops.conv(u['fwd'], [Src(sb)], B3, H, W, ps=(y1, 2)), 2.0 * B3 * H * W * 256 * 576, B3 * H * W * (64 * 2 + 256 * 4), 5)
+y1 = ops.empty(B3, 2 * H, 2 * W, 64, dtype=bf)
+timeit('up1.fwd(ps)', lambda: ops.conv(u['fwd'], [Src(sb)], B3, H, W, ps=(y1, 2)), 2.0 * B3 * H * W * 256 * 576, B3 * H * W * (64 * 2 + 256 * 2), 5)
 ysrcs = [Src(y1, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
 dsb = ops.empty(B3, H, W, 64, dtype=bf)
 timeit('up1.dgrad', lambda: ops.conv(u['dgrad'], ysrcs, B3, H, W, dsts=[Dst(dsb, 64)]), 2.0 * B3 * H * W * 64 * 2304, B3 * H * W * (256 * 4 + 64 * 2), 5)
