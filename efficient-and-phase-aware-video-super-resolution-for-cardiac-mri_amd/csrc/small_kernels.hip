@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) inconv_fwd_kernel(const float *x, const f
     }
 }
 
-constexpr int INB_BLOCKS = 512;
+constexpr int INB_BLOCKS = 2048;    // 32 waves per CU: the pixel loop is a chain of dependent loads, only occupancy hides it (512 blocks: 1.17 ms at
+                                    // BASELINE config 2, round 3)
 constexpr int INB_MAXK = 36;     // 9 * Cin, Cin <= 4
 
 // thread = (co, sub); partial[block][co][9*Cin + 2] = {dW taps..., db, dslope}

@@ -143,20 +143,7 @@ __global__ void uptail_wcontract_kernel(const float *M, const float *S, const fl
                 }
             float *o = isb ? db2 + idx : dw2 + idx;
             *o = acc2 ? *o + s : s;
-        } else if (e < n2 + nb2 + n3) {                       // dW3[co][c2][t3]
-            const int idx = e - n2 - nb2;
-            const int t3 = idx % 9, c2 = (idx / 9) % Cq, co = idx / (9 * Cq);
-            float s = 0.f;
-            for (int ij = 0; ij < r2; ++ij) {
-                const int dl = (ij / r - (t3 / 3 - 1) + 1) * ND + (ij % r - (t3 % 3 - 1) + 1);
-                const float *Mp = M + (long)(co * ND * ND + dl) * C1 * 9;
-                const float *Wp = w2 + (long)(c2 * r2 + ij) * C1 * 9;
-                float ss = 0.f;
-                for (int x = 0; x < C1 * 9; ++x) ss += Wp[x] * Mp[x];
-                s += ss + b2[c2 * r2 + ij] * S[co * ND * ND + dl];
-            }
-            float *o = dw3 + idx;
-            *o = acc3 ? *o + s : s;
+        } else if (e < n2 + nb2 + n3) {                       // dW3[co][c2][t3]: uptail_wcontract3_kernel (one wave per entry)
         } else {                                              // db3[co] = sum over the r*r sub-positions of S[(co, delta = ij)]
             const int co = e - n2 - nb2 - n3;
             float s = 0.f;
@@ -164,6 +151,28 @@ __global__ void uptail_wcontract_kernel(const float *M, const float *S, const fl
             db3[co] = acc3 ? db3[co] + s : s;
         }
     }
+}
+
+// dW3[co][c2][t3] = sum_ij ( <W2[(c2,ij)], M[(co, ij - t3)]> + b2[(c2,ij)] S[(co, ij - t3)] ): r*r dot products of C1*9 terms each.
+// One wave per entry, lanes over the C1*9 terms, fixed-order butterfly reduction (in uptail_wcontract_kernel a single thread
+// walked all r*r*C1*9 = 2304 terms of an entry: 0.41 ms per call at C1 = 64, r = 2 for 576 busy threads).
+__global__ void __launch_bounds__(256) uptail_wcontract3_kernel(const float *M, const float *S, const float *w2, const float *b2, float *dw3,
+                                                                int C1, int Cq, int r, int Co, int acc3) {
+    const int ND = r + 2, r2 = r * r, n3 = Co * Cq * 9;
+    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= n3) return;
+    const int t3 = idx % 9, c2 = (idx / 9) % Cq, co = idx / (9 * Cq);
+    float s = 0.f;
+    for (int ij = 0; ij < r2; ++ij) {
+        const int dl = (ij / r - (t3 / 3 - 1) + 1) * ND + (ij % r - (t3 % 3 - 1) + 1);
+        const float *Mp = M + (long)(co * ND * ND + dl) * C1 * 9;
+        const float *Wp = w2 + (long)(c2 * r2 + ij) * C1 * 9;
+        for (int x = lane; x < C1 * 9; x += 64) s += Wp[x] * Mp[x];
+        if (lane == 0) s += b2[c2 * r2 + ij] * S[co * ND * ND + dl];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) dw3[idx] = acc3 ? dw3[idx] + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -304,23 +313,20 @@ __global__ void __launch_bounds__(256) uptail_border_kernel(const T *y1, const f
     else { const int k2 = k - 2 * Wh; py = 1 + (k2 >> 1); px = (k2 & 1) ? Wh - 1 : 0; }
     for (int co = 0; co < Co; ++co) {
         float s = 0.f;
-        for (int idx = lane; idx < 81 * C4; idx += 64) {
-            const int c4 = idx % C4, tt = idx / C4, t2 = tt % 9, t3 = tt / 9;
+        // the missing t3 (3 on an edge, 5 in a corner) in a wave-uniform loop; lanes over (t2, 4-channel group) of one t3
+        for (int t3 = 0; t3 < 9; ++t3) {
             const int ppy = py + t3 / 3 - 1, ppx = px + t3 % 3 - 1;
             if ((unsigned)ppy < (unsigned)Hh && (unsigned)ppx < (unsigned)Wh) continue;      // this path exists
             const int sy = floordiv(ppy, r), sx = floordiv(ppx, r), ij = (ppy - sy * r) * r + (ppx - sx * r);
-            const int yy = sy + t2 / 3 - 1, xx = sx + t2 % 3 - 1;
-            if ((unsigned)yy >= (unsigned)Hm || (unsigned)xx >= (unsigned)Wm) continue;
-            const float4 a = ld4t(y1 + (((long)b * Hm + yy) * Wm + xx) * C1 + c4 * 4);
-            const float4 g = rnh_ld4(Gf + ((((long)co * 9 + t2) * r2 + ij) * 9 + t3) * C1 + c4 * 4);
-            s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-        }
-        if (lane < 9) {
-            const int t3 = lane, ppy = py + t3 / 3 - 1, ppx = px + t3 % 3 - 1;
-            if (!((unsigned)ppy < (unsigned)Hh && (unsigned)ppx < (unsigned)Wh)) {
-                const int sy = floordiv(ppy, r), sx = floordiv(ppx, r);
-                s += beta[(co * r2 + (ppy - sy * r) * r + (ppx - sx * r)) * 9 + t3];
+            for (int idx = lane; idx < 9 * C4; idx += 64) {
+                const int c4 = idx % C4, t2 = idx / C4;
+                const int yy = sy + t2 / 3 - 1, xx = sx + t2 % 3 - 1;
+                if ((unsigned)yy >= (unsigned)Hm || (unsigned)xx >= (unsigned)Wm) continue;
+                const float4 a = ld4t(y1 + (((long)b * Hm + yy) * Wm + xx) * C1 + c4 * 4);
+                const float4 g = rnh_ld4(Gf + ((((long)co * 9 + t2) * r2 + ij) * 9 + t3) * C1 + c4 * 4);
+                s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
             }
+            if (lane == 0) s += beta[(co * r2 + ij) * 9 + t3];
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
@@ -533,19 +539,24 @@ __global__ void __launch_bounds__(256) uptail_mborder_kernel(const T *y1, const 
     const int c4 = o % C4, dl = o / C4, ty = t2 / 3 - 1, tx = t2 % 3 - 1, ddy = dl / ND - 1, ddx = dl % ND - 1;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int b1 = min(B, (chunk + 1) * ipc);
-    if (t2 != 4)
-        for (int b = chunk * ipc; b < b1; ++b)
-            for (int k = 0; k < nper; ++k) {
-                int qy, qx;
-                if (!border_pixel(k, Hm, Wm, qy, qx)) continue;
-                const int sy = qy - ty, sx = qx - tx;
-                if ((unsigned)sy < (unsigned)Hm && (unsigned)sx < (unsigned)Wm) continue;   // counted by M as well
-                const int py = sy * r + ddy, px = sx * r + ddx;
-                if ((unsigned)py >= (unsigned)Hh || (unsigned)px >= (unsigned)Wh) continue;
-                const float d = dO[((long)b * Hh + py) * Wh + px];
-                const float4 a = ld4t(y1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c4 * 4);
-                acc.x += d * a.x; acc.y += d * a.y; acc.z += d * a.z; acc.w += d * a.w;
-            }
+    (void)nper;
+    // q' - t2 leaves the image exactly on one border row (ty != 0) and / or one border column (tx != 0): walk those, not all
+    // 2 (Hm + Wm) border candidates
+    const int rowy = ty < 0 ? Hm - 1 : 0, colx = tx < 0 ? Wm - 1 : 0;
+    auto add = [&](int b, int qy, int qx) {
+        const int py = (qy - ty) * r + ddy, px = (qx - tx) * r + ddx;
+        if ((unsigned)py >= (unsigned)Hh || (unsigned)px >= (unsigned)Wh) return;
+        const float d = dO[((long)b * Hh + py) * Wh + px];
+        const float4 a = ld4t(y1 + (((long)b * Hm + qy) * Wm + qx) * C1 + c4 * 4);
+        acc.x += d * a.x; acc.y += d * a.y; acc.z += d * a.z; acc.w += d * a.w;
+    };
+    for (int b = chunk * ipc; b < b1; ++b) {
+        if (ty != 0)
+            for (int qx = 0; qx < Wm; ++qx) add(b, rowy, qx);
+        if (tx != 0)
+            for (int qy = 0; qy < Hm; ++qy)
+                if (ty == 0 || qy != rowy) add(b, qy, colx);
+    }
     rnh_st4(Cs + (((long)chunk * 9 + t2) * ND * ND + dl) * C1 + c4 * 4, acc);
 }
 
@@ -675,6 +686,9 @@ extern "C" int rnh_uptail_wcontract(const float *M, const float *S, const float 
     hipLaunchKernelGGL(uptail_wcontract_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, M, S, w2, b2, w3, dw2, db2, dw3, db3,
                        C1, Cq, r, Co, accumulate2, accumulate3);
     RNH_CHECK_LAUNCH("rnh_uptail_wcontract");
+    hipLaunchKernelGGL(uptail_wcontract3_kernel, dim3((Co * Cq * 9 + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, S, w2, b2, dw3, C1, Cq, r, Co,
+                       accumulate3);
+    RNH_CHECK_LAUNCH("rnh_uptail_wcontract(dW3)");
     return 0;
 }
 
