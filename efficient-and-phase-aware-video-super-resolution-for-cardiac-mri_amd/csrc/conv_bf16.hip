@@ -122,10 +122,6 @@ __device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
 #define RNH_EXP 0
 #endif
 
-#ifndef RNH_SCHED
-#define RNH_SCHED 2
-#endif
-
 #ifdef RNH_STAMPS
 __device__ unsigned long long g_bf16_stamps[64];
 #define BSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_bf16_stamps[i] = __builtin_readcyclecounter(); } while (0)
@@ -144,11 +140,19 @@ __device__ unsigned long long g_bf16_stamps[64];
 // the halo (16 KB per buffer, double-buffered), the staging phase per chunk shrinks from 12 to 3 16-byte LDS writes per
 // thread, and the epilogue parks 128 pixels at a time for 128-column tiles (two rounds): 68 KB of LDS per workgroup, TWO
 // workgroups of 8 x 32 pixels per CU - one's prologue, barriers and epilogue run under the other's MFMAs.
-template <int NCOLS>
+// KC = channels per chunk (= per barrier).  16: any mix of fp32 / bf16 sources, channel counts in multiples of 8.  32 (round 3): bf16
+// sources of 32-channel multiples only (the ConvLSTM cell, its data gradient, the PixelShuffle convolutions): half the barriers and
+// halo-staging events per MFMA, 64 instead of 32 bytes of every 128-byte line per staging load, no fp32 staging registers - which
+// pays for a weight-fragment ring of SIX sets: the fragments are requested five steps (40 MFMAs) ahead instead of two, so that a
+// wait for them no longer sits out the younger-than-them halo loads from HBM (vector-memory loads return in order)
+template <int NCOLS, int KC = 16>
 struct GeoD {
     static constexpr int TH = 8, MB = 4, NB = NCOLS / 64;
     static constexpr int HPH = TH + 2, HP = HPW * HPH;
-    static constexpr int A_BYTES = HP * PITCH, A_PIECES = 2 * HP, A_ITERS = (A_PIECES + 255) / 256;
+    static constexpr int KS = KC / 16;                          // MFMA k steps per tap
+    static constexpr int APITCH = KC == 32 ? 80 : PITCH;        // bytes per halo pixel: data + 16 B pad (fragment reads conflict-free for both)
+    static constexpr int PPP = 2 * KS;                          // 16-byte pieces per halo pixel
+    static constexpr int A_BYTES = HP * APITCH, A_PIECES = PPP * HP, A_ITERS = (A_PIECES + 255) / 256;
     static constexpr int OPITCH = NCOLS + 4;                    // floats per parked pixel
     static constexpr int PXR = NCOLS == 128 ? 128 : 256;        // pixels parked per epilogue round
     static constexpr int OUT_BYTES = PXR * OPITCH * 4;
@@ -156,11 +160,13 @@ struct GeoD {
     static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int EPI, int NCOLS, int NTAPS>
+template <int EPI, int NCOLS, int NTAPS, int KC = 16>
 __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_args_t P, const int TYn, const int TXn, const int NT) {
-    using G = GeoD<NCOLS>;
+    using G = GeoD<NCOLS, KC>;
     constexpr int TH = G::TH, NB = G::NB, MB = G::MB, A_BYTES = G::A_BYTES, A_PIECES = G::A_PIECES, A_ITERS = G::A_ITERS;
+    constexpr int KS = G::KS, APITCH = G::APITCH, PPP = G::PPP;
     static_assert(NTAPS % 3 == 0 || NTAPS == 1, "the fragment ring has three sets");
+    static_assert(KC == 16 || (KC == 32 && NTAPS == 9), "32-channel chunks serve the 3x3 kernels");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
@@ -179,34 +185,35 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     int apix[A_ITERS], alds[A_ITERS], ahalf[A_ITERS];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-        const int p = tid + 256 * i, px = p >> 1, hr = px / HPW, hc = px - hr * HPW;
+        const int p = tid + 256 * i, px = p / PPP, hr = px / HPW, hc = px - hr * HPW;
         const int y = y0 - 1 + hr, x = x0 - 1 + hc;
         const bool in = p < A_PIECES && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        ahalf[i] = p & 1;
-        alds[i] = p < A_PIECES ? px * PITCH + (p & 1) * 16 : -1;
+        ahalf[i] = p % PPP;
+        alds[i] = p < A_PIECES ? px * APITCH + (p % PPP) * 16 : -1;
         apix[i] = in ? (y * sc) * Ws + x * sc : -1;
     }
 
-    uint4 ra[A_ITERS], rh[A_ITERS];
+    uint4 ra[A_ITERS];
+    [[maybe_unused]] uint4 rh[KC == 16 ? A_ITERS : 1];           // second halves of fp32 pieces (16-channel chunks only)
     int ra_f32 = 0;
     int si = 0, cc = 0;
     auto load_chunk = [&]() {
         const rnh_msrc_t &S = P.src[si];
-        const int es = S.dtype == RNH_DT_BF16 ? 2 : 4;
+        const int es = (KC == 32 || S.dtype == RNH_DT_BF16) ? 2 : 4;
         const char *base = reinterpret_cast<const char *>(S.ptr) +
-                           ((((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x) * S.C + S.c0 + cc * 16) * es;
+                           ((((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x) * S.C + S.c0 + cc * KC) * es;
         const __amdgpu_buffer_rsrc_t rs = bdesc(base);
-        const int pstride = S.C * es, left = S.nch - cc * 16;
-        ra_f32 = S.dtype != RNH_DT_BF16;
+        const int pstride = S.C * es, left = S.nch - cc * KC;
+        if constexpr (KC == 16) ra_f32 = S.dtype != RNH_DT_BF16;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int ch = ahalf[i] * 8;
             const bool ok = apix[i] >= 0 && ch < left;
             const int off = apix[i] * pstride + ch * es;
             ra[i] = bld16(rs, ok ? off : -1);
-            rh[i] = bld16(rs, ok && ra_f32 && ch + 4 < left ? off + 16 : -1);
+            if constexpr (KC == 16) rh[i] = bld16(rs, ok && ra_f32 && ch + 4 < left ? off + 16 : -1);
         }
-        if (++cc * 16 >= S.nch) {
+        if (++cc * KC >= S.nch) {
             cc = 0;
             ++si;
         }
@@ -215,7 +222,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         unsigned char *Ab = smem + buf * A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const uint4 v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
+            uint4 v = ra[i];
+            if constexpr (KC == 16) v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
             if (alds[i] >= 0) *reinterpret_cast<uint4 *>(Ab + alds[i]) = v;
         }
     };
@@ -225,12 +233,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
     const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
     const int nslabs = P.nchunks * NTAPS;
-    constexpr int RING = NTAPS == 1 ? 1 : 3;
+    constexpr int RING = NTAPS == 1 ? 1 : (KC == 32 ? 6 : 3), AHEAD = RING - 1;
+    constexpr int NSTEP = NTAPS * KS;                            // (tap, k step) pairs per chunk; NSTEP % RING == 0: the set of a step is static
+    static_assert(NTAPS == 1 || NSTEP % RING == 0, "the fragment ring must divide the steps of a chunk");
     uint4 bq[RING][NB];
-    auto bload = [&](int g, int set) {                         // fragments of global tap index g (beyond the end: zeros, unused)
-        const int base = g < nslabs ? g * slab : -1;
+    // fragments of step g = chunk * NSTEP + tap * KS + ks of the launch: slab (16-channel chunk KS * chunk + ks, tap); beyond the end: zeros, unused
+    auto bload = [&](int g, int set) {
+        const int c = g / NSTEP, r = g - c * NSTEP, tap = r / KS, ks = r - tap * KS;
+        const bool ok = g < nslabs;
+        const int base = ((KS * c + ks) * NTAPS + tap) * slab;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, g < nslabs ? base + wlane + n * 32 * 32 : -1);
+        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, ok ? base + wlane + n * 32 * 32 : -1);
     };
 
     f32x16 acc[MB][NB];
@@ -240,25 +253,26 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
-    const int nch = P.nchunks;
+    const int nch = P.nchunks / KS;
 
-    // One chunk.  The halo of chunk c + 1 sits in registers since tap 2 of chunk c - 1 (a whole chunk of MFMAs ago, so the
-    // wait in store_chunk costs nothing); at tap 2 it goes to the other LDS buffer - nobody reads that one before the
+    // One chunk.  The halo of chunk c + 1 sits in registers since step 2 KS of chunk c - 1 (a whole chunk of MFMAs ago, so the
+    // wait in store_chunk costs nothing); at step 2 KS it goes to the other LDS buffer - nobody reads that one before the
     // barrier at the end of this chunk - and the loads of chunk c + 2 are issued into the same registers.
     auto compute = [&](int buf, int c) {
-        const unsigned char *Ab = smem + buf * A_BYTES + (MB * ph * HPW + l31) * PITCH + kh * 16;
+        const unsigned char *Ab = smem + buf * A_BYTES + (MB * ph * HPW + l31) * APITCH + kh * 16;
         bf16x8 a[2][MB];
-        auto afrags = [&](int tap, int set) {
+        auto afrags = [&](int step, int set) {
+            const int tap = step / KS, ks = step - tap * KS;
             const int dy = NTAPS == 9 ? tap / 3 : 1, dx = NTAPS == 9 ? tap % 3 : 1;
 #pragma unroll
-            for (int m = 0; m < MB; ++m) a[set][m] = *reinterpret_cast<const bf16x8 *>(Ab + ((m + dy) * HPW + dx) * PITCH);
+            for (int m = 0; m < MB; ++m) a[set][m] = *reinterpret_cast<const bf16x8 *>(Ab + ((m + dy) * HPW + dx) * APITCH + ks * 32);
         };
         afrags(0, 0);
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            if (tap + 1 < NTAPS && !(RNH_EXP & 2)) afrags(tap + 1, (tap + 1) & 1);
-            if constexpr (NTAPS == 9 && !(RNH_EXP & 1)) bload(c * NTAPS + tap + 2, (tap + 2) % 3);      // two taps ahead; (9 c + tap) % 3 == tap % 3
-            if (tap == (NTAPS == 9 ? 2 : 0) && !(RNH_EXP & 4)) {
+        for (int step = 0; step < NSTEP; ++step) {
+            if (step + 1 < NSTEP && !(RNH_EXP & 2)) afrags(step + 1, (step + 1) & 1);
+            if constexpr (NTAPS == 9 && !(RNH_EXP & 1)) bload(c * NSTEP + step + AHEAD, (step + AHEAD) % RING);      // AHEAD steps ahead
+            if (step == (NTAPS == 9 ? 2 * KS : 0) && !(RNH_EXP & 4)) {
                 if (c + 1 < nch) store_chunk(buf ^ 1);
                 if (c + 2 < nch) load_chunk();
             }
@@ -266,42 +280,20 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (tap & 1)][m], __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? tap % 3 : 0][n]),
-                                                                        acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (step & 1)][m],
+                                                                        __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
             if constexpr (NTAPS == 1) bload(c + 1, 0);
-            if constexpr (NTAPS == 9 && RNH_SCHED == 1 && MB * NB - NB - MB >= 0) {
-                // pin the issue order hipcc would otherwise undo (it sinks the weight loads to their first use, two taps later, and
-                // waits for them with vmcnt(0) between two MFMAs): the next tap's four halo fragment reads and the two weight loads
-                // of the tap after next are spread over this tap's first six MFMAs
-                if (tap + 1 < NTAPS) {
-#pragma unroll
-                    for (int i = 0; i < MB; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, MB * NB - NB - MB, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, MB * NB - NB, 0);
-                }
-            }
-            if constexpr (NTAPS == 9 && RNH_SCHED == 2) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NTAPS == 9) __builtin_amdgcn_sched_barrier(0);     // pin the issue order: hipcc otherwise sinks the weight loads to their first use
         }
     };
 
     // ---- K loop: double-buffered halo, one barrier per chunk ------------------------------------------------------------
     BSTAMP(0);
     bload(0, 0);
-    if constexpr (NTAPS == 9) bload(1, 1);
+    if constexpr (NTAPS == 9) {
+#pragma unroll
+        for (int g = 1; g < AHEAD; ++g) bload(g, g);
+    }
     load_chunk();
     store_chunk(0);
     if (nch > 1) load_chunk();
@@ -526,7 +518,15 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
     if (blocks >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: grid too large");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(256);
+    // 32-channel chunks (deeper weight-fragment ring, half the barriers) where every source is bf16 with a multiple of 32 channels
+    bool k32 = a.ntaps == 9 && !(getenv("RNH_BF16_KC") && getenv("RNH_BF16_KC")[0] == '1');
+    for (int i = 0; i < a.nsrc; ++i) k32 = k32 && a.src[i].dtype == RNH_DT_BF16 && a.src[i].nch % 32 == 0;
 #define RNH_LAUNCH(EPI, NC, NTP) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, NTP>), grid, block, 0, st, a, TYn, TXn, NT)
+#define RNH_LAUNCH9(EPI, NC)                                                                                             \
+    do {                                                                                                                 \
+        if (k32) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 32>), grid, block, 0, st, a, TYn, TXn, NT);          \
+        else hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 16>), grid, block, 0, st, a, TYn, TXn, NT);              \
+    } while (0)
     switch (a.epilogue) {
         case RNH_EPI_STORE:
             if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad destination count");
@@ -536,8 +536,8 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
                 if ((D.C & 7) || (D.c0 & 7) || (D.ncols & 7)) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_bf16: destination channels must be multiples of 8");
             }
             if (a.ntaps == 9) {
-                if (ncols == 128) RNH_LAUNCH(RNH_EPI_STORE, 128, 9);
-                else RNH_LAUNCH(RNH_EPI_STORE, 64, 9);
+                if (ncols == 128) RNH_LAUNCH9(RNH_EPI_STORE, 128);
+                else RNH_LAUNCH9(RNH_EPI_STORE, 64);
             } else {
                 if (ncols == 128) RNH_LAUNCH(RNH_EPI_STORE, 128, 1);
                 else RNH_LAUNCH(RNH_EPI_STORE, 64, 1);
@@ -547,18 +547,19 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
             if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the pixel-shuffle epilogue serves 3x3 convolutions");
             if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 8 || (a.ps_cq & 7) || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
                 RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad pixel-shuffle destination");
-            if (ncols == 128) RNH_LAUNCH(RNH_EPI_PS, 128, 9);
-            else RNH_LAUNCH(RNH_EPI_PS, 64, 9);
+            if (ncols == 128) RNH_LAUNCH9(RNH_EPI_PS, 128);
+            else RNH_LAUNCH9(RNH_EPI_PS, 64);
             break;
         case RNH_EPI_LSTM:
             if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the LSTM epilogue serves 3x3 convolutions");
             if (!a.h_out || !a.c_out || a.hd < 8 || (a.hd & 7) || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM epilogue needs h_out, c_out, hd % 8 == 0, bias");
             if (a.Npad != 128 * ((a.hd + 31) / 32)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: LSTM column layout (plans.lstm_colmap)");
-            RNH_LAUNCH(RNH_EPI_LSTM, 128, 9);
+            RNH_LAUNCH9(RNH_EPI_LSTM, 128);
             break;
         default:
             RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: epilogue %d not available", a.epilogue);
     }
+#undef RNH_LAUNCH9
 #undef RNH_LAUNCH
     RNH_CHECK_LAUNCH("rnh_conv_bf16");
     return 0;
