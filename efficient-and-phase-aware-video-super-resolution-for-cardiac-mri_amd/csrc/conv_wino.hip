@@ -548,7 +548,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(co
                     // (plain stores: with the nt bit, 16-byte pieces of one 128-byte line written by the workgroups of four
                     // column blocks came out corrupted now and then - tools/debug/lstm_mismatch.py)
                     f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + item_o[q] * 4 * hd + nt * CW + c4);
+#ifdef RNH_GATES_NT      // experiment (tools/nt_store_probe.hip found nothing wrong with nt pieces of shared lines): gates past the caches
+                    __builtin_nontemporal_store(gi, gp); __builtin_nontemporal_store(gf, gp + hd / 4);
+                    __builtin_nontemporal_store(go, gp + 2 * (hd / 4)); __builtin_nontemporal_store(gg, gp + 3 * (hd / 4));
+#else
                     gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
+#endif
                 }
                 f32x4w cn, hn;
 #pragma unroll

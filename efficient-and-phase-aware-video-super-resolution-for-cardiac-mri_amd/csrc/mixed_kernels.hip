@@ -125,6 +125,45 @@ __global__ void __launch_bounds__(256) phase_plane_m_kernel(const float *pos, vo
     }
 }
 
+// Frame-wise side path of ONE output channel of refine conv1 in the bf16-storage path (the channel c0 = 2 Cl that makes 129 out of
+// 128 columns): z (F' N, H, W, 8) fp32 holds, per SOURCE frame, the J slot convolutions of that channel (one small rnh_conv_bf16 over
+// the frames); a window's value is bias + sum_j z[frame i + j][slot j].  The 8 channels c0 .. c0 + 7 of out are written: (value, 0 x 7)
+__global__ void __launch_bounds__(256) xcol_combine_m_kernel(const float *z, const float *bias, void *out, int odt, long npix, int N, int nwin,
+                                                             int J, int C, int c0) {
+    const long total = (long)nwin * N * npix;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long img = idx / npix, p = idx - img * npix;
+        const int i = (int)(img / N), n = (int)(img - (long)i * N);
+        float s = bias[c0];
+        for (int j = 0; j < J; ++j) s += z[((((long)(i + j) * N + n) * npix) + p) * 8 + j];
+        const float v[8] = {s, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        mstore8(out, odt, idx * C + c0, v);
+    }
+}
+
+// ... and its backward: E (F' N, H, W, 8)[frame f][slot j] = dy[window f - j][channel c] (0 where f - j is no window; slots >= J: 0):
+// the gradient operand of the per-frame convolution's weight gradient
+__global__ void __launch_bounds__(256) xcol_gather_m_kernel(const void *dy, int ydt, void *E, int edt, long npix, int N, int nwin, int J, int C,
+                                                            int c) {
+    const long total = (long)(nwin + J - 1) * N * npix;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long img = idx / npix, p = idx - img * npix;
+        const int f = (int)(img / N), n = (int)(img - (long)f * N);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = f - j;
+            v[j] = 0.f;
+            if (j < J && w >= 0 && w < nwin) {
+                const long e = ((((long)w * N + n) * npix) + p) * C + c;
+                v[j] = ydt == RNH_DT_BF16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(dy)[e] << 16)
+                                          : reinterpret_cast<const float *>(dy)[e];
+            }
+        }
+        mstore8(E, edt, idx * 8, v);
+    }
+}
+
 inline int mgrid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -165,6 +204,25 @@ extern "C" int rnh_phase_plane_m(const float *pos, void *out, int out_dt, int N,
     if (!pos || !out || N < 1 || F < 1 || H < 1 || W < 1 || bad_dt(out_dt)) RNH_FAIL(RNH_E_ARG, "rnh_phase_plane_m: bad arguments");
     hipLaunchKernelGGL(phase_plane_m_kernel, dim3(mgrid((long)N * F * H * W)), dim3(256), 0, (hipStream_t)stream, pos, out, out_dt, N, F, (long)H * W);
     RNH_CHECK_LAUNCH("rnh_phase_plane_m");
+    return 0;
+}
+
+extern "C" int rnh_xcol_combine_m(const float *z, const float *bias, void *out, int out_dt, int64_t npix, int N, int nwin, int J, int C, int c0,
+                                  void *stream) {
+    if (!z || !bias || !out || npix < 1 || N < 1 || nwin < 1 || J < 1 || J > 8 || bad_dt(out_dt)) RNH_FAIL(RNH_E_ARG, "rnh_xcol_combine_m: bad arguments");
+    if ((C & 7) || (c0 & 7) || c0 + 8 > C) RNH_FAIL(RNH_E_ALIGN, "rnh_xcol_combine_m: c0 .. c0 + 7 must be an aligned group of 8 channels of C");
+    hipLaunchKernelGGL(xcol_combine_m_kernel, dim3(mgrid((long)nwin * N * npix)), dim3(256), 0, (hipStream_t)stream, z, bias, out, out_dt,
+                       (long)npix, N, nwin, J, C, c0);
+    RNH_CHECK_LAUNCH("rnh_xcol_combine_m");
+    return 0;
+}
+
+extern "C" int rnh_xcol_gather_m(const void *dy, int dy_dt, void *E, int e_dt, int64_t npix, int N, int nwin, int J, int C, int c, void *stream) {
+    if (!dy || !E || npix < 1 || N < 1 || nwin < 1 || J < 1 || J > 8 || c < 0 || c >= C || bad_dt(dy_dt) || bad_dt(e_dt))
+        RNH_FAIL(RNH_E_ARG, "rnh_xcol_gather_m: bad arguments");
+    hipLaunchKernelGGL(xcol_gather_m_kernel, dim3(mgrid((long)(nwin + J - 1) * N * npix)), dim3(256), 0, (hipStream_t)stream, dy, dy_dt, E, e_dt,
+                       (long)npix, N, nwin, J, C, c);
+    RNH_CHECK_LAUNCH("rnh_xcol_gather_m");
     return 0;
 }
 

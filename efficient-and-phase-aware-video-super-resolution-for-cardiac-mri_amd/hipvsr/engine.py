@@ -57,6 +57,16 @@ class RefineNetEngine:
         from .spec import state_dict_spec
         return list(state_dict_spec(self.cfg).keys())
 
+    def _views(self, params):
+        """Views of parameters that plans address under a key of their own (no copy): the last output channel of refine conv1 as a
+        (window, C1, 3, 3) convolution over single frames (plans.xcol_m)."""
+        P = self.plans
+        if getattr(P, 'xcol_m', False) and P.r1x_key not in params:
+            params = dict(params)
+            w1 = params[P.r1_fwd.wkey]
+            params[P.r1x_key] = w1[P.C1 - 1].view(self.cfg.refine_window_size, P.C1, 3, 3)
+        return params
+
     def _pack(self, params, which):
         P = self.plans
         for pl in P.conv_plans():
@@ -85,6 +95,7 @@ class RefineNetEngine:
 
         ctx = Context()
         ctx.N, ctx.H, ctx.W, ctx.F, ctx.T = N, H, W, F, T
+        params = self._views(params)
         x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
         ctx.x_all = x_all
         self._pack(params, 'fwd')
@@ -166,6 +177,14 @@ class RefineNetEngine:
                 if P.r1_wino:
                     ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                     ops.refine_phase_bias(R1, P4[lo:hi], params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
+                elif P.xcol_m:
+                    # bf16 path: 2*Cl columns in one launch; the last channel frame by frame (one small convolution over the source
+                    # frames whose columns are the window slots, then a sum over the slots)
+                    ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 2 * Cl)])
+                    nfr = nwin + w - 1
+                    Z5 = ops.empty(nfr * N, H, W, 8)
+                    ops.conv(P.r1x_fwd, [Src(Hf, img_off=lo), Src(Hbk, img_off=lo), Src(P4, img_off=lo)], nfr * N, H, W, dsts=[Dst(Z5, 8)])
+                    ops.xcol_combine_m(Z5, params[P.r1_fwd.bkey], R1, N, w, 2 * Cl)
                 elif P.r1_split:
                     ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 2 * Cl)])
                     ops.conv(P.r1_fwd_b, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p - 2 * Cl, c0=2 * Cl)])
@@ -240,6 +259,7 @@ class RefineNetEngine:
         nf, Lr, C, Cl = P.nf, P.L, P.C, P.Cl
         TN = T * N
         act = self.act
+        params = self._views(params)
         self._pack(params, 'bwd')
 
         grads, touched = OrderedDict(), set()
@@ -339,7 +359,16 @@ class RefineNetEngine:
                 a = acc(k1)
                 acc(b1)
                 ysrc = [Src(dR1p, nch=P.r1_cols, img_off=hw * N)]
-                if P.r1_wino:
+                if P.xcol_m:
+                    # 2*Cl columns against the window sources; the last channel's weights as the gradient of the per-frame convolution
+                    ops.wgrad(P.r1_wgrad_a, xs, [Src(dR1p, nch=2 * Cl, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                    E = ops.xcol_gather_m(dR1p[hw * N:(hw + T) * N], N, w, 2 * Cl, act)
+                    f0, nfr = (U - hw) * N, T + w - 1
+                    dbx = ops.zeros(8)                                   # (zeros: the launch below may run in accumulate mode)
+                    ops.wgrad(P.r1x_wgrad, [Src(Hf, img_off=f0), Src(Hbk, img_off=f0), Src(ctx.P4, img_off=f0)], [Src(E)], nfr * N, H, W,
+                              grads[k1][P.C1 - 1].view(w, P.C1, 3, 3), dbx[:w], accumulate=a)
+                    ops.put_scalar(grads[b1][P.C1 - 1:P.C1], dbx[0:1], a)
+                elif P.r1_wino:
                     # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
                     ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                     ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)

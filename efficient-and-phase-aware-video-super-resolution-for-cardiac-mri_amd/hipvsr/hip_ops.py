@@ -507,6 +507,32 @@ class HipOps:
         L.check(self.lib.rnh_xcol_combine(_ptr(zs[0]), _ptr(zs[1]), _ptr(zs[2]), b1.data_ptr() + 4 * co, _ptr(R1), H * W, N, nwin, J, C, co,
                                           self._stream()), 'rnh_xcol_combine')
 
+    def xcol_combine_m(self, z, b1, R1, N, J, c0):
+        """bf16-storage path: R1[window i][..., c0] = b1[c0] + sum_j z[frame i + j][..., j] (channels c0 + 1 .. c0 + 7 := 0); z holds
+        the J slot convolutions of conv1's channel c0 per source frame (one small rnh_conv_bf16 over the frames)."""
+        self._chk(z, b1)
+        self._chk(R1, mixed=True)
+        nwin, H, W, C = R1.shape[0] // N, R1.shape[1], R1.shape[2], R1.shape[3]
+        if tuple(z.shape) != ((nwin + J - 1) * N, H, W, 8):
+            raise L.HipKernelError('xcol_combine_m: shapes')
+        L.check(self.lib.rnh_xcol_combine_m(_ptr(z), _ptr(b1), _ptr(R1), L.dt_of(R1), H * W, N, nwin, J, C, c0, self._stream()), 'rnh_xcol_combine_m')
+
+    def xcol_gather_m(self, dy, N, J, c, dtype):
+        """E ((nwin + J - 1)*N, H, W, 8)[frame f][..., j] = dy[window f - j][..., c]: the gradient operand of the per-frame convolution."""
+        self._chk(dy, mixed=True)
+        nwin, H, W, C = dy.shape[0] // N, dy.shape[1], dy.shape[2], dy.shape[3]
+        E = self.empty((nwin + J - 1) * N, H, W, 8, dtype=dtype)
+        L.check(self.lib.rnh_xcol_gather_m(_ptr(dy), L.dt_of(dy), _ptr(E), L.dt_of(E), H * W, N, nwin, J, C, c, self._stream()), 'rnh_xcol_gather_m')
+        return E
+
+    @staticmethod
+    def put_scalar(dst, src, accumulate):
+        """dst (a 1-element view of a gradient) = or += src (a 1-element view): plumbing, one tiny ATen launch."""
+        if accumulate:
+            dst.add_(src)
+        else:
+            dst.copy_(src)
+
     def refine_phase_bias(self, R1, P4, w1, N, J, cl, ncols):
         """R1[..., :ncols] += conv1 over the J phase planes (input channel 2*cl of every frame slot), as a bias field."""
         self._chk(R1, P4, w1)

@@ -276,7 +276,7 @@ class NetPlans:
 
         Cl, w = self.Cl, cfg.refine_window_size
         self.pos = bool(cfg.positional_encoding)
-        self.xcol = self.r1_wino = self.r1_split = self.r2_wino = False
+        self.xcol = self.r1_wino = self.r1_split = self.r2_wino = self.xcol_m = False
         if self.pos:
             C1 = 2 * Cl + 1
             self.C1, self.C1p = C1, (_pad_to(C1, 8) if bf else r4(C1))
@@ -320,6 +320,19 @@ class NetPlans:
                 self.r1_fwd_b = ConvPlan_('refine1.fwd.b', k1, b1, ws1, segs, tail)
                 self.r2_dgrad_a = ConvPlan_('refine2.dgrad.a', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(C1 - 1)), transposed=True)
                 self.r2_dgrad_b = ConvPlan_('refine2.dgrad.b', k2, None, ws2, [KSeg(Cl, Cl, 0)], tail, transposed=True)
+            # round 3: instead of the 8-column launch .b (a 64-column kernel over K = 5 x 136 channels for ONE real column) the last
+            # channel of conv1 goes frame by frame: slot j of that channel is a convolution of source frame k + j that does not depend
+            # on the window, so ONE small convolution over the F' source frames with the J = w slots as columns (weight = the VIEW
+            # w1[2*Cl].view(w, C1, 3, 3), key r1x_key) and a sum over the slots replace it - 1/4.4 of the MFMA work - and the weight
+            # gradient of that channel is one small rnh_wgrad_bf16 into the same view of the gradient (the main one keeps 2*Cl columns)
+            self.xcol_m = self.r1_split and os.environ.get('RNH_XCOL_M', '1') != '0'
+            if self.xcol_m:
+                self.r1x_key = k1 + '[last channel as (w, C1, 3, 3)]'
+                fsegs = [KSeg(Cl, Cl, 0), KSeg(Cl, Cl, Cl), KSeg(pw, 1, 2 * Cl)]
+                self.r1x_fwd = ConvPlan_('refine1.fwd.x', self.r1x_key, None, (w, C1, 3, 3), fsegs, list(range(w)))
+                self.r1x_wgrad = WgradPlan_('refine1.wgrad.x', self.r1x_key, None, (w, C1, 3, 3),
+                                           [XSeg(Cl, Cl, 0), XSeg(Cl, Cl, Cl), XSeg(pw, 1, 2 * Cl)], [YSeg(8, w, 0)])
+                self.r1_wgrad_a = WgradPlan_('refine1.wgrad.a', k1, b1, ws1, xsegs, [YSeg(C1 - 1, C1 - 1, 0)])
             # conv2 (C1 -> Cl channels) the same way: its 2*Cl hidden-state input channels in Winograd form, the phase channel (and
             # the pad channels behind it) through the implicit GEMM, accumulating; its data gradient as a 2*Cl-column Winograd
             # launch plus a launch for the columns of the last channel
@@ -381,7 +394,7 @@ class NetPlans:
             out += [v['full'], v['first'], v['dgrad']]
         out += [self.r1_fwd, self.r1_dgrad]
         if getattr(self, 'r1_split', False):
-            out += [self.r1_fwd_a, self.r1_fwd_b, self.r2_dgrad_a, self.r2_dgrad_b]
+            out += [self.r1_fwd_a, self.r2_dgrad_a, self.r2_dgrad_b] + ([self.r1x_fwd] if self.xcol_m else [self.r1_fwd_b])
         if self.r1_wino:
             out += [self.r1_fwd_h, self.r1_fwd_p, self.r1_dgrad_h, self.r1_dgrad_x]
         if self.pos:

@@ -230,6 +230,14 @@ int rnh_xcol_unpack(const float *dwx, const float *dbx, float *dw, float *db, in
 int rnh_xcol_combine(const float *z0, const float *z1, const float *z2, const float *bias, float *out, int64_t npix, int N,
                      int nwin, int J, int C, int c0, void *stream);
 int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, int nwin, int J, int C, int c, void *stream);
+/* The same side path in the bf16-storage path (csrc/mixed_kernels.hip), where the J slot convolutions of channel c0 run as ONE small
+ * rnh_conv_bf16 over the source frames against the view w[c0].view(J, cstride, 3, 3) of conv1's weight (and their weight gradient as
+ * one rnh_wgrad_bf16 into the same view of the gradient): z (F' N, H, W, 8) fp32, F' = nwin + J - 1.
+ *   rnh_xcol_combine_m: out[(i*N + n)][p][c0 .. c0+7] = (bias[c0] + sum_j z[((i + j)*N + n)][p][j], 0 x 7); out fp32 or bf16, C channels
+ *   rnh_xcol_gather_m : E[((f*N + n)][p][j] = dy[((f - j)*N + n)][p][c] for 0 <= f - j < nwin, else 0; 8 channels, slots >= J zero */
+int rnh_xcol_combine_m(const float *z, const float *bias, void *out, int out_dt, int64_t npix, int N, int nwin, int J, int C, int c0,
+                       void *stream);
+int rnh_xcol_gather_m(const void *dy, int dy_dt, void *E, int e_dt, int64_t npix, int N, int nwin, int J, int C, int c, void *stream);
 
 /* Phase planes of _RefineBlock conv1 (refine_net.py:168-177: pos_codes repeated over H x W, concatenated as channel
  * 2*Cl of every frame slot) as a bias field: inside the image the plane of slot j is the constant p, so its 3x3

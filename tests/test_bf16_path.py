@@ -552,3 +552,29 @@ def test_bf16_tail_backward_kernels_vs_float64(B, Hm, Wm):
     for nm, mine, r_ in (('M', M, Mr), ('S', S, Sr)):
         e = float((mine.cpu().double() - r_.double()).abs().max())
         assert e <= 3e-5 * float(r_.abs().max()) + 1e-6, (nm, e, float(r_.abs().max()))
+
+
+@pytest.mark.parametrize('out_dt', [torch.bfloat16, torch.float32])
+def test_xcol_m_kernels_vs_torch(out_dt):
+    """rnh_xcol_combine_m / rnh_xcol_gather_m (the frame-wise side path of refine conv1's last channel in the bf16-storage path,
+    reference refine_net.py:147-151, :176-183) against the torch double: exact (sums of at most 5 fp32 terms, one rounding)."""
+    from hipvsr.hip_ops import HipOps
+    from torch_ops import TorchOps
+    dev = _dev()
+    ops, ref = HipOps(dev), TorchOps('cpu')
+    g = torch.Generator('cpu').manual_seed(31)
+    N, J, nwin, H, W, C, c0 = 2, 5, 3, 7, 9, 136, 128
+    z = torch.randn((nwin + J - 1) * N, H, W, 8, generator=g)
+    b1 = torch.randn(C, generator=g)
+    R1 = torch.randn(nwin * N, H, W, C, generator=g).to(out_dt)
+    R1d = R1.clone().to(dev)
+    ops.xcol_combine_m(z.to(dev), b1.to(dev), R1d, N, J, c0)
+    ref.xcol_combine_m(z, b1, R1, N, J, c0)
+    torch.cuda.synchronize()
+    assert torch.equal(R1d.cpu()[..., :c0], R1[..., :c0])                          # other channels untouched
+    torch.testing.assert_close(R1d.cpu().float()[..., c0:], R1.float()[..., c0:], atol=1e-6 if out_dt == torch.float32 else 0, rtol=1e-6 if out_dt == torch.float32 else 8e-3)
+    dy = torch.randn(nwin * N, H, W, C, generator=g).to(out_dt)
+    E = ops.xcol_gather_m(dy.to(dev), N, J, c0, out_dt)
+    Er = ref.xcol_gather_m(dy, N, J, c0, out_dt)
+    torch.cuda.synchronize()
+    assert E.dtype == out_dt and torch.equal(E.cpu(), Er)

@@ -200,3 +200,43 @@ def test_winograd_geometry_choice_of_the_plans(monkeypatch):
     P8 = NetPlans(cfg([8, 8]))
     pl = P8.lstm[('forward', 0)]
     assert not pl['full'].wino and pl['full'].gate_group == 32 and pl['full'].colmap[:len(lstm_colmap(8))] == lstm_colmap(8)
+
+
+def test_bf16_last_channel_of_refine_conv1_frame_by_frame(monkeypatch):
+    """bf16-storage path, round 3 (plans.xcol_m): the 129th output channel of refine conv1 computed frame by frame - one small
+    convolution over the source frames against the view w1[2*Cl].view(w, C1, 3, 3), summed over the window slots - and its weight
+    gradient written through the same view of the gradient, against (a) the 8-column launch it replaces (RNH_XCOL_M=0: same
+    rounding points up to the order of two fp32 sums) and (b) the fp32 oracle (== reference refine_net.py:147-151, :166-183).
+    Channel width 32 (the narrowest that takes this path), both through the torch double of the kernel interface."""
+    from oracle import refinenet_oracle as orc
+    from hipvsr.spec import state_dict_spec
+    cfg_o = orc.Config(in_channels=1, out_channels=1, num_features=[32, 32], num_stages=2, refine_window_size=5, upscale_factor=4,
+                       update_memory=True, num_updated_frames=2, positional_encoding=True)
+    sd = orc.init_state_dict(cfg_o, seed=5)
+    inputs, targets, pos = orc.synthetic_batch(cfg_o, n=2, t=2, h=6, w=5, seed=6)
+    ref_out, ref_loss, ref_grads = orc.step(sd, cfg_o, [x.clone() for x in inputs], targets, pos)
+    c = dict(kwargs=dict(cfg_o), state_dict=sd, inputs=inputs, targets=targets, pos_codes=pos)
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RNH_XCOL_M', flag)
+        cfg, O_all, total, grads = run_engine(c, dtype='bf16')
+        res[flag] = (O_all, total, grads)
+    from hipvsr.plans import NetPlans
+    monkeypatch.setenv('RNH_XCOL_M', '1')
+    P = NetPlans(NetConfig(**dict(cfg_o)), bf16=True)
+    assert P.xcol_m and P.r1x_fwd.Npad == 64 and P.r1_wgrad_a.ycols_pad64 == 64 and P.r1x_key not in state_dict_spec(cfg)
+    O1, t1, g1_ = res['1']
+    O0, t0, g0_ = res['0']
+    assert float((O1 - O0).norm()) <= 2e-3 * float(O0.norm())
+    assert abs(float(t1) - float(t0)) <= 1e-3 * abs(float(t0))
+    for k, v in g0_.items():
+        if v is None:
+            assert g1_[k] is None
+        else:
+            assert float((g1_[k] - v).norm()) <= 1e-2 * float(v.norm()) + 1e-7, (k, float((g1_[k] - v).norm()), float(v.norm()))
+    assert abs(float(t1) - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))
+    k1 = 'refine_block.body.conv1.weight'
+    last = g1_[k1][2 * 32]                                       # the row written through the view: all 5 x 65 x 9 entries
+    assert float((last - ref_grads[k1][64]).norm()) <= 6e-2 * float(ref_grads[k1][64].norm())
+    b1 = 'refine_block.body.conv1.bias'
+    assert abs(float(g1_[b1][64]) - float(ref_grads[b1][64])) <= 6e-2 * float(ref_grads[b1].abs().max())

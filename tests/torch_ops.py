@@ -237,6 +237,29 @@ class TorchOps:
             dw1[co] = w0.grad[0]
             db1[co] = b0.grad[0]
 
+    def xcol_combine_m(self, z, b1, R1, N, J, c0):
+        nwin = R1.shape[0] // N
+        for i in range(nwin):
+            v = b1[c0] + sum(z[(i + j) * N:(i + j + 1) * N, ..., j] for j in range(J))
+            R1[i * N:(i + 1) * N, ..., c0:c0 + 8] = 0
+            R1[i * N:(i + 1) * N, ..., c0] = v.to(R1.dtype)
+
+    def xcol_gather_m(self, dy, N, J, c, dtype):
+        nwin, H, W = dy.shape[0] // N, dy.shape[1], dy.shape[2]
+        E = torch.zeros((nwin + J - 1) * N, H, W, 8, device=self.device)
+        for f in range(nwin + J - 1):
+            for j in range(J):
+                if 0 <= f - j < nwin:
+                    E[f * N:(f + 1) * N, ..., j] = dy[(f - j) * N:(f - j + 1) * N, ..., c].float()
+        return E.to(dtype)
+
+    @staticmethod
+    def put_scalar(dst, src, accumulate):
+        if accumulate:
+            dst.add_(src)
+        else:
+            dst.copy_(src)
+
     def uptail_fwd(self, y1, w2, b2, w3, b3, r, out):
         z = F.pixel_shuffle(F.conv2d(y1.float().permute(0, 3, 1, 2), w2, b2, padding=1), r)
         out.copy_(F.conv2d(z, w3, b3, padding=1).permute(0, 2, 3, 1))
