@@ -705,6 +705,131 @@ __global__ void phase_bias_add_kernel(float *out, const float *planes, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the phase-plane input channels (round 3; the transpose of rnh_phase_bias_add): the plane of frame slot j is
+// the constant p inside the image, so  dW[co][j*cstride + c0][t] = sum_{img = (i, n)} p[(i + j)*N + n] * S_t[img][co]  with
+// S_t = the sum of dy[img][.][co] over the pixels at which tap t stays inside the image = total - border row - border column +
+// corner: nine sums per (image, channel) - Q = {total, first row, last row, first column, last column, four corners} - instead of a
+// pixel-contraction GEMM over five 4-channel sources (1.2 ms per stage at BASELINE config 2, 75 % padding).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PWG_ROWS = 8;           // image rows per block of the first stage
+
+// block = (image, strip of PWG_ROWS rows); thread = (4 channels g, pixel lane s of 256 / G); partial Q per block
+__global__ void __launch_bounds__(256) phase_wgrad_sum_kernel(const float *dy, float *part, int H, int W, int C, int ncols, int nstrips) {
+    extern __shared__ __attribute__((aligned(16))) float red[];             // [lanes][9][ncols]
+    const int img = blockIdx.x / nstrips, strip = blockIdx.x - img * nstrips;
+    const int G = ncols >> 2, lanes = 256 / G, g = threadIdx.x % G, sl = threadIdx.x / G;
+    float4 q[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int y0 = strip * PWG_ROWS, y1 = min(H, y0 + PWG_ROWS);
+    if (sl < lanes)
+        for (int p = y0 * W + sl; p < y1 * W; p += lanes) {
+            const int y = p / W, x = p - y * W;
+            const float4 v = rnh_ld4(dy + ((long)img * H * W + p) * C + g * 4);
+            const bool r0 = y == 0, r1 = y == H - 1, c0 = x == 0, c1 = x == W - 1;
+            const bool sel[9] = {true, r0, r1, c0, c1, r0 && c0, r0 && c1, r1 && c0, r1 && c1};
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (sel[k]) { q[k].x += v.x; q[k].y += v.y; q[k].z += v.z; q[k].w += v.w; }
+        }
+    if (sl < lanes)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rnh_st4(red + ((long)sl * 9 + k) * ncols + g * 4, q[k]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * ncols; e += 256) {                     // fixed order over the pixel lanes
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[(long)l * 9 * ncols + e];
+        part[((long)img * nstrips + strip) * 9 * ncols + e] = s;
+    }
+}
+
+// Q[img][k][co] = sum over strips (fixed order)
+__global__ void phase_wgrad_q_kernel(const float *part, float *Q, int nimg, int nstrips, int ncols) {
+    const long total = (long)nimg * 9 * ncols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long img = e / (9 * ncols), r = e - img * 9 * ncols;
+        float s = 0.f;
+        for (int b = 0; b < nstrips; ++b) s += part[(img * nstrips + b) * 9 * ncols + r];
+        Q[e] = s;
+    }
+}
+
+// dw[co][j*cstride + c0][t] (+)= sum_img p[(i + j)*N + n] * S_t[img][co]
+__global__ void phase_wgrad_finish_kernel(const float *Q, const float *planes, float *dw, long npix, int N, int nwin, int J, int Cin, int cstride,
+                                          int c0, int ncols, int accumulate) {
+    const int total = ncols * J * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int t = e % 9, j = (e / 9) % J, co = e / (9 * J);
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const int kr = dy < 0 ? 1 : (dy > 0 ? 2 : -1), kc = dx < 0 ? 3 : (dx > 0 ? 4 : -1);          // excluded border row / column
+        const int kk = (kr < 0 || kc < 0) ? -1 : 5 + (kr - 1) * 2 + (kc - 3);                        // their common corner
+        float s = 0.f;
+        for (int img = 0; img < nwin * N; ++img) {
+            const float *q = Q + (long)img * 9 * ncols + co;
+            float v = q[0];
+            if (kr >= 0) v -= q[(long)kr * ncols];
+            if (kc >= 0) v -= q[(long)kc * ncols];
+            if (kk >= 0) v += q[(long)kk * ncols];
+            s += planes[(img + (long)j * N) * npix * 4] * v;
+        }
+        float *o = dw + ((long)co * Cin + j * cstride + c0) * 9 + t;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Data gradient of ONE output channel c of a J-slot convolution (refine conv1's channel 2*Cl, round 3): every frame collects, from the
+// J windows that used it, a 45-tap stencil of that single gradient plane per input channel:
+//   dX[(f, n)][p][ci] += sum_j sum_t g[(f + 2 hw - j, n)][p - off(t)][c] * w[c][j*cstride + ci][t],   ci < 2 Cl
+// (g = the gradient planes with their window halo of zero frames; dX = two tensors of Cl channels each).  Replaces an implicit GEMM whose
+// K is 5 x 4 channels (one real) padded to 16-channel steps: 1.9 ms per stage at 5 TFLOP/s.  Structure of uptail_dgrad_tile_kernel:
+// thread = pixel of a 16 x 16 tile, the J gradient patches in LDS, weights wave-uniform (scalar loads), 64 channels per thread.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void xdgrad_pack_kernel(const float *w, float *wx, int Cin, int c, int J, int cstride, int ncols) {
+    const int total = J * 9 * ncols;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ci = e % ncols, t = (e / ncols) % 9, j = e / (9 * ncols);
+        wx[e] = w[((long)c * Cin + j * cstride + ci) * 9 + t];
+    }
+}
+
+constexpr int XDT = 16, XDP = XDT + 2;
+template <int CCH>
+__global__ void __launch_bounds__(256) xdgrad_tile_kernel(const float *__restrict__ g, const float *__restrict__ wx, float *__restrict__ d0,
+                                                          float *__restrict__ d1, int H, int W, int N, int J, int C, int c, int Cl, int ncols,
+                                                          int TX, int TY, int hw2) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];          // [J][XDP][XDP]
+    const int tb = blockIdx.x;
+    const int b = tb / (TX * TY), trem = tb - b * TX * TY, tyb = trem / TX, txb = trem - tyb * TX;
+    const int y0 = tyb * XDT, x0 = txb * XDT, ch0 = blockIdx.y * CCH;
+    const int f = b / N, n = b - f * N;
+    for (int e = threadIdx.x; e < J * XDP * XDP; e += 256) {
+        const int j = e / (XDP * XDP), r = e - j * XDP * XDP, py = y0 - 1 + r / XDP, px = x0 - 1 + r % XDP;
+        const long img = (long)(f + hw2 - j) * N + n;
+        patch[e] = ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) ? g[((img * H + py) * W + px) * C + c] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / XDT, lx = threadIdx.x % XDT, qy = y0 + ly, qx = x0 + lx;
+    float acc[CCH];
+#pragma unroll
+    for (int k = 0; k < CCH; ++k) acc[k] = 0.f;
+    for (int j = 0; j < J; ++j)
+        for (int t = 0; t < 9; ++t) {
+            const float d = patch[(j * XDP + ly + 1 - (t / 3 - 1)) * XDP + lx + 1 - (t % 3 - 1)];      // dY[p - off(t)]
+            const float *k = wx + ((long)j * 9 + t) * ncols + ch0;
+#pragma unroll
+            for (int q = 0; q < CCH; ++q) acc[q] = fmaf(d, k[q], acc[q]);
+        }
+    if (qy >= H || qx >= W) return;
+    float *o = (ch0 < Cl ? d0 + ch0 : d1 + (ch0 - Cl)) + (((long)b * H + qy) * W + qx) * Cl;
+#pragma unroll
+    for (int q = 0; q < CCH; q += 4) {
+        const float4 v = rnh_ld4(o + q);
+        rnh_st4(o + q, make_float4(v.x + acc[q], v.y + acc[q + 1], v.z + acc[q + 2], v.w + acc[q + 3]));
+    }
+}
+
 inline int grid_for(long work_items, int block = 256, int cap = 8192) {
     long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -893,6 +1018,48 @@ extern "C" int rnh_xcol_gather(const float *dy, float *E, int64_t npix, int N, i
     hipLaunchKernelGGL(xcol_gather_kernel, dim3(grid_for((long)(nwin + J - 1) * N * npix * J)), dim3(256), 0, (hipStream_t)stream, dy, E,
                        (long)npix, N, nwin, J, C, c);
     RNH_CHECK_LAUNCH("rnh_xcol_gather");
+    return 0;
+}
+
+extern "C" int64_t rnh_phase_wgrad_ws_floats(int H, int N, int nwin, int ncols) {
+    const int64_t nstrips = (H + PWG_ROWS - 1) / PWG_ROWS;
+    return (int64_t)nwin * N * (nstrips + 1) * 9 * ncols + 64;
+}
+
+extern "C" int rnh_phase_wgrad(const float *dy, const float *planes, float *dw, float *ws, int H, int W, int N, int nwin, int J, int Cin,
+                               int cstride, int c0, int C, int ncols, int accumulate, void *stream) {
+    if (!dy || !planes || !dw || !ws || H < 1 || W < 1 || N < 1 || nwin < 1 || J < 1 || ncols < 4 || ncols > C || (J - 1) * cstride + c0 >= Cin)
+        RNH_FAIL(RNH_E_ARG, "rnh_phase_wgrad: bad arguments");
+    if ((ncols & 3) || (C & 3) || 256 % (ncols / 4)) RNH_FAIL(RNH_E_ALIGN, "rnh_phase_wgrad: ncols / 4 must divide 256, C a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    const int nstrips = (H + PWG_ROWS - 1) / PWG_ROWS, nimg = nwin * N, lanes = 256 / (ncols / 4);
+    const size_t shm = (size_t)lanes * 9 * ncols * sizeof(float);
+    if (shm > 160 * 1024) RNH_FAIL(RNH_E_RANGE, "rnh_phase_wgrad: ncols too large");
+    float *part = ws, *Q = ws + (long)nimg * nstrips * 9 * ncols;
+    hipLaunchKernelGGL(phase_wgrad_sum_kernel, dim3((unsigned)(nimg * nstrips)), dim3(256), shm, st, dy, part, H, W, C, ncols, nstrips);
+    RNH_CHECK_LAUNCH("rnh_phase_wgrad(sum)");
+    hipLaunchKernelGGL(phase_wgrad_q_kernel, dim3(grid_for((long)nimg * 9 * ncols)), dim3(256), 0, st, part, Q, nimg, nstrips, ncols);
+    RNH_CHECK_LAUNCH("rnh_phase_wgrad(Q)");
+    hipLaunchKernelGGL(phase_wgrad_finish_kernel, dim3(grid_for((long)ncols * J * 9)), dim3(256), 0, st, Q, planes, dw, (long)H * W, N, nwin, J,
+                       Cin, cstride, c0, ncols, accumulate);
+    RNH_CHECK_LAUNCH("rnh_phase_wgrad");
+    return 0;
+}
+
+extern "C" int rnh_xcol_dgrad(const float *g, const float *w, float *dx0, float *dx1, float *ws, int H, int W, int N, int T, int J, int Cin,
+                              int cstride, int c, int C, int Cl, void *stream) {
+    if (!g || !w || !dx0 || !dx1 || !ws || H < 1 || W < 1 || N < 1 || T < 1 || J < 1 || !(J & 1) || c < 0 || c >= C || (J - 1) * cstride + 2 * Cl > Cin)
+        RNH_FAIL(RNH_E_ARG, "rnh_xcol_dgrad: bad arguments");
+    if (Cl % 64) RNH_FAIL(RNH_E_RANGE, "rnh_xcol_dgrad: built for hidden widths in multiples of 64");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncols = 2 * Cl;
+    hipLaunchKernelGGL(xdgrad_pack_kernel, dim3(grid_for((long)J * 9 * ncols)), dim3(256), 0, st, w, ws, Cin, c, J, cstride, ncols);
+    RNH_CHECK_LAUNCH("rnh_xcol_dgrad(pack)");
+    const int TX = (W + XDT - 1) / XDT, TY = (H + XDT - 1) / XDT;
+    const size_t shm = (size_t)J * XDP * XDP * sizeof(float);
+    hipLaunchKernelGGL(xdgrad_tile_kernel<64>, dim3((unsigned)(T * N * TX * TY), ncols / 64), dim3(256), shm, st, g, ws, dx0, dx1, H, W, N, J, C, c,
+                       Cl, ncols, TX, TY, J - 1);
+    RNH_CHECK_LAUNCH("rnh_xcol_dgrad");
     return 0;
 }
 

@@ -371,7 +371,12 @@ class RefineNetEngine:
                 elif P.r1_wino:
                     # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
                     ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
-                    ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
+                    if Cl % 64 == 0 and (P.r1_cols // 4) in (8, 16, 32, 64):
+                        # the five phase-plane rows from border-class sums of the gradient (rnh_phase_wgrad)
+                        lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
+                        ops.refine_phase_wgrad(dR1p[hw * N:(hw + T) * N], ctx.P4[lo:hi], grads[k1], N, w, Cl, P.r1_cols, a)
+                    else:
+                        ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
                 else:
                     ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                 if P.xcol:
@@ -391,8 +396,11 @@ class RefineNetEngine:
                 nm = P.r1_cols
                 ops.conv(P.r1_dgrad_h, [Src(gsrc, nch=nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
                          dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
-                ops.conv(P.r1_dgrad_x, [Src(gsrc, c0=nm, nch=P.C1p - nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
-                         dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+                if Cl % 64 == 0:
+                    ops.refine_xcol_dgrad(gsrc, params[k1], dHf, dHb, N, w, Cl)      # the last channel's contribution: a 45-tap stencil
+                else:
+                    ops.conv(P.r1_dgrad_x, [Src(gsrc, c0=nm, nch=P.C1p - nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                             dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
             else:
                 ops.conv(P.r1_dgrad, [Src(gsrc, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
                          dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])

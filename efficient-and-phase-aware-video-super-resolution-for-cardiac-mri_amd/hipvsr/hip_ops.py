@@ -507,6 +507,27 @@ class HipOps:
         L.check(self.lib.rnh_xcol_combine(_ptr(zs[0]), _ptr(zs[1]), _ptr(zs[2]), b1.data_ptr() + 4 * co, _ptr(R1), H * W, N, nwin, J, C, co,
                                           self._stream()), 'rnh_xcol_combine')
 
+    def refine_phase_wgrad(self, dy, P4, dw1, N, J, cl, ncols, accumulate):
+        """dw1[:ncols, j*(2*cl + 1) + 2*cl] (+)= weight gradient of conv1 w.r.t. its J phase-plane input channels, from border-class sums of
+        dy (nwin*N, H, W, C) - the transpose of refine_phase_bias."""
+        self._chk(dy, P4, dw1)
+        nwin, H, W, C = dy.shape[0] // N, dy.shape[1], dy.shape[2], dy.shape[3]
+        if P4.shape[0] != (nwin + J - 1) * N or tuple(P4.shape[1:]) != (H, W, 4):
+            raise L.HipKernelError('refine_phase_wgrad: plane shape')
+        ws = self._workspace('phase_wgrad', self.lib.rnh_phase_wgrad_ws_floats(H, N, nwin, ncols))
+        L.check(self.lib.rnh_phase_wgrad(_ptr(dy), _ptr(P4), _ptr(dw1), _ptr(ws), H, W, N, nwin, J, dw1.shape[1], 2 * cl + 1, 2 * cl, C, ncols,
+                                         int(accumulate), self._stream()), 'rnh_phase_wgrad')
+
+    def refine_xcol_dgrad(self, g, w1, dHf, dHb, N, J, cl):
+        """dHf / dHb += the data gradient of conv1's output channel 2*cl (g = gradient planes with the window halo): a 45-tap stencil."""
+        self._chk(g, w1, dHf, dHb)
+        T, H, W, C = dHf.shape[0] // N, dHf.shape[1], dHf.shape[2], g.shape[3]
+        if g.shape[0] != (T + J - 1) * N or tuple(dHf.shape) != tuple(dHb.shape) or dHf.shape[3] != cl or tuple(g.shape[1:3]) != (H, W):
+            raise L.HipKernelError('refine_xcol_dgrad: shapes')
+        ws = self._workspace('xcol_dgrad', J * 9 * 2 * cl)
+        L.check(self.lib.rnh_xcol_dgrad(_ptr(g), _ptr(w1), _ptr(dHf), _ptr(dHb), _ptr(ws), H, W, N, T, J, w1.shape[1], 2 * cl + 1, 2 * cl, C, cl,
+                                        self._stream()), 'rnh_xcol_dgrad')
+
     def xcol_combine_m(self, z, b1, R1, N, J, c0):
         """bf16-storage path: R1[window i][..., c0] = b1[c0] + sum_j z[frame i + j][..., j] (channels c0 + 1 .. c0 + 7 := 0); z holds
         the J slot convolutions of conv1's channel c0 per source frame (one small rnh_conv_bf16 over the frames)."""

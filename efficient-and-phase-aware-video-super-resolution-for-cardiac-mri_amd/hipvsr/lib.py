@@ -30,7 +30,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
            'rnh_uptail_g_floats', 'rnh_uptail_xcorr_supported', 'rnh_uptail_xcorr_ws_floats', 'rnh_uptail_xcorr',
            'rnh_uptail_bf16_supported', 'rnh_uptail_fwd_bf16_ws_floats', 'rnh_uptail_fwd_bf16', 'rnh_uptail_dgrad_bf16_ws_floats',
-           'rnh_uptail_dgrad_bf16', 'rnh_uptail_xcorr_bf16', 'rnh_xcol_combine_m', 'rnh_xcol_gather_m',
+           'rnh_uptail_dgrad_bf16', 'rnh_uptail_xcorr_bf16', 'rnh_xcol_combine_m', 'rnh_xcol_gather_m', 'rnh_phase_wgrad', 'rnh_phase_wgrad_ws_floats', 'rnh_xcol_dgrad',
            'rnh_xcol_pack', 'rnh_xcol_unpack', 'rnh_xcol_combine', 'rnh_xcol_gather', 'rnh_conv_wino', 'rnh_wino_pack_weights', 'rnh_phase_bias_add',
            'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
            'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
@@ -164,6 +164,10 @@ def load():
     lib.rnh_uptail_dgrad_bf16_ws_floats.restype = i64
     lib.rnh_uptail_dgrad_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_uptail_xcorr_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_phase_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_phase_wgrad_ws_floats.argtypes = [i32, i32, i32, i32]
+    lib.rnh_phase_wgrad_ws_floats.restype = i64
+    lib.rnh_xcol_dgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_combine_m.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_gather_m.argtypes = [vp, i32, vp, i32, i64, i32, i32, i32, i32, i32, vp]
     lib.rnh_xcol_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

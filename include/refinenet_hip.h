@@ -247,6 +247,20 @@ int rnh_xcol_gather_m(const void *dy, int dy_dt, void *E, int e_dt, int64_t npix
  * ws: 16*J*ncols floats (T, rebuilt on every call). */
 int rnh_phase_bias_add(float *out, const float *planes, const float *w, float *ws, int H, int W, int N, int nwin, int J,
                        int Cin, int cstride, int c0, int C, int ncols, void *stream);
+/* ... and its transpose, the weight gradient of those input channels (autograd of refine_net.py:149 w.r.t. the 129th, 258th, ... input
+ * channel of conv1): dw[co][j*cstride + c0][t] (+)= sum_{img = (i, n)} planes[((i + j)*N + n)][0][0][0] * S_t[img][co], S_t = the sum of
+ * dy (nwin*N, H, W, C)[img][.][co] over the pixels at which tap t stays inside the image (total - border row - border column + corner),
+ * co < ncols.  ws: rnh_phase_wgrad_ws_floats(H, N, nwin, ncols) floats.  Fixed summation order. */
+int rnh_phase_wgrad(const float *dy, const float *planes, float *dw, float *ws, int H, int W, int N, int nwin, int J, int Cin,
+                    int cstride, int c0, int C, int ncols, int accumulate, void *stream);
+int64_t rnh_phase_wgrad_ws_floats(int H, int N, int nwin, int ncols);
+/* Data gradient of ONE output channel c of the J-slot convolution (conv1's channel 2*Cl) as a 45-tap stencil (autograd of
+ * refine_net.py:149, :176-183 w.r.t. the hidden states, restricted to that output channel):
+ *   dx[(f, n)][p][ci] += sum_j sum_t g[((f + J - 1 - j), n)][p - off(t)][c] * w[c][j*cstride + ci][t],  ci < 2*Cl: dx0 takes ci < Cl, dx1 the rest
+ * g: ((T + J - 1)*N, H, W, C) gradient planes with (J - 1)/2 zero frames on both sides; dx0 / dx1: (T*N, H, W, Cl), accumulated into.
+ * ws: J*9*2*Cl floats.  Cl % 64 == 0. */
+int rnh_xcol_dgrad(const float *g, const float *w, float *dx0, float *dx1, float *ws, int H, int W, int N, int T, int J, int Cin,
+                   int cstride, int c, int C, int Cl, void *stream);
 
 /* Backward of the upsampler's tail = [last conv + PixelShuffle(r)] -> [final conv C -> out_channels]
  * (refine_net.py:199-205), collapsed algebraically because the tail is affine with out_channels (= 1) outputs

@@ -240,3 +240,29 @@ def test_bf16_last_channel_of_refine_conv1_frame_by_frame(monkeypatch):
     assert float((last - ref_grads[k1][64]).norm()) <= 6e-2 * float(ref_grads[k1][64].norm())
     b1 = 'refine_block.body.conv1.bias'
     assert abs(float(g1_[b1][64]) - float(ref_grads[b1][64])) <= 6e-2 * float(ref_grads[b1].abs().max())
+
+
+def test_full_width_refine_side_paths_vs_oracle():
+    """Width 64 (the reference YAML's): refine conv1 takes the Winograd split with its side paths - channel 128 forward / weight gradient
+    (xcol), the phase planes as a bias field forward and, since round 3, as border-class sums in the weight gradient
+    (ops.refine_phase_wgrad) and the 45-tap stencil for channel 128's data gradient (ops.refine_xcol_dgrad).  The engine's index maps
+    for all of them, through the torch double, against the oracle (== reference refine_net.py:147-151, :157-185): fp32 tolerances."""
+    from oracle import refinenet_oracle as orc
+    cfg_o = orc.Config(in_channels=1, out_channels=1, num_features=[64, 64], num_stages=2, refine_window_size=5, upscale_factor=2,
+                       update_memory=True, num_updated_frames=2, positional_encoding=True)
+    sd = orc.init_state_dict(cfg_o, seed=11)
+    inputs, targets, pos = orc.synthetic_batch(cfg_o, n=2, t=2, h=5, w=6, seed=12)
+    ref_out, ref_loss, ref_grads = orc.step(sd, cfg_o, [x.clone() for x in inputs], targets, pos)
+    c = dict(kwargs=dict(cfg_o), state_dict=sd, inputs=inputs, targets=targets, pos_codes=pos)
+    cfg, O_all, total, grads = run_engine(c)
+    from hipvsr.plans import NetPlans
+    P = NetPlans(cfg)
+    assert P.r1_wino and P.xcol and P.r1_cols == 128
+    torch.testing.assert_close(total, ref_loss, atol=1e-5, rtol=1e-5)
+    for k, gref in ref_grads.items():
+        if gref is None:
+            assert grads[k] is None
+            continue
+        scale = float(gref.abs().max()) + 1e-12
+        err = float((grads[k] - gref).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)

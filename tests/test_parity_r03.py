@@ -295,3 +295,64 @@ def test_gates_bwd_m_equals_the_four_element_kernel_bitwise(with_state):
         assert not torch.isnan(dg).any() and not torch.isnan(dcp).any()
         res.append((dg.cpu(), dcp.cpu()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# refine conv1 side paths of round 3 (fp32): phase-plane weight gradient from border-class sums, 45-tap data-gradient stencil
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,T,H,W', [(1, 1, 1, 1), (2, 2, 3, 17), (1, 3, 16, 16), (2, 1, 37, 9), (1, 2, 40, 33)])
+def test_refine_side_path_kernels_vs_float64(N, T, H, W):
+    """rnh_phase_wgrad (dW of conv1 w.r.t. its five phase-plane input channels, from nine border-class sums per image and channel)
+    and rnh_xcol_dgrad (data gradient of conv1's output channel 128: 45 taps per hidden channel) against float64 autograd of the
+    convolutions they stand for (reference refine_net.py:149, :176-183), on single-pixel / single-row images, tile and strip tails."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(H * 100 + W)
+    J, cl, hw = 5, 64, 2
+    C1, Cin = 129, 645
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    w1 = R(C1, Cin, 3, 3) * 0.05
+    # --- phase-plane weight gradient: windows i = 0..T-1, planes of frames i + j
+    pv = R((T + J - 1) * N)
+    P4 = torch.zeros((T + J - 1) * N, H, W, 4)
+    P4[..., 0] = pv.view(-1, 1, 1)
+    dy = R(T * N, H, W, 132)
+    dw = torch.full((C1, Cin, 3, 3), 7.0)
+    dwd = dw.clone().to(dev)
+    ops.refine_phase_wgrad(dy.to(dev), P4.to(dev), dwd, N, J, cl, 128, False)
+    dwd2 = dwd.clone()
+    ops.refine_phase_wgrad(dy.to(dev), P4.to(dev), dwd2, N, J, cl, 128, True)
+    torch.cuda.synchronize()
+    ref = torch.zeros(128, J, 3, 3, dtype=torch.float64)
+    for i in range(T):
+        x = torch.cat([P4[(i + j) * N:(i + j + 1) * N, ..., :1] for j in range(J)], dim=-1).permute(0, 3, 1, 2).double()
+        w0 = torch.zeros(128, J, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x, w0, padding=1).backward(dy[i * N:(i + 1) * N, ..., :128].permute(0, 3, 1, 2).double())
+        ref += w0.grad
+    rows = [j * C1 + 2 * cl for j in range(J)]
+    mine = dwd.cpu().double()[:128, rows]
+    scale = float(ref.abs().max()) + 1e-12
+    assert float((mine - ref).abs().max()) <= 2e-5 * scale + 1e-6, float((mine - ref).abs().max())
+    assert float((dwd2.cpu().double()[:128, rows] - 2 * ref).abs().max()) <= 4e-5 * scale + 1e-6          # accumulate
+    mask = torch.ones(C1, Cin, dtype=torch.bool)
+    mask[:128, rows] = False
+    assert float((dwd.cpu()[mask] - 7.0).abs().max()) == 0.0                       # everything else untouched
+    # --- data gradient of channel 128: gradient planes with hw zero frames on both sides
+    gp = torch.zeros((T + 2 * hw) * N, H, W, 132)
+    gp[hw * N:(hw + T) * N] = R(T * N, H, W, 132)
+    dHf, dHb = R(T * N, H, W, cl), R(T * N, H, W, cl)
+    a, b = dHf.clone().to(dev), dHb.clone().to(dev)
+    ops.refine_xcol_dgrad(gp.to(dev), w1.to(dev), a, b, N, J, cl)
+    torch.cuda.synchronize()
+    rf, rb = dHf.double().clone(), dHb.double().clone()
+    for f in range(T):
+        for j in range(J):
+            gj = gp[(f + J - 1 - j) * N:(f + J - j) * N, ..., 128:129].permute(0, 3, 1, 2).double()
+            d = F.conv_transpose2d(gj, w1[128:129, j * C1:j * C1 + 2 * cl].double(), padding=1).permute(0, 2, 3, 1)
+            rf[f * N:(f + 1) * N] += d[..., :cl]
+            rb[f * N:(f + 1) * N] += d[..., cl:]
+    for nm, m_, r_ in (('dHf', a, rf), ('dHb', b, rb)):
+        e = float((m_.cpu().double() - r_).abs().max())
+        assert e <= 2e-5 * float(r_.abs().max()) + 1e-6, (nm, e)

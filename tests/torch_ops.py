@@ -237,6 +237,33 @@ class TorchOps:
             dw1[co] = w0.grad[0]
             db1[co] = b0.grad[0]
 
+    def refine_phase_wgrad(self, dy, P4, dw1, N, J, cl, ncols, accumulate):
+        nwin = dy.shape[0] // N
+        cs, c0 = 2 * cl + 1, 2 * cl
+        g = torch.zeros(ncols, J, 3, 3, device=self.device)
+        for i in range(nwin):
+            x = torch.cat([P4[(i + j) * N:(i + j + 1) * N, ..., :1] for j in range(J)], dim=-1).permute(0, 3, 1, 2)
+            w0 = torch.zeros(ncols, J, 3, 3, device=self.device, requires_grad=True)
+            with torch.enable_grad():
+                F.conv2d(x, w0, padding=1).backward(dy[i * N:(i + 1) * N, ..., :ncols].permute(0, 3, 1, 2))
+            g += w0.grad
+        for j in range(J):
+            if accumulate:
+                dw1[:ncols, j * cs + c0] += g[:, j]
+            else:
+                dw1[:ncols, j * cs + c0] = g[:, j]
+
+    def refine_xcol_dgrad(self, g, w1, dHf, dHb, N, J, cl):
+        T = dHf.shape[0] // N
+        cs, c = 2 * cl + 1, 2 * cl
+        for f in range(T):
+            for j in range(J):
+                gj = g[(f + J - 1 - j) * N:(f + J - j) * N, ..., c:c + 1].permute(0, 3, 1, 2)
+                wj = w1[c:c + 1, j * cs:j * cs + 2 * cl]                                  # (1, 2*cl, 3, 3)
+                d = F.conv_transpose2d(gj, wj, padding=1).permute(0, 2, 3, 1)
+                dHf[f * N:(f + 1) * N] += d[..., :cl]
+                dHb[f * N:(f + 1) * N] += d[..., cl:]
+
     def xcol_combine_m(self, z, b1, R1, N, J, c0):
         nwin = R1.shape[0] // N
         for i in range(nwin):
