@@ -309,19 +309,42 @@ __global__ void __launch_bounds__(256, (MI * NI * 16 + 4 * D * (MI + NI) > 200 ?
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float *slab, const float *bslab, int nsplit, int ntaps, int XP, int YP,
-                                    const int *rowmap, const int *colmap, int Cin, float *dw, float *db, int accumulate) {
-    const long total = (long)ntaps * XP * YP;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+// One thread sums four consecutive columns of one (tap, row) over the splits: 16-byte loads, eight of them in flight, added in split
+// order (the same sums, element by element, as a plain loop over the splits; the scalar version - one column per thread, one 4-byte load at
+// a time - read the ConvLSTM weight gradient's 75 MB of partial sums at 0.6 TB/s: 120 us, 3.6 ms per bf16 step).  YP % 4 == 0.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ bslab, int nsplit, int ntaps,
+                                                           int XP, int YP, const int *__restrict__ rowmap, const int *__restrict__ colmap, int Cin,
+                                                           float *dw, float *db, int accumulate) {
+    const long total = (long)ntaps * XP * YP, total4 = total >> 2;
+    for (long e4 = (long)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (long)gridDim.x * blockDim.x) {
+        const long e = e4 << 2;
         const int j = (int)(e % YP);
         const long r = e / YP;
         const int i = (int)(r % XP), tap = (int)(r / XP);
-        const int ci = rowmap[i], co = colmap[j];
-        if (ci < 0 || co < 0) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += slab[(long)sp * total + e];
-        const long o = ((long)co * Cin + ci) * ntaps + tap;
-        dw[o] = accumulate ? dw[o] + s : s;
+        const int ci = rowmap[i];
+        const int co[4] = {colmap[j], colmap[j + 1], colmap[j + 2], colmap[j + 3]};
+        if (ci < 0 || (co[0] < 0 && co[1] < 0 && co[2] < 0 && co[3] < 0)) continue;
+        const float *p = slab + e;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = rnh_ld4(p + (long)(sp + q) * total);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s.x += v[q].x, s.y += v[q].y, s.z += v[q].z, s.w += v[q].w;
+        }
+        for (; sp < nsplit; ++sp) {
+            const float4 v = rnh_ld4(p + (long)sp * total);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (co[q] < 0) continue;
+            const long o = ((long)co[q] * Cin + ci) * ntaps + tap;
+            dw[o] = accumulate ? dw[o] + sv[q] : sv[q];
+        }
     }
     if (bslab && db) {
         for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < YP; j += (long)gridDim.x * blockDim.x) {
@@ -387,9 +410,11 @@ extern "C" int rnh_wgrad_reduce(const float *slab, const float *bslab, int nspli
                                 void *stream) {
     if (!slab || !rowmap || !colmap || !dw || nsplit < 1 || ntaps < 1 || xcols_pad < 1 || ycols_pad < 1 || Cin < 1)
         RNH_FAIL(RNH_E_ARG, "rnh_wgrad_reduce: bad arguments");
+    if (ycols_pad & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_wgrad_reduce: ycols_pad must be a multiple of 4");
     const long total = (long)ntaps * xcols_pad * ycols_pad;
-    int blocks = (int)((total + 255) / 256);
+    int blocks = (int)((total / 4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, bslab, nsplit, ntaps,
                        xcols_pad, ycols_pad, rowmap, colmap, Cin, dw, db, accumulate);
     RNH_CHECK_LAUNCH("rnh_wgrad_reduce");

@@ -116,24 +116,31 @@ constexpr int INB_BLOCKS = 2048;    // 32 waves per CU: the pixel loop is a chai
                                     // BASELINE config 2, round 3)
 constexpr int INB_MAXK = 36;     // 9 * Cin, Cin <= 4
 
-// thread = (co, sub); partial[block][co][9*Cin + 2] = {dW taps..., db, dslope}
+// thread = (4 output channels g, pixel lane sub of 256 / (Cout / 4)); partial[block][co][9*Cin + 2] = {dW taps..., db, dslope}.
+// (Round 3: one 16-byte load of dy per pixel and thread instead of a 4-byte one - the loop is bound by its load instructions, a wave
+// now covers 4 x 64 (pixel, channel) pairs per iteration instead of 64: 1.17 -> see profiles/README.md.)
+template <int INB_MAXK>      // 9 for in_channels == 1 (every reference YAML), 36 up to 4 input channels
 __global__ void __launch_bounds__(256) inconv_bwd_kernel(const float *x, const float *w, const float *bias, const float *slope,
                                                          const float *dy, float *ws, int B, int H, int W, int Cin, int Cout) {
-    __shared__ float red[256];
+    __shared__ float red[1024];
     const int K = 9 * Cin;
-    const int co = threadIdx.x % Cout, sub = threadIdx.x / Cout, nsub = blockDim.x / Cout;
-    float wr[INB_MAXK], acc[INB_MAXK];
+    const int G = Cout >> 2, g = threadIdx.x % G, sub = threadIdx.x / G, nsub = blockDim.x / G;
+    float wr[INB_MAXK][4], acc[INB_MAXK][4];
 #pragma unroll
-    for (int k = 0; k < INB_MAXK; ++k) {
-        acc[k] = 0.f;
-        wr[k] = 0.f;
-        if (k < K) {
-            const int tap = k / Cin, ci = k - tap * Cin;
-            wr[k] = w[(co * Cin + ci) * 9 + tap];
+    for (int k = 0; k < INB_MAXK; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[k][c] = 0.f;
+            wr[k][c] = 0.f;
+            if (k < K) {
+                const int tap = k / Cin, ci = k - tap * Cin;
+                wr[k][c] = w[((g * 4 + c) * Cin + ci) * 9 + tap];
+            }
         }
-    }
-    float db = 0.f, ds = 0.f;
-    const float a = slope[0], bv = bias[co];
+    float db[4] = {0.f, 0.f, 0.f, 0.f}, ds[4] = {0.f, 0.f, 0.f, 0.f};
+    const float a = slope[0];
+    const float4 bv = rnh_ld4(bias + g * 4);
+    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
     const long M = (long)B * H * W;
     const long per = (M + gridDim.x - 1) / gridDim.x;
     const long p0 = (long)blockIdx.x * per;
@@ -143,7 +150,6 @@ __global__ void __launch_bounds__(256) inconv_bwd_kernel(const float *x, const f
         const int xx = (int)(p % W);
         const int yy = (int)((p / W) % H);
         float xv[INB_MAXK];
-        float z = bv;
 #pragma unroll
         for (int k = 0; k < INB_MAXK; ++k) {
             xv[k] = 0.f;
@@ -152,33 +158,43 @@ __global__ void __launch_bounds__(256) inconv_bwd_kernel(const float *x, const f
                 const int dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
                 if ((unsigned)(yy + dy_) < (unsigned)H && (unsigned)(xx + dx_) < (unsigned)W)
                     xv[k] = x[(p + dy_ * W + dx_) * Cin + ci];
-                z += xv[k] * wr[k];
             }
         }
-        const float g = dy[p * Cout + co];
-        const float dz = z > 0.f ? g : a * g;
-        ds += z > 0.f ? 0.f : g * z;
-        db += dz;
+        const float4 gv = rnh_ld4(dy + p * Cout + g * 4);
+        const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-        for (int k = 0; k < INB_MAXK; ++k)
-            if (k < K) acc[k] += dz * xv[k];
+        for (int c = 0; c < 4; ++c) {
+            float z = bvv[c];
+#pragma unroll
+            for (int k = 0; k < INB_MAXK; ++k)
+                if (k < K) z += xv[k] * wr[k][c];
+            const float dz = z > 0.f ? gg[c] : a * gg[c];
+            ds[c] += z > 0.f ? 0.f : gg[c] * z;
+            db[c] += dz;
+#pragma unroll
+            for (int k = 0; k < INB_MAXK; ++k)
+                if (k < K) acc[k][c] += dz * xv[k];
+        }
     }
-    // reduce over sub through LDS, one quantity at a time (nsub is small)
-    float *out = ws + ((long)blockIdx.x * Cout + co) * (K + 2);
+    // reduce over sub through LDS, one quantity at a time, in fixed order
     for (int k = 0; k < K + 2; ++k) {
-        float v = 0.f;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < INB_MAXK; ++kk)
-            if (kk == k) v = acc[kk];
-        if (k == K) v = db;
-        if (k == K + 1) v = ds;
+            if (kk == k) { v[0] = acc[kk][0]; v[1] = acc[kk][1]; v[2] = acc[kk][2]; v[3] = acc[kk][3]; }
+        if (k == K) { v[0] = db[0]; v[1] = db[1]; v[2] = db[2]; v[3] = db[3]; }
+        if (k == K + 1) { v[0] = ds[0]; v[1] = ds[1]; v[2] = ds[2]; v[3] = ds[3]; }
         __syncthreads();
-        red[threadIdx.x] = v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[(sub * G + g) * 4 + c] = v[c];
         __syncthreads();
         if (sub == 0) {
-            float s = 0.f;
-            for (int q = 0; q < nsub; ++q) s += red[q * Cout + co];
-            out[k] = s;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float s = 0.f;
+                for (int q = 0; q < nsub; ++q) s += red[(q * G + g) * 4 + c];
+                ws[((long)blockIdx.x * Cout + g * 4 + c) * (K + 2) + k] = s;
+            }
         }
     }
 }
@@ -875,9 +891,10 @@ extern "C" int rnh_inconv_prelu_bwd(const float *x, const float *w, const float 
     if (!x || !w || !bias || !slope || !dy || !dw || !db || !dslope || !ws || B < 1 || H < 1 || W < 1)
         RNH_FAIL(RNH_E_ARG, "rnh_inconv_prelu_bwd: bad arguments");
     if (9 * Cin > INB_MAXK) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_bwd: Cin > 4 not supported");
-    if (Cout < 1 || Cout > 256 || 256 % Cout) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_bwd: Cout must divide 256");
+    if (Cout < 4 || Cout > 256 || (Cout & 3) || 256 % (Cout / 4)) RNH_FAIL(RNH_E_RANGE, "rnh_inconv_prelu_bwd: Cout / 4 must divide 256");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(inconv_bwd_kernel, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
+    if (Cin == 1) hipLaunchKernelGGL(inconv_bwd_kernel<9>, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
+    else hipLaunchKernelGGL(inconv_bwd_kernel<INB_MAXK>, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
     RNH_CHECK_LAUNCH("rnh_inconv_prelu_bwd");
     hipLaunchKernelGGL(inconv_bwd_reduce_kernel, dim3(grid_for(Cout * (9 * Cin + 1))), dim3(256), 0, st, ws, INB_BLOCKS, dw, db,
                        dslope, Cin, Cout, accumulate);

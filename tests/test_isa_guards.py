@@ -132,3 +132,40 @@ def test_no_copies_of_async_load_targets(tmp_path, src, pattern, nmin):
         copies = suspicious_copies(lines)
         assert not copies, (name, copies[:8])
     assert seen >= nmin
+
+
+TR_RE = re.compile(r'ds_read_b64_tr_b16\s+v\[(\d+):(\d+)\]')
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
+def test_lds_dma_weight_gradient_kernel_keeps_its_pipeline(tmp_path):
+    """wgrad_bf16_dma_kernel (csrc/wgrad_bf16.hip, round 3) hides its row loads only while (a) the rows arrive by LDS-DMA, (b) the only
+    vector-memory waits are the hand-counted ones - hipcc drains every outstanding DMA (vmcnt(0)) in front of an LDS read it knows of,
+    which is why the fragment reads are inline asm - and (c) no register that an asm fragment read writes is copied or spilled between
+    the read and the MFMAs (the compiler does not know those reads are asynchronous).  Static check of the shipped code, no GPU."""
+    text = _asm(os.path.join(CSRC, 'wgrad_bf16.hip'), str(tmp_path))
+    kernels = list(_kernels(text, 'wgrad_bf16_dma_kernel'))
+    assert len(kernels) == 1
+    name, lines = kernels[0]
+    assert sum(ln.startswith('global_load_lds_dwordx4') for ln in lines) >= 20
+    assert not any(ln.startswith(('global_load_dword', 'buffer_load_dword')) and 'lds' not in ln for ln in lines), 'a register-staged load crept in'
+    waits = [ln for ln in lines if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
+    counted = sorted(int(re.search(r'vmcnt\((\d+)\)', ln).group(1)) for ln in waits)
+    # the drain at the top of a run of steps and the one before the workgroup retires, plus the two counted waits of the step loop
+    assert counted == [0, 0, 8, 12], waits
+    mf = [i for i, ln in enumerate(lines) if ln.startswith('v_mfma')]
+    assert len(mf) == 40                                          # 36 per step + 4 for the bias gradient
+    first_tr = min(i for i, ln in enumerate(lines) if TR_RE.match(ln))
+    targets = set()
+    for ln in lines:
+        m = TR_RE.match(ln)
+        if m:
+            targets.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    bad = []
+    for ln in lines[first_tr:mf[-1] + 1]:
+        m = MOVE_RE.match(ln) or SPILL_RE.match(ln)
+        if m and any(r in targets for r in _regs(m)):
+            bad.append(ln)
+        if ln.startswith('scratch_'):
+            bad.append(ln)
+    assert not bad, bad[:8]
