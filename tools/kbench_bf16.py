@@ -23,6 +23,8 @@ cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_
 P = NetPlans(cfg, bf16=True)
 ops = HipOps(dev)
 params = {k: torch.randn(*s, device=dev) * 0.05 for k, s in state_dict_spec(cfg).items()}
+if getattr(P, 'xcol_m', False):                         # the last channel of refine conv1 as a per-frame convolution: a view of the weight
+    params[P.r1x_key] = params[P.r1_fwd.wkey][P.C1 - 1].view(cfg.refine_window_size, P.C1, 3, 3)
 for pl in P.conv_plans():
     ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None)
 N, H, W, T, F = 8, 128, 128, 7, 19
@@ -91,8 +93,14 @@ srcs = []
 for j in range(5):
     srcs += [Src(Hf, img_off=j * N), Src(Hb, img_off=j * N), Src(P8, img_off=j * N)]
 R1 = ops.empty(nwin * N, H, W, P.C1p, dtype=bf)
-def r1_fwd():                                               # as the engine runs it (hipvsr/engine.py): columns 0..127 and the rest as two launches
-    if P.r1_split:
+Z5 = ops.empty(F * N, H, W, 8)
+b1 = params[P.r1_fwd.bkey]
+def r1_fwd():                                               # as the engine runs it (hipvsr/engine.py)
+    if getattr(P, 'xcol_m', False):                         # columns 0..127 + the last channel frame by frame
+        ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 128)])
+        ops.conv(P.r1x_fwd, [Src(Hf), Src(Hb), Src(P8)], F * N, H, W, dsts=[Dst(Z5, 8)])
+        ops.xcol_combine_m(Z5, b1, R1, N, 5, 128)
+    elif P.r1_split:
         ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 128)])
         ops.conv(P.r1_fwd_b, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p - 128, c0=128)])
     else:
@@ -108,8 +116,18 @@ xs1 = []
 for j in range(5):
     xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P8, img_off=(4 + j) * N)]
 dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
-timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9,
-       TN * H * W * (5 * 136 + 136) * 2, 3)
+dbx = ops.zeros(8)
+def r1_wgrad():
+    if getattr(P, 'xcol_m', False):
+        ops.wgrad(P.r1_wgrad_a, xs1, [Src(dR1p, nch=128, img_off=2 * N)], TN, H, W, dw1, db1)
+        E = ops.xcol_gather_m(dR1p[2 * N:(2 + T) * N], N, 5, 128, bf)
+        ops.wgrad(P.r1x_wgrad, [Src(Hf, img_off=4 * N), Src(Hb, img_off=4 * N), Src(P8, img_off=4 * N)], [Src(E)], (T + 4) * N, H, W,
+                  dw1[128].view(5, 129, 3, 3), dbx[:5])
+    else:
+        ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1)
+
+
+timeit('refine1.wgrad', r1_wgrad, 2.0 * TN * H * W * 129 * 645 * 9, TN * H * W * (5 * 136 + 136) * 2, 3)
 dHf, dHb = ops.zeros(TN, H, W, 64, dtype=bf), ops.zeros(TN, H, W, 64, dtype=bf)
 timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
                                         dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9,
