@@ -410,6 +410,75 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                     }
                 }
             }
+        } else if constexpr (EPI == RNH_EPI_LSTM_BWD) {
+            // Data gradient of a ConvLSTM cell + gate backward of the frame its chain processes next (include/refinenet_hip.h).  The parked
+            // tile holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
+            const rnh_mdst_t &D = P.dst[0];
+            const int ncx = D.ncols, ncx8 = ncx >> 3, hd = P.hd, hd8 = hd >> 3;
+            for (int it = tid; it < PXR * ncx8; it += 256) {        // items (pixel, 8 columns of the input gradient)
+                const int px = it / ncx8, c8 = it - px * ncx8;
+                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                if (y >= H || x >= W) continue;
+                const float *o = ot + px * G::OPITCH + c8 * 8;
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = o[e];
+                const long e = ((((long)img + D.img_off) * H + y) * W + x) * D.C + D.c0 + c8 * 8;
+                if (D.accumulate) {
+                    float old[8];
+                    load8(D.ptr, D.dtype, e, old);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] += old[q];
+                }
+                store8(D.ptr, D.dtype, e, f);
+            }
+            // items (pixel, 8 hidden channels): the body of gates_bwd_m_kernel (mixed_kernels.hip), expression by expression, with
+            // dh2 := dh_rec out of LDS, rounded to the element type the unfused path would have stored it in
+            const void *dhp = P.bw_dh, *gp = P.bw_gates;
+            const float *dcn = P.bw_dc_next, *cprev = P.bw_c_prev, *cnext = P.bw_c_next;
+            void *dgp = P.bw_dgates;
+            float *dcprev = P.bw_dc_prev;
+            const int hdt = P.bw_dh_dtype, gdt = P.gates_dtype, dgdt = P.bw_dgates_dtype, rdt = P.bw_rec_dtype;
+            for (int it = tid; it < PXR * hd8; it += 256) {
+                const int px = it / hd8, g = it - px * hd8;
+                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                if (y >= H || x >= W) continue;
+                const long p = ((long)img * H + y) * W + x;
+                const long o = p * hd + g * 8, og = p * 4 * hd + g * 8;
+                float vdh[8], t[8], vdc[8], vcp[8], vcn[8], gi[8], gf[8], go[8], gg[8];
+                load8(dhp, hdt, o, vdh);
+                const float *rec = ot + px * G::OPITCH + ncx + g * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    t[e] = rec[e];
+                    if (rdt == RNH_DT_BF16) t[e] = (float)(__bf16)t[e];
+                    vdh[e] += t[e];
+                }
+                if (dcn) load8(dcn, RNH_DT_F32, o, vdc);
+                if (cprev) load8(cprev, RNH_DT_F32, o, vcp);
+                load8(cnext, RNH_DT_F32, o, vcn);
+                load8(gp, gdt, og, gi);
+                load8(gp, gdt, og + hd, gf);
+                load8(gp, gdt, og + 2 * hd, go);
+                load8(gp, gdt, og + 3 * hd, gg);
+                float di[8], df[8], dgo[8], dg[8], dcp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float th = tanhf(vcn[e]);
+                    const float d_o = vdh[e] * th;
+                    const float dct = (dcn ? vdc[e] : 0.f) + vdh[e] * go[e] * (1.f - th * th);
+                    di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+                    df[e] = dct * (cprev ? vcp[e] : 0.f) * gf[e] * (1.f - gf[e]);
+                    dgo[e] = d_o * go[e] * (1.f - go[e]);
+                    dg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+                    dcp[e] = dct * gf[e];
+                }
+                store8(dgp, dgdt, og, di);
+                store8(dgp, dgdt, og + hd, df);
+                store8(dgp, dgdt, og + 2 * hd, dgo);
+                store8(dgp, dgdt, og + 3 * hd, dg);
+                if (dcprev) store8(dcprev, RNH_DT_F32, o, dcp);
+            }
         } else {
             // a thread's 8 columns are the same in every step (256 % G8 == 0): destination segment / sub-pixel once per thread
             constexpr int G8 = NCOLS / 8;
@@ -550,6 +619,22 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
             if (ncols == 128) RNH_LAUNCH9(RNH_EPI_PS, 128);
             else RNH_LAUNCH9(RNH_EPI_PS, 64);
             break;
+        case RNH_EPI_LSTM_BWD: {
+            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the LSTM-backward epilogue serves 3x3 convolutions");
+            const rnh_mdst_t &D = a.dst[0];
+            if (a.ndst != 1 || !D.ptr || D.ncols < 8 || (D.dtype != RNH_DT_F32 && D.dtype != RNH_DT_BF16) || (D.C & 7) || (D.c0 & 7) || (D.ncols & 7))
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: the LSTM-backward epilogue stores the input gradient to dst[0] (channels in multiples of 8)");
+            if (a.hd < 8 || (a.hd & 7) || NT != 1 || D.ncols + a.hd > a.Npad)
+                RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: LSTM-backward epilogue: input-gradient + hd columns must fit ONE column tile (Npad %d)", a.Npad);
+            if (!a.bw_dh || !a.bw_gates || !a.bw_c_next || !a.bw_dgates) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM-backward epilogue needs bw_dh, bw_gates, bw_c_next, bw_dgates");
+            if ((a.bw_dh_dtype != RNH_DT_F32 && a.bw_dh_dtype != RNH_DT_BF16) || (a.bw_dgates_dtype != RNH_DT_F32 && a.bw_dgates_dtype != RNH_DT_BF16) ||
+                (a.bw_rec_dtype != RNH_DT_F32 && a.bw_rec_dtype != RNH_DT_BF16) ||
+                (a.gates_dtype != RNH_DT_F32 && a.gates_dtype != RNH_DT_BF16))
+                RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM-backward epilogue: bad element type");
+            if (ncols == 128) RNH_LAUNCH9(RNH_EPI_LSTM_BWD, 128);
+            else RNH_LAUNCH9(RNH_EPI_LSTM_BWD, 64);
+            break;
+        }
         case RNH_EPI_LSTM:
             if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the LSTM epilogue serves 3x3 convolutions");
             if (!a.h_out || !a.c_out || a.hd < 8 || (a.hd & 7) || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM epilogue needs h_out, c_out, hd % 8 == 0, bias");

@@ -16,6 +16,7 @@ out by hand so that every step is one of the kernels of include/refinenet_hip.h:
 The ``ops`` object is ``hipvsr.hip_ops.HipOps`` in the product.  tests/ substitutes a torch implementation of
 the same interface to check this scheduling logic against the oracle on machines without a GPU.
 """
+import os
 from collections import OrderedDict
 
 from . import lib as L
@@ -414,16 +415,60 @@ class RefineNetEngine:
             Gd = {d: [ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] for d in dirs}
             DX = {d: [ops.empty(TN, H, W, P.lstm[(d, l)]['cx'], dtype=act) if l > 0 else None for l in range(Lr)] for d in dirs}
             dfeat_d = {d: ops.empty(TN, H, W, C, dtype=act) for d in dirs}          # layer-0 input gradients per direction
-            dh_next = {d: [None] * Lr for d in dirs}
-            dc_next = {d: [None] * Lr for d in dirs}
             # state gradients handed from a frame to the previous one of the same (direction, layer): two buffers each, used in
             # turn, allocated HERE on the main stream - an allocation inside a side-stream block would, under HIP-graph
             # capture, come from the graph's pool on a stream other than the capture's origin (the capture then fails)
+            fused = cfg.memory and all(ops.lstm_bwd_fusable(P.lstm[(d, l)]['dgrad'], P.lstm[(d, l)]['cx'], P.lstm[(d, l)]['hd'])
+                                       for d in dirs for l in range(Lr))
             DCP = {d: [[ops.empty(N, H, W, hd) for _ in range(2)] for hd in nf] for d in dirs}
-            DHP = {d: [[ops.empty(N, H, W, hd, dtype=act) for _ in range(2)] for hd in nf] for d in dirs} if cfg.memory else None
+            DHP = {d: [[ops.empty(N, H, W, hd, dtype=act) for _ in range(2)] for hd in nf] for d in dirs} if cfg.memory and not fused else None
             TMP = None if cfg.memory else {d: [ops.empty(N, H, W, P.lstm[(d, l)]['cx'], dtype=act) for l in range(Lr)] for d in dirs}
+            dh_next = {d: [None] * Lr for d in dirs}
+            dc_next = {d: [None] * Lr for d in dirs}
             ops.fork(2 * Lr, bank=1)
-            for idx in range(T):
+            if fused:
+                # The gate backward of a frame rides in the epilogue of the data-gradient launch of the frame its chain processed just before
+                # (conv(..., lstm_bwd=...): the recurrent state gradient never reaches memory, one launch per cell and frame instead of
+                # two, and the HBM-bound gate math of some workgroups overlaps the MFMAs of others - as separate launches the two
+                # kinds of kernels excluded each other from the CUs and alternated in lockstep across the streams).  That launch
+                # needs the input gradient of the layer above for the NEXT frame of the chain, so layer l runs one frame behind layer
+                # l + 1: a skewed wavefront over tau = frame index + (Lr - 1 - l).  Only the first frame of a chain still has a launch of
+                # its own for the gate backward.
+                evs = {}
+                for tau in range(T + Lr - 1):
+                    for di, d in enumerate(dirs):
+                        step = 1 if d == 'forward' else -1
+                        sd, top = st[d], tops[d]
+                        Cb, Gb = sd['C'], sd['G']
+                        for l in range(Lr - 1, -1, -1):
+                            idx = tau - (Lr - 1 - l)
+                            if not 0 <= idx < T:
+                                continue
+                            k = U + T - 1 - idx if d == 'forward' else U + idx
+                            fi, k2 = k - U, k - step
+                            fi2, has_next = k2 - U, idx + 1 < T
+                            pl = P.lstm[(d, l)]
+                            hd, cx = pl['hd'], pl['cx']
+                            dh_of = (lambda f: top[f * N:(f + 1) * N]) if l == Lr - 1 else (lambda f, l=l: DX[d][l + 1][f * N:(f + 1) * N])
+                            c_at = lambda kk, l=l: Cb[l][kk * N:(kk + 1) * N] if 0 <= kk < F else None
+                            with ops.side(di * Lr + l):
+                                if idx == 0:                        # head of the chain
+                                    if l < Lr - 1:
+                                        ops.wait(evs[(d, l + 1, 0)])
+                                    ops.lstm_gates_bwd(dh_of(fi), None, Gb[l][fi * N:(fi + 1) * N], c_at(k2), c_at(k),
+                                                       Gd[d][l][fi * N:(fi + 1) * N], DCP[d][l][0] if has_next else None)
+                                dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
+                                bw = None
+                                if has_next:
+                                    if l < Lr - 1:
+                                        ops.wait(evs[(d, l + 1, idx + 1)])
+                                    bw = dict(dh=dh_of(fi2), dc_next=DCP[d][l][idx & 1], gates=Gb[l][fi2 * N:(fi2 + 1) * N], c_prev=c_at(k2 - step),
+                                              c_next=c_at(k2), dgates=Gd[d][l][fi2 * N:(fi2 + 1) * N],
+                                              dc_prev=DCP[d][l][(idx + 1) & 1] if idx + 2 < T else None, hd=hd, rec_dtype=act)
+                                ops.conv(pl['dgrad'], [Src(Gd[d][l][fi * N:(fi + 1) * N])], N, H, W, dsts=[Dst(dxbuf, cx)], lstm_bwd=bw)
+                                if l > 0:
+                                    evs[(d, l, idx)] = ops.record()
+            for idx in range(T if not fused else 0):
                 for di, d in enumerate(dirs):
                     step = 1 if d == 'forward' else -1
                     k = U + T - 1 - idx if d == 'forward' else U + idx

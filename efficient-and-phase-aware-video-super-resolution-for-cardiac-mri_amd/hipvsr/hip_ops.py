@@ -235,15 +235,20 @@ class HipOps:
         dst.img_off, dst.scale, dst.sub_y, dst.sub_x = s.img_off, s.scale, s.sub[0], s.sub[1]
 
     # ---- convolution --------------------------------------------------------------------------------
-    def conv(self, plan: ConvPlan, srcs, B, H, W, dsts=None, ps=None, lstm=None):
+    def conv(self, plan: ConvPlan, srcs, B, H, W, dsts=None, ps=None, lstm=None, lstm_bwd=None):
         """One rnh_conv_igemm launch.  ``dsts``: list[Dst] (STORE), ``ps``: (tensor, r) with the tensor
-        (B, rH, rW, cq) (PS), ``lstm``: dict(c_prev, h_out, c_out, gates_out, hd) (LSTM)."""
+        (B, rH, rW, cq) (PS), ``lstm``: dict(c_prev, h_out, c_out, gates_out, hd) (LSTM).  ``lstm_bwd`` (only where
+        lstm_bwd_fusable(plan, ...)): the data gradient of a ConvLSTM cell with the gate backward of the chain's next frame in its
+        epilogue - dict(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, hd, rec_dtype); dsts = [the input gradient] alone, the hd columns
+        behind it (the recurrent state gradient) are consumed in the kernel."""
         if id(plan) not in self._packed:
             raise L.HipKernelError(f'{plan.name}: weights were not packed')
         if len(srcs) != len(plan.ksegs):
             raise L.HipKernelError(f'{plan.name}: {len(srcs)} sources for {len(plan.ksegs)} K segments')
         if plan.bf16:
-            return self._conv_bf16(plan, srcs, B, H, W, dsts, ps, lstm)
+            return self._conv_bf16(plan, srcs, B, H, W, dsts, ps, lstm, lstm_bwd)
+        if lstm_bwd is not None:
+            raise L.HipKernelError(f'{plan.name}: the fused gate backward is an epilogue of rnh_conv_bf16')
         a = L.ConvArgs()
         for i, (s, sg) in enumerate(zip(srcs, plan.ksegs)):
             self._fill_src(a.src[i], s)
@@ -315,7 +320,17 @@ class HipOps:
         dst.img_off, dst.scale, dst.sub_y, dst.sub_x = s.img_off, s.scale, s.sub[0], s.sub[1]
         self._check_src_range(dst, t, B, H, W, who)
 
-    def _conv_bf16(self, plan, srcs, B, H, W, dsts, ps, lstm):
+    @staticmethod
+    def lstm_bwd_fusable(plan, cx, hd):
+        """Can conv(plan, ..., lstm_bwd=...) serve this cell's data gradient?  (bf16 kernel, all cx + hd columns in ONE column tile;
+        RNH_FUSE_GATES_BWD=0 keeps the separate rnh_lstm_gates_bwd_m launches for A/B measurements.)"""
+        if os.environ.get('RNH_FUSE_GATES_BWD', '1') == '0':
+            return False
+        tile = 64 if plan.Npad % 128 else 128
+        return bool(plan.bf16 and plan.ntaps == 9 and plan.epilogue == L.EPI_STORE and plan.Npad == tile and cx + hd <= tile and
+                    cx % 8 == 0 and hd % 8 == 0)
+
+    def _conv_bf16(self, plan, srcs, B, H, W, dsts, ps, lstm, lstm_bwd=None):
         a = L.ConvBf16Args()
         for i, (s, sg) in enumerate(zip(srcs, plan.ksegs)):
             self._fill_msrc(a.src[i], s, B, H, W, plan.name)
@@ -325,6 +340,24 @@ class HipOps:
         a.nsrc, a.B, a.H, a.W, a.ntaps, a.nchunks = len(srcs), B, H, W, plan.ntaps, plan.nchunks
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
         a.Npad, a.epilogue = plan.Npad, plan.epilogue
+        if lstm_bwd is not None:
+            hd = lstm_bwd['hd']
+            if plan.epilogue != L.EPI_STORE or len(dsts) != 1 or not self.lstm_bwd_fusable(plan, dsts[0].ncols, hd):
+                raise L.HipKernelError(f'{plan.name}: not a convolution the gate backward can be fused into')
+            for k, mixed, width in (('dh', True, 1), ('dc_next', False, 1), ('gates', True, 4), ('c_prev', False, 1), ('c_next', False, 1),
+                                    ('dgates', True, 4), ('dc_prev', False, 1)):
+                t = lstm_bwd.get(k)
+                if t is None and k in ('dh', 'gates', 'c_next', 'dgates'):
+                    raise L.HipKernelError(f'{plan.name}: lstm_bwd needs {k}')
+                self._chk(t, mixed=mixed)
+                if t is not None and tuple(t.shape) != (B, H, W, hd * width):
+                    raise L.HipKernelError(f'{plan.name}: lstm_bwd {k} shape {tuple(t.shape)}')
+            a.epilogue, a.hd = L.EPI_LSTM_BWD, hd
+            a.bw_dh, a.bw_dc_next, a.bw_gates = _ptr(lstm_bwd['dh']), _ptr(lstm_bwd.get('dc_next')), _ptr(lstm_bwd['gates'])
+            a.bw_c_prev, a.bw_c_next = _ptr(lstm_bwd.get('c_prev')), _ptr(lstm_bwd['c_next'])
+            a.bw_dgates, a.bw_dc_prev = _ptr(lstm_bwd['dgates']), _ptr(lstm_bwd.get('dc_prev'))
+            a.bw_dh_dtype, a.gates_dtype, a.bw_dgates_dtype = L.dt_of(lstm_bwd['dh']), L.dt_of(lstm_bwd['gates']), L.dt_of(lstm_bwd['dgates'])
+            a.bw_rec_dtype = L.DT_BF16 if lstm_bwd['rec_dtype'] == torch.bfloat16 else L.DT_F32
         if plan.epilogue == L.EPI_STORE:
             a.ndst = len(dsts)
             tot = 0

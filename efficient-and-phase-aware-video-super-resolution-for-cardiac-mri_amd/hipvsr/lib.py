@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
 
 MAX_SRC, MAX_DST = 16, 4
-EPI_STORE, EPI_PS, EPI_LSTM = 0, 1, 2
+EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
 TILE_128x128, TILE_128x128_G, TILE_256x64, TILE_128x160, TILE_256x128 = 0, 1, 2, 3, 6
 TILE_COLS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 64, TILE_128x160: 160, TILE_256x128: 128}
 TILE_ROWS = {TILE_128x128: 128, TILE_128x128_G: 128, TILE_256x64: 256, TILE_128x160: 128, TILE_256x128: 256}
@@ -95,7 +95,10 @@ class ConvBf16Args(C.Structure):
                 ('ntaps', C.c_int32), ('nchunks', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p),
                 ('Npad', C.c_int32), ('epilogue', C.c_int32), ('ndst', C.c_int32), ('ps_r', C.c_int32), ('ps_cq', C.c_int32),
                 ('hd', C.c_int32), ('dst', MDst * MAX_DST), ('c_prev', C.c_void_p), ('c_out', C.c_void_p),
-                ('h_out', C.c_void_p), ('gates_out', C.c_void_p), ('h_dtype', C.c_int32), ('gates_dtype', C.c_int32)]
+                ('h_out', C.c_void_p), ('gates_out', C.c_void_p), ('h_dtype', C.c_int32), ('gates_dtype', C.c_int32),
+                ('bw_dh', C.c_void_p), ('bw_dc_next', C.c_void_p), ('bw_gates', C.c_void_p), ('bw_c_prev', C.c_void_p),
+                ('bw_c_next', C.c_void_p), ('bw_dgates', C.c_void_p), ('bw_dc_prev', C.c_void_p), ('bw_dh_dtype', C.c_int32),
+                ('bw_dgates_dtype', C.c_int32), ('bw_rec_dtype', C.c_int32), ('_pad2', C.c_int32)]
 
 
 class WgradBf16Args(C.Structure):

@@ -69,6 +69,7 @@ typedef struct rnh_dst {
 #define RNH_EPI_STORE 0   /* bias add, store / accumulate into the destination segments           */
 #define RNH_EPI_PS    1   /* bias add, nn.PixelShuffle(ps_r) fused into the store (dst[0])        */
 #define RNH_EPI_LSTM  2   /* bias add, ConvLSTM gate math, writes h, c (and the gates for backward)*/
+#define RNH_EPI_LSTM_BWD 3 /* rnh_conv_bf16 only: data gradient of a ConvLSTM cell + gate backward of the chain's previous frame */
 
 /* Output-tile shapes (rows x columns of one workgroup) */
 #define RNH_TILE_128x128 0   /* 2x2 waves of 64x64          */
@@ -438,6 +439,21 @@ typedef struct rnh_conv_bf16_args {
     void *h_out;                /* [B][H][W][hd] of h_dtype                                              */
     void *gates_out;            /* [B][H][W][4*hd] of gates_dtype or 0                                   */
     int32_t h_dtype, gates_dtype;
+    /* RNH_EPI_LSTM_BWD - the data gradient of ConvLSTM cell (layer l, frame t) fused with the gate backward of frame t' = the frame
+     * the chain processes next (autograd of refine_net.py:258-265; replaces one rnh_lstm_gates_bwd_m launch and the round trip of
+     * the recurrent state gradient through HBM).  Npad == the column tile (all columns in one workgroup); columns [0, dst[0].ncols)
+     * = the input gradient, stored to dst[0] as RNH_EPI_STORE does; the next hd columns = dh_rec, the gradient w.r.t. h_{t'}: rounded to
+     * bw_rec_dtype (the element type the unfused path stores it in) and consumed in place:  dh = bw_dh + dh_rec, then exactly rnh_lstm_gates_bwd_m
+     * (dh, dc_next = bw_dc_next, gates = bw_gates, c_prev = bw_c_prev, c_next = bw_c_next) -> bw_dgates, bw_dc_prev. */
+    const void *bw_dh;          /* [B][H][W][hd] of bw_dh_dtype: the summand of dh that does not come from this convolution */
+    const float *bw_dc_next;    /* fp32 [B][H][W][hd] or 0                                                */
+    const void *bw_gates;       /* [B][H][W][4*hd] of gates_dtype: the gates of frame t'                  */
+    const float *bw_c_prev;     /* fp32: the cell state before frame t' (0: zeros)                        */
+    const float *bw_c_next;     /* fp32: the cell state after frame t'                                    */
+    void *bw_dgates;            /* out [B][H][W][4*hd] of bw_dgates_dtype                                 */
+    float *bw_dc_prev;          /* out fp32 [B][H][W][hd] or 0                                            */
+    int32_t bw_dh_dtype, bw_dgates_dtype, bw_rec_dtype;
+    int32_t _pad2;
 } rnh_conv_bf16_args_t;
 
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA: one workgroup = 8 x 32 output pixels x 128 (64) columns; per

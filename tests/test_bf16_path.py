@@ -578,3 +578,71 @@ def test_xcol_m_kernels_vs_torch(out_dt):
     Er = ref.xcol_gather_m(dy, N, J, c0, out_dt)
     torch.cuda.synchronize()
     assert E.dtype == out_dt and torch.equal(E.cpu(), Er)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W', [(2, 8, 32), (1, 11, 45), (2, 5, 13), (1, 24, 64)])
+@pytest.mark.parametrize('nf,dh_dt,rec_dt,edge', [(64, torch.bfloat16, torch.bfloat16, 'mid'), (64, torch.float32, torch.bfloat16, 'first'),
+                                                  (64, torch.bfloat16, torch.float32, 'last'), (8, torch.bfloat16, torch.bfloat16, 'mid'),
+                                                  (32, torch.float32, torch.float32, 'mid')])
+def test_fused_gate_backward_epilogue_equals_the_two_launches_bitwise(nf, dh_dt, rec_dt, edge, B, H, W):
+    """rnh_conv_bf16 with RNH_EPI_LSTM_BWD (the data gradient of a ConvLSTM cell with the gate backward of the chain's next frame in its
+    epilogue) against what it replaces: the same convolution storing [input gradient | recurrent state gradient] followed by
+    rnh_lstm_gates_bwd_m - bit for bit, in the 128-column (64 + 64) and the 64-column tile (8 + 8, 32 + 32), on whole and ragged tiles,
+    with and without c_prev / dc_next / dc_prev, fp32 and bf16 summands.  (The two-launch path itself is held against float64 by
+    test_conv_bf16_kernel_vs_torch_float64[lstm_dgrad] and test_mixed_type_helpers_vs_torch.)"""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = _full_cfg(num_features=[nf, nf])
+    P, ops = NetPlans(cfg, bf16=True), HipOps(dev)
+    pl = P.lstm[('backward', 1)]
+    hd, cx = pl['hd'], pl['cx']
+    assert ops.lstm_bwd_fusable(pl['dgrad'], cx, hd)
+    spec = state_dict_spec(cfg)
+    g = torch.Generator('cpu').manual_seed(7 * W + H + nf)
+    R = lambda *sh: torch.randn(*sh, generator=g)                           # noqa: E731
+    bf = torch.bfloat16
+    ops.pack(pl['dgrad'], (R(*spec[pl['full'].wkey]) * 0.05).to(dev), None)
+    dg_t = R(B, H, W, 4 * hd).to(bf).to(dev)                                  # gate gradients of frame t (the convolution's input)
+    dh = (R(B, H, W, hd) * 0.5).to(dh_dt).to(dev)
+    gates = torch.sigmoid(R(B, H, W, 4 * hd)).to(bf).to(dev)
+    c_prev = None if edge == 'first' else R(B, H, W, hd).to(dev)
+    c_next = R(B, H, W, hd).to(dev)
+    dc_next = None if edge == 'first' else (R(B, H, W, hd) * 0.5).to(dev)
+    nan = lambda *sh, dt=torch.float32: torch.full(sh, float('nan'), device=dev, dtype=dt)      # noqa: E731
+    # two launches
+    dx_a, rec = nan(B, H, W, cx, dt=bf), nan(B, H, W, hd, dt=rec_dt)
+    dgates_a, dcp_a = nan(B, H, W, 4 * hd, dt=bf), (None if edge == 'last' else nan(B, H, W, hd))
+    ops.conv(pl['dgrad'], [Src(dg_t)], B, H, W, dsts=[Dst(dx_a, cx), Dst(rec, hd)])
+    ops.lstm_gates_bwd(dh, dc_next, gates, c_prev, c_next, dgates_a, dcp_a, dh2=rec)
+    # one launch
+    dx_b, dgates_b, dcp_b = nan(B, H, W, cx, dt=bf), nan(B, H, W, 4 * hd, dt=bf), (None if edge == 'last' else nan(B, H, W, hd))
+    ops.conv(pl['dgrad'], [Src(dg_t)], B, H, W, dsts=[Dst(dx_b, cx)],
+             lstm_bwd=dict(dh=dh, dc_next=dc_next, gates=gates, c_prev=c_prev, c_next=c_next, dgates=dgates_b, dc_prev=dcp_b, hd=hd, rec_dtype=rec_dt))
+    torch.cuda.synchronize()
+    assert not torch.isnan(dgates_b.float()).any() and not torch.isnan(dx_b.float()).any()
+    assert torch.equal(dx_a, dx_b)
+    assert torch.equal(dgates_a, dgates_b), (dgates_a.float() - dgates_b.float()).abs().max()
+    if dcp_a is not None:
+        assert torch.equal(dcp_a, dcp_b), (dcp_a - dcp_b).abs().max()
+
+
+@pytest.mark.gpu
+def test_fused_and_two_launch_training_steps_agree_bitwise(monkeypatch):
+    """The bf16-storage training step with the gate backward fused into the data-gradient launches (default) and with
+    RNH_FUSE_GATES_BWD=0 (a launch of its own per cell and frame): outputs and every gradient bit-identical, at full width, on a
+    ragged shape, T = 4 supervised frames (chains of head + 3 fused launches)."""
+    cfg = orc.exp1_x4_config(num_updated_frames=2)
+    sd = orc.init_state_dict(cfg, seed=5)
+    inputs, targets, pos = orc.synthetic_batch(cfg, 2, 4, 24, 40, seed=3)
+    res = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('RNH_FUSE_GATES_BWD', flag)
+        net, _, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, 'bf16')
+        res[flag] = (loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res['1'][0], res['0'][0])
+    assert res['1'][1].keys() == res['0'][1].keys() and len(res['1'][1]) > 20
+    for k in res['1'][1]:
+        assert torch.equal(res['1'][1][k], res['0'][1][k]), k

@@ -266,3 +266,41 @@ def test_full_width_refine_side_paths_vs_oracle():
         scale = float(gref.abs().max()) + 1e-12
         err = float((grads[k] - gref).abs().max())
         assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', ['x4_pos1_mem1', 'x2_pos0_mem1'])
+def test_fused_gate_backward_schedule_equals_the_two_launch_schedule(g1, monkeypatch, case, dtype):
+    """The skewed wavefront with the gate backward in the data-gradient launch's epilogue (engine.backward, conv(..., lstm_bwd=...))
+    asks for the same arithmetic as a gate-backward launch + a data-gradient launch per cell and frame: on the test double every
+    gradient comes out bit-identical, and both match the reference's goldens (the first parametrised tests of this file)."""
+    calls = {'fused': 0, 'gates': 0}
+    conv, gates = TorchOps.conv, TorchOps.lstm_gates_bwd
+
+    def count_conv(self, *a, **k):
+        calls['fused'] += k.get('lstm_bwd') is not None
+        return conv(self, *a, **k)
+
+    def count_gates(self, *a, **k):
+        calls['gates'] += 1
+        return gates(self, *a, **k)
+
+    monkeypatch.setattr(TorchOps, 'conv', count_conv)
+    monkeypatch.setattr(TorchOps, 'lstm_gates_bwd', count_gates)
+    monkeypatch.setenv('RNH_FUSE_GATES_BWD', '0')
+    _, _, tot_a, ga = run_engine(g1[case], dtype=dtype)
+    assert calls['fused'] == 0 and calls['gates'] > 0
+    two = calls['gates']
+    calls['gates'] = 0
+    monkeypatch.setenv('RNH_FUSE_GATES_BWD', '1')
+    monkeypatch.setenv('RNH_FUSE_ANY', '1')
+    cfg, _, tot_b, gb = run_engine(g1[case], dtype=dtype)
+    T = len(g1[case]['targets'])
+    chains = cfg.num_stages * 2 * len(cfg.num_features)
+    assert calls['fused'] == chains * (T - 1)                    # every frame but the head of its chain
+    assert calls['gates'] == two                                 # (the double's fused op calls its own gate backward: same count)
+    assert torch.equal(tot_a, tot_b)
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None)
+        if ga[k] is not None:
+            assert torch.equal(ga[k], gb[k]), k

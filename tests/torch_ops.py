@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from hipvsr import lib as L
-from hipvsr.plans import ConvPlan, WgradPlan
+from hipvsr.plans import ConvPlan, Dst, WgradPlan
 
 
 def gather_src(s, B):
@@ -102,7 +102,28 @@ class TorchOps:
                     bp[n] = b[cm]
         self._w[id(plan)] = (weff, bp)
 
-    def conv(self, plan, srcs, B, H, W, dsts=None, ps=None, lstm=None):
+    @staticmethod
+    def lstm_bwd_fusable(plan, cx, hd):
+        # the same rule as HipOps (the double follows the product's scheduling decisions); RNH_FUSE_ANY=1 lets the CPU tests drive
+        # the fused schedule through nets of any width
+        import os
+        if os.environ.get('RNH_FUSE_GATES_BWD', '1') == '0':
+            return False
+        if os.environ.get('RNH_FUSE_ANY') == '1':
+            return plan.ntaps == 9 and plan.epilogue == L.EPI_STORE
+        tile = 64 if plan.Npad % 128 else 128
+        return bool(getattr(plan, 'bf16', False) and plan.ntaps == 9 and plan.epilogue == L.EPI_STORE and plan.Npad == tile and
+                    cx + hd <= tile and cx % 8 == 0 and hd % 8 == 0)
+
+    def conv(self, plan, srcs, B, H, W, dsts=None, ps=None, lstm=None, lstm_bwd=None):
+        if lstm_bwd is not None:
+            # the data gradient with the gate backward of the chain's next frame behind it: dh_rec = the hd columns after the input
+            # gradient, rounded to rec_dtype (the element type the unfused path stores it in)
+            hd, b = lstm_bwd['hd'], lstm_bwd
+            rec = torch.empty(B, H, W, hd, dtype=b['rec_dtype'], device=self.device)
+            self.conv(plan, srcs, B, H, W, dsts=[dsts[0], Dst(rec, hd)])
+            self.lstm_gates_bwd(b['dh'], b.get('dc_next'), b['gates'], b.get('c_prev'), b['c_next'], b['dgates'], b.get('dc_prev'), dh2=rec)
+            return
         weff, bp = self._w[id(plan)]
         bf = getattr(plan, 'bf16', False)
         x = torch.cat([self._r(gather_src(s, B), bf) for s in srcs], dim=-1).permute(0, 3, 1, 2)
