@@ -74,6 +74,12 @@ dgo, dcp = ops.empty(N, H, W, 256, dtype=bf), ops.empty(N, H, W, 64)
 timeit('lstm.gates_bwd', lambda: ops.lstm_gates_bwd(dgs[0], cst[0], dgs[2], cst[1], cst[2], dgo, dcp, dh2=dgs[1]), 0.0,
        px * (64 * 2 * 2 + 64 * 4 * 4 + 256 * 2 * 2), 20)
 
+dgf = ops.empty(N, H, W, 256, dtype=bf)
+timeit('lstm.dgrad+gates_bwd', lambda: ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dx, 64)],
+                                                lstm_bwd=dict(dh=dgs[0], dc_next=cst[0], gates=dgs[2], c_prev=cst[1], c_next=cst[2], dgates=dgf,
+                                                              dc_prev=dcp, hd=64, rec_dtype=bf)),
+       2.0 * px * 128 * 2304, px * (256 * 2 + 64 * 2 + 64 * 2 + 64 * 4 * 4 + 256 * 2 * 2), 20)
+
 # upsampler conv1 at 128x128 (3 branches x T frames), bf16 output (the bf16 tail kernels read it, csrc/uptail_bf16.hip)
 B3 = 3 * TN
 u = P.up[0]
