@@ -17,8 +17,9 @@ pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_
 do that work).  `secondary` carries the SAME step in the bf16-storage path (BASELINE config 3 per GPU: same N, T,
 size, steps and warm-up, timed the same way in the same process right after the headline) with its own `ms_per_step`, `value`,
 `roofline` (conv_bf16d_kernel<LSTM> against the dense bf16 MFMA peak; executed = algorithmic there) and `dtype: "bf16"`;
-`--no-secondary` skips it, `--dtype bf16` makes it the only line as before.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (profiles/lstm_kernel_hbm_bytes.json), reported
-only if that file was measured on THIS kernel source (sha256 of the Winograd kernel's source file, csrc/conv_wino.hip), else null.  `cpu_baseline` times
+`--no-secondary` skips it, `--dtype bf16` makes it the only line as before.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
+(profiles/lstm_kernel_hbm_bytes.json; profiles/lstm_bf16_kernel_hbm_bytes.json for the secondary), reported only if that record was measured on THIS
+kernel source (sha256 of csrc/conv_wino.hip / csrc/conv_bf16.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 """
@@ -136,9 +137,11 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
         flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
         byts = n * h * w * (2 * cx + 2 * hd + 4 * hd + 4 * hd + 2 * hd + 2 * 4 * hd)
         tf, tbs = flops / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e12
+        traffic, traffic_src = quoted_traffic('lstm_bf16_kernel_hbm_bytes.json', 'conv_bf16.hip')
         return {'bound': 'mfma', 'kernel': 'conv_bf16_kernel<LSTM,128,9> (ConvLSTM cell 128->256, direct 3x3 on v_mfma_f32_32x32x16_bf16, fused gates)',
                 'achieved': round(tf, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_MFMA_TFLOPS, 4),
-                'traffic': None, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops, 'algorithmic_flop_per_launch': flops,
+                'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops,
+                'algorithmic_flop_per_launch': flops,
                 'algorithmic_bytes_per_launch': byts, 'hbm_algorithmic_tbs': round(tbs, 3), 'hbm_frac_of_8tbs': round(tbs / PEAK_HBM_TBS, 4)}
     # ALGORITHMIC work of the launch: 589 824 FLOP per pixel at cx = hd = 64, the direct 3x3 form
     flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
@@ -146,16 +149,7 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     flops_exec = flops * 4.0 / 9.0 if wino else flops
     algorithmic = flops / (ms * 1e-3) / 1e12
     executed = flops_exec / (ms * 1e-3) / 1e12
-    traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, 'profiles', 'lstm_kernel_hbm_bytes.json')
-    if os.path.exists(prof):
-        try:
-            rec = json.load(open(prof))
-            if rec.get('kernel_source_sha256') == kernel_source_sha256():     # measured on this kernel, not an older revision
-                traffic = rec.get('hbm_bytes_per_launch')
-                traffic_src = {k: rec.get(k) for k in ('commit', 'date', 'command')}
-        except Exception:
-            traffic = None
+    traffic, traffic_src = quoted_traffic('lstm_kernel_hbm_bytes.json', 'conv_wino.hip')
     name = f'{wino_kernel_name()}<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
         'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)'
     out = {'bound': 'mfma', 'kernel': name, 'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -172,11 +166,24 @@ def wino_kernel_name():
     return 'conv_winoh_kernel'
 
 
-def kernel_source_sha256():
-    """sha256 of the source file of that kernel: profiles/lstm_kernel_hbm_bytes.json is only quoted while it matches."""
+def kernel_source_sha256(source='conv_wino.hip'):
+    """sha256 of the source file of a kernel: the PMC record under profiles/ is only quoted while it matches."""
     import hashlib
-    with open(os.path.join(PKG, 'csrc', 'conv_wino.hip'), 'rb') as f:
+    with open(os.path.join(PKG, 'csrc', source), 'rb') as f:
         return hashlib.sha256(f.read()).hexdigest()
+
+
+def quoted_traffic(record, source):
+    """(HBM bytes per launch, where they come from) out of profiles/<record> (rocprofv3 PMC passes, FETCH_SIZE / WRITE_SIZE corrected as
+    MI355X_MICROARCH.md prescribes) - or (None, None) when the record was measured on another revision of csrc/<source>."""
+    prof = os.path.join(ROOT, 'profiles', record)
+    try:
+        rec = json.load(open(prof))
+        if rec.get('kernel_source_sha256') == kernel_source_sha256(source):
+            return rec.get('hbm_bytes_per_launch'), {k: rec.get(k) for k in ('commit', 'date', 'command')}
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline():

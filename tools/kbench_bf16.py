@@ -59,7 +59,7 @@ x, hp, cp = R(N, H, W, 64), R(N, H, W, 64), R(N, H, W, 64, dtype=torch.float32)
 ho, co, go = ops.empty(N, H, W, 64, dtype=bf), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256, dtype=bf)
 timeit('lstm.fwd', lambda: ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go)),
        2.0 * px * 256 * 1152, px * (128 * 2 + 64 * 4 + 64 * 4 + 64 * 2 + 256 * 2), 20)
-timeit('lstm.fwd(no gates_out)', lambda: ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=None)),
+timeit('lstm.nogates_fwd', lambda: ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=None)),
        2.0 * px * 256 * 1152, px * (128 * 2 + 64 * 4 + 64 * 4 + 64 * 2), 20)
 dg = R(N, H, W, 256)
 dx, dh = ops.empty(N, H, W, 64, dtype=bf), ops.empty(N, H, W, 64, dtype=bf)
