@@ -511,6 +511,273 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_lds_kernel(const rnh_wgrad_
     }
 }
 
+constexpr int WH_STRIDE = 20;                                   // floats per (group, lane) in LDS: 8 xi x (tile a, tile b) + 4 pad (b128 reads of 16 lanes: disjoint banks)
+constexpr int WH_BUF = 4 * 64 * WH_STRIDE;                      // floats per buffer (4 groups x 64 lanes)
+
+// One HALF of the transform domain per workgroup (HH: the positions xi = 4 i + 2 HH + jj, jj = 0, 1), two workgroups per CU: a wave keeps
+// 128 accumulators instead of 256 and the two waves of a SIMD - one of each workgroup - fill each other's non-MFMA time, which the
+// one-wave-per-SIMD kernel above cannot (0.67 of the fp32 MFMA rate: every load, transform add and LDS access of the only wave idles the
+// matrix core).  Price: both workgroups load and column-transform the same patches (the row transform, the LDS traffic and the output-
+// gradient transform are halved with the positions).  Same sums in the same order as the kernel above: bit-identical slabs.
+__global__ void __launch_bounds__(256, 2) wino_wgrad_half_kernel(const rnh_wgrad_args_t P, const int Cx, const int Cy, const int KS, const int rows_per) {
+    __shared__ __attribute__((aligned(16))) float sV[2 * WH_BUF];   // 40 KB: two workgroups per CU
+    // consecutive blocks (the same XCD after the remap, dispatched together) = the two halves of one quad of items: they read the same
+    // patches and output gradients within microseconds of each other
+    const int lb2 = rnh_xcd_remap(blockIdx.x, gridDim.x);
+    const int lb = lb2 >> 1;
+    // (the half is a compile-time constant of the body: accumulator registers cannot be indexed at run time)
+    auto body = [&](auto hh_tag) {
+    constexpr int HH = decltype(hh_tag)::value;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int RT = Cx >> 5, CT = Cy >> 5;
+    const int item = lb * 4 + wave;                             // CT % 4 == 0: the four waves share (ks, rt)
+    const int ks = item / (RT * CT), rc = item - ks * RT * CT, rt = rc / CT, ct = rc - rt * CT;
+    const int H = P.H, W = P.W, TY = H >> 1, G = W >> 3, Q = G >> 2;
+    const int rows_total = P.B * TY;
+    const int r0 = ks * rows_per, r1 = min(rows_total, r0 + rows_per);
+
+    int ysrc = 0, cy0 = ct * 32;
+    while (cy0 >= P.ys[ysrc].nch) cy0 -= P.ys[ysrc++].nch;
+    const rnh_src_t &Y = P.ys[ysrc];
+    const int sc = Y.scale, Hs = H * sc, Ws = W * sc;
+    // input source of this row tile (32 channels never straddle two sources: nch % 32 == 0)
+    int xsrc = 0, cx0 = rt * 32;
+    while (cx0 >= P.xs[xsrc].nch) cx0 -= P.xs[xsrc++].nch;
+    const rnh_src_t &X = P.xs[xsrc];
+    const int XC = X.C;
+    // The patches come straight from the unpadded sources (no gathered copy): the descriptor base sits one pixel LEFT of
+    // the image, so column j of tile t is at (2 (kh + 2t) + j) pixels; the one column left of the first group / right of
+    // the last one gets offset 0xFFFFFFFF (hardware range check: zero, no access; the other lane half is in range, so
+    // the load still goes to memory in order); rows above / below the image are clamped and zeroed after the load
+    // (a load with ALL lanes out of range would return ahead of older loads).
+    int vx[2][4], vy[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[t][j] = ((2 * (kh + 2 * t) + j) * XC + l31) * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) vy[t][b] = ((2 * (kh + 2 * t) + b) * sc * Y.C + l31) * 4;
+    }
+    const int xrow = W * XC * 4, xgrp = 8 * XC * 4, yrow = sc * Ws * Y.C * 4, ygrp = 8 * sc * Y.C * 4;
+    // Row pointers advance by constants (no multiplications in the loop): both tensors are dense.
+    const long ximg = (long)H * W * XC, ystep = (long)2 * sc * Ws * Y.C;
+    auto ximg_ptr = [&](int img) { return X.ptr + X.c0 + cx0 + ((long)img + X.img_off) * ximg - XC; };
+    auto yrow_ptr = [&](int img, int ty) {
+        return Y.ptr + Y.c0 + cy0 + ((((long)img + Y.img_off) * Hs + (long)2 * ty * sc + Y.sub_y) * Ws + Y.sub_x) * Y.C;
+    };
+
+    f32x16 acc[8];                                              // acc[2 i + jj] = position (row i, column 2 HH + jj)
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[xi][v] = 0.f;
+    float bsum = 0.f;
+
+    // The output gradients of a lane's two tiles ride in the halves of packed registers (x = tile a, y = tile b): their
+    // transform is an add / subtract network, one v_pk_add_f32 per pair (written as asm: hipcc scalarises packed adds; the
+    // s_nop covers the VALU-write -> MFMA-read wait states, which hipcc does not add behind an asm statement).
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    auto pk_add = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    auto pk_sub = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    // (results that only go to other VALU instructions or to LDS need no pad)
+    auto pk_add0 = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    auto pk_sub0 = [&](f32x2w p, f32x2w r) {
+        f32x2w o;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(p), "v"(r));
+        return o;
+    };
+    // x patches of this wave's group (quad position q of row r): tiles a and b, 32 loads
+    auto load_x = [&](f32x2w (&d)[16], const float *ximg_p, int ty, int q) {
+        const __amdgpu_buffer_rsrc_t xd = wg_rsrc(ximg_p);
+        const int gq = 4 * q + wave;
+        const int gx = __builtin_amdgcn_readfirstlane(gq * xgrp);
+        int vo[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vo[t][j] = vx[t][j];
+        if (gq == 0 && kh == 0) vo[0][0] = -1;                    // x = -1
+        if (gq == G - 1 && kh == 1) vo[1][3] = -1;                // x = W
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yi = 2 * ty - 1 + i;
+            const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi);
+            const int so = __builtin_amdgcn_readfirstlane(gx + yc * xrow);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[i * 4 + j].x = wg_ld(xd, vo[0][j], so);
+                d[i * 4 + j].y = wg_ld(xd, vo[1][j], so);
+            }
+        }
+        const bool top = ty == 0, bottom = ty == TY - 1;          // wave-uniform: selects
+        const f32x2w zero = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[0 * 4 + j] = top ? zero : d[0 * 4 + j];
+            d[3 * 4 + j] = bottom ? zero : d[3 * 4 + j];
+        }
+    };
+    // V = B^T d B of both tiles (packed) -> LDS buffer `buf`, slot of this wave's group: [group][lane][xi][tile]
+    auto xform_store = [&](const f32x2w (&d)[16], int buf) {
+        f32x2w tq[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tq[0 * 4 + j] = pk_sub0(d[0 * 4 + j], d[2 * 4 + j]);
+            tq[1 * 4 + j] = pk_add0(d[1 * 4 + j], d[2 * 4 + j]);
+            tq[2 * 4 + j] = pk_sub0(d[2 * 4 + j], d[1 * 4 + j]);
+            tq[3 * 4 + j] = pk_sub0(d[1 * 4 + j], d[3 * 4 + j]);
+        }
+        float *o = sV + buf * WH_BUF + (wave * 64 + lane) * WH_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                              // the two columns of this half only
+            const f32x2w va = HH == 0 ? pk_sub0(tq[i * 4 + 0], tq[i * 4 + 2]) : pk_sub0(tq[i * 4 + 2], tq[i * 4 + 1]);
+            const f32x2w vb = HH == 0 ? pk_add0(tq[i * 4 + 1], tq[i * 4 + 2]) : pk_sub0(tq[i * 4 + 1], tq[i * 4 + 3]);
+            *reinterpret_cast<f32x4v *>(o + 4 * i) = f32x4v{va.x, va.y, vb.x, vb.y};
+        }
+    };
+    auto read_v = [&](f32x4v (&V)[4], int buf, int j) {
+        const float *o = sV + buf * WH_BUF + (j * 64 + lane) * WH_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) V[i] = *reinterpret_cast<const f32x4v *>(o + 4 * i);
+    };
+    auto load_y = [&](f32x2w (&y)[4], __amdgpu_buffer_rsrc_t yd, int g) {
+        const int gy = __builtin_amdgcn_readfirstlane(g * ygrp);
+        y[0].x = wg_ld(yd, vy[0][0], gy);
+        y[1].x = wg_ld(yd, vy[0][1], gy);
+        y[2].x = wg_ld(yd, vy[0][0], gy + yrow);
+        y[3].x = wg_ld(yd, vy[0][1], gy + yrow);
+        y[0].y = wg_ld(yd, vy[1][0], gy);
+        y[1].y = wg_ld(yd, vy[1][1], gy);
+        y[2].y = wg_ld(yd, vy[1][0], gy + yrow);
+        y[3].y = wg_ld(yd, vy[1][1], gy + yrow);
+    };
+    auto mfma_group = [&](const f32x4v (&V)[4], const f32x2w (&y)[4]) {
+        f32x2w tz[8], Z[8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {                              // Z' = A' dY A'^T,  A' = [1 0; 1 1; 1 -1; 0 1]
+            tz[0 * 2 + b] = y[0 * 2 + b];
+            tz[1 * 2 + b] = pk_add(y[0 * 2 + b], y[1 * 2 + b]);
+            tz[2 * 2 + b] = pk_sub(y[0 * 2 + b], y[1 * 2 + b]);
+            tz[3 * 2 + b] = y[1 * 2 + b];                          // sign folded into the reduction
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (HH == 0) {
+                Z[i * 2 + 0] = tz[i * 2 + 0];
+                Z[i * 2 + 1] = pk_add(tz[i * 2 + 0], tz[i * 2 + 1]);
+            } else {
+                Z[i * 2 + 0] = pk_sub(tz[i * 2 + 0], tz[i * 2 + 1]);
+                Z[i * 2 + 1] = tz[i * 2 + 1];
+            }
+        }
+        if constexpr (HH == 0) {                                   // the bias gradient rides with the first half
+            const f32x2w bs = pk_add(tz[1 * 2 + 0], tz[1 * 2 + 1]);    // (y0 + y2) + (y1 + y3) of both tiles
+            bsum += bs.x;
+            bsum += bs.y;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[a >> 1][(a & 1) * 2], Z[a].x, acc[a], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[a >> 1][(a & 1) * 2 + 1], Z[a].y, acc[a], 0, 0, 0);
+    };
+
+    // ---- quads: NQ = rows * Q, software-pipelined over the quads ---------------------------------------------------
+    // Vector-memory loads return in order, so the ORDER of issue decides what a wait covers: the output gradients of a
+    // group are issued one group ahead of their use and always BEFORE the 32 long-latency patch loads of the next quad
+    // (which are needed only at the end of the iteration); the first group's gradients of quad n + 1 are issued in front
+    // of the last MFMAs of quad n.  Only the LDS reads of a quad's first group (behind the barrier) are exposed.
+    const int NQ = (r1 - r0) * Q;
+    f32x2w xn[16];
+    f32x4v Va[4], Vb[4];
+    f32x2w ya[4], yb[4];
+    int ty = r0 % TY, q = 0, n = 0;
+    const float *px = ximg_ptr(r0 / TY), *py = yrow_ptr(r0 / TY, ty);          // current image of the input / tile row of the gradients
+    if (NQ > 0) {
+        load_x(xn, px, ty, 0);
+        load_y(ya, wg_rsrc(py), 0);
+        xform_store(xn, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NQ > 0) read_v(Va, 0, 0);
+    // The body is branch-free (the last quad is peeled off through the same lambda): with an `if (more)` inside, hipcc keeps
+    // the transform of the next quad out of the MFMA stream and merges the wait counts of both paths conservatively.
+    // The quad's barrier sits in front of its LAST group's MFMAs (as in conv_wino.hip): by then every wave has written the
+    // next quad's V and issued its last reads of this one, so the next quad's first operands are fetched from LDS under
+    // the cover of those MFMAs.  Va enters a quad holding its first group.
+    auto quad = [&](auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        const int buf = n & 1;
+        int tyn = ty, qn = q + 1;
+        const float *pxn = px, *pyn = py;
+        if (qn == Q) {                                            // (wave-uniform: scalar selects, no branch)
+            qn = 0;
+            pyn += ystep;
+            if (++tyn == TY) tyn = 0, pxn += ximg;
+        }
+        const __amdgpu_buffer_rsrc_t yd = wg_rsrc(py);
+        read_v(Vb, buf, 1);
+        load_y(yb, yd, 4 * q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) load_x(xn, pxn, tyn, qn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Va, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(Va, buf, 2);
+        load_y(ya, yd, 4 * q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Vb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(Vb, buf, 3);
+        load_y(yb, yd, 4 * q + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (more) {                                     // the next quad's patches were loaded two groups ago
+            xform_store(xn, buf ^ 1);
+        }
+        mfma_group(Va, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (more) {
+            load_y(ya, wg_rsrc(pyn), 4 * qn);                     // first group of the next quad
+            read_v(Va, buf ^ 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(Vb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        px = pxn, py = pyn, ty = tyn, q = qn, ++n;
+    };
+    while (n + 1 < NQ) quad(std::true_type());
+    if (NQ > 0) quad(std::false_type());
+
+    float *out = P.slab + (((long)ks * 16) * Cx + rt * 32) * Cy + ct * 32 + l31;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * kh, xi = 4 * (a >> 1) + 2 * HH + (a & 1);
+            out[((long)xi * Cx + row) * Cy] = acc[a][v];
+        }
+    if (HH == 0 && P.bslab && rt == 0) {
+        const float b = bsum + __shfl_xor(bsum, 32, 64);
+        if (kh == 0) P.bslab[(long)ks * Cy + ct * 32 + l31] = b;
+    }
+    };
+    if (lb2 & 1) body(std::integral_constant<int, 1>());
+    else body(std::integral_constant<int, 0>());
+}
+
 // stage 1: U[xi][ci][co] = sum over the tile-row ranges, in fixed order (one thread per element: coalesced, 16*Cx*Cy threads)
 // (n is a multiple of 4: 16 * Cx * Cy.)  One float4 column per thread; the partial slabs are fetched eight at a time so
 // that eight 16-byte loads are in flight per lane, and added in slab order - the same sums, element by element, as a
@@ -663,7 +930,11 @@ extern "C" int rnh_wino_wgrad(const rnh_wgrad_args_t *args, float *xp, const int
         hipLaunchKernelGGL(wino_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, s.Cx);
         RNH_CHECK_LAUNCH("rnh_wino_wgrad(pad)");
     }
-    if (lds)
+    // RNH_WGRAD_HALF=0 keeps the one-workgroup-per-CU kernel for A/B measurements (bit-identical results)
+    const char *eh = getenv("RNH_WGRAD_HALF");
+    if (lds && !(eh && eh[0] == '0'))
+        hipLaunchKernelGGL(wino_wgrad_half_kernel, dim3(items / 2), dim3(256), 0, st, b, s.Cx, s.Cy, s.KS, s.rows_per);
+    else if (lds)
         hipLaunchKernelGGL(wino_wgrad_lds_kernel, dim3(items / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);
     else
         hipLaunchKernelGGL(wino_wgrad_kernel, dim3((items + 3) / 4), dim3(256), 0, st, b, xp, s.Cx, s.Cy, s.KS, s.rows_per);

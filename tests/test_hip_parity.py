@@ -562,8 +562,8 @@ def test_weight_gradient_kernels_vs_torch_float64(which, B, H, W):
     W % 32 == 0: the variant that shares the input transform through LDS, W = 16: the per-lane variant on the padded
     copy) and, where the Winograd form does not apply (odd sizes), rnh_conv_wgrad.  ConvLSTM (two 64-channel sources,
     256 columns), PixelShuffle conv (dy gathered from the 2x larger tensor, strided column map) and refine conv1's
-    hidden-state rows (ten sources with frame offsets).  Where both Winograd variants apply they accumulate the tiles
-    in the same order and must agree bit for bit."""
+    hidden-state rows (ten sources with frame offsets).  Where the Winograd variants apply (per lane, LDS-shared with one workgroup
+    per CU, LDS-shared with half the transform domain per workgroup) they accumulate the tiles in the same order and must agree bit for bit."""
     import torch.nn.functional as F
     from hipvsr.hip_ops import HipOps
     from hipvsr.plans import NetPlans, Src
@@ -612,10 +612,12 @@ def test_weight_gradient_kernels_vs_torch_float64(which, B, H, W):
         rb[:128] = rb128
         sel = True
     res = {}
-    old = os.environ.get('RNH_WGRAD_LDS')
+    old = {k: os.environ.get(k) for k in ('RNH_WGRAD_LDS', 'RNH_WGRAD_HALF')}
     try:
-        for name, wino, lds in (('lds', True, '1'), ('lane', True, '0'), ('pixel', False, '1')):
-            os.environ['RNH_WGRAD_LDS'] = lds
+        # 'half' = the product's choice where W % 32 == 0 (two workgroups per CU, each half of the transform domain), 'lds' = one workgroup
+        # per CU with all 16 positions, 'lane' = no LDS sharing, 'pixel' = the direct (non-Winograd) kernel
+        for name, wino, lds, half in (('half', True, '1', '1'), ('lds', True, '1', '0'), ('lane', True, '0', '1'), ('pixel', False, '1', '1')):
+            os.environ['RNH_WGRAD_LDS'], os.environ['RNH_WGRAD_HALF'] = lds, half
             ops = HipOps(dev)
             ops.wino_wgrad = wino
             dw, db = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
@@ -623,10 +625,11 @@ def test_weight_gradient_kernels_vs_torch_float64(which, B, H, W):
             torch.cuda.synchronize()
             res[name] = (dw.cpu(), db.cpu())
     finally:
-        if old is None:
-            os.environ.pop('RNH_WGRAD_LDS', None)
-        else:
-            os.environ['RNH_WGRAD_LDS'] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for name, (dw, db) in res.items():
         _kernel_close(dw, rw, f'{which}.dw[{name}]', ulps=64)
         _kernel_close(db, rb, f'{which}.db[{name}]', ulps=64)
@@ -635,6 +638,7 @@ def test_weight_gradient_kernels_vs_torch_float64(which, B, H, W):
             mask[:128, hidx] = False
             assert float(dw[mask].abs().max()) == 0.0                      # entries the plan does not map stay untouched
     assert torch.equal(res['lds'][0], res['lane'][0]) and torch.equal(res['lds'][1], res['lane'][1])
+    assert torch.equal(res['half'][0], res['lds'][0]) and torch.equal(res['half'][1], res['lds'][1])
 
 
 def _cfg2_step(n, seed=202):
