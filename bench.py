@@ -293,8 +293,8 @@ def run_case(args, dtype, dev, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
     ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
     ap.add_argument('--size', type=int, default=128, help='LR height = width')
