@@ -169,3 +169,23 @@ def test_lds_dma_weight_gradient_kernel_keeps_its_pipeline(tmp_path):
         if ln.startswith('scratch_'):
             bad.append(ln)
     assert not bad, bad[:8]
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
+def test_half_domain_weight_gradient_kernel_fits_two_workgroups_per_cu(tmp_path):
+    """wino_wgrad_half_kernel (csrc/wgrad_wino.hip, round 3) is faster than the one-workgroup kernel only because TWO of its workgroups fit
+    a CU - one wave of each per SIMD, one's loads and transform adds under the other's MFMAs: at most 256 registers per wave, at most
+    80 KB of LDS per workgroup, no scratch, and all 128 accumulators of a half (64 MFMAs per group pass pair) in the loop."""
+    text = _asm(os.path.join(CSRC, 'wgrad_wino.hip'), str(tmp_path))
+    m = re.search(r'\.amdhsa_kernel (\S*wino_wgrad_half_kernel\S*)(.*?)\.end_amdhsa_kernel', text, re.S)
+    assert m, 'kernel not found'
+    meta = m.group(2)
+    val = lambda k: int(re.search(k + r'\s+(\d+)', meta).group(1))                              # noqa: E731
+    assert val('amdhsa_next_free_vgpr') <= 256, 'more than 256 registers: one workgroup per CU again'
+    assert val('amdhsa_group_segment_fixed_size') <= 80 * 1024
+    assert val('amdhsa_private_segment_fixed_size') == 0, 'scratch in the weight-gradient kernel'
+    kernels = list(_kernels(text, 'wino_wgrad_half_kernel'))
+    assert len(kernels) == 1
+    lines = kernels[0][1]
+    assert not any(ln.startswith('scratch_') for ln in lines)
+    assert sum(ln.startswith('v_mfma_f32_32x32x2') for ln in lines) >= 2 * 4 * 16 * 2            # both halves x 4 groups x 16 MFMAs x (steady state + peeled last quad)
