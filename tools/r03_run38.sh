@@ -1,0 +1,16 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r03_ah
+mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+for dt in f32 bf16; do
+  mkdir -p $O/trace_$dt
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$dt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --dtype $dt > $O/trace_$dt/bench_line.json 2> $O/trace_$dt/err.log
+  f=$(find $O/trace_$dt -name '*kernel_trace.csv' | head -1)
+  python tools/step_window.py $f > $O/${dt}_step_window.txt
+  cp $(find $O/trace_$dt -name '*kernel_stats.csv' | head -1) $O/${dt}_kernel_stats.csv
+  rm -rf $O/trace_$dt
+done
+python profiles/summarize.py $O/f32_kernel_stats.csv 4 | head -12
+python profiles/summarize.py $O/bf16_kernel_stats.csv 4 | head -14
+head -2 $O/f32_step_window.txt; head -2 $O/bf16_step_window.txt
