@@ -585,7 +585,7 @@ def test_xcol_m_kernels_vs_torch(out_dt):
 @pytest.mark.parametrize('nf,dh_dt,rec_dt,edge', [(64, torch.bfloat16, torch.bfloat16, 'mid'), (64, torch.float32, torch.bfloat16, 'first'),
                                                   (64, torch.bfloat16, torch.float32, 'last'), (8, torch.bfloat16, torch.bfloat16, 'mid'),
                                                   (32, torch.float32, torch.float32, 'mid')])
-def test_fused_gate_backward_epilogue_equals_the_two_launches_bitwise(nf, dh_dt, rec_dt, edge, B, H, W):
+def test_fused_gate_backward_epilogue_equals_the_two_launches_bitwise(nf, dh_dt, rec_dt, edge, B, H, W, monkeypatch):
     """rnh_conv_bf16 with RNH_EPI_LSTM_BWD (the data gradient of a ConvLSTM cell with the gate backward of the chain's next frame in its
     epilogue) against what it replaces: the same convolution storing [input gradient | recurrent state gradient] followed by
     rnh_lstm_gates_bwd_m - bit for bit, in the 128-column (64 + 64) and the 64-column tile (8 + 8, 32 + 32), on whole and ragged tiles,
@@ -594,6 +594,7 @@ def test_fused_gate_backward_epilogue_equals_the_two_launches_bitwise(nf, dh_dt,
     from hipvsr.hip_ops import HipOps
     from hipvsr.plans import Dst, NetPlans, Src
     from hipvsr.spec import state_dict_spec
+    monkeypatch.setenv('RNH_FUSE_GATES_BWD', '1')                              # (the suite may run with the A/B switch set the other way)
     dev = _dev()
     cfg = _full_cfg(num_features=[nf, nf])
     P, ops = NetPlans(cfg, bf16=True), HipOps(dev)
