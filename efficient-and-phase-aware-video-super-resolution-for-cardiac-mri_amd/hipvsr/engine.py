@@ -23,13 +23,105 @@ from . import lib as L
 from .plans import Dst, NetPlans, Src
 
 
+def _span_src(store, k0, n):
+    t, o = store.span(k0, n)
+    return Src(t, img_off=o)
+
+
 class Context:
     """What the forward keeps for the backward."""
-    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad', 'tail_bf16')
+    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad', 'tail_bf16', 'recompute')
 
     def __init__(self):
         self.stages = []
         self.packed_dgrad = False
+        self.recompute = False
+
+
+class FrameStore:
+    """N images for every frame k in [lo, hi) of one per-frame tensor of a stage (a hidden state, a cell state, the features).
+
+    Liveness (reference src/model/nets/refine_net.py:61-135 keeps every frame's tensors alive through autograd; what the hand-written
+    backward reads again is less): of a ConvLSTM layer's h only the frames around the T supervised ones come back - as the second
+    K source of the cell's weight gradient and, for the top layer, as refine windows -, of c the supervised frames and their
+    predecessors, of the features the supervised frames.  So a store is allocated in up to three pieces - the frames before
+    ``keep`` = [klo, khi), the frames of ``keep``, the frames behind - and ``release()`` drops the outer two as soon as the stage's forward
+    has passed them (no copy, no event: the pieces are separate allocations, every access below is per frame or inside ``keep``).
+    ``ring`` > 0: the frames outside ``keep`` share ``ring`` slots in processing order (``step`` = +1: ascending k) instead of having a piece
+    each - only for tensors whose frame k is read by nobody but the same chain's next cell, i.e. the cell state: the two launches
+    are ordered by their stream, so slot reuse needs no event."""
+
+    def __init__(self, ops, N, lo, hi, keep, shape, dtype, ring=0, step=1, alloc=True):
+        self.N, self.lo, self.hi, self.step, self.R = N, lo, hi, step, ring
+        self.segs = []                                           # (k0, k1, tensor, kept)
+        self.ring = None
+        if not alloc:                                            # the caller hands the pieces over (put)
+            self.klo, self.khi = keep if keep is not None else (lo, lo)
+            return
+        if keep is None:
+            keep = (lo, lo)
+        klo, khi = max(keep[0], lo), min(keep[1], hi)
+        if khi <= klo:
+            klo = khi = lo
+        self.klo, self.khi = klo, khi
+        mk = lambda a, b: ops.empty((b - a) * N, *shape, dtype=dtype)               # noqa: E731
+        if ring:
+            self.ring = mk(0, ring) if (klo - lo) + (hi - khi) > 0 else None
+            if khi > klo:
+                self.segs.append((klo, khi, mk(klo, khi), True))
+        else:
+            self.ring = None
+            for a, b, kept in ((lo, klo, False), (klo, khi, True), (khi, hi, False)):
+                if b > a:
+                    self.segs.append((a, b, mk(a, b), kept))
+
+    def put(self, a, b, t):
+        """Frames [a, b) are the tensor t (a piece produced elsewhere); kept if that is the ``keep`` range."""
+        self.segs.append((a, b, t, (a, b) == (self.klo, self.khi)))
+
+    def loc(self, k):
+        """(tensor, image offset) of frame k."""
+        for a, b, t, _ in self.segs:
+            if a <= k < b:
+                return t, (k - a) * self.N
+        if self.ring is None or not self.lo <= k < self.hi:
+            raise IndexError(f'frame {k} is not held (frames [{self.lo}, {self.hi}), kept [{self.klo}, {self.khi}))')
+        idx = k - self.lo if self.step > 0 else self.hi - 1 - k
+        return self.ring, (idx % self.R) * self.N
+
+    def src(self, k, **kw):
+        t, o = self.loc(k)
+        return Src(t, img_off=o, **kw)
+
+    def view(self, k):
+        t, o = self.loc(k)
+        return t[o:o + self.N]
+
+    def span(self, k0, n):
+        """(tensor, image offset) of the n consecutive frames from k0 - they must lie in one piece."""
+        for a, b, t, _ in self.segs:
+            if a <= k0 and k0 + n <= b:
+                return t, (k0 - a) * self.N
+        raise IndexError(f'frames [{k0}, {k0 + n}) do not lie in one piece of {[(a, b) for a, b, _, _ in self.segs]}')
+
+    def frames(self, k0, k1):
+        t, o = self.span(k0, k1 - k0)
+        return t[o:o + (k1 - k0) * self.N]
+
+    def pieces(self, k0=None, k1=None):
+        """[(a, b)]: the frame ranges of [k0, k1) piece by piece."""
+        k0, k1 = self.lo if k0 is None else k0, self.hi if k1 is None else k1
+        return [(max(a, k0), min(b, k1)) for a, b, _, _ in self.segs if min(b, k1) > max(a, k0)]
+
+    def release(self):
+        """Drop everything outside ``keep``."""
+        self.segs = [sg for sg in self.segs if sg[3]]
+        self.ring = None
+        self.lo, self.hi = self.klo, self.khi
+
+    def nbytes(self):
+        ts = [t for _, _, t, _ in self.segs] + ([self.ring] if self.ring is not None else [])
+        return sum(t.numel() * t.element_size() for t in ts)
 
 
 class RefineNetEngine:
@@ -52,6 +144,51 @@ class RefineNetEngine:
             raise ValueError(f'refine_window_size {cfg.refine_window_size} needs more than {L.MAX_SRC} conv sources')
         if cfg.num_features[0] != cfg.num_features[-1]:
             raise ValueError('num_features[0] must equal num_features[-1] (residual add, refine_net.py:102)')
+
+    # ------------------------------------------------------------------------------------------------
+    # activation memory ("activation-memory plan (recompute vs. store)")
+    gate_memory = 'auto'          # 'store' | 'recompute' | 'auto' (RNH_GATES overrides): see recompute_gates
+    AUTO_FRACTION = 0.80          # 'auto' stores the gates while the estimated peak of the step stays below this share of the device memory
+
+    def memory_plan(self, N, H, W, F, recompute=False):
+        """Estimated HBM bytes of one training step (forward with gradients + backward) at this shape: what every stage keeps for the
+        backward (see FrameStore: the hidden / cell states around the supervised frames, the gates of the supervised frames unless
+        they are recomputed, the upsampler's intermediates), the largest transient working set on top of it, and their sum."""
+        cfg, P = self.cfg, self.plans
+        U, S, hw, w = cfg.num_updated_frames, cfg.num_stages, self.hw, cfg.refine_window_size
+        T = F - 2 * U
+        px, ea = N * H * W, (2 if self.bf16 else 4)
+        nf, C, Cl = P.nf, P.C, P.Cl
+        c1p = getattr(P, 'C1p', 0)
+        tail_bf16 = self.bf16 and len(P.up) > 1
+        e_sb = 4 if len(P.up) == 1 else ea
+        e_y = ea if tail_bf16 else 4
+        per = dict(h_lower=2 * sum(nf[:-1]) * (T + 1) * px * ea, c=2 * sum(nf) * (T + 1) * px * 4,
+                   gates=0 if recompute else 2 * sum(nf) * 4 * T * px * ea, feat=T * px * C * ea, r1=T * px * c1p * ea, sb=3 * T * px * C * e_sb)
+        ys, scale = 0, 1
+        for u in P.up[:-1]:                                     # the PixelShuffle stages in front of the collapsed tail keep their output
+            scale *= u['r']
+            ys += 3 * T * px * scale * scale * C * e_y
+        per['ys'] = ys
+        kept = S * sum(per.values()) + 2 * nf[-1] * px * ea * ((S - 1) * F + (U + T + hw))        # + the top layer's h, whole
+        o_all = 2 * S * 3 * T * px * cfg.upscale_factor ** 2 * cfg.out_channels * 4               # outputs and their gradient
+        fwd_t = (2 * sum(nf[:-1]) * (F - T - 1) * px * ea + 4 * sum(nf) * 2 * px * 4 + (F - 2 * hw) * px * Cl * ea +
+                 max(U - hw, 1) * px * c1p * ea + 2 * F * px * C * ea)
+        bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
+                 4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if recompute else 0))
+        return dict(per_stage=per, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
+                    peak=kept + o_all + max(fwd_t, bwd_t))
+
+    def recompute_gates(self, N, H, W, F):
+        """Does the backward recompute the ConvLSTM gates (one more cell launch per cell and supervised frame) instead of reading
+        gates the forward stored?  'auto': only where the stored-gates step is estimated not to fit the device."""
+        mode = os.environ.get('RNH_GATES', self.gate_memory)
+        if mode not in ('store', 'recompute', 'auto'):
+            raise ValueError(f"gate memory plan must be 'store', 'recompute' or 'auto', got {mode!r}")
+        if mode != 'auto':
+            return mode == 'recompute'
+        total = self.ops.total_memory() if hasattr(self.ops, 'total_memory') else None
+        return bool(total) and self.memory_plan(N, H, W, F, recompute=False)['peak'] > self.AUTO_FRACTION * total
 
     # ------------------------------------------------------------------------------------------------
     def param_order(self):
@@ -96,15 +233,22 @@ class RefineNetEngine:
 
         ctx = Context()
         ctx.N, ctx.H, ctx.W, ctx.F, ctx.T = N, H, W, F, T
+        ctx.recompute = recompute = bool(need_grad and self.recompute_gates(N, H, W, F))
         params = self._views(params)
         x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
         ctx.x_all = x_all
         self._pack(params, 'fwd')
         act, f32 = self.act, self.f32
-        feat = ops.inconv_fwd(x_all, params['in_block.conv.weight'], params['in_block.conv.bias'],
-                              params['in_block.prelu.weight'])
-        if self.bf16:
-            feat = ops.cast(feat, act)                            # the input block's features cross into bf16 storage here
+        # the features of the F frames, in pieces: the backward reads the T supervised frames again (first K source of layer 0's
+        # weight gradient), the update frames on both sides only feed this stage's forward
+        sup = (U, U + T) if need_grad else None
+        feat = FrameStore(ops, N, 0, F, sup, (H, W, C), act, alloc=False)
+        for a, b in ([(0, U), (U, U + T), (U + T, F)] if need_grad else [(0, F)]):
+            y = ops.inconv_fwd(x_all[a * N:b * N], params['in_block.conv.weight'], params['in_block.conv.bias'],
+                               params['in_block.prelu.weight'])
+            if self.bf16:
+                y = ops.cast(y, act)                              # the input block's features cross into bf16 storage here
+            feat.put(a, b, y)
         P4 = (ops.phase_plane(pos_codes, N, F, H, W, dtype=act, channels=P.pw) if self.bf16 else
               ops.phase_plane(pos_codes, N, F, H, W)) if P.pos else None
         # the tail kernels read their input in fp32 (csrc/uptail.hip) or, for the x4 / x8 nets' r = 2 tail, in bf16
@@ -124,21 +268,27 @@ class RefineNetEngine:
             # stream, ordered along k by the stream and against the layer below by an event, and up to 2*L cells
             # of the layer/frame wavefront run concurrently.
             dirs = ('forward', 'backward')
-            for d in dirs:
-                st[d] = dict(H=[ops.empty(F * N, H, W, hd, dtype=act) for hd in nf], C=[ops.empty(F * N, H, W, hd) for hd in nf],
-                             G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad else None)
             # In the last stage nothing reads the hidden states past the last refine window (the feature update after it is
             # dead, quirk Q5): the forward direction stops at frame U+T-1+hw, the backward one at U-hw, and the refine
             # block only computes the T supervised windows.  Outputs and gradients are unchanged.
             last = s == S - 1
             F_s = U + T + hw if last else F
+            for d in dirs:
+                fwd = d == 'forward'
+                lo_d, hi_d = (0, F_s) if fwd else (F - F_s, F)
+                # what the backward reads again: the supervised frames and, per direction, the frame in front of them (second K source of
+                # the weight gradient, previous cell state); the top layer's h feeds the refine windows and stays whole
+                keep = ((U - 1, U + T) if fwd else (U, U + T + 1)) if need_grad else None
+                st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), act) for l, hd in enumerate(nf)],
+                             C=[FrameStore(ops, N, lo_d, hi_d, keep, (H, W, hd), f32, ring=2, step=1 if fwd else -1) for hd in nf],
+                             G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and not recompute else None)
             ops.fork(2 * Lr)
             for idx in range(F_s):
                 for di, d in enumerate(dirs):
                     k = idx if d == 'forward' else F - 1 - idx
                     prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
                     Hb, Cb, Gb = st[d]['H'], st[d]['C'], st[d]['G']
-                    grad_frame = need_grad and U <= k < U + T
+                    grad_frame = Gb is not None and U <= k < U + T
                     below = None
                     for l in range(Lr):
                         with ops.side(di * Lr + l):
@@ -146,64 +296,83 @@ class RefineNetEngine:
                                 ops.wait(below)
                             pl = P.lstm[(d, l)]
                             xin = feat if l == 0 else Hb[l - 1]
-                            srcs = [Src(xin, img_off=k * N)]
+                            srcs = [xin.src(k)]
                             if cfg.memory:
                                 if prev is not None:
-                                    srcs.append(Src(Hb[l], img_off=prev * N))
+                                    srcs.append(Hb[l].src(prev))
                                     plan = pl['full']
                                 else:
                                     plan = pl['first']
                             else:
-                                srcs.append(Src(xin, img_off=k * N))
+                                srcs.append(xin.src(k))
                                 plan = pl['full']
                             ops.conv(plan, srcs, N, H, W, lstm=dict(
-                                hd=pl['hd'], c_prev=Cb[l][prev * N:(prev + 1) * N] if prev is not None else None,
-                                h_out=Hb[l][k * N:(k + 1) * N], c_out=Cb[l][k * N:(k + 1) * N],
+                                hd=pl['hd'], c_prev=Cb[l].view(prev) if prev is not None else None,
+                                h_out=Hb[l].view(k), c_out=Cb[l].view(k),
                                 gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
                             below = ops.record() if l + 1 < Lr else None
             ops.join(2 * Lr)
-            Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
+            for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
+                for l in range(Lr):
+                    if l < Lr - 1:
+                        st[d]['H'][l].release()
+                    st[d]['C'][l].release()
+            HF, HB = st['forward']['H'][-1], st['backward']['H'][-1]      # top layer: every frame of [lo, hi) in one piece
 
             # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
             w0, nwin = (U - hw, T) if last else (0, F - 2 * hw)     # first window computed, number of windows
-            srcs = []
-            for j in range(w):
-                srcs += [Src(Hf, img_off=(w0 + j) * N), Src(Hbk, img_off=(w0 + j) * N)]
-                if P.pos:
-                    srcs.append(Src(P4, img_off=(w0 + j) * N))
             R = ops.empty(nwin * N, H, W, Cl, dtype=act)
+
+            def win_srcs(a):
+                out = []
+                for j in range(w):
+                    out += [HF.src(a + j), HB.src(a + j)]
+                    if P.pos:
+                        out.append(Src(P4, img_off=(a + j) * N))
+                return out
             if P.pos:
-                R1 = ops.empty(nwin * N, H, W, P.C1p, dtype=act)
-                lo, hi = w0 * N, (w0 + nwin + w - 1) * N            # the source frames of these windows
-                if P.r1_wino:
-                    ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
-                    ops.refine_phase_bias(R1, P4[lo:hi], params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
-                elif P.xcol_m:
-                    # bf16 path: 2*Cl columns in one launch; the last channel frame by frame (one small convolution over the source
-                    # frames whose columns are the window slots, then a sum over the slots)
-                    ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 2 * Cl)])
-                    nfr = nwin + w - 1
-                    Z5 = ops.empty(nfr * N, H, W, 8)
-                    ops.conv(P.r1x_fwd, [Src(Hf, img_off=lo), Src(Hbk, img_off=lo), Src(P4, img_off=lo)], nfr * N, H, W, dsts=[Dst(Z5, 8)])
-                    ops.xcol_combine_m(Z5, params[P.r1_fwd.bkey], R1, N, w, 2 * Cl)
-                elif P.r1_split:
-                    ops.conv(P.r1_fwd_a, srcs, nwin * N, H, W, dsts=[Dst(R1, 2 * Cl)])
-                    ops.conv(P.r1_fwd_b, srcs, nwin * N, H, W, dsts=[Dst(R1, P.C1p - 2 * Cl, c0=2 * Cl)])
-                else:
-                    ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)])
-                if P.xcol:
-                    ops.refine_xcol_fwd([Hf[lo:hi], Hbk[lo:hi], P4[lo:hi]], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
-                if P.r2_wino:
-                    ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nwin * N, H, W, dsts=[Dst(R, Cl)])
-                    ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nwin * N, H, W, dsts=[Dst(R, Cl, accumulate=True)])
-                else:
-                    ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(R, Cl)])
-                st['R1'], st['w0'] = (R1 if need_grad else None), w0
+                # conv1's output R1 comes back in the backward for the T supervised windows only (conv2's weight gradient): they get
+                # a buffer of their own, the windows on both sides a transient one each
+                wsegs = [(w0, U - hw), (U - hw, U - hw + T), (U - hw + T, w0 + nwin)] if need_grad else [(w0, w0 + nwin)]
+                for a, b in wsegs:
+                    if b <= a:
+                        continue
+                    nw = b - a
+                    srcs = win_srcs(a)
+                    R1 = ops.empty(nw * N, H, W, P.C1p, dtype=act)
+                    hfs, hbs, p4s = HF.frames(a, b + w - 1), HB.frames(a, b + w - 1), P4[a * N:(b + w - 1) * N]   # the source frames of these windows
+                    if P.r1_wino:
+                        ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+                        ops.refine_phase_bias(R1, p4s, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
+                    elif P.xcol_m:
+                        # bf16 path: 2*Cl columns in one launch; the last channel frame by frame (one small convolution over the source
+                        # frames whose columns are the window slots, then a sum over the slots)
+                        ops.conv(P.r1_fwd_a, srcs, nw * N, H, W, dsts=[Dst(R1, 2 * Cl)])
+                        nfr = nw + w - 1
+                        Z5 = ops.empty(nfr * N, H, W, 8)
+                        ops.conv(P.r1x_fwd, [HF.src(a), HB.src(a), Src(P4, img_off=a * N)], nfr * N, H, W, dsts=[Dst(Z5, 8)])
+                        ops.xcol_combine_m(Z5, params[P.r1_fwd.bkey], R1, N, w, 2 * Cl)
+                    elif P.r1_split:
+                        ops.conv(P.r1_fwd_a, srcs, nw * N, H, W, dsts=[Dst(R1, 2 * Cl)])
+                        ops.conv(P.r1_fwd_b, srcs, nw * N, H, W, dsts=[Dst(R1, P.C1p - 2 * Cl, c0=2 * Cl)])
+                    else:
+                        ops.conv(P.r1_fwd, srcs, nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
+                    if P.xcol:
+                        ops.refine_xcol_fwd([hfs, hbs, p4s], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
+                    ro = (a - w0) * N
+                    if P.r2_wino:
+                        ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
+                        ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, accumulate=True, img_off=ro)])
+                    else:
+                        ops.conv(P.r2_fwd, [Src(R1)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
+                    if need_grad and a == U - hw:
+                        st['R1'] = R1                           # windows U-hw .. U-hw+T-1
+                    del R1
             else:
-                ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R, Cl)])
+                ops.conv(P.r1_fwd, win_srcs(w0), nwin * N, H, W, dsts=[Dst(R, Cl)])
 
             # ---- three output groups through the upsampler (refine_net.py:100-113, :194-205) --------------
-            fc = feat[U * N:(U + T) * N]
+            fc = feat.frames(U, U + T)
             skip_up = last_only and not need_grad
             if skip_up and s < S - 1:
                 nb = 0                                        # no output group of this stage is consumed
@@ -214,8 +383,8 @@ class RefineNetEngine:
             else:
                 nb = 3
                 Sb = ops.empty(3 * TN, H, W, C, dtype=sb_dt)
-                ops.add(Sb[0:TN], fc, Hf[U * N:(U + T) * N])
-                ops.add(Sb[TN:2 * TN], fc, Hbk[U * N:(U + T) * N])
+                ops.add(Sb[0:TN], fc, HF.frames(U, U + T))
+                ops.add(Sb[TN:2 * TN], fc, HB.frames(U, U + T))
                 ops.add(Sb[2 * TN:], fc, R[(U - hw - w0) * N:(U - hw - w0 + T) * N])
             Oview = O_all[s] if nb == 3 else O_all[s, 2:3]
             cur, h, wd, Ys = (Sb if nb else None), H, W, []
@@ -242,11 +411,16 @@ class RefineNetEngine:
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
             if S > 1 and s < S - 1:
-                nfeat = ops.empty(F * N, H, W, C, dtype=act)
-                ops.add(nfeat[0:hw * N], feat[0:hw * N], Hf[0:hw * N])
-                ops.add(nfeat[hw * N:(F - hw) * N], feat[hw * N:(F - hw) * N], R)
-                ops.add(nfeat[(F - hw) * N:], feat[(F - hw) * N:], Hbk[(F - hw) * N:])
+                nfeat = FrameStore(ops, N, 0, F, sup, (H, W, C), act)
+                for lo_r, hi_r, other in ((0, hw, lambda a, b: HF.frames(a, b)), (hw, F - hw, lambda a, b: R[(a - hw) * N:(b - hw) * N]),
+                                          (F - hw, F, lambda a, b: HB.frames(a, b))):
+                    for a, b in nfeat.pieces(lo_r, hi_r):
+                        ops.add(nfeat.frames(a, b), feat.frames(a, b), other(a, b))
+                feat.release()                                # (the stage's entry keeps the supervised frames alive)
                 feat = nfeat
+            del R
+        if need_grad:
+            feat.release()
         return O_all, (ctx if need_grad else None)
 
     # ------------------------------------------------------------------------------------------------
@@ -287,7 +461,7 @@ class RefineNetEngine:
         for s in range(S - 1, -1, -1):
             st = ctx.stages[s]
             feat, Sb, Ys = st['feat'], st['Sb'], st['Ys']
-            Hf, Hbk = st['forward']['H'][-1], st['backward']['H'][-1]
+            HF, HB = st['forward']['H'][-1], st['backward']['H'][-1]
             # ---- upsampler backward (3 branches x T frames at once) -----------------------------------------
             sH, sW = dO_all.shape[3], dO_all.shape[4]
             dO = dO_all[s].view(3 * TN, sH, sW, cfg.out_channels)
@@ -338,7 +512,7 @@ class RefineNetEngine:
             # ---- refine block backward on the T supervised windows --------------------------------------------
             xs = []
             for j in range(w):
-                xs += [Src(Hf, img_off=(U - hw + j) * N), Src(Hbk, img_off=(U - hw + j) * N)]
+                xs += [HF.src(U - hw + j), HB.src(U - hw + j)]
                 if P.pos:
                     xs.append(Src(ctx.P4, img_off=(U - hw + j) * N))
             k1, b1 = P.r1_wgrad.wkey, P.r1_wgrad.bkey
@@ -355,7 +529,7 @@ class RefineNetEngine:
                     ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
-                ops.wgrad(P.r2_wgrad, [Src(st['R1'], img_off=(U - hw - st['w0']) * N)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
+                ops.wgrad(P.r2_wgrad, [Src(st['R1'])], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
                           grads[P.r2_wgrad.bkey], accumulate=a)
                 a = acc(k1)
                 acc(b1)
@@ -366,7 +540,7 @@ class RefineNetEngine:
                     E = ops.xcol_gather_m(dR1p[hw * N:(hw + T) * N], N, w, 2 * Cl, act)
                     f0, nfr = (U - hw) * N, T + w - 1
                     dbx = ops.zeros(8)                                   # (zeros: the launch below may run in accumulate mode)
-                    ops.wgrad(P.r1x_wgrad, [Src(Hf, img_off=f0), Src(Hbk, img_off=f0), Src(ctx.P4, img_off=f0)], [Src(E)], nfr * N, H, W,
+                    ops.wgrad(P.r1x_wgrad, [HF.src(U - hw), HB.src(U - hw), Src(ctx.P4, img_off=f0)], [Src(E)], nfr * N, H, W,
                               grads[k1][P.C1 - 1].view(w, P.C1, 3, 3), dbx[:w], accumulate=a)
                     ops.put_scalar(grads[b1][P.C1 - 1:P.C1], dbx[0:1], a)
                 elif P.r1_wino:
@@ -382,8 +556,8 @@ class RefineNetEngine:
                     ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                 if P.xcol:
                     lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
-                    ops.refine_xcol_wgrad([Hf[lo:hi], Hbk[lo:hi], ctx.P4[lo:hi]], dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w,
-                                          Cl, a)
+                    ops.refine_xcol_wgrad([HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]],
+                                          dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w, Cl, a)
                 gsrc = dR1p
                 st['R1'] = None
             else:
@@ -425,6 +599,25 @@ class RefineNetEngine:
             TMP = None if cfg.memory else {d: [ops.empty(N, H, W, P.lstm[(d, l)]['cx'], dtype=act) for l in range(Lr)] for d in dirs}
             dh_next = {d: [None] * Lr for d in dirs}
             dc_next = {d: [None] * Lr for d in dirs}
+            # gate recomputation (ctx.recompute: the forward stored no gates): the cell's forward launch runs again, on the cell's own
+            # stream right in front of the launch that consumes the gates, from the saved layer input, previous hidden and cell state
+            # (all inside the stores' kept ranges) - the same kernel on the same operands, so the gates and therefore every gradient
+            # are bit-identical to the stored-gates step; its h' / c' go to scratch
+            RG = {d: [(ops.empty(N, H, W, 4 * hd, dtype=act), ops.empty(N, H, W, hd, dtype=act), ops.empty(N, H, W, hd)) for hd in nf]
+                  for d in dirs} if ctx.recompute else None
+
+            def gates_of(d, l, k):
+                """The saved gates of cell (d, l) at supervised frame k (call inside the cell's ops.side block)."""
+                sd = st[d]
+                if sd['G'] is not None:
+                    return sd['G'][l][(k - U) * N:(k - U + 1) * N]
+                kp = k - (1 if d == 'forward' else -1)
+                pl = P.lstm[(d, l)]
+                xin = feat if l == 0 else sd['H'][l - 1]
+                g, hs, cs = RG[d][l]
+                ops.conv(pl['full'], [xin.src(k), sd['H'][l].src(kp) if cfg.memory else xin.src(k)], N, H, W,
+                         lstm=dict(hd=pl['hd'], c_prev=sd['C'][l].view(kp), h_out=hs, c_out=cs, gates_out=g))
+                return g
             ops.fork(2 * Lr, bank=1)
             if fused:
                 # The gate backward of a frame rides in the epilogue of the data-gradient launch of the frame its chain processed just before
@@ -450,19 +643,19 @@ class RefineNetEngine:
                             pl = P.lstm[(d, l)]
                             hd, cx = pl['hd'], pl['cx']
                             dh_of = (lambda f: top[f * N:(f + 1) * N]) if l == Lr - 1 else (lambda f, l=l: DX[d][l + 1][f * N:(f + 1) * N])
-                            c_at = lambda kk, l=l: Cb[l][kk * N:(kk + 1) * N] if 0 <= kk < F else None
+                            c_at = lambda kk, l=l: Cb[l].view(kk) if 0 <= kk < F else None
                             with ops.side(di * Lr + l):
                                 if idx == 0:                        # head of the chain
                                     if l < Lr - 1:
                                         ops.wait(evs[(d, l + 1, 0)])
-                                    ops.lstm_gates_bwd(dh_of(fi), None, Gb[l][fi * N:(fi + 1) * N], c_at(k2), c_at(k),
+                                    ops.lstm_gates_bwd(dh_of(fi), None, gates_of(d, l, k), c_at(k2), c_at(k),
                                                        Gd[d][l][fi * N:(fi + 1) * N], DCP[d][l][0] if has_next else None)
                                 dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
                                 bw = None
                                 if has_next:
                                     if l < Lr - 1:
                                         ops.wait(evs[(d, l + 1, idx + 1)])
-                                    bw = dict(dh=dh_of(fi2), dc_next=DCP[d][l][idx & 1], gates=Gb[l][fi2 * N:(fi2 + 1) * N], c_prev=c_at(k2 - step),
+                                    bw = dict(dh=dh_of(fi2), dc_next=DCP[d][l][idx & 1], gates=gates_of(d, l, k2), c_prev=c_at(k2 - step),
                                               c_next=c_at(k2), dgates=Gd[d][l][fi2 * N:(fi2 + 1) * N],
                                               dc_prev=DCP[d][l][(idx + 1) & 1] if idx + 2 < T else None, hd=hd, rec_dtype=act)
                                 ops.conv(pl['dgrad'], [Src(Gd[d][l][fi * N:(fi + 1) * N])], N, H, W, dsts=[Dst(dxbuf, cx)], lstm_bwd=bw)
@@ -485,10 +678,10 @@ class RefineNetEngine:
                             pl = P.lstm[(d, l)]
                             hd, cx = pl['hd'], pl['cx']
                             dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
-                            c_prev = Cb[l][prevk * N:(prevk + 1) * N] if 0 <= prevk < F else None
+                            c_prev = Cb[l].view(prevk) if 0 <= prevk < F else None
                             dg = Gd[d][l][fi * N:(fi + 1) * N]
                             dcp = DCP[d][l][idx & 1] if prev_grad else None
-                            ops.lstm_gates_bwd(dh, dc_next[d][l], Gb[l][fi * N:(fi + 1) * N], c_prev, Cb[l][k * N:(k + 1) * N], dg,
+                            ops.lstm_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg,
                                                dcp, dh2=dh_next[d][l])
                             dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
                             dhp = None
@@ -513,11 +706,11 @@ class RefineNetEngine:
                     with ops.side(di * Lr + l):
                         pl = P.lstm[(d, l)]
                         xin = feat if l == 0 else Hb[l - 1]
-                        second = Src(Hb[l], img_off=(U - step) * N) if cfg.memory else Src(xin, img_off=U * N)
+                        second = _span_src(Hb[l], U - step, T) if cfg.memory else _span_src(xin, U, T)
                         wk, bk = pl['wgrad'].wkey, pl['wgrad'].bkey
                         a = acc(wk)
                         acc(bk)
-                        ops.wgrad(pl['wgrad'], [Src(xin, img_off=U * N), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
+                        ops.wgrad(pl['wgrad'], [_span_src(xin, U, T), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
                                   accumulate=a)
             ops.join(2 * Lr)
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)

@@ -75,6 +75,10 @@ class HipOps:
     def zeros(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
+    def total_memory(self):
+        """HBM bytes of the device (what the engine's 'auto' gate-memory plan is sized against)."""
+        return torch.cuda.get_device_properties(self.device).total_memory
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -76,12 +76,23 @@ class RefineNet(BaseNet):
         # accumulation, BASELINE.json configs[2]).  Not a constructor argument - the reference's constructor is the
         # boundary - and never visible in state_dict(): parameters and checkpoints are fp32 either way.
         self.compute_dtype = os.environ.get('RNH_DTYPE', 'f32')
+        # activation-memory plan of the training step (hipvsr.engine.RefineNetEngine.recompute_gates): 'store' keeps the ConvLSTM gates of
+        # the supervised frames for the backward, 'recompute' re-runs the cell launch there instead (bit-identical gradients, one more
+        # launch per cell and frame), 'auto' recomputes only where the stored-gates step is estimated not to fit the device
+        self.gate_memory = 'auto'
 
     def set_compute_dtype(self, dtype):
         """'f32' or 'bf16'; takes effect at the next forward (the engine and its packed weights are rebuilt)."""
         if dtype not in ('f32', 'bf16'):
             raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
         self.compute_dtype = dtype
+        return self
+
+    def set_gate_memory(self, mode):
+        """'store', 'recompute' or 'auto' (see above); takes effect at the next forward."""
+        if mode not in ('store', 'recompute', 'auto'):
+            raise ValueError(f"gate memory plan must be 'store', 'recompute' or 'auto', got {mode!r}")
+        self.gate_memory = mode
         return self
 
     def _engine(self):
@@ -93,6 +104,7 @@ class RefineNet(BaseNet):
             from hipvsr.engine import RefineNetEngine
             from hipvsr.hip_ops import HipOps
             self._eng = RefineNetEngine(self.cfg, HipOps(dev), dtype=self.compute_dtype)
+        self._eng.gate_memory = self.gate_memory
         return self._eng
 
     def forward(self, inputs, pos_codes):

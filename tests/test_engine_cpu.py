@@ -304,3 +304,136 @@ def test_fused_gate_backward_schedule_equals_the_two_launch_schedule(g1, monkeyp
         assert (ga[k] is None) == (gb[k] is None)
         if ga[k] is not None:
             assert torch.equal(ga[k], gb[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: activation-memory plan (liveness of the ConvLSTM states, gate recomputation)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fuse', ['0', 'any'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', ['x4_pos1_mem1', 'x2_pos1_mem0', 'x3_pos0_mem1'])
+def test_gate_recomputation_equals_the_stored_gates_step_bitwise(g1, monkeypatch, case, dtype, fuse):
+    """RNH_GATES=recompute: the forward stores no gates, the backward re-runs the cell's forward launch in front of every gate
+    backward (engine.backward, gates_of) - same operands, same operator, so loss and every gradient must equal the stored-gates step
+    bit for bit, in the frame-by-frame and in the fused (skewed) BPTT schedule; the extra launches are counted."""
+    calls = {'cell': 0}
+    conv = TorchOps.conv
+
+    def count_conv(self, plan, *a, **k):
+        calls['cell'] += k.get('lstm') is not None
+        return conv(self, plan, *a, **k)
+
+    monkeypatch.setattr(TorchOps, 'conv', count_conv)
+    monkeypatch.setenv('RNH_FUSE_GATES_BWD', '0' if fuse == '0' else '1')
+    if fuse == 'any':
+        monkeypatch.setenv('RNH_FUSE_ANY', '1')
+    monkeypatch.setenv('RNH_GATES', 'store')
+    cfg, Oa, ta, ga = run_engine(g1[case], dtype=dtype)
+    n_store = calls['cell']
+    calls['cell'] = 0
+    monkeypatch.setenv('RNH_GATES', 'recompute')
+    _, Ob, tb, gb = run_engine(g1[case], dtype=dtype)
+    T = len(g1[case]['targets'])
+    assert calls['cell'] == n_store + cfg.num_stages * 2 * len(cfg.num_features) * T     # one more cell launch per (cell, supervised frame)
+    assert torch.equal(Oa, Ob) and torch.equal(ta, tb)
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None)
+        if ga[k] is not None:
+            assert torch.equal(ga[k], gb[k]), k
+
+
+def test_forward_keeps_only_what_the_backward_reads(g1, monkeypatch):
+    """Liveness: after the forward a stage holds, per direction, the hidden states of the lower layers and the cell
+    states of T + 1 frames (the supervised ones and the one in front of them), the top layer's hidden states of the frames the stage
+    computed, the gates / features / refine intermediates of the T supervised frames - not F frames of everything; frames outside are
+    gone (an access raises), and the bytes agree with engine.memory_plan()['per_stage'] to the byte."""
+    from hipvsr.engine import FrameStore
+    monkeypatch.setenv('RNH_GATES', 'store')
+    c = g1['x4_pos1_mem1']
+    cfg = NetConfig(**c['kwargs'])
+    eng = RefineNetEngine(cfg, TorchOps('cpu'))
+    params = {k: v.clone() for k, v in c['state_dict'].items()}
+    _, ctx = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
+    N, _, H, W = c['inputs'][0].shape
+    F, U, S = len(c['inputs']), cfg.num_updated_frames, cfg.num_stages
+    T, hw, Lr = F - 2 * U, cfg.refine_window_size // 2, len(cfg.num_features)
+    plan = eng.memory_plan(N, H, W, F)
+    nb = lambda t: t.numel() * t.element_size()                       # noqa: E731
+    kept = 0
+    for s, st in enumerate(ctx.stages):
+        per = dict(h_lower=0, c=0, gates=0, feat=st['feat'].nbytes(), r1=nb(st['R1']), sb=nb(st['Sb']), ys=sum(nb(y) for y in st['Ys']))
+        top = 0
+        for d, (klo, khi) in (('forward', (U - 1, U + T)), ('backward', (U, U + T + 1))):
+            for l in range(Lr):
+                hs, cs = st[d]['H'][l], st[d]['C'][l]
+                assert isinstance(hs, FrameStore) and cs.ring is None and (cs.klo, cs.khi) == (klo, khi)
+                per['c'] += cs.nbytes()
+                if l < Lr - 1:
+                    assert (hs.lo, hs.hi) == (klo, khi)
+                    per['h_lower'] += hs.nbytes()
+                    with pytest.raises(IndexError):
+                        hs.view(klo - 1)
+                    with pytest.raises(IndexError):
+                        hs.view(khi)
+                else:
+                    top += hs.nbytes()
+                with pytest.raises(IndexError):
+                    cs.view(khi)
+                per['gates'] += nb(st[d]['G'][l])
+        assert (st['feat'].lo, st['feat'].hi) == (U, U + T) and st['R1'].shape[0] == T * N
+        frames_top = F if s < S - 1 else U + T + hw
+        assert top == 2 * frames_top * N * H * W * cfg.num_features[-1] * 4
+        assert per == plan['per_stage'], (s, per, plan['per_stage'])
+        kept += sum(per.values()) + top
+    assert kept == plan['kept']
+    # and the same step with recomputation keeps no gates at all
+    monkeypatch.setenv('RNH_GATES', 'recompute')
+    _, ctx2 = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
+    assert ctx2.recompute and all(st[d]['G'] is None for st in ctx2.stages for d in ('forward', 'backward'))
+    assert eng.memory_plan(N, H, W, F, recompute=True)['per_stage']['gates'] == 0
+
+
+def test_cell_state_ring_and_frame_store_pieces():
+    """FrameStore: three separately allocated pieces around ``keep``; ring mode shares two slots in processing order, in both directions."""
+    from hipvsr.engine import FrameStore
+    ops = TorchOps('cpu')
+    fs = FrameStore(ops, 2, 0, 10, (3, 6), (4, 4, 8), torch.float32)
+    assert [(a, b, k) for a, b, _, k in fs.segs] == [(0, 3, False), (3, 6, True), (6, 10, False)]
+    assert fs.view(4).data_ptr() == fs.segs[1][2][2:4].data_ptr() and fs.span(3, 3)[1] == 0 and fs.pieces(2, 7) == [(2, 3), (3, 6), (6, 7)]
+    with pytest.raises(IndexError):
+        fs.span(2, 3)                                               # straddles two pieces
+    fs.release()
+    assert len(fs.segs) == 1 and fs.frames(3, 6).shape[0] == 6
+    for step, lo, hi in ((1, 0, 9), (-1, 2, 11)):
+        rs = FrameStore(ops, 2, lo, hi, (4, 7), (4, 4, 8), torch.float32, ring=2, step=step)
+        order = list(range(lo, hi)) if step > 0 else list(range(hi - 1, lo - 1, -1))
+        prev = None
+        for k in order:
+            t, o = rs.loc(k)
+            if not 4 <= k < 7:
+                assert t is rs.ring
+                if prev is not None and prev[0] is rs.ring:
+                    assert o != prev[1]                              # a cell never writes the slot it reads its predecessor from
+            else:
+                assert t is not rs.ring
+            prev = (t, o)
+    none = FrameStore(ops, 2, 0, 5, None, (4, 4, 8), torch.float32, ring=2)
+    assert none.segs == [] and none.ring.shape[0] == 4
+
+
+def test_auto_gate_plan_recomputes_only_where_the_stored_step_does_not_fit():
+    """'auto' (the default): BASELINE config 2 / 5 and config 4 in bf16 store their gates on a 288 GB card, config 4 in fp32 (N = 16, T = 5,
+    256 x 256: an estimated 235 GB peak with stored gates, 154 GB without) recomputes them; RNH_GATES / gate_memory override."""
+    from oracle import refinenet_oracle as orc
+
+    class Ops288(TorchOps):
+        def total_memory(self):
+            return 288 * 10**9
+    for over, n, t, size, dt, want in ((dict(), 8, 7, 128, 'f32', False), (dict(), 8, 11, 96, 'f32', False),
+                                       (dict(upscale_factor=2), 16, 5, 256, 'bf16', False), (dict(upscale_factor=2), 16, 5, 256, 'f32', True),
+                                       (dict(upscale_factor=2), 4, 5, 256, 'f32', False)):
+        eng = RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), Ops288('cpu'), dtype=dt)
+        assert eng.recompute_gates(n, size, size, t + 12) is want, (over, n, dt)
+        eng.gate_memory = 'recompute'
+        assert eng.recompute_gates(n, size, size, t + 12) is True
+    assert RefineNetEngine(NetConfig(**orc.exp1_x4_config()), TorchOps('cpu')).recompute_gates(64, 512, 512, 19) is False    # no device: store
