@@ -6,6 +6,11 @@ N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 ->
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, weak scaling: 8 samples per rank)
+  python bench.py --gpus N ...                            (no WORLD_SIZE in the environment: starts exactly that torchrun command
+                                                           itself, before anything touches the GPU, relays rank 0's line and exits
+                                                           with the children's code; WORLD_SIZE != --gpus is an error)
+  python bench.py --config {2,4,5}                        (BASELINE.json configs[1] (default), [3]: x2, N=16, T=5, 256x256 and [4]: x4 with
+                                                           phase codes, N=8 per GPU, T=11, 96x96; the bf16 step of the same shape as `secondary`)
 
 Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
 ranks); `ms_per_step_median` is the median of the per-step HIP-event times of the same steps.  `roofline` prices the
@@ -35,6 +40,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import subprocess                 # noqa: E402
+
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -54,6 +61,8 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
     w = 4.0 / 9.0 if executed else 1.0        # convolutions that run in Winograd form execute 4/9 of their direct FLOPs
     if executed and scale == 4:
         out_f, out_b = w * 294912 + 51200, 2 * w * 294912 + 65536             # first PixelShuffle conv: fwd, dgrad, wgrad Winograd; tail collapsed
+    elif executed and scale == 2:
+        out_f, out_b = 12800, 16384                                           # the whole upsampler IS the collapsed tail (one PixelShuffle stage)
     lstm_f, lstm_b = w * 589824, 2 * w * 589824                               # fwd, dgrad, wgrad Winograd
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
     r2h, r2x = 128 * 64 * 18, 1 * 64 * 18                                     # conv2: the 128 hidden-state channels / channel 128
@@ -68,24 +77,24 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
     return fwd + bwd
 
 
-def step_flops_bf16(T, U=6, S=3, L=3):
+def step_flops_bf16(T, U=6, S=3, L=3, scale=4):
     """Executed conv FLOPs per LR pixel per sample of the bf16-storage path (x4): every convolution in direct form, refine
     conv1 on 192 padded columns and its phase planes as 8-channel sources are NOT counted (only the reference's 129 x 645),
     the upsampler tail collapsed as in the fp32 path, the dead last-stage work skipped."""
     F = T + 2 * U
     lstm = 589824
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18
-    out_f, out_b = 294912 + 51200, 2 * 294912 + 65536
+    out_f, out_b = (294912 + 51200, 2 * 294912 + 65536) if scale == 4 else (12800, 16384)
     nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
     fwd = F * 1152 + 2 * nfr * L * lstm + nwin * (r1 + r2) + 3 * S * T * out_f
     bwd = T * 1152 + S * 2 * T * L * 2 * lstm + S * T * 2 * (r1 + r2) + 3 * S * T * out_b
     return fwd + bwd
 
 
-def make_net(dev, seed=0):
+def make_net(dev, seed=0, scale=4):
     from src.model.nets import RefineNet
     torch.manual_seed(seed)
-    net = RefineNet(in_channels=1, out_channels=1, num_features=[64, 64, 64], upscale_factor=4, num_stages=3,
+    net = RefineNet(in_channels=1, out_channels=1, num_features=[64, 64, 64], upscale_factor=scale, num_stages=3,
                     update_memory=True, num_updated_frames=6, refine_window_size=5, positional_encoding=True)
     return net.to(dev).train()
 
@@ -209,13 +218,26 @@ def cpu_baseline():
             'tflops': round(step_flops_per_lr_pixel(3) * 64 * 64 / dt / 1e12, 3)}
 
 
+# BASELINE.json configs by their 1-based number: per-GPU batch, supervised frames T, LR size, scale
+CONFIGS = {2: dict(batch=8, frames=7, size=128, scale=4), 4: dict(batch=16, frames=5, size=256, scale=2), 5: dict(batch=8, frames=11, size=96, scale=4)}
+
+
+def config_label(args, bf):
+    c = CONFIGS[args.config]
+    if (args.batch, args.frames, args.size, args.scale) != (c['batch'], c['frames'], c['size'], c['scale']):
+        return 'a shape of its own: --batch / --frames / --size given'
+    if args.config == 2:
+        return f'BASELINE config {3 if bf else 2}'
+    return f'BASELINE config {args.config}' + (', bf16 storage' if bf else '') + (' per GPU' if args.config == 5 else '')
+
+
 def run_case(args, dtype, dev, world, rank):
     """W warm-up steps, then exactly K timed steps of the training step in `dtype`, bracketed by barrier + synchronize on both
     sides; the step time is the max over ranks.  Returns the fields of the JSON line that belong to this case."""
     from hipvsr import dp
     from hipvsr.step_tail import FlatAdam
     from src.runner.trainers import AcdcVSRRefineNetTrainer
-    net = make_net(dev, seed=0)
+    net = make_net(dev, seed=0, scale=args.scale)
     net.set_compute_dtype(dtype)
     dp.broadcast_parameters(net)
     opt = FlatAdam(net.parameters(), lr=1e-4, weight_decay=0)      # exp1_x4.yaml:56-60; one launch per run of parameters
@@ -223,7 +245,7 @@ def run_case(args, dtype, dev, world, rank):
     tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
     tr.loss_weights = torch.tensor([1.0], device=dev)
     tr.graph, tr._graphed = args.graph == 'on', None
-    inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + 2 + rank)
+    inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + args.config + rank, s=args.scale)
 
     def barrier():
         if world > 1:
@@ -251,23 +273,24 @@ def run_case(args, dtype, dev, world, rank):
     dt = float(tt)
     n_global = args.batch * world
     bf = dtype == 'bf16'
-    flop_step = step_flops_per_lr_pixel(args.frames) * args.size * args.size * n_global
-    flop_exec = step_flops_per_lr_pixel(args.frames, executed=True) * args.size * args.size * n_global
+    flop_step = step_flops_per_lr_pixel(args.frames, scale=args.scale) * args.size * args.size * n_global
+    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
-        flop_exec = step_flops_bf16(args.frames) * args.size * args.size * n_global
+        flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
     out = None
     if rank == 0:
         roof = lstm_kernel_roofline(net, dev, args.batch, args.size, args.size)
         out = {
-            'metric': 'cine-frames/sec fwd+bwd, x4 SR 128->512 T=7', 'value': round(n_global * args.frames * args.steps / dt, 3), 'unit': 'frames/s',
+            'metric': f'cine-frames/sec fwd+bwd, x{args.scale} SR {args.size}->{args.scale * args.size} T={args.frames}', 'value': round(n_global * args.frames * args.steps / dt, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
             'ms_per_step_median': round(median_ms, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': f'RefineNet x4 training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
+            'config': {'workload': f'RefineNet x{args.scale} training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
-                                   f'{4 * args.size}x{4 * args.size}, {prec}, exp1_x4 net (BASELINE config {3 if bf else 2})',
+                                   f'{args.scale * args.size}x{args.scale * args.size}, {prec}, exp1_x4 net'
+                                   f'{" with upscale_factor=2" if args.scale == 2 else ""} ({config_label(args, bf)})',
                        'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
                        'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
                        'hip_graph_step': tr._graphed is not None,
@@ -278,6 +301,7 @@ def run_case(args, dtype, dev, world, rank):
                        ('executed_frac_of_bf16_mfma_peak' if bf else 'executed_frac_of_f32_mfma_peak'):
                            round(flop_exec / world / (dt / args.steps) / 1e12 / peak, 4),
                        'final_loss': round(float(loss.detach()), 6),
+                       'gates': 'recomputed' if net._engine().recompute_gates(args.batch, args.size, args.size, args.frames + 12) else 'stored',
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,
         }
@@ -290,14 +314,17 @@ def run_case(args, dtype, dev, world, rank):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
-    ap.add_argument('--frames', type=int, default=7, help='supervised frames T')
-    ap.add_argument('--size', type=int, default=128, help='LR height = width')
+    ap.add_argument('--config', type=int, choices=sorted(CONFIGS), default=2,
+                    help='BASELINE.json config (1-based): 2 = x4, N=8, T=7, 128x128 (the headline; 3 is its bf16 `secondary`), 4 = x2, N=16, T=5, '
+                         '256x256, 5 = x4 with phase codes, N=8 per GPU, T=11, 96x96')
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU (default: the config\'s)')
+    ap.add_argument('--frames', type=int, default=None, help='supervised frames T (default: the config\'s)')
+    ap.add_argument('--size', type=int, default=None, help='LR height = width (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bf16-storage run that rides along as `secondary`')
     ap.add_argument('--graph', choices=['on', 'off'], default='off',
@@ -306,11 +333,89 @@ def main():
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32: the headline (BASELINE config 2, the reference's precision) with the bf16-storage step of BASELINE "
                          "config 3 as `secondary` in the same line; bf16: that bf16 step alone as the line")
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU: the launch / rendezvous / barrier / max-over-ranks protocol over gloo with a stub step (what tests/ checks on CPU)')
+    ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    c = CONFIGS[args.config]
+    args.scale = c['scale']
+    for k in ('batch', 'frames', 'size'):
+        if getattr(args, k) is None:
+            setattr(args, k, c[k])
+    return args
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(gpus, argv, port):
+    """What `python bench.py --gpus N ...` runs when it is not itself a rank: the driver's own multi-GPU command line."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks as a child torchrun (this process never touches the GPU), relay their output -
+    rank 0's JSON line - and return the children's exit code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.run(launcher_command(args.gpus, argv, free_port()), env=env)
+    return proc.returncode
+
+
+def dry_run(args, world, rank):
+    """The multi-rank protocol of run_case without the GPU: process group (gloo), W + K stub steps, barrier on both sides, max over ranks."""
+    if 'RANK' in os.environ:
+        dist.init_process_group('gloo')
+    if rank == args.dry_run_fail_rank:
+        raise SystemExit(3)
+    bar = (lambda: dist.barrier()) if dist.is_initialized() else (lambda: None)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    bar()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    bar()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist.is_initialized():
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no GPU work)', 'value': round(args.batch * world * args.frames * args.steps / float(tt), 3), 'unit': 'frames/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(float(tt) / args.steps * 1e3, 3),
+                          'dry_run': True, 'config': {'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                                                      'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
+                                                      'local_rank_env': os.environ.get('LOCAL_RANK'), 'master_addr': os.environ.get('MASTER_ADDR')}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            # not a rank: become the launcher.  Nothing above has initialised the GPU (importing torch does not), and the ranks are
+            # child processes - never an exec of a process that has touched the device
+            raise SystemExit(launch_ranks(args, argv))
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ['WORLD_SIZE'])
+        rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree; '
+                             f'run `python bench.py --gpus {args.gpus}` (it starts the ranks itself) or torchrun with --nproc-per-node {args.gpus}')
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     dev = torch.device(f'cuda:{local}')
