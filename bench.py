@@ -146,8 +146,8 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
         flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
         byts = n * h * w * (2 * cx + 2 * hd + 4 * hd + 4 * hd + 2 * hd + 2 * 4 * hd)
         tf, tbs = flops / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e12
-        traffic, traffic_src = quoted_traffic('lstm_bf16_kernel_hbm_bytes.json', 'conv_bf16.hip')
-        return {'bound': 'mfma', 'kernel': 'conv_bf16_kernel<LSTM,128,9> (ConvLSTM cell 128->256, direct 3x3 on v_mfma_f32_32x32x16_bf16, fused gates)',
+        traffic, traffic_src = quoted_traffic('lstm_bf16_kernel_hbm_bytes.json', 'conv_bf16.hip', (n, h, w))
+        return {'bound': 'mfma', 'kernel': 'conv_bf16d_kernel<LSTM,128,9,KC 32> (ConvLSTM cell 128->256, direct 3x3 on v_mfma_f32_32x32x16_bf16, fused gates)',
                 'achieved': round(tf, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_MFMA_TFLOPS, 4),
                 'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops,
                 'algorithmic_flop_per_launch': flops,
@@ -158,7 +158,7 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
     flops_exec = flops * 4.0 / 9.0 if wino else flops
     algorithmic = flops / (ms * 1e-3) / 1e12
     executed = flops_exec / (ms * 1e-3) / 1e12
-    traffic, traffic_src = quoted_traffic('lstm_kernel_hbm_bytes.json', 'conv_wino.hip')
+    traffic, traffic_src = quoted_traffic('lstm_kernel_hbm_bytes.json', 'conv_wino.hip', (n, h, w))
     name = f'{wino_kernel_name()}<LSTM> (ConvLSTM cell 128->256 in Winograd F(2x2,3x3) form, fused gates)' if wino else \
         'conv_igemm_kernel<4,1,1,4,LSTM> (ConvLSTM cell 128->256, fused gates)'
     out = {'bound': 'mfma', 'kernel': name, 'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -182,12 +182,18 @@ def kernel_source_sha256(source='conv_wino.hip'):
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def quoted_traffic(record, source):
+def quoted_traffic(record, source, shape=(8, 128, 128)):
     """(HBM bytes per launch, where they come from) out of profiles/<record> (rocprofv3 PMC passes, FETCH_SIZE / WRITE_SIZE corrected as
-    MI355X_MICROARCH.md prescribes) - or (None, None) when the record was measured on another revision of csrc/<source>."""
+    MI355X_MICROARCH.md prescribes) - or (None, None) when the record was measured on another revision of csrc/<source>, at another
+    launch shape than (N, H, W) = ``shape`` (the records are config 2's launch), or when the library in use is not the product build
+    (tools/bench_with_lib.py: a diagnostic build of the same source)."""
+    from hipvsr import lib as L
     prof = os.path.join(ROOT, 'profiles', record)
     try:
         rec = json.load(open(prof))
+        default_lib = os.path.join(PKG, 'hipvsr', 'librefinenet_hip.so')
+        if tuple(shape) != tuple(rec.get('launch_shape', (8, 128, 128))) or os.path.realpath(getattr(L, 'LIB_PATH', default_lib)) != os.path.realpath(default_lib):
+            return None, None
         if rec.get('kernel_source_sha256') == kernel_source_sha256(source):
             return rec.get('hbm_bytes_per_launch'), {k: rec.get(k) for k in ('commit', 'date', 'command')}
     except Exception:
@@ -229,6 +235,11 @@ def config_label(args, bf):
     if args.config == 2:
         return f'BASELINE config {3 if bf else 2}'
     return f'BASELINE config {args.config}' + (', bf16 storage' if bf else '') + (' per GPU' if args.config == 5 else '')
+
+
+def gates_label(net, args):
+    n = net._engine().recompute_stages(args.batch, args.size, args.size, args.frames + 12)
+    return 'stored' if n == 0 else f'recomputed in the backward of {n} of {net.num_stages} stages (activation-memory plan: the stored-gates step does not fit)'
 
 
 def run_case(args, dtype, dev, world, rank):
@@ -277,6 +288,9 @@ def run_case(args, dtype, dev, world, rank):
     flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
+    # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages
+    n_rc = net._engine().recompute_stages(args.batch, args.size, args.size, args.frames + 12)
+    flop_exec += n_rc * 2 * args.frames * 3 * 589824 * (1.0 if bf else 4.0 / 9.0) * args.size * args.size * n_global
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
     out = None
@@ -301,7 +315,7 @@ def run_case(args, dtype, dev, world, rank):
                        ('executed_frac_of_bf16_mfma_peak' if bf else 'executed_frac_of_f32_mfma_peak'):
                            round(flop_exec / world / (dt / args.steps) / 1e12 / peak, 4),
                        'final_loss': round(float(loss.detach()), 6),
-                       'gates': 'recomputed' if net._engine().recompute_gates(args.batch, args.size, args.size, args.frames + 12) else 'stored',
+                       'gates': gates_label(net, args),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,
         }

@@ -35,7 +35,7 @@ class Context:
     def __init__(self):
         self.stages = []
         self.packed_dgrad = False
-        self.recompute = False
+        self.recompute = 0
 
 
 class FrameStore:
@@ -153,9 +153,11 @@ class RefineNetEngine:
     def memory_plan(self, N, H, W, F, recompute=False):
         """Estimated HBM bytes of one training step (forward with gradients + backward) at this shape: what every stage keeps for the
         backward (see FrameStore: the hidden / cell states around the supervised frames, the gates of the supervised frames unless
-        they are recomputed, the upsampler's intermediates), the largest transient working set on top of it, and their sum."""
+        they are recomputed, the upsampler's intermediates), the largest transient working set on top of it, and their sum.
+        ``recompute``: how many stages (the first ones; True = all) recompute their gates instead of storing them."""
         cfg, P = self.cfg, self.plans
         U, S, hw, w = cfg.num_updated_frames, cfg.num_stages, self.hw, cfg.refine_window_size
+        n_rc = S if recompute is True else int(recompute)
         T = F - 2 * U
         px, ea = N * H * W, (2 if self.bf16 else 4)
         nf, C, Cl = P.nf, P.C, P.Cl
@@ -164,31 +166,50 @@ class RefineNetEngine:
         e_sb = 4 if len(P.up) == 1 else ea
         e_y = ea if tail_bf16 else 4
         per = dict(h_lower=2 * sum(nf[:-1]) * (T + 1) * px * ea, c=2 * sum(nf) * (T + 1) * px * 4,
-                   gates=0 if recompute else 2 * sum(nf) * 4 * T * px * ea, feat=T * px * C * ea, r1=T * px * c1p * ea, sb=3 * T * px * C * e_sb)
+                   gates=0 if n_rc == S else 2 * sum(nf) * 4 * T * px * ea, feat=T * px * C * ea, r1=T * px * c1p * ea, sb=3 * T * px * C * e_sb)
         ys, scale = 0, 1
         for u in P.up[:-1]:                                     # the PixelShuffle stages in front of the collapsed tail keep their output
             scale *= u['r']
             ys += 3 * T * px * scale * scale * C * e_y
         per['ys'] = ys
-        kept = S * sum(per.values()) + 2 * nf[-1] * px * ea * ((S - 1) * F + (U + T + hw))        # + the top layer's h, whole
+        kept = S * sum(per.values()) - n_rc * per['gates'] + 2 * nf[-1] * px * ea * ((S - 1) * F + (U + T + hw))        # + the top layer's h, whole
         o_all = 2 * S * 3 * T * px * cfg.upscale_factor ** 2 * cfg.out_channels * 4               # outputs and their gradient
         fwd_t = (2 * sum(nf[:-1]) * (F - T - 1) * px * ea + 4 * sum(nf) * 2 * px * 4 + (F - 2 * hw) * px * Cl * ea +
                  max(U - hw, 1) * px * c1p * ea + 2 * F * px * C * ea)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
-                 4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if recompute else 0))
-        return dict(per_stage=per, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
+                 4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
+        return dict(per_stage=per, recomputing_stages=n_rc, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
                     peak=kept + o_all + max(fwd_t, bwd_t))
 
-    def recompute_gates(self, N, H, W, F):
-        """Does the backward recompute the ConvLSTM gates (one more cell launch per cell and supervised frame) instead of reading
-        gates the forward stored?  'auto': only where the stored-gates step is estimated not to fit the device."""
-        mode = os.environ.get('RNH_GATES', self.gate_memory)
+    def _mem(self, label):
+        """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
+        if os.environ.get('RNH_MEMLOG') == '1' and hasattr(self.ops, 'mem_allocated'):
+            self.__dict__.setdefault('memlog', []).append((label, self.ops.mem_allocated()))
+
+    def recompute_stages(self, N, H, W, F):
+        """How many stages (the first n of S) recompute their ConvLSTM gates in the backward - one more cell launch per cell and supervised
+        frame of those stages - instead of reading gates the forward stored.  'store': 0, 'recompute': all, an integer: that many,
+        'auto': the fewest with which the estimated peak of the step fits AUTO_FRACTION of the device memory (0 wherever the
+        stored-gates step fits)."""
+        S = self.cfg.num_stages
+        mode = str(os.environ.get('RNH_GATES', self.gate_memory))
+        if mode.isdigit():
+            return min(int(mode), S)
         if mode not in ('store', 'recompute', 'auto'):
-            raise ValueError(f"gate memory plan must be 'store', 'recompute' or 'auto', got {mode!r}")
+            raise ValueError(f"gate memory plan must be 'store', 'recompute', 'auto' or a number of stages, got {mode!r}")
         if mode != 'auto':
-            return mode == 'recompute'
+            return S if mode == 'recompute' else 0
         total = self.ops.total_memory() if hasattr(self.ops, 'total_memory') else None
-        return bool(total) and self.memory_plan(N, H, W, F, recompute=False)['peak'] > self.AUTO_FRACTION * total
+        if not total:
+            return 0
+        for n in range(S):
+            if self.memory_plan(N, H, W, F, recompute=n)['peak'] <= self.AUTO_FRACTION * total:
+                return n
+        return S
+
+    def recompute_gates(self, N, H, W, F):
+        """Does any stage recompute its gates at this shape?"""
+        return self.recompute_stages(N, H, W, F) > 0
 
     # ------------------------------------------------------------------------------------------------
     def param_order(self):
@@ -233,7 +254,7 @@ class RefineNetEngine:
 
         ctx = Context()
         ctx.N, ctx.H, ctx.W, ctx.F, ctx.T = N, H, W, F, T
-        ctx.recompute = recompute = bool(need_grad and self.recompute_gates(N, H, W, F))
+        ctx.recompute = n_rc = self.recompute_stages(N, H, W, F) if need_grad else 0       # stages 0 .. n_rc-1 store no gates
         params = self._views(params)
         x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
         ctx.x_all = x_all
@@ -260,7 +281,9 @@ class RefineNetEngine:
         ctx.P4 = P4
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
-        for s in range(S):
+        def run_stage(s, feat):
+            """Stage s of the forward; returns the features the next stage starts from.  A function of its own so that the stage's transients die
+            with its locals before the next stage allocates."""
             st = dict(feat=feat)
             # ---- bidirectional ConvLSTM over the frames (refine_net.py:82-93) ----------------------------
             # One cell launch (N images) fills the chip for well under a millisecond, so its ramp-up and tail matter.
@@ -281,7 +304,7 @@ class RefineNetEngine:
                 keep = ((U - 1, U + T) if fwd else (U, U + T + 1)) if need_grad else None
                 st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), act) for l, hd in enumerate(nf)],
                              C=[FrameStore(ops, N, lo_d, hi_d, keep, (H, W, hd), f32, ring=2, step=1 if fwd else -1) for hd in nf],
-                             G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and not recompute else None)
+                             G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and s >= n_rc else None)
             ops.fork(2 * Lr)
             for idx in range(F_s):
                 for di, d in enumerate(dirs):
@@ -312,6 +335,7 @@ class RefineNetEngine:
                                 gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
                             below = ops.record() if l + 1 < Lr else None
             ops.join(2 * Lr)
+            self._mem(f'fwd stage {s}: wavefront done')
             for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
                 for l in range(Lr):
                     if l < Lr - 1:
@@ -418,7 +442,11 @@ class RefineNetEngine:
                         ops.add(nfeat.frames(a, b), feat.frames(a, b), other(a, b))
                 feat.release()                                # (the stage's entry keeps the supervised frames alive)
                 feat = nfeat
-            del R
+            return feat
+
+        for s in range(S):
+            feat = run_stage(s, feat)
+            self._mem(f'fwd stage {s}: end')
         if need_grad:
             feat.release()
         return O_all, (ctx if need_grad else None)
@@ -458,7 +486,11 @@ class RefineNetEngine:
             return a
 
         dfeat_next = None
-        for s in range(S - 1, -1, -1):
+
+        def stage_backward(s, dfeat_next):
+            """The backward of stage s; returns the gradient w.r.t. the stage's input features on the supervised frames.  A function of its own so that
+            every buffer of the stage - stored gates, dgates, state gradients - dies with its locals BEFORE the next (earlier) stage allocates
+            (a loop body's rebinding `Gd = {...}` builds the new buffers while the old are alive: 30 GiB of overlap at config 4's peak)."""
             st = ctx.stages[s]
             feat, Sb, Ys = st['feat'], st['Sb'], st['Ys']
             HF, HB = st['forward']['H'][-1], st['backward']['H'][-1]
@@ -508,6 +540,7 @@ class RefineNetEngine:
                 ops.add(dfeat, dfeat_next, accumulate=True)
                 ops.add(dR, dfeat_next, accumulate=True)
             st['Sb'] = st['Ys'] = None
+            self._mem(f'bwd stage {s}: upsampler done')
 
             # ---- refine block backward on the T supervised windows --------------------------------------------
             xs = []
@@ -580,6 +613,7 @@ class RefineNetEngine:
                 ops.conv(P.r1_dgrad, [Src(gsrc, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
                          dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
 
+            self._mem(f'bwd stage {s}: refine done')
             # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
             # Same wavefront as the forward, reversed: cell (d, l, k) needs the input gradient of (d, l+1, k) (an
             # event) and the state gradients of its own next-processed frame (stream order).  Buffers that cross
@@ -599,12 +633,12 @@ class RefineNetEngine:
             TMP = None if cfg.memory else {d: [ops.empty(N, H, W, P.lstm[(d, l)]['cx'], dtype=act) for l in range(Lr)] for d in dirs}
             dh_next = {d: [None] * Lr for d in dirs}
             dc_next = {d: [None] * Lr for d in dirs}
-            # gate recomputation (ctx.recompute: the forward stored no gates): the cell's forward launch runs again, on the cell's own
+            # gate recomputation (stages below ctx.recompute: the forward stored no gates): the cell's forward launch runs again, on the cell's own
             # stream right in front of the launch that consumes the gates, from the saved layer input, previous hidden and cell state
             # (all inside the stores' kept ranges) - the same kernel on the same operands, so the gates and therefore every gradient
             # are bit-identical to the stored-gates step; its h' / c' go to scratch
             RG = {d: [(ops.empty(N, H, W, 4 * hd, dtype=act), ops.empty(N, H, W, hd, dtype=act), ops.empty(N, H, W, hd)) for hd in nf]
-                  for d in dirs} if ctx.recompute else None
+                  for d in dirs} if st['forward']['G'] is None else None
 
             def gates_of(d, l, k):
                 """The saved gates of cell (d, l) at supervised frame k (call inside the cell's ops.side block)."""
@@ -713,10 +747,14 @@ class RefineNetEngine:
                         ops.wgrad(pl['wgrad'], [_span_src(xin, U, T), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
                                   accumulate=a)
             ops.join(2 * Lr)
+            self._mem(f'bwd stage {s}: BPTT done')
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
             st['forward'] = st['backward'] = None
-            dfeat_next = dfeat
             ctx.stages[s] = None
+            return dfeat
+
+        for s in range(S - 1, -1, -1):
+            dfeat_next = stage_backward(s, dfeat_next)
 
         # ---- input block backward (supervised frames only, refine_net.py:66-67) --------------------------------
         xc = ctx.x_all[U * N:(U + T) * N]

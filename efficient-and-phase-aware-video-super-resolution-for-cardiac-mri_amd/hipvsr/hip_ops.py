@@ -79,6 +79,9 @@ class HipOps:
         """HBM bytes of the device (what the engine's 'auto' gate-memory plan is sized against)."""
         return torch.cuda.get_device_properties(self.device).total_memory
 
+    def mem_allocated(self):
+        return torch.cuda.memory_allocated(self.device)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -309,13 +309,15 @@ def test_fused_gate_backward_schedule_equals_the_two_launch_schedule(g1, monkeyp
 # ---------------------------------------------------------------------------------------------------------------------
 # round 4: activation-memory plan (liveness of the ConvLSTM states, gate recomputation)
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['recompute', '1'])
 @pytest.mark.parametrize('fuse', ['0', 'any'])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', ['x4_pos1_mem1', 'x2_pos1_mem0', 'x3_pos0_mem1'])
-def test_gate_recomputation_equals_the_stored_gates_step_bitwise(g1, monkeypatch, case, dtype, fuse):
+def test_gate_recomputation_equals_the_stored_gates_step_bitwise(g1, monkeypatch, case, dtype, fuse, mode):
     """RNH_GATES=recompute: the forward stores no gates, the backward re-runs the cell's forward launch in front of every gate
     backward (engine.backward, gates_of) - same operands, same operator, so loss and every gradient must equal the stored-gates step
-    bit for bit, in the frame-by-frame and in the fused (skewed) BPTT schedule; the extra launches are counted."""
+    bit for bit, in the frame-by-frame and in the fused (skewed) BPTT schedule; the extra launches are counted.  mode '1': only the
+    first stage recomputes (what 'auto' picks when all but one stage's gates fit)."""
     calls = {'cell': 0}
     conv = TorchOps.conv
 
@@ -331,10 +333,11 @@ def test_gate_recomputation_equals_the_stored_gates_step_bitwise(g1, monkeypatch
     cfg, Oa, ta, ga = run_engine(g1[case], dtype=dtype)
     n_store = calls['cell']
     calls['cell'] = 0
-    monkeypatch.setenv('RNH_GATES', 'recompute')
+    monkeypatch.setenv('RNH_GATES', mode)
     _, Ob, tb, gb = run_engine(g1[case], dtype=dtype)
     T = len(g1[case]['targets'])
-    assert calls['cell'] == n_store + cfg.num_stages * 2 * len(cfg.num_features) * T     # one more cell launch per (cell, supervised frame)
+    stages = cfg.num_stages if mode == 'recompute' else 1
+    assert calls['cell'] == n_store + stages * 2 * len(cfg.num_features) * T     # one more cell launch per (cell, supervised frame) of those stages
     assert torch.equal(Oa, Ob) and torch.equal(ta, tb)
     for k in ga:
         assert (ga[k] is None) == (gb[k] is None)
