@@ -231,14 +231,15 @@ def test_ten_training_steps_follow_the_oracle_trajectory():
           f'parameters {worst_p:.2e} relative L2, accumulated update {worst_d:.2e}')
 
 
-_TRAIN = dict(steps=300, batch=16, crop=32, t=7, pool=64, lr=1e-4)
+_TRAIN = dict(steps=600, batch=16, crop=32, t=7, pool=64, lr=1e-4, check=50)
 
 
 @pytest.fixture(scope='module')
 def trained():
-    """300 training steps at the reference YAML's training shape (exp1_x4.yaml:21-33: batch 16, 32 x 32 crops, T = 7, Adam lr 1e-4, L1) on the
-    structured cine, from the same initialisation, once in fp32 and once in the bf16-storage path: loss curves, validation PSNR against
-    the TRUE high-resolution frames during training, final weights."""
+    """600 training steps at the reference YAML's training shape (exp1_x4.yaml:21-33: batch 16, 32 x 32 crops, T = 7, Adam lr 1e-4, L1) on the
+    structured cine, from the same initialisation: in fp32, in fp32 from an initialisation perturbed by 1e-6 relative (the noise floor: how
+    far two equally valid fp32 trajectories drift apart), and in the bf16-storage path.  Loss curves, validation PSNR against the TRUE
+    high-resolution frames every 50 steps, final weights."""
     cfg = orc.exp1_x4_config()
     c = _TRAIN
     sd0 = orc.init_state_dict(cfg, seed=61)
@@ -247,43 +248,55 @@ def trained():
     pin, ptg, ppos = [x.to(dev) for x in pool[0]], [y.to(dev) for y in pool[1]], pool[2].to(dev)
     val = orc.structured_cine(cfg, 4, c['t'], 64, 64, seed=63)
     vin, vtg, vpos = [x.to(dev) for x in val[0]], [y.to(dev) for y in val[1]], val[2].to(dev)
-    out = dict(cfg=cfg, val=val)
+    out = dict(cfg=cfg)
     nb = c['pool'] // c['batch']
-    for dt in ('f32', 'bf16'):
-        net = _net(cfg, sd0, dt).train()
+    for name, dt, eps in (('f32', 'f32', 0.0), ('f32 perturbed', 'f32', 1e-6), ('bf16', 'bf16', 0.0)):
+        g = torch.Generator().manual_seed(5)
+        sd = {k: v * (1 + eps * torch.randn(v.shape, generator=g)) for k, v in sd0.items()}
+        net = _net(cfg, sd, dt).train()
         tr = _train_trainer(net, c['lr'])
         losses, psnrs = [], []
         for i in range(c['steps']):
             sl = slice((i % nb) * c['batch'], (i % nb + 1) * c['batch'])
             _, loss, _ = tr.train_step([x[sl] for x in pin], [y[sl] for y in ptg], ppos[sl])
             losses.append(loss.detach())
-            if (i + 1) % 100 == 0:
+            if (i + 1) % c['check'] == 0:
                 net.eval()
                 with torch.no_grad():
-                    o = net(vin, vpos)
-                    psnrs.append(float(tr._compute_metrics(o, vtg)[0]))
+                    psnrs.append(float(tr._compute_metrics(net(vin, vpos), vtg)[0]))
                 net.train()
         torch.cuda.synchronize()
-        out[dt] = dict(losses=[float(x) for x in losses], psnr=psnrs, sd={k: p.detach().cpu().clone() for k, p in net.state_dict().items()})
+        losses = [float(x) for x in losses]
+        out[name] = dict(losses=losses, windows=[sum(losses[i:i + 25]) / 25 for i in range(0, c['steps'], 25)], psnr=psnrs,
+                         sd={k: p.detach().cpu().clone() for k, p in net.state_dict().items()})
         del net, tr
         torch.cuda.empty_cache()
     return out
 
 
 def test_bf16_training_run_tracks_the_fp32_run(trained):
-    """where the bf16-storage run ends up against where the fp32 run ends up - validation PSNR against the true HR
-    frames within 0.05 dB at every check point, loss curves (means over 25-step windows) within 1 %."""
-    f, b = trained['f32'], trained['bf16']
-    w = 25
-    wf = [sum(f['losses'][i:i + w]) / w for i in range(0, len(f['losses']), w)]
-    wb = [sum(b['losses'][i:i + w]) / w for i in range(0, len(b['losses']), w)]
-    worst = max(abs(x - y) / x for x, y in zip(wf, wb))
-    print(f'{_TRAIN["steps"]} steps at batch {_TRAIN["batch"]}, {_TRAIN["crop"]}x{_TRAIN["crop"]} crops: loss {f["losses"][0]:.4f} -> {wf[-1]:.4f} (fp32) / {wb[-1]:.4f} (bf16), '
-          f'worst 25-step window {worst:.2e} apart; validation PSNR vs true HR every 100 steps: fp32 {f["psnr"]}, bf16 {b["psnr"]}')
-    assert wf[-1] < 0.7 * f['losses'][0]                        # the run did train
-    assert worst <= 1e-2, (worst, wf, wb)
-    for x, y in zip(f['psnr'], b['psnr']):
-        assert abs(x - y) < 0.05, (f['psnr'], b['psnr'])
+    """where the bf16-storage run ends up against where the fp32 run ends up.  Training is chaotic: an fp32 run whose
+    initialisation differs by 1e-6 relative leaves the fp32 run after ~150 steps and from then on sits 1-2 % away in the 25-step loss
+    windows and 0.05-0.17 dB away in validation PSNR (profiles/r04_e_training_trajectories.txt) - so "within 1 % / 0.05 dB of the fp32
+    run" is not a property even fp32 has.  Asserted instead: (1) before the trajectories decorrelate (the first 125 steps, loss
+    6.4 -> 0.5, PSNR 25 -> 30 dB) the bf16 run follows the fp32 run to 1e-3 in every loss window and 0.02 dB in PSNR; (2) over the
+    whole run its distance from the fp32 run stays within twice that noise floor, in loss and in PSNR; (3) no systematic lag: the mean
+    signed PSNR difference over the 12 check points is within 0.05 dB of the perturbed run's; (4) it trains: same final loss level."""
+    f, p, b = trained['f32'], trained['f32 perturbed'], trained['bf16']
+    rel = lambda x, y: [abs(u - v) / u for u, v in zip(x, y)]                 # noqa: E731
+    wp, wb = rel(f['windows'], p['windows']), rel(f['windows'], b['windows'])
+    dp_, db = [v - u for u, v in zip(f['psnr'], p['psnr'])], [v - u for u, v in zip(f['psnr'], b['psnr'])]
+    print(f'{_TRAIN["steps"]} steps at batch {_TRAIN["batch"]}, {_TRAIN["crop"]}x{_TRAIN["crop"]} crops: loss {f["losses"][0]:.4f} -> {f["windows"][-1]:.4f} (fp32) / '
+          f'{b["windows"][-1]:.4f} (bf16), PSNR vs true HR {f["psnr"][0]:.2f} -> {f["psnr"][-1]:.2f} / {b["psnr"][-1]:.2f} dB; first 5 windows: bf16 within '
+          f'{max(wb[:5]):.1e} (perturbed fp32 {max(wp[:5]):.1e}); whole run: loss windows within {max(wb):.1e} (perturbed fp32 {max(wp):.1e}), |dPSNR| <= '
+          f'{max(abs(x) for x in db):.3f} dB (perturbed fp32 {max(abs(x) for x in dp_):.3f}), mean signed dPSNR {sum(db) / len(db):+.3f} ({sum(dp_) / len(dp_):+.3f})')
+    assert f['windows'][-1] < 0.05 * f['losses'][0] and f['psnr'][-1] > 38.0           # the run did train
+    assert max(wb[:5]) <= 1e-3, wb[:5]
+    assert abs(db[0]) <= 0.02 and abs(db[1]) <= 0.02, db[:2]
+    assert max(wb) <= 2 * max(wp) + 1e-3, (max(wb), max(wp))
+    assert max(abs(x) for x in db) <= 2 * max(abs(x) for x in dp_) + 0.01, (db, dp_)
+    assert abs(sum(db) / len(db) - sum(dp_) / len(dp_)) <= 0.05, (db, dp_)
+    assert abs(b['windows'][-1] - f['windows'][-1]) <= 0.03 * f['windows'][-1]
 
 
 @pytest.mark.parametrize('name,n,t,size', [('config 1', 1, 3, 64), ('config 2 geometry', 2, 7, 128)])
