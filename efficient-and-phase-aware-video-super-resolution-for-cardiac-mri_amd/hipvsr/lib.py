@@ -12,6 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
+ABI_VERSION = 2          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -212,7 +213,7 @@ def load():
     mine = [C.sizeof(Src), C.sizeof(Dst), C.sizeof(ConvArgs), C.sizeof(WgradArgs)]
     if list(sizes) != mine:
         raise HipKernelError(f'struct layout mismatch between the binding {mine} and the library {list(sizes)}')
-    if lib.rnh_abi_version() != 1:
+    if lib.rnh_abi_version() != ABI_VERSION:
         raise HipKernelError('ABI version mismatch')
     _lib = lib
     return lib

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 1
+#define RNH_ABI_VERSION 2       /* 2 (round 4): rnh_conv_bf16's RNH_EPI_LSTM column layout; argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -188,7 +188,9 @@ int rnh_wino_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, const int
 
 /* Sum the partial slabs and scatter into the reference-layout gradient:
  *   dw[(colmap[j]*Cin + rowmap[i])*ntaps + tap] (+)= sum_s slab[s][tap][i][j]   (rowmap/colmap < 0: skipped)
- *   db[colmap[j]] (+)= sum_s bslab[s][j]                                         (if bslab and db)        */
+ *   db[colmap[j]] (+)= sum_s bslab[s][j]                                         (if bslab and db)
+ * ycols_pad % 4 == 0 (since ABI 2: the slabs are summed with 16-byte loads; RNH_E_ALIGN otherwise - every producer of slabs pads its
+ * columns to a multiple of 32). */
 int rnh_wgrad_reduce(const float *slab, const float *bslab, int nsplit, int ntaps, int xcols_pad, int ycols_pad,
                      const int32_t *rowmap, const int32_t *colmap, int Cin, float *dw, float *db, int accumulate,
                      void *stream);
@@ -199,7 +201,9 @@ int rnh_inconv_prelu_fwd(const float *x, const float *w, const float *bias, cons
                          int B, int H, int W, int Cin, int Cout, void *stream);
 
 /* _InBlock backward: recomputes the pre-activation, returns dW, db, dslope (stored, or accumulated).
- * ws: workspace of rnh_inconv_bwd_ws_floats(Cin, Cout) floats. */
+ * ws: workspace of rnh_inconv_bwd_ws_floats(Cin, Cout) floats.  4 <= Cout <= 256, Cout % 4 == 0 and Cout / 4 a divisor of 256
+ * (since ABI 2: four output channels per thread; RNH_E_RANGE otherwise - num_features[0] of every reference YAML is 64; the
+ * engine (hipvsr/plans.py) refuses other widths when the net is planned). */
 int rnh_inconv_prelu_bwd(const float *x, const float *w, const float *bias, const float *slope, const float *dy,
                          float *dw, float *db, float *dslope, float *ws, int B, int H, int W, int Cin, int Cout,
                          int accumulate, void *stream);
@@ -432,7 +436,10 @@ typedef struct rnh_conv_bf16_args {
     int32_t epilogue;           /* RNH_EPI_*                                                             */
     int32_t ndst;
     int32_t ps_r, ps_cq;        /* RNH_EPI_PS: dst[0] is the (B, rH, rW, cq) tensor; cq % 8 == 0         */
-    int32_t hd;                 /* RNH_EPI_LSTM: hidden channels (multiple of 8), columns as rnh_conv_args_t */
+    int32_t hd;                 /* RNH_EPI_LSTM: hidden channels (multiple of 8); Npad = 128 * ceil(hd / 32), column
+                                 * tile*128 + blk*32 + gate*8 + c = gate `gate` (i, f, o, g) of hidden channel tile*32 + blk*8 + c
+                                 * (hipvsr/plans.py lstm_colmap8) - NOT rnh_conv_args_t's layout: the kernel computes the transposed
+                                 * product, a lane's accumulator quad is one gate of four channels of its pixel */
     rnh_mdst_t dst[RNH_MAX_DST];
     const float *c_prev;        /* fp32 [B][H][W][hd] or 0                                               */
     float *c_out;               /* fp32 [B][H][W][hd]                                                    */
@@ -457,8 +464,9 @@ typedef struct rnh_conv_bf16_args {
 } rnh_conv_bf16_args_t;
 
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA: one workgroup = 8 x 32 output pixels x 128 (64) columns; per
- * 16-channel chunk the 10 x 34 pixel halo of the inputs (converted to bf16 if the source is fp32) and the chunk's
- * packed weights of all taps go through LDS once and serve all 9 taps.  Same call sites as rnh_conv_igemm. */
+ * 16- / 32-channel chunk the 10 x 34 pixel halo of the inputs (converted to bf16 if the source is fp32) goes through LDS once
+ * and serves all 9 taps, the packed weights stream from L2 into registers; the epilogue stays in registers (transposed
+ * product: 16-byte pieces of one pixel per lane).  Same call sites as rnh_conv_igemm. */
 int rnh_conv_bf16(const rnh_conv_bf16_args_t *args /* host */, void *stream);
 /* wp[ks][n][kk] (bf16, kk = 0..15 in natural order) with the index conventions of rnh_pack_weights; biasp fp32. */
 int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,

@@ -147,12 +147,12 @@ class TorchOps:
             t.copy_(v.permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, cq))
         else:
             hd = lstm['hd']
-            if plan.gate_group == 16:                               # 64-column gate groups (plans.lstm_colmap64)
-                ng = (hd + 15) // 16
-                v = y[..., :ng * 64].reshape(B, H, W, ng, 4, 16).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, ng * 16)[..., :hd]
-            else:
-                nt = (hd + 31) // 32
-                v = y.reshape(B, H, W, nt, 4, 32).permute(0, 1, 2, 4, 3, 5).reshape(B, H, W, 4, nt * 32)[..., :hd]
+            # undo the plan's gate layout (plans.lstm_colmap / lstm_colmap64 / lstm_colmap8): column n holds reference output channel colmap[n]
+            cm = torch.tensor(plan.colmap, dtype=torch.long, device=y.device)
+            keep = cm >= 0
+            v = torch.empty(B, H, W, 4 * hd, dtype=y.dtype, device=y.device)
+            v[..., cm[keep]] = y[..., keep]
+            v = v.reshape(B, H, W, 4, hd)
             gi, gf, go = torch.sigmoid(v[..., 0, :]), torch.sigmoid(v[..., 1, :]), torch.sigmoid(v[..., 2, :])
             gg = torch.tanh(v[..., 3, :])
             cp = lstm.get('c_prev')
