@@ -79,19 +79,6 @@ __device__ __forceinline__ float b_tanh(float x) {
 // conv_wino.hip) - in the bf16-storage path h' = o tanh(c') is rounded to 8 bits anyway
 __device__ __forceinline__ float b_tanh_fast(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
 
-// the lane halves trade: afterwards lanes 0..31 hold (their x, the x of lane + 32), lanes 32..63 (the y of lane - 32, their y)
-__device__ __forceinline__ void swap_halves(unsigned &x, unsigned &y) {
-    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);      // v_permlane32_swap_b32: x[32..63] <-> y[0..31]
-    x = r[0];
-    y = r[1];
-}
-__device__ __forceinline__ void swap_halves(float &x, float &y) {
-    unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
-    swap_halves(a, b);
-    x = __builtin_bit_cast(float, a);
-    y = __builtin_bit_cast(float, b);
-}
-
 // wp[ks][n][kk] = W[o][i][tap] as bf16, index conventions of rnh_pack_weights (conv_igemm.hip), kk in natural order
 __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned short *wp, float *biasp, const int *kbase, const int *knv,
                                  const int *ktap, const int *kcoff, const int *colmap, int nk, int Npad, int Cout, int Cin, int ntaps,
@@ -166,7 +153,10 @@ struct GeoD {
     static constexpr int APITCH = KC == 32 ? 80 : PITCH;        // bytes per halo pixel: data + 16 B pad (fragment reads conflict-free for both)
     static constexpr int PPP = 2 * KS;                          // 16-byte pieces per halo pixel
     static constexpr int A_BYTES = HP * APITCH, A_PIECES = PPP * HP, A_ITERS = (A_PIECES + 255) / 256;
-    static constexpr int SMEM = 2 * A_BYTES;                    // the two halo buffers; the epilogue stays in registers
+    static constexpr int OPITCH = NCOLS + 4;                    // floats per parked pixel
+    static constexpr int PXR = NCOLS == 128 ? 128 : 256;        // pixels parked per epilogue round
+    static constexpr int OUT_BYTES = PXR * OPITCH * 4;
+    static constexpr int SMEM = 2 * A_BYTES > OUT_BYTES ? 2 * A_BYTES : OUT_BYTES;
     static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -240,12 +230,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
 
     // weight fragments: descriptor over the packed weights, per-lane offset inside a (chunk, tap) slab, slab stride
     const __amdgpu_buffer_rsrc_t wrs = bdesc(P.wp);
-    // the wave's 32-column blocks of the tile: block(n) = BLK0 + BSTR * n.  Column halves (blocks NB chalf + n) everywhere but in the
-    // LSTM-backward epilogue, whose tile is [input gradient | dh_rec]: there the waves take the blocks in turn (2 n + chalf), so that
-    // every wave finishes one block of each kind - the gate backward (11 loads and 5 stores per item) is spread over all four waves
-    constexpr int BSTR = (EPI == RNH_EPI_LSTM_BWD && NB == 2) ? 2 : 1;
-    const int BLK0 = (EPI == RNH_EPI_LSTM_BWD && NB == 2) ? chalf : NB * chalf;
-    const int wlane = ((nt * NCOLS + BLK0 * 32 + l31) * 16 + kh * 8) * 2;
+    const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
     const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
     const int nslabs = P.nchunks * NTAPS;
     constexpr int RING = NTAPS == 1 ? 1 : (KC == 32 ? 6 : 3), AHEAD = RING - 1;
@@ -258,26 +243,16 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         const bool ok = g < nslabs;
         const int base = ((KS * c + ks) * NTAPS + tap) * slab;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, ok ? base + wlane + n * BSTR * 32 * 32 : -1);
+        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, ok ? base + wlane + n * 32 * 32 : -1);
     };
 
-    // accumulators of the transposed product (see the epilogue): register v of block n = column (v & 3) + 8 (v >> 2) + 4 kh; they start
-    // from the bias of their column
     f32x16 acc[MB][NB];
 #pragma unroll
-    for (int n = 0; n < NB; ++n)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = P.bias ? *reinterpret_cast<const float4 *>(P.bias + nt * NCOLS + (BLK0 + BSTR * n) * 32 + 8 * q + 4 * kh)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                acc[m][n][4 * q] = bv.x;
-                acc[m][n][4 * q + 1] = bv.y;
-                acc[m][n][4 * q + 2] = bv.z;
-                acc[m][n][4 * q + 3] = bv.w;
-            }
-        }
+            for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
     const int nch = P.nchunks / KS;
 
     // One chunk.  The halo of chunk c + 1 sits in registers since step 2 KS of chunk c - 1 (a whole chunk of MFMAs ago, so the
@@ -305,8 +280,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]),
-                                                                        a[(RNH_EXP & 2) ? 0 : (step & 1)][m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (step & 1)][m],
+                                                                        __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
             if constexpr (NTAPS == 1) bload(c + 1, 0);
             if constexpr (NTAPS == 9) __builtin_amdgcn_sched_barrier(0);     // pin the issue order: hipcc otherwise sinks the weight loads to their first use
         }
@@ -327,7 +302,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         BSTAMP(8 + 3 * (c & 15));
         compute(c & 1, c);
         BSTAMP(9 + 3 * (c & 15));
-        if (!(RNH_EXP & 8) && c + 1 < nch) __syncthreads();     // (behind the last chunk nobody writes LDS any more)
+        BSTAMP(10 + 3 * (c & 15));
+        if (!(RNH_EXP & 8)) __syncthreads();
     }
     BSTAMP(1);
     if (RNH_EXP & 16) {                                         // keep the accumulators alive, skip the epilogue
@@ -342,202 +318,212 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         return;
     }
 
-    // ---- epilogue, in registers (round 4; until then the accumulators were parked in LDS as a [pixel][column] tile, two barriers
-    // and 128 four-byte LDS stores per lane: 9.5 k cycles per workgroup for a plain store, 15 k with the gate math).  The MFMAs
-    // computed the TRANSPOSED product - weights as the A operand, pixels as B - so lane l holds pixel x0 + (l & 31) of each of its
-    // MB image rows and, per 32-column block, the columns (v & 3) + 8 (v >> 2) + 4 kh: FOUR consecutive columns per register quad,
-    // and after one v_permlane32_swap_b32 per register (the lane halves trade quads) EIGHT consecutive ones.  Every global
-    // access is a 16-byte piece of one pixel, nothing goes through LDS, no barrier follows the main loop: a wave enters its
-    // epilogue behind its own last MFMA, under the other waves' MFMAs.
-    const int xg = x0 + l31;
-    const bool xin = xg < W;
+    // ---- epilogue: the accumulators (+ bias) are parked as an fp32 [pixel][column] tile, PXR pixels at a time (128-column
+    // tiles: the two pixel halves in turn, parked by the two waves that own them; 64-column tiles: all 256 at once), and
+    // all 256 threads finish 8 columns of a pixel per step with whole-row 16-byte accesses ------------------------------
+    float *ot = reinterpret_cast<float *>(smem);
+    constexpr int PXR = G::PXR, ROUNDS = TH * TW / PXR;
+    // ConvLSTM: the previous cell state of ALL the thread's items (ROUNDS x PXR / 64 pixels x 8 channels, fp32) is requested
+    // here, before the accumulators are parked, as unconditional asm loads from clamped (always valid) addresses; left to
+    // hipcc each load sat right in front of its use, one exposed memory round trip per item - 10 k of the 16 k cycles of the
+    // finishing phase (tools/bf16_stamps.py).  No previous state: any valid address, zeros behind the wait.
+    constexpr int NIT = EPI == RNH_EPI_LSTM ? ROUNDS * (PXR / 64) : 1;
+    typedef float f32x4q __attribute__((ext_vector_type(4)));       // (a plain vector type: HIP's float4 struct would be passed to the asm through memory)
+    [[maybe_unused]] f32x4q cpq[NIT][2];
     if constexpr (EPI == RNH_EPI_LSTM) {
-        // columns (plans.lstm_colmap8): block bb = 2 chalf + n of the tile, register quad q = gate, so v = 4 gate + e is gate `gate` of
-        // hidden channel nt * 32 + bb * 8 + 4 kh + e - the four gates of four hidden channels of a pixel in ONE lane.
-        const int hd = P.hd;
+        const int hd = P.hd, hcl = min(nt * 32 + (tid & 3) * 8, hd - 8);
         const float *csrc = P.c_prev ? P.c_prev : P.c_out;
-        typedef float f32x4q __attribute__((ext_vector_type(4)));       // (a plain vector type: HIP's float4 struct would be passed to the asm through memory)
-        f32x4q cpq[MB][NB];
-        long pix[MB];
-        // the previous cell state of all the lane's items: unconditional asm loads from clamped (always valid) addresses, requested
-        // before the gate activations and awaited behind them (left to hipcc each load sits right in front of its use)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int y = y0 + MB * ph + m;
-            pix[m] = ((long)img * H + min(y, H - 1)) * W + min(xg, W - 1);
+        for (int q = 0; q < NIT; ++q) {
+            const int r = q / (PXR / 64), px = (tid >> 2) + 64 * (q % (PXR / 64));
+            const int y = min(y0 + r * (PXR / TW) + px / TW, H - 1), x = min(x0 + (px & (TW - 1)), W - 1);
+            const float *p = csrc + (((long)img * H + y) * W + x) * hd + hcl;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpq[q][0]) : "v"(p) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cpq[q][1]) : "v"(p) : "memory");
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r > 0) __syncthreads();                             // the previous round has been read
+        if (ROUNDS == 1 || ph == r) {
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                const int hcl = min(nt * 32 + (2 * chalf + n) * 8 + 4 * kh, hd - 4);
-                const float *p = csrc + pix[m] * hd + hcl;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpq[m][n]) : "v"(p) : "memory");
+                const int col = chalf * (NCOLS / 2) + n * 32 + l31;
+                const float bv = P.bias ? P.bias[nt * NCOLS + col] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int px = (ROUNDS == 1 ? MB * ph + m : m) * TW + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                        ot[px * G::OPITCH + col] = acc[m][n][v] + bv;
+                    }
             }
         }
-        // activations in place: 8 of the 10 transcendental pairs per (pixel, channel), no memory operation - they cover the loads above
+        __syncthreads();
+        if (r == 0) BSTAMP(2);
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            if (r == 0) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int n = 0; n < NB; ++n)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[m][n][v] = (v >> 2) == 3 ? b_tanh_fast(acc[m][n][v]) : b_sigmoid(acc[m][n][v]);
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int n = 0; n < NB; ++n) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpq[m][n]));
-        BSTAMP(2);
-        const bool has_c = P.c_prev != nullptr;
-        float *cout = P.c_out;
-        unsigned short *hout16 = reinterpret_cast<unsigned short *>(P.h_out), *gout16 = reinterpret_cast<unsigned short *>(P.gates_out);
-        float *hout32 = reinterpret_cast<float *>(P.h_out), *gout32 = reinterpret_cast<float *>(P.gates_out);
-        const bool h16 = P.h_dtype == RNH_DT_BF16, g16 = P.gates_dtype == RNH_DT_BF16, wantg = P.gates_out != nullptr;
-        const int hc8 = nt * 32 + (2 * chalf + kh) * 8;               // after the swap: the lane's eight hidden channels
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const bool valid = xin && y0 + MB * ph + m < H;
-            float hn[NB][4];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const int hc = nt * 32 + (2 * chalf + n) * 8 + 4 * kh;
-                float cn[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float cp = has_c ? cpq[m][n][e] : 0.f;
-                    cn[e] = acc[m][n][4 + e] * cp + acc[m][n][e] * acc[m][n][12 + e];
-                    hn[n][e] = acc[m][n][8 + e] * b_tanh_fast(cn[e]);
-                }
-                if (valid && hc < hd) {
-                    *reinterpret_cast<float4 *>(cout + pix[m] * hd + hc) = make_float4(cn[0], cn[1], cn[2], cn[3]);
-                    if (!h16) *reinterpret_cast<float4 *>(hout32 + pix[m] * hd + hc) = make_float4(hn[n][0], hn[n][1], hn[n][2], hn[n][3]);
-                    if (wantg && !g16) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<float4 *>(gout32 + pix[m] * 4 * hd + g * hd + hc) =
-                                make_float4(acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
-                    }
-                }
-            }
-            // bf16 destinations: pack the two blocks' quads and let the lane halves trade them - lane half kh then owns the eight
-            // channels of block 2 chalf + kh: one 16-byte store per tensor row piece
-            if constexpr (NB == 2) {
-                if (h16) {
-                    unsigned a0 = pk2(hn[0][0], hn[0][1]), a1 = pk2(hn[0][2], hn[0][3]), b0 = pk2(hn[1][0], hn[1][1]), b1 = pk2(hn[1][2], hn[1][3]);
-                    swap_halves(a0, b0);
-                    swap_halves(a1, b1);
-                    if (valid && hc8 < hd) *reinterpret_cast<uint4 *>(hout16 + pix[m] * hd + hc8) = make_uint4(a0, a1, b0, b1);
-                }
-                if (wantg && g16) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        unsigned a0 = pk2(acc[m][0][4 * g], acc[m][0][4 * g + 1]), a1 = pk2(acc[m][0][4 * g + 2], acc[m][0][4 * g + 3]);
-                        unsigned b0 = pk2(acc[m][1][4 * g], acc[m][1][4 * g + 1]), b1 = pk2(acc[m][1][4 * g + 2], acc[m][1][4 * g + 3]);
-                        swap_halves(a0, b0);
-                        swap_halves(a1, b1);
-                        if (valid && hc8 < hd) *reinterpret_cast<uint4 *>(gout16 + pix[m] * 4 * hd + g * hd + hc8) = make_uint4(a0, a1, b0, b1);
-                    }
-                }
+                for (int q = 0; q < NIT; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpq[q][0]), "+v"(cpq[q][1]));
             }
         }
-    } else {
-        // STORE / PS / LSTM_BWD: per (block n, quad pair p) the lane halves trade quads; lane half kh then holds the eight consecutive
-        // columns from c8 = 32 block(n) + 16 p + 8 kh of the tile.  What those columns are is looked up once per (n, p).
+        const int ybase = y0 + r * (PXR / TW);
+        if constexpr (EPI == RNH_EPI_LSTM) {
+            // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap).  A thread's 8 channels
+            // are the same in every step (256 % 4 == 0): everything but the pixel is hoisted out of the loop
+            const int hd = P.hd, j0 = (tid & 3) * 8, hc = nt * 32 + j0;
+            const float *cprev = P.c_prev;
+            float *cout = P.c_out;
+            void *hout = P.h_out, *gout = P.gates_out;
+            const int hdt = P.h_dtype, gdt = P.gates_dtype;
+            if (hc < hd) {
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+                for (int k = 0; k < PXR / 64; ++k) {
+                    const int px = (tid >> 2) + 64 * k;
+                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const float *o = ot + px * G::OPITCH + j0;
+                    const long pe = ((long)img * H + y) * W + x;
+                    float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
+                    const f32x4q ca = cpq[r * (PXR / 64) + k][0], cb = cpq[r * (PXR / 64) + k][1];
+                    cp[0] = ca.x; cp[1] = ca.y; cp[2] = ca.z; cp[3] = ca.w; cp[4] = cb.x; cp[5] = cb.y; cp[6] = cb.z; cp[7] = cb.w;
+                    if (!cprev) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int c8 = (BLK0 + BSTR * n) * 32 + 16 * p + 8 * kh, n0 = nt * NCOLS + c8;
-                bool live;
-                void *dptr;
-                int ddt, dacc = 0;
-                long dimg = 0, dch = 0, dC = 0;                      // element = ((img' * H + y) * W' + x') * dC + dch with the strides below
-                int ps_r = 1, ps_i = 0, ps_j = 0;
-                [[maybe_unused]] int rec = -1;                       // LSTM_BWD: first hidden channel of a dh_rec group, -1 for a column group of the input gradient
-                if constexpr (EPI == RNH_EPI_PS) {
-                    const int rr = P.ps_r, cq = P.ps_cq;
-                    live = n0 < cq * rr * rr;
-                    const int sub = n0 / cq;
-                    ps_r = rr, ps_i = sub / rr, ps_j = sub - (sub / rr) * rr;
-                    dptr = P.dst[0].ptr, ddt = P.dst[0].dtype, dC = cq, dch = n0 - sub * cq, dimg = img;
-                } else if constexpr (EPI == RNH_EPI_LSTM_BWD) {
-                    // the tile's columns: [input gradient: dst[0].ncols | dh_rec: hd]
-                    const rnh_mdst_t &D = P.dst[0];
-                    live = c8 < D.ncols;
-                    rec = !live && c8 - D.ncols < P.hd ? c8 - D.ncols : -1;
-                    dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (live ? c8 : 0), dimg = img + D.img_off;
-                } else {
-                    int seg = -1, cbase = 0;
-                    for (int d = 0; d < P.ndst; ++d) {
-                        if (seg < 0 && n0 < cbase + P.dst[d].ncols) seg = d;
-                        if (seg < 0) cbase += P.dst[d].ncols;
+                        for (int e = 0; e < 8; ++e) cp[e] = 0.f;
                     }
-                    live = seg >= 0;
-                    const rnh_mdst_t &D = P.dst[live ? seg : 0];
-                    dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
-                }
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const int y = y0 + MB * ph + m;
-                    const bool valid = xin && y < H;
+                    for (int e = 0; e < 8; ++e) {
+                        gi[e] = b_sigmoid(o[e]);
+                        gf[e] = b_sigmoid(o[32 + e]);
+                        go[e] = b_sigmoid(o[64 + e]);
+                        gg[e] = b_tanh_fast(o[96 + e]);
+                        cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                        hn[e] = go[e] * b_tanh_fast(cn[e]);
+                    }
+                    store8(cout, RNH_DT_F32, pe * hd + hc, cn);
+                    store8(hout, hdt, pe * hd + hc, hn);
+                    if (gout) {
+                        store8(gout, gdt, pe * 4 * hd + hc, gi);
+                        store8(gout, gdt, pe * 4 * hd + hd + hc, gf);
+                        store8(gout, gdt, pe * 4 * hd + 2 * hd + hc, go);
+                        store8(gout, gdt, pe * 4 * hd + 3 * hd + hc, gg);
+                    }
+                }
+            }
+        } else if constexpr (EPI == RNH_EPI_LSTM_BWD) {
+            // Data gradient of a ConvLSTM cell + gate backward of the frame its chain processes next (include/refinenet_hip.h).  The parked
+            // tile holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
+            const rnh_mdst_t &D = P.dst[0];
+            const int ncx = D.ncols, ncx8 = ncx >> 3, hd = P.hd, hd8 = hd >> 3;
+            for (int it = tid; it < PXR * ncx8; it += 256) {        // items (pixel, 8 columns of the input gradient)
+                const int px = it / ncx8, c8 = it - px * ncx8;
+                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                if (y >= H || x >= W) continue;
+                const float *o = ot + px * G::OPITCH + c8 * 8;
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = o[e];
+                const long e = ((((long)img + D.img_off) * H + y) * W + x) * D.C + D.c0 + c8 * 8;
+                if (D.accumulate) {
+                    float old[8];
+                    load8(D.ptr, D.dtype, e, old);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] += old[q];
+                }
+                store8(D.ptr, D.dtype, e, f);
+            }
+            // items (pixel, 8 hidden channels): the body of gates_bwd_m_kernel (mixed_kernels.hip), expression by expression, with
+            // dh2 := dh_rec out of LDS, rounded to the element type the unfused path would have stored it in
+            const void *dhp = P.bw_dh, *gp = P.bw_gates;
+            const float *dcn = P.bw_dc_next, *cprev = P.bw_c_prev, *cnext = P.bw_c_next;
+            void *dgp = P.bw_dgates;
+            float *dcprev = P.bw_dc_prev;
+            const int hdt = P.bw_dh_dtype, gdt = P.gates_dtype, dgdt = P.bw_dgates_dtype, rdt = P.bw_rec_dtype;
+            for (int it = tid; it < PXR * hd8; it += 256) {
+                const int px = it / hd8, g = it - px * hd8;
+                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                if (y >= H || x >= W) continue;
+                const long p = ((long)img * H + y) * W + x;
+                const long o = p * hd + g * 8, og = p * 4 * hd + g * 8;
+                float vdh[8], t[8], vdc[8], vcp[8], vcn[8], gi[8], gf[8], go[8], gg[8];
+                load8(dhp, hdt, o, vdh);
+                const float *rec = ot + px * G::OPITCH + ncx + g * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    t[e] = rec[e];
+                    if (rdt == RNH_DT_BF16) t[e] = (float)(__bf16)t[e];
+                    vdh[e] += t[e];
+                }
+                if (dcn) load8(dcn, RNH_DT_F32, o, vdc);
+                if (cprev) load8(cprev, RNH_DT_F32, o, vcp);
+                load8(cnext, RNH_DT_F32, o, vcn);
+                load8(gp, gdt, og, gi);
+                load8(gp, gdt, og + hd, gf);
+                load8(gp, gdt, og + 2 * hd, go);
+                load8(gp, gdt, og + 3 * hd, gg);
+                float di[8], df[8], dgo[8], dg[8], dcp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float th = tanhf(vcn[e]);
+                    const float d_o = vdh[e] * th;
+                    const float dct = (dcn ? vdc[e] : 0.f) + vdh[e] * go[e] * (1.f - th * th);
+                    di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+                    df[e] = dct * (cprev ? vcp[e] : 0.f) * gf[e] * (1.f - gf[e]);
+                    dgo[e] = d_o * go[e] * (1.f - go[e]);
+                    dg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+                    dcp[e] = dct * gf[e];
+                }
+                store8(dgp, dgdt, og, di);
+                store8(dgp, dgdt, og + hd, df);
+                store8(dgp, dgdt, og + 2 * hd, dgo);
+                store8(dgp, dgdt, og + 3 * hd, dg);
+                if (dcprev) store8(dcprev, RNH_DT_F32, o, dcp);
+            }
+        } else {
+            // a thread's 8 columns are the same in every step (256 % G8 == 0): destination segment / sub-pixel once per thread
+            constexpr int G8 = NCOLS / 8;
+            const int c8 = tid % G8, n0 = nt * NCOLS + c8 * 8;
+            bool live;
+            void *dptr;
+            int ddt, dacc = 0;
+            long dimg = 0, dpix = 0, dch = 0, dC = 0;                // element = ((img' * H + y) * W' + x') * dC + dch with the strides below
+            int ps_r = 1, ps_i = 0, ps_j = 0;
+            if constexpr (EPI == RNH_EPI_PS) {
+                const int rr = P.ps_r, cq = P.ps_cq;
+                live = n0 < cq * rr * rr;
+                const int sub = n0 / cq;
+                ps_r = rr, ps_i = sub / rr, ps_j = sub - (sub / rr) * rr;
+                dptr = P.dst[0].ptr, ddt = P.dst[0].dtype, dC = cq, dch = n0 - sub * cq, dimg = img;
+            } else {
+                int seg = -1, cbase = 0;
+                for (int d = 0; d < P.ndst; ++d) {
+                    if (seg < 0 && n0 < cbase + P.dst[d].ncols) seg = d;
+                    if (seg < 0) cbase += P.dst[d].ncols;
+                }
+                live = seg >= 0;
+                const rnh_mdst_t &D = P.dst[live ? seg : 0];
+                dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
+            }
+            (void)dpix;
+            if (live) {
+                for (int px = tid / G8; px < PXR; px += 256 / G8) {
+                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const float *o = ot + px * G::OPITCH + c8 * 8;
                     float f[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[e] = acc[m][n][8 * p + e];
-                        f[4 + e] = acc[m][n][8 * p + 4 + e];
-                        swap_halves(f[e], f[4 + e]);
-                    }
-                    if (live && valid) {
-                        const long e = ((dimg * H + y) * ps_r + ps_i) * ((long)W * ps_r) * dC + ((long)xg * ps_r + ps_j) * dC + dch;
-                        if (dacc) {
-                            float old[8];
-                            load8(dptr, ddt, e, old);
+                    for (int e = 0; e < 8; ++e) f[e] = o[e];
+                    const long e = ((dimg * H + y) * ps_r + ps_i) * ((long)W * ps_r) * dC + ((long)x * ps_r + ps_j) * dC + dch;
+                    if (dacc) {
+                        float old[8];
+                        load8(dptr, ddt, e, old);
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) f[q] += old[q];
-                        }
-                        store8(dptr, ddt, e, f);
+                        for (int q = 0; q < 8; ++q) f[q] += old[q];
                     }
-                    if constexpr (EPI == RNH_EPI_LSTM_BWD) {
-                        // item (pixel, 8 hidden channels): the body of gates_bwd_m_kernel (mixed_kernels.hip), expression by expression, with
-                        // dh2 := dh_rec out of the accumulators, rounded to the element type the unfused path would have stored it in
-                        if (rec >= 0 && valid) {
-                            const int hd = P.hd;
-                            const long pp = ((long)img * H + y) * W + xg;
-                            const long o = pp * hd + rec, og = pp * 4 * hd + rec;
-                            const float *dcn = P.bw_dc_next, *cprev = P.bw_c_prev;
-                            const int gdt = P.gates_dtype, dgdt = P.bw_dgates_dtype;
-                            float vdh[8], vdc[8], vcp[8], vcn[8], gi[8], gf[8], go[8], gg[8];
-                            load8(P.bw_dh, P.bw_dh_dtype, o, vdh);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                float t = f[q];
-                                if (P.bw_rec_dtype == RNH_DT_BF16) t = (float)(__bf16)t;
-                                vdh[q] += t;
-                            }
-                            if (dcn) load8(dcn, RNH_DT_F32, o, vdc);
-                            if (cprev) load8(cprev, RNH_DT_F32, o, vcp);
-                            load8(P.bw_c_next, RNH_DT_F32, o, vcn);
-                            load8(P.bw_gates, gdt, og, gi);
-                            load8(P.bw_gates, gdt, og + hd, gf);
-                            load8(P.bw_gates, gdt, og + 2 * hd, go);
-                            load8(P.bw_gates, gdt, og + 3 * hd, gg);
-                            float di[8], df[8], dgo[8], dg[8], dcp[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float th = tanhf(vcn[q]);
-                                const float d_o = vdh[q] * th;
-                                const float dct = (dcn ? vdc[q] : 0.f) + vdh[q] * go[q] * (1.f - th * th);
-                                di[q] = dct * gg[q] * gi[q] * (1.f - gi[q]);
-                                df[q] = dct * (cprev ? vcp[q] : 0.f) * gf[q] * (1.f - gf[q]);
-                                dgo[q] = d_o * go[q] * (1.f - go[q]);
-                                dg[q] = dct * gi[q] * (1.f - gg[q] * gg[q]);
-                                dcp[q] = dct * gf[q];
-                            }
-                            store8(P.bw_dgates, dgdt, og, di);
-                            store8(P.bw_dgates, dgdt, og + hd, df);
-                            store8(P.bw_dgates, dgdt, og + 2 * hd, dgo);
-                            store8(P.bw_dgates, dgdt, og + 3 * hd, dg);
-                            if (P.bw_dc_prev) store8(P.bw_dc_prev, RNH_DT_F32, o, dcp);
-                        }
-                    }
+                    store8(dptr, ddt, e, f);
                 }
             }
+        }
     }
     BSTAMP(3);
 }

@@ -215,20 +215,6 @@ def lstm_colmap64(hd):
     return cm
 
 
-def lstm_colmap8(hd):
-    """rnh_conv_bf16's gate layout (csrc/conv_bf16.hip, round 4): column n = tile*128 + blk*32 + gate*8 + c  <->  reference output channel
-    gate*hd + tile*32 + blk*8 + c.  The kernel computes the transposed product, so a lane's accumulator quad q of a 32-column block is
-    gate q of four consecutive hidden channels of its pixel: the four gates of a (pixel, channel) meet in one lane."""
-    cm = []
-    for tl in range((hd + 31) // 32):
-        for blk in range(4):
-            for g in range(4):
-                for c in range(8):
-                    hc = tl * 32 + blk * 8 + c
-                    cm.append(g * hd + hc if hc < hd else -1)
-    return cm
-
-
 def ps_colmap(cq, r):
     """Column n = (i*r + j)*cq + c  <->  nn.PixelShuffle input channel c*r*r + i*r + j."""
     return [(n % cq) * r * r + n // cq for n in range(cq * r * r)]
@@ -274,8 +260,6 @@ class NetPlans:
                 # the cell as 128-column blocks (the four gates of 32 hidden channels: gate layout lstm_colmap) where cx, hd % 32 == 0
                 wcols = 128 if wino and os.environ.get('RNH_WINO_COLS', '128') != '64' and cx % 32 == 0 and second % 32 == 0 and hd % 32 == 0 else 64
                 lcm = lstm_colmap64(hd) if ltile in (L.TILE_128x128, L.TILE_256x64) or (wino and wcols == 64) else lstm_colmap(hd)
-                if bf:
-                    lcm = lstm_colmap8(hd)
                 def mk(lcm_, wino_):
                     full_ = ConvPlan_(f'{d}{l}.fwd', wk, bk, ws, [KSeg(cx, cx, 0), KSeg(second, second, cx)], lcm_,
                                      tile=ltile, epilogue=L.EPI_LSTM, wino=wino_, wino_cols=wcols)
@@ -287,7 +271,7 @@ class NetPlans:
                     wino, lcm = False, lstm_colmap(hd)
                     full, first = mk(lcm, False)
                 for pl_ in (full, first):                           # hidden channels per column group of the gate layout
-                    pl_.gate_group = 8 if bf else 16 if len(lcm) == 64 * ((hd + 15) // 16) and lcm == lstm_colmap64(hd) else 32
+                    pl_.gate_group = 16 if len(lcm) == 64 * ((hd + 15) // 16) and lcm == lstm_colmap64(hd) else 32
                 dgrad = ConvPlan_(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
                                  wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
                 wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],

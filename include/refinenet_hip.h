@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 2       /* 2 (round 4): rnh_conv_bf16's RNH_EPI_LSTM column layout; argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce */
+#define RNH_ABI_VERSION 2       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -436,10 +436,7 @@ typedef struct rnh_conv_bf16_args {
     int32_t epilogue;           /* RNH_EPI_*                                                             */
     int32_t ndst;
     int32_t ps_r, ps_cq;        /* RNH_EPI_PS: dst[0] is the (B, rH, rW, cq) tensor; cq % 8 == 0         */
-    int32_t hd;                 /* RNH_EPI_LSTM: hidden channels (multiple of 8); Npad = 128 * ceil(hd / 32), column
-                                 * tile*128 + blk*32 + gate*8 + c = gate `gate` (i, f, o, g) of hidden channel tile*32 + blk*8 + c
-                                 * (hipvsr/plans.py lstm_colmap8) - NOT rnh_conv_args_t's layout: the kernel computes the transposed
-                                 * product, a lane's accumulator quad is one gate of four channels of its pixel */
+    int32_t hd;                 /* RNH_EPI_LSTM: hidden channels (multiple of 8), columns as rnh_conv_args_t */
     rnh_mdst_t dst[RNH_MAX_DST];
     const float *c_prev;        /* fp32 [B][H][W][hd] or 0                                               */
     float *c_out;               /* fp32 [B][H][W][hd]                                                    */
@@ -465,8 +462,8 @@ typedef struct rnh_conv_bf16_args {
 
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA: one workgroup = 8 x 32 output pixels x 128 (64) columns; per
  * 16- / 32-channel chunk the 10 x 34 pixel halo of the inputs (converted to bf16 if the source is fp32) goes through LDS once
- * and serves all 9 taps, the packed weights stream from L2 into registers; the epilogue stays in registers (transposed
- * product: 16-byte pieces of one pixel per lane).  Same call sites as rnh_conv_igemm. */
+ * and serves all 9 taps, the packed weights stream from L2 into registers; the epilogue parks the accumulators in LDS so that
+ * every global access is a contiguous run of a pixel's channels.  Same call sites as rnh_conv_igemm. */
 int rnh_conv_bf16(const rnh_conv_bf16_args_t *args /* host */, void *stream);
 /* wp[ks][n][kk] (bf16, kk = 0..15 in natural order) with the index conventions of rnh_pack_weights; biasp fp32. */
 int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,

@@ -36,9 +36,9 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 ops.lib.rnh_debug_bf16_stamps(buf)
 z = list(buf)
-print(f'{which}: prologue..loop end {z[1] - z[0]} cycles, epilogue until the previous state has arrived (activations) {z[2] - z[1]}, rest (state update, stores) {z[3] - z[2]}, total {z[3] - z[0]}')
+print(f'{which}: prologue..loop end {z[1] - z[0]} cycles, park {z[2] - z[1]}, finish {z[3] - z[2]}, total {z[3] - z[0]}')
 nch = 8 if which == 'lstm' else 16
 for c in range(min(nch, 16)):
-    a, b = z[8 + 3 * c], z[9 + 3 * c]
+    a, b, d = z[8 + 3 * c], z[9 + 3 * c], z[10 + 3 * c]
     nxt = z[8 + 3 * (c + 1)] if c + 1 < nch else z[1]
-    print(f'  chunk {c}: compute {b - a:6d}  barrier {nxt - b:6d}')
+    print(f'  chunk {c}: phase A {b - a:6d}  phase B {d - b:6d}  phase C {nxt - d:6d}   (variant D: compute / store / barrier; variant L: store+barrier / compute / barrier)')
