@@ -732,7 +732,17 @@ class RefineNetEngine:
                             dh_next[d][l], dc_next[d][l] = dhp, dcp
                             dx_above = dxbuf if l > 0 else None
                             above = ops.record() if l > 0 else None
-            # weight gradients of the cells, batched over the T frames (each on its cell's stream)
+            # weight gradients of the cells, batched over the T frames (each on its cell's stream).  Nothing of this stage's backward waits
+            # for them: the main stream joins the chains as they stand HERE (the events below) and goes on with the upsampler / refine
+            # backward of the next (earlier) stage - kernels that have the chip to themselves otherwise - while the weight gradients
+            # run beside them on the side streams; what they read is handed to the caller, who keeps it until the next join that
+            # covers them (RNH_DEFER_WGRAD=0: join right here, as until round 3)
+            defer = os.environ.get('RNH_DEFER_WGRAD', '1') != '0'
+            chains_done = []
+            if defer:
+                for i in range(2 * Lr):
+                    with ops.side(i):
+                        chains_done.append(ops.record())
             for di, d in enumerate(dirs):
                 step = 1 if d == 'forward' else -1
                 Hb = st[d]['H']
@@ -746,15 +756,25 @@ class RefineNetEngine:
                         acc(bk)
                         ops.wgrad(pl['wgrad'], [_span_src(xin, U, T), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
                                   accumulate=a)
-            ops.join(2 * Lr)
+            if defer:
+                for ev in chains_done:
+                    ops.wait(ev)
+            else:
+                ops.join(2 * Lr)
             self._mem(f'bwd stage {s}: BPTT done')
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
-            st['forward'] = st['backward'] = None
+            in_flight = (st, feat, Gd) if defer else None          # what the weight-gradient launches still read
             ctx.stages[s] = None
-            return dfeat
+            return dfeat, in_flight
 
+        pending = None
         for s in range(S - 1, -1, -1):
-            dfeat_next = stage_backward(s, dfeat_next)
+            # the previous stage's weight gradients sit in front of this stage's chains on the same side streams: once this stage's
+            # chains have been joined (inside stage_backward) they are done, and what they read can go
+            dfeat_next, pending_new = stage_backward(s, dfeat_next)
+            pending = pending_new
+        ops.join(2 * Lr)                                          # the last stage's weight gradients
+        pending = None
 
         # ---- input block backward (supervised frames only, refine_net.py:66-67) --------------------------------
         xc = ctx.x_all[U * N:(U + T) * N]
