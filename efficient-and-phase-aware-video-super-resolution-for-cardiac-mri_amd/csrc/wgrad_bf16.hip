@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
 // ---------------------------------------------------------------------------------------------------------------------
 // The same kernel for bf16 sources with the rows brought in by LDS-DMA (global_load_lds_dwordx4), three steps ahead.
 //
-// Ablation of the register-staged kernel above at the ConvLSTM shape (tools/r03_run8.sh): 715 us per launch, 467 us without its
+// Ablation of the register-staged kernel above at the ConvLSTM shape (tools/experiments/r03/r03_run8.sh): 715 us per launch, 467 us without its
 // global loads, 430 us with MFMAs only - the pieces requested at the top of a step are needed at its end, one step (~1 us)
 // later, which is less than the latency of an HBM / Infinity-Cache read under load: SQ_WAIT_ANY was 47 % of the wave cycles.
 // Here nothing passes through registers: every thread's 16-byte piece (pixel tid >> 3, channels 8 (tid & 7)) goes straight
@@ -539,7 +539,10 @@ extern "C" int rnh_wgrad_bf16(const rnh_wgrad_bf16_args_t *args, void *stream) {
         else if (yf) hipLaunchKernelGGL((wgrad_bf16_kernel<NTP, false, true>), grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);     \
         else hipLaunchKernelGGL((wgrad_bf16_kernel<NTP, false, false>), grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);            \
     } while (0)
-    static const bool use_dma = !(getenv("RNH_WGRAD_DMA") && getenv("RNH_WGRAD_DMA")[0] == '0');
+    // RNH_WGRAD_DMA=0 keeps the register-staged kernel for A/B measurements; read per call like the other switches, so that one process
+    // can compare the two (tests/test_bf16_path.py)
+    const char *ed = getenv("RNH_WGRAD_DMA");
+    const bool use_dma = !(ed && ed[0] == '0');
     if (a.ntaps == 9 && !xf && !yf && use_dma)
         hipLaunchKernelGGL(wgrad_bf16_dma_kernel, grid, block, 0, st, a, RT, CT, nseg, RPI, (int)nitems);
     else if (a.ntaps == 9) RNH_WG(9);

@@ -178,8 +178,14 @@ class RefineNetEngine:
                  max(U - hw, 1) * px * c1p * ea + 2 * F * px * C * ea)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
+        # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
+        # joined, the stage's dgates and hidden states stay alive although the stage itself has been released
+        dgates = 2 * sum(nf) * 4 * T * px * ea
+        held = dgates + per['h_lower'] + per['feat'] + 2 * nf[-1] * px * ea * (U + T + hw)
+        last = sum(per.values()) - (per['gates'] if n_rc == S else 0) + 2 * nf[-1] * px * ea * (U + T + hw)      # what the last stage keeps
+        peak = kept + o_all + max(fwd_t, bwd_t, bwd_t + held - last if S > 1 else 0)
         return dict(per_stage=per, recomputing_stages=n_rc, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
-                    peak=kept + o_all + max(fwd_t, bwd_t))
+                    held_for_weight_gradients=held, peak=peak)
 
     def _mem(self, label):
         """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
@@ -562,8 +568,13 @@ class RefineNetEngine:
                     ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
-                ops.wgrad(P.r2_wgrad, [Src(st['R1'])], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
-                          grads[P.r2_wgrad.bkey], accumulate=a)
+                if P.r2_wino and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0':
+                    ops.wgrad(P.r2_wgrad_h, [Src(st['R1'], nch=2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], grads[P.r2_wgrad.bkey], accumulate=a)
+                    ops.wgrad(P.r2_wgrad_x, [Src(st['R1'], c0=2 * Cl, nch=P.C1p - 2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], None,
+                              accumulate=a)                         # (its own rows of the gradient: the same store / accumulate mode)
+                else:
+                    ops.wgrad(P.r2_wgrad, [Src(st['R1'])], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
+                              grads[P.r2_wgrad.bkey], accumulate=a)
                 a = acc(k1)
                 acc(b1)
                 ysrc = [Src(dR1p, nch=P.r1_cols, img_off=hw * N)]
@@ -763,7 +774,9 @@ class RefineNetEngine:
                 ops.join(2 * Lr)
             self._mem(f'bwd stage {s}: BPTT done')
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
-            in_flight = (st, feat, Gd) if defer else None          # what the weight-gradient launches still read
+            for d in dirs:                                          # (the weight gradients read neither the stored gates nor the cell states)
+                st[d]['G'] = st[d]['C'] = None
+            in_flight = (st, feat, Gd) if defer else None          # what the weight-gradient launches still read: h, features, dgates
             ctx.stages[s] = None
             return dfeat, in_flight
 

@@ -347,6 +347,10 @@ class NetPlans:
                 self.r2_dgrad_h = ConvPlan_('refine2.dgrad.h', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(2 * Cl)), transposed=True, wino=True)
                 self.r2_dgrad_x = ConvPlan_('refine2.dgrad.x', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                            list(range(2 * Cl, C1)) + [-1] * (self.C1p - C1), transposed=True)
+                # ... and its weight gradient (round 4; until then one pixel-contraction GEMM over all C1p rows, 2 % of the fp32 step): the 2*Cl
+                # hidden-state rows in Winograd form, the row of the phase channel (and the pad rows behind it) through the pixel contraction
+                self.r2_wgrad_h = WgradPlan_('refine2.wgrad.h', k2, b2, ws2, [XSeg(2 * Cl, 2 * Cl, 0)], [YSeg(Cl, Cl, 0)])
+                self.r2_wgrad_x = WgradPlan_('refine2.wgrad.x', k2, None, ws2, [XSeg(self.C1p - 2 * Cl, C1 - 2 * Cl, 2 * Cl)], [YSeg(Cl, Cl, 0)])
             self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                      list(range(C1)) + [-1] * (self.C1p - C1), transposed=True)

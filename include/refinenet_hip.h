@@ -69,7 +69,9 @@ typedef struct rnh_dst {
 #define RNH_EPI_STORE 0   /* bias add, store / accumulate into the destination segments           */
 #define RNH_EPI_PS    1   /* bias add, nn.PixelShuffle(ps_r) fused into the store (dst[0])        */
 #define RNH_EPI_LSTM  2   /* bias add, ConvLSTM gate math, writes h, c (and the gates for backward)*/
-#define RNH_EPI_LSTM_BWD 3 /* rnh_conv_bf16 only: data gradient of a ConvLSTM cell + gate backward of the chain's previous frame */
+#define RNH_EPI_LSTM_BWD 3 /* rnh_conv_bf16 only: data gradient of a ConvLSTM cell at frame t + the gate backward of frame t', the frame
+                            * back-propagation through time visits NEXT (one time step earlier in the cell's own direction): see
+                            * rnh_conv_bf16_args_t.  One term everywhere: t' = "the frame the chain processes next" */
 
 /* Output-tile shapes (rows x columns of one workgroup) */
 #define RNH_TILE_128x128 0   /* 2x2 waves of 64x64          */
@@ -453,7 +455,8 @@ typedef struct rnh_conv_bf16_args {
     const float *bw_dc_next;    /* fp32 [B][H][W][hd] or 0                                                */
     const void *bw_gates;       /* [B][H][W][4*hd] of gates_dtype: the gates of frame t'                  */
     const float *bw_c_prev;     /* fp32: the cell state before frame t' (0: zeros)                        */
-    const float *bw_c_next;     /* fp32: the cell state after frame t'                                    */
+    const float *bw_c_next;     /* fp32: the cell state AFTER frame t' itself, c_{t'} (the argument rnh_lstm_gates_bwd[_m] calls
+                                 * c_next: "next" relative to c_prev, not the next frame; hipvsr/engine.py passes it as c_next too) */
     void *bw_dgates;            /* out [B][H][W][4*hd] of bw_dgates_dtype                                 */
     float *bw_dc_prev;          /* out fp32 [B][H][W][hd] or 0                                            */
     int32_t bw_dh_dtype, bw_dgates_dtype, bw_rec_dtype;

@@ -279,6 +279,22 @@ def test_wgrad_bf16_kernel_vs_torch_float64(which, B, H, W):
     ops.wgrad(plan, xs, ys, B, H, W, dw2, db2, accumulate=True)               # accumulate: exactly twice; and bitwise repeatable
     torch.cuda.synchronize()
     assert torch.equal(dw2, dw + dw) and torch.equal(db2, db + db)
+    # the register-staged kernel (RNH_WGRAD_DMA=0, read per call) against the LDS-DMA kernel that serves bf16 x bf16 sources by default:
+    # the same products, partitioned over the workgroups differently (row strips vs contiguous step ranges) - fp32 re-association only
+    old = os.environ.get('RNH_WGRAD_DMA')
+    os.environ['RNH_WGRAD_DMA'] = '0'
+    try:
+        dw3, db3 = torch.full(shape, float('nan'), device=dev), torch.full(shape[:1], float('nan'), device=dev)
+        ops.wgrad(plan, xs, ys, B, H, W, dw3, db3)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop('RNH_WGRAD_DMA', None)
+        else:
+            os.environ['RNH_WGRAD_DMA'] = old
+    _close_f32(dw3, rw, f'{which}.dw[register-staged]', rel=3e-5)
+    _close_f32(db3, rb, f'{which}.db[register-staged]', rel=3e-5)
+    assert float((dw3 - dw).abs().max()) <= 3e-5 * float(rw.abs().max()) and float((db3 - db).abs().max()) <= 3e-5 * float(rb.abs().max())
 
 
 def test_mixed_type_helpers_vs_torch():
