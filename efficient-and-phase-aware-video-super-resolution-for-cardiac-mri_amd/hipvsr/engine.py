@@ -580,7 +580,9 @@ class RefineNetEngine:
                 ysrc = [Src(dR1p, nch=P.r1_cols, img_off=hw * N)]
                 if P.xcol_m:
                     # 2*Cl columns against the window sources; the last channel's weights as the gradient of the per-frame convolution
-                    ops.wgrad(P.r1_wgrad_a, xs, [Src(dR1p, nch=2 * Cl, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                    # (the plan's row order: hidden-state sources first, then the phase planes)
+                    ops.wgrad(P.r1_wgrad_a, [sc for i, sc in enumerate(xs) if i % 3 != 2] + [sc for i, sc in enumerate(xs) if i % 3 == 2],
+                              [Src(dR1p, nch=2 * Cl, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
                     E = ops.xcol_gather_m(dR1p[hw * N:(hw + T) * N], N, w, 2 * Cl, act)
                     f0, nfr = (U - hw) * N, T + w - 1
                     dbx = ops.zeros(8)                                   # (zeros: the launch below may run in accumulate mode)

@@ -336,7 +336,12 @@ class NetPlans:
                 self.r1x_fwd = ConvPlan_('refine1.fwd.x', self.r1x_key, None, (w, C1, 3, 3), fsegs, list(range(w)))
                 self.r1x_wgrad = WgradPlan_('refine1.wgrad.x', self.r1x_key, None, (w, C1, 3, 3),
                                            [XSeg(Cl, Cl, 0), XSeg(Cl, Cl, Cl), XSeg(pw, 1, 2 * Cl)], [YSeg(8, w, 0)])
-                self.r1_wgrad_a = WgradPlan_('refine1.wgrad.a', k1, b1, ws1, xsegs, [YSeg(C1 - 1, C1 - 1, 0)])
+                # rows: the 2*w hidden-state sources first, the w phase planes behind them (NOT slot by slot: rnh_wgrad_bf16 works on 64-row
+                # tiles, and an 8-channel plane in front of a hidden-state source shifts it off the tile grid - every 128-byte pixel
+                # line of that source is then fetched by two row tiles: 2.10 -> see profiles/r04_k for the launch at config 2)
+                self.r1_wgrad_a = WgradPlan_('refine1.wgrad.a', k1, b1, ws1,
+                                            [sg for i, sg in enumerate(xsegs) if i % 3 != 2] + [sg for i, sg in enumerate(xsegs) if i % 3 == 2],
+                                            [YSeg(C1 - 1, C1 - 1, 0)])
             # conv2 (C1 -> Cl channels) the same way: its 2*Cl hidden-state input channels in Winograd form, the phase channel (and
             # the pad channels behind it) through the implicit GEMM, accumulating; its data gradient as a 2*Cl-column Winograd
             # launch plus a launch for the columns of the last channel

@@ -121,11 +121,12 @@ dR1p = R((T + 4) * N, H, W, P.C1p)
 xs1 = []
 for j in range(5):
     xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P8, img_off=(4 + j) * N)]
+xs1a = [sc for i, sc in enumerate(xs1) if i % 3 != 2] + [sc for i, sc in enumerate(xs1) if i % 3 == 2]      # the row order of plans.r1_wgrad_a
 dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
 dbx = ops.zeros(8)
 def r1_wgrad():
     if getattr(P, 'xcol_m', False):
-        ops.wgrad(P.r1_wgrad_a, xs1, [Src(dR1p, nch=128, img_off=2 * N)], TN, H, W, dw1, db1)
+        ops.wgrad(P.r1_wgrad_a, xs1a, [Src(dR1p, nch=128, img_off=2 * N)], TN, H, W, dw1, db1)
         E = ops.xcol_gather_m(dR1p[2 * N:(2 + T) * N], N, 5, 128, bf)
         ops.wgrad(P.r1x_wgrad, [Src(Hf, img_off=4 * N), Src(Hb, img_off=4 * N), Src(P8, img_off=4 * N)], [Src(E)], (T + 4) * N, H, W,
                   dw1[128].view(5, 129, 3, 3), dbx[:5])
@@ -134,6 +135,16 @@ def r1_wgrad():
 
 
 timeit('refine1.wgrad', r1_wgrad, 2.0 * TN * H * W * 129 * 645 * 9, TN * H * W * (5 * 136 + 136) * 2, 3)
+if getattr(P, 'xcol_m', False):                             # its two launches apart: the 128-column main part, the last channel frame by frame
+    timeit('refine1.wgrad.main', lambda: ops.wgrad(P.r1_wgrad_a, xs1a, [Src(dR1p, nch=128, img_off=2 * N)], TN, H, W, dw1, db1),
+           2.0 * TN * H * W * 128 * 645 * 9, TN * H * W * (5 * 136 + 128) * 2, 3)
+    E_ = ops.xcol_gather_m(dR1p[2 * N:(2 + T) * N], N, 5, 128, bf)
+    timeit('refine1.wgrad.lastch', lambda: ops.wgrad(P.r1x_wgrad, [Src(Hf, img_off=4 * N), Src(Hb, img_off=4 * N), Src(P8, img_off=4 * N)], [Src(E_)],
+                                                     (T + 4) * N, H, W, dw1[128].view(5, 129, 3, 3), dbx[:5]),
+           2.0 * (T + 4) * N * H * W * 5 * 129 * 9, (T + 4) * N * H * W * (136 + 8) * 2, 3)
+dy2 = R(TN, H, W, 64)
+dw2_, db2_ = ops.empty(64, 129, 3, 3), ops.empty(64)
+timeit('refine2.wgrad', lambda: ops.wgrad(P.r2_wgrad, [Src(R1)], [Src(dy2)], TN, H, W, dw2_, db2_), 2.0 * TN * H * W * 64 * 129 * 9, TN * H * W * (136 + 64) * 2, 3)
 dHf, dHb = ops.zeros(TN, H, W, 64, dtype=bf), ops.zeros(TN, H, W, 64, dtype=bf)
 timeit('refine1.dgrad', lambda: ops.conv(P.r1_dgrad, [Src(dR1p, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
                                         dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 645 * 9,

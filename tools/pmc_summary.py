@@ -24,6 +24,7 @@ args = sys.argv[1:]
 root = args[0]
 jout = args[args.index('--json') + 1] if '--json' in args else None
 hout = args[args.index('--hbm') + 1] if '--hbm' in args else None
+hbf = args[args.index('--hbm-bf16') + 1] if '--hbm-bf16' in args else None
 sub = args[1] if len(args) > 1 and not args[1].startswith('--') else None
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -59,7 +60,8 @@ if hout:
     src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc', 'conv_wino.hip')
     if key and 'hbm_bytes_per_launch' in summary[key]:
         try:
-            commit = subprocess.run(['git', '-C', here, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+            # (the GPU box has no .git: the caller passes the commit of the tree it sent, RNH_COMMIT=$(git rev-parse --short HEAD))
+            commit = os.environ.get('RNH_COMMIT') or subprocess.run(['git', '-C', here, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
         except Exception:
             commit = None
         json.dump({'kernel': key.split('<')[0] + '<LSTM> at N=8,128x128 (one ConvLSTM cell launch, Winograd F(2x2,3x3))',
@@ -70,3 +72,20 @@ if hout:
                    'commit': commit, 'date': time.strftime('%Y-%m-%d'),
                    'command': 'tools/prof_pmc_wino.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/kbench.py lstm'},
                   open(hout, 'w'), indent=1)
+
+if hbf:
+    # the bf16 ConvLSTM cell kernel of the run: conv_bf16d_kernel<LSTM, 128, 9, 32> (csrc/conv_bf16.hip); run over `tools/kbench_bf16.py lstm.fwd`
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    key = next((k for k in summary if k.startswith('conv_bf16d_kernel<2')), None)
+    src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc', 'conv_bf16.hip')
+    if key and 'hbm_bytes_per_launch' in summary[key]:
+        json.dump({'kernel': 'conv_bf16d_kernel<LSTM,128,9,KC 32> at N=8,128x128 (one ConvLSTM cell launch of the bf16-storage path)',
+                   'FETCH_SIZE_KB_raw': summary[key]['FETCH_SIZE'], 'WRITE_SIZE_KB': summary[key]['WRITE_SIZE'],
+                   'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact',
+                   'hbm_bytes_per_launch': summary[key]['hbm_bytes_per_launch'], 'algorithmic_bytes_per_launch': 184549376,
+                   'kernel_source_sha256': hashlib.sha256(open(src, 'rb').read()).hexdigest(),
+                   'commit': os.environ.get('RNH_COMMIT'), 'date': time.strftime('%Y-%m-%d'),
+                   'command': 'tools/prof_pmc_bf16.sh <tag> lstm.fwd: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python '
+                              'tools/kbench_bf16.py lstm.fwd (the launch that stores the gates)',
+                   'mfma_pipe_busy_frac': summary[key].get('mfma_pipe_busy_frac'), 'kernel_cycles': summary[key].get('kernel_cycles')},
+                  open(hbf, 'w'), indent=1)

@@ -14,6 +14,6 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_A
     i=$((i + 1))
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pass$i -- python tools/kbench_bf16.py $flt > $out/pass$i.log 2> $out/pass$i.err || { echo "pass $i FAILED"; tail -5 $out/pass$i.err; }
 done
-python tools/pmc_summary.py $out --json $out/summary.json
+python tools/pmc_summary.py $out --json $out/summary.json --hbm-bf16 $out/lstm_bf16_kernel_hbm_bytes.json
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
