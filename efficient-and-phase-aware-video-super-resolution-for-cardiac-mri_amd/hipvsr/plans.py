@@ -172,7 +172,9 @@ class WgradPlan:
         """Pixel-range splits of rnh_wgrad_bf16: tiles x splits = about two workgroups per CU (the kernel keeps two resident:
         one's staging latency hides behind the other's MFMAs)."""
         tiles = (self.xrows_pad64 // 64) * (self.ycols_pad64 // 64)
-        return int(max(1, min(nitems, 256, -(-512 // tiles))))
+        # floor, not ceil: 22 tiles x 24 splits = 528 workgroups on 512 slots ran as two rounds, the second one nearly empty (refine conv1's
+        # weight gradient 2.03 -> see profiles/r04_k; the ConvLSTM's 8 tiles x 64 were exact already)
+        return int(max(1, min(nitems, 256, 512 // tiles)))
 
     def nsplit(self, npix):
         import os
