@@ -199,26 +199,30 @@ __global__ void __launch_bounds__(256) inconv_bwd_kernel(const float *x, const f
     }
 }
 
-__global__ void inconv_bwd_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, float *dslope, int Cin, int Cout,
-                                         int accumulate) {
+// One workgroup per output value (Cout * (9 Cin + 1) weight / bias entries + the PReLU slope): 256 threads take the partial sums of the
+// INB_BLOCKS blocks in a fixed interleaved order, then a fixed-order tree - bitwise repeatable.  (Until round 4 one THREAD walked the 2048
+// partials of an entry, a chain of dependent loads: 0.6 ms on three workgroups at the very end of the backward.)
+__global__ void __launch_bounds__(256) inconv_bwd_reduce_kernel(const float *ws, int nblocks, float *dw, float *db, float *dslope, int Cin, int Cout,
+                                                                int accumulate) {
     __shared__ float red[4];
     const int K = 9 * Cin;
-    const int total = Cout * (K + 1);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int total = Cout * (K + 1), e = blockIdx.x;
+    float v = 0.f;
+    if (e < total) {
         const int co = e / (K + 1), k = e - co * (K + 1);
-        float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += ws[((long)b * Cout + co) * (K + 2) + k];
-        if (k < K) {
-            const int tap = k / Cin, ci = k - tap * Cin;
-            float *o = dw + (co * Cin + ci) * 9 + tap;
-            *o = accumulate ? *o + s : s;
-        } else {
-            db[co] = accumulate ? db[co] + s : s;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += ws[((long)b * Cout + co) * (K + 2) + k];
+        const float s = block_sum(v, red);
+        if (threadIdx.x == 0) {
+            if (k < K) {
+                const int tap = k / Cin, ci = k - tap * Cin;
+                float *o = dw + (co * Cin + ci) * 9 + tap;
+                *o = accumulate ? *o + s : s;
+            } else {
+                db[co] = accumulate ? db[co] + s : s;
+            }
         }
-    }
-    if (blockIdx.x == 0) {
-        float v = 0.f;
-        for (int e = threadIdx.x; e < nblocks * Cout; e += blockDim.x) v += ws[(long)e * (K + 2) + K + 1];
+    } else {
+        for (int i = threadIdx.x; i < nblocks * Cout; i += blockDim.x) v += ws[(long)i * (K + 2) + K + 1];
         const float s = block_sum(v, red);
         if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + s : s;
     }
@@ -896,7 +900,7 @@ extern "C" int rnh_inconv_prelu_bwd(const float *x, const float *w, const float 
     if (Cin == 1) hipLaunchKernelGGL(inconv_bwd_kernel<9>, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
     else hipLaunchKernelGGL(inconv_bwd_kernel<INB_MAXK>, dim3(INB_BLOCKS), dim3(256), 0, st, x, w, bias, slope, dy, ws, B, H, W, Cin, Cout);
     RNH_CHECK_LAUNCH("rnh_inconv_prelu_bwd");
-    hipLaunchKernelGGL(inconv_bwd_reduce_kernel, dim3(grid_for(Cout * (9 * Cin + 1))), dim3(256), 0, st, ws, INB_BLOCKS, dw, db,
+    hipLaunchKernelGGL(inconv_bwd_reduce_kernel, dim3((unsigned)(Cout * (9 * Cin + 1) + 1)), dim3(256), 0, st, ws, INB_BLOCKS, dw, db,
                        dslope, Cin, Cout, accumulate);
     RNH_CHECK_LAUNCH("rnh_inconv_prelu_bwd(reduce)");
     return 0;

@@ -788,14 +788,13 @@ class RefineNetEngine:
             # chains have been joined (inside stage_backward) they are done, and what they read can go
             dfeat_next, pending_new = stage_backward(s, dfeat_next)
             pending = pending_new
-        ops.join(2 * Lr)                                          # the last stage's weight gradients
-        pending = None
-
-        # ---- input block backward (supervised frames only, refine_net.py:66-67) --------------------------------
+        # ---- input block backward (supervised frames only, refine_net.py:66-67), beside the first stage's weight gradients -----------
         xc = ctx.x_all[U * N:(U + T) * N]
         if self.bf16:
             dfeat_next = ops.cast(dfeat_next, self.f32)           # back across the precision boundary of the input block
         ops.inconv_bwd(xc, params['in_block.conv.weight'], params['in_block.conv.bias'], params['in_block.prelu.weight'],
                        dfeat_next, grads['in_block.conv.weight'], grads['in_block.conv.bias'], grads['in_block.prelu.weight'],
                        accumulate=False)
+        ops.join(2 * Lr)                                          # the first stage's weight gradients (the last ones launched)
+        pending = None
         return grads
