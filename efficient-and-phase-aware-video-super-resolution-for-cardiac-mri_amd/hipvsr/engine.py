@@ -287,6 +287,8 @@ class RefineNetEngine:
         ctx.P4 = P4
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
+        aside_keep = []
+
         def run_stage(s, feat):
             """Stage s of the forward; returns the features the next stage starts from.  A function of its own so that the stage's transients die
             with its locals before the next stage allocates."""
@@ -419,21 +421,29 @@ class RefineNetEngine:
             Oview = O_all[s] if nb == 3 else O_all[s, 2:3]
             cur, h, wd, Ys = (Sb if nb else None), H, W, []
             fused_tail = ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)
-            for ui, u in enumerate(P.up if nb else []):
-                r = u['r']
-                if fused_tail and ui == len(P.up) - 1:
+            # Nothing of the next stage reads this stage's outputs: the upsampler runs ASIDE (ops.aside: a helper stream behind the sums
+            # above), beside the next stage's ConvLSTM wavefront, and the forward rejoins it at its end.  Its buffers are allocated here,
+            # on the main stream (an allocation on another stream than the capture's origin fails under HIP-graph capture).
+            tail_u = P.up[-1] if (nb and fused_tail) else None
+            Yb, hh, ww = [], H, W
+            for u in (P.up[:-1] if tail_u is not None else P.up) if nb else []:
+                hh, ww = hh * u['r'], ww * u['r']
+                Yb.append(ops.empty(nb * TN, hh, ww, C, dtype=act if tail_bf16 else f32))
+            with ops.aside():
+                for u, Y in zip(P.up, Yb):
+                    ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, u['r']))
+                    Ys.append(Y)
+                    cur, h, wd = Y, h * u['r'], wd * u['r']
+                if tail_u is not None:
                     # last PixelShuffle conv + final conv as one composed 5x5 convolution (csrc/uptail.hip): the
                     # r*r*C-channel tensor between them is never formed, neither here nor in the backward
-                    ops.uptail_fwd(cur, params[u['fwd'].wkey], params[u['fwd'].bkey], params[P.last_w], params[P.last_b], r,
+                    r = tail_u['r']
+                    ops.uptail_fwd(cur, params[tail_u['fwd'].wkey], params[tail_u['fwd'].bkey], params[P.last_w], params[P.last_b], r,
                                    Oview.reshape(nb * TN, h * r, wd * r, cfg.out_channels))
-                    cur = None
-                    break
-                Y = ops.empty(nb * TN, h * r, wd * r, C, dtype=act if tail_bf16 else f32)
-                ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, r))
-                Ys.append(Y)
-                cur, h, wd = Y, h * r, wd * r
-            if cur is not None:
-                ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=Oview.reshape(nb * TN, h, wd, cfg.out_channels))
+                elif nb:
+                    ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=Oview.reshape(nb * TN, h, wd, cfg.out_channels))
+            aside_keep.append((Sb if nb else None, Yb))        # alive until the forward has rejoined the helper stream
+            if tail_u is None and nb:
                 Ys = Ys[:-1]                                  # the tail's output is not needed by the collapsed backward
             if need_grad:
                 st['Sb'], st['Ys'] = Sb, Ys
@@ -453,6 +463,8 @@ class RefineNetEngine:
         for s in range(S):
             feat = run_stage(s, feat)
             self._mem(f'fwd stage {s}: end')
+        ops.rejoin()                                              # the upsamplers of all stages have written their outputs
+        aside_keep.clear()
         if need_grad:
             feat.release()
         return O_all, (ctx if need_grad else None)
@@ -497,9 +509,16 @@ class RefineNetEngine:
             """The backward of stage s; returns the gradient w.r.t. the stage's input features on the supervised frames.  A function of its own so that
             every buffer of the stage - stored gates, dgates, state gradients - dies with its locals BEFORE the next (earlier) stage allocates
             (a loop body's rebinding `Gd = {...}` builds the new buffers while the old are alive: 30 GiB of overlap at config 4's peak)."""
+            # Weight gradients feed nothing but the optimizer: every one of this stage's runs ASIDE (ops.aside: the helper stream, behind the
+            # launch that produces its last operand), off the chain tail -> upsampler -> refine -> BPTT that the next stage waits for.
+            # `hold`: what those launches read - alive until the next stage has rejoined the helper (which it does before it rewrites the
+            # one buffer that outlives a stage, the refine block's gradient planes)
+            ops.rejoin()
+            hold = []
             st = ctx.stages[s]
             feat, Sb, Ys = st['feat'], st['Sb'], st['Ys']
             HF, HB = st['forward']['H'][-1], st['backward']['H'][-1]
+            hold += [Sb, Ys, st.get('R1')]
             # ---- upsampler backward (3 branches x T frames at once) -----------------------------------------
             sH, sW = dO_all.shape[3], dO_all.shape[4]
             dO = dO_all[s].view(3 * TN, sH, sW, cfg.out_channels)
@@ -511,19 +530,23 @@ class RefineNetEngine:
             h_in, w_in = xin.shape[1], xin.shape[2]
             w2, b2, w3 = params[ut['wgrad'].wkey], params[ut['wgrad'].bkey], params[P.last_w]
             G = ops.uptail_compose(w2, w3, rt)
-            if ops.uptail_xcorr_supported(C, rt, cfg.out_channels):
-                M, Sd = ops.uptail_xcorr(xin, dO, rt)
-            else:
-                D = ops.uptail_expand(dO, rt, P.tail_dc)
-                M = ops.empty(P.tail_m.Cout, C, 3, 3)
-                Sd = ops.empty(P.tail_m.Cout)
-                ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
             a2 = acc(ut['wgrad'].wkey)
             acc(ut['wgrad'].bkey)
             a3 = acc(P.last_w)
             acc(P.last_b)
-            ops.uptail_wcontract(M, Sd, w2, b2, w3, grads[ut['wgrad'].wkey], grads[ut['wgrad'].bkey], grads[P.last_w],
-                                 grads[P.last_b], rt, a2, a3)
+            M, Sd = ops.empty(P.tail_m.Cout, C, 3, 3), ops.empty(P.tail_m.Cout)
+            if ops.uptail_xcorr_supported(C, rt, cfg.out_channels):
+                D = None
+            else:
+                D = ops.uptail_expand(dO, rt, P.tail_dc)
+            hold += [M, Sd, D, dO]
+            with ops.aside():                            # the tail's weight gradients: cross-correlation (or the expanded GEMM) + contraction
+                if D is None:
+                    ops.uptail_xcorr(xin, dO, rt, out=(M, Sd))
+                else:
+                    ops.wgrad(P.tail_m, [Src(xin)], [Src(D)], 3 * TN, h_in, w_in, M, Sd, accumulate=False)
+                ops.uptail_wcontract(M, Sd, w2, b2, w3, grads[ut['wgrad'].wkey], grads[ut['wgrad'].bkey], grads[P.last_w],
+                                     grads[P.last_b], rt, a2, a3)
             dcur = ops.uptail_dgrad(dO, G, C, rt, dtype=act) if ctx.tail_bf16 else ops.uptail_dgrad(dO, G, C, rt)
             for ui in range(len(P.up) - 2, -1, -1):
                 u = P.up[ui]
@@ -533,12 +556,15 @@ class RefineNetEngine:
                 ysrcs = [Src(dcur, scale=r, sub=(ij // r, ij % r)) for ij in range(r * r)]
                 a = acc(u['wgrad'].wkey)
                 acc(u['wgrad'].bkey)
-                ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
-                          accumulate=a)
+                hold.append(dcur)
+                with ops.aside():
+                    ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
+                              accumulate=a)
                 dnext = ops.empty(3 * TN, h_in, w_in, C, dtype=act)
                 ops.conv(u['dgrad'], ysrcs, 3 * TN, h_in, w_in, dsts=[Dst(dnext, C)])
                 dcur = dnext
             dS = dcur
+            hold.append(dS)
             dHf, dHb, dR = dS[0:TN], dS[TN:2 * TN], dS[2 * TN:3 * TN]
             dfeat = ops.empty(TN, H, W, C, dtype=act)
             ops.add(dfeat, dHf, dHb, dR)
@@ -568,38 +594,44 @@ class RefineNetEngine:
                     ops.conv(P.r2_dgrad, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p, img_off=hw * N)])
                 a = acc(P.r2_wgrad.wkey)
                 acc(P.r2_wgrad.bkey)
-                if P.r2_wino and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0':
-                    ops.wgrad(P.r2_wgrad_h, [Src(st['R1'], nch=2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], grads[P.r2_wgrad.bkey], accumulate=a)
-                    ops.wgrad(P.r2_wgrad_x, [Src(st['R1'], c0=2 * Cl, nch=P.C1p - 2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], None,
-                              accumulate=a)                         # (its own rows of the gradient: the same store / accumulate mode)
-                else:
-                    ops.wgrad(P.r2_wgrad, [Src(st['R1'])], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
-                              grads[P.r2_wgrad.bkey], accumulate=a)
-                a = acc(k1)
+                a1 = acc(k1)
                 acc(b1)
                 ysrc = [Src(dR1p, nch=P.r1_cols, img_off=hw * N)]
-                if P.xcol_m:
-                    # 2*Cl columns against the window sources; the last channel's weights as the gradient of the per-frame convolution
-                    # (the plan's row order: hidden-state sources first, then the phase planes)
-                    ops.wgrad(P.r1_wgrad_a, [sc for i, sc in enumerate(xs) if i % 3 != 2] + [sc for i, sc in enumerate(xs) if i % 3 == 2],
-                              [Src(dR1p, nch=2 * Cl, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                E = dbx = None
+                if P.xcol_m:                                 # (the helper stream allocates nothing: its operands are made here)
                     E = ops.xcol_gather_m(dR1p[hw * N:(hw + T) * N], N, w, 2 * Cl, act)
-                    f0, nfr = (U - hw) * N, T + w - 1
-                    dbx = ops.zeros(8)                                   # (zeros: the launch below may run in accumulate mode)
-                    ops.wgrad(P.r1x_wgrad, [HF.src(U - hw), HB.src(U - hw), Src(ctx.P4, img_off=f0)], [Src(E)], nfr * N, H, W,
-                              grads[k1][P.C1 - 1].view(w, P.C1, 3, 3), dbx[:w], accumulate=a)
-                    ops.put_scalar(grads[b1][P.C1 - 1:P.C1], dbx[0:1], a)
-                elif P.r1_wino:
-                    # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
-                    ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
-                    if Cl % 64 == 0 and (P.r1_cols // 4) in (8, 16, 32, 64):
-                        # the five phase-plane rows from border-class sums of the gradient (rnh_phase_wgrad)
-                        lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
-                        ops.refine_phase_wgrad(dR1p[hw * N:(hw + T) * N], ctx.P4[lo:hi], grads[k1], N, w, Cl, P.r1_cols, a)
+                    dbx = ops.zeros(8)                       # (zeros: the launch below may run in accumulate mode)
+                    hold += [E, dbx]
+                with ops.aside():                            # the refine block's weight gradients (behind conv2's data gradient above)
+                    if P.r2_wino and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0':
+                        ops.wgrad(P.r2_wgrad_h, [Src(st['R1'], nch=2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], grads[P.r2_wgrad.bkey],
+                                  accumulate=a)
+                        ops.wgrad(P.r2_wgrad_x, [Src(st['R1'], c0=2 * Cl, nch=P.C1p - 2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], None,
+                                  accumulate=a)                     # (its own rows of the gradient: the same store / accumulate mode)
                     else:
-                        ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
-                else:
-                    ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
+                        ops.wgrad(P.r2_wgrad, [Src(st['R1'])], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey],
+                                  grads[P.r2_wgrad.bkey], accumulate=a)
+                    a = a1
+                    if P.xcol_m:
+                        # 2*Cl columns against the window sources; the last channel's weights as the gradient of the per-frame convolution
+                        # (the plan's row order: hidden-state sources first, then the phase planes)
+                        ops.wgrad(P.r1_wgrad_a, [sc for i, sc in enumerate(xs) if i % 3 != 2] + [sc for i, sc in enumerate(xs) if i % 3 == 2],
+                                  [Src(dR1p, nch=2 * Cl, img_off=hw * N)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                        f0, nfr = (U - hw) * N, T + w - 1
+                        ops.wgrad(P.r1x_wgrad, [HF.src(U - hw), HB.src(U - hw), Src(ctx.P4, img_off=f0)], [Src(E)], nfr * N, H, W,
+                                  grads[k1][P.C1 - 1].view(w, P.C1, 3, 3), dbx[:w], accumulate=a)
+                        ops.put_scalar(grads[b1][P.C1 - 1:P.C1], dbx[0:1], a)
+                    elif P.r1_wino:
+                        # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
+                        ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
+                        if Cl % 64 == 0 and (P.r1_cols // 4) in (8, 16, 32, 64):
+                            # the five phase-plane rows from border-class sums of the gradient (rnh_phase_wgrad)
+                            lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
+                            ops.refine_phase_wgrad(dR1p[hw * N:(hw + T) * N], ctx.P4[lo:hi], grads[k1], N, w, Cl, P.r1_cols, a)
+                        else:
+                            ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
+                    else:
+                        ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                 if P.xcol:
                     lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
                     ops.refine_xcol_wgrad([HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]],
@@ -611,7 +643,8 @@ class RefineNetEngine:
                 ops.add(gsrc[hw * N:(hw + T) * N], dR)
                 a = acc(k1)
                 acc(b1)
-                ops.wgrad(P.r1_wgrad, xs, [Src(dR)], TN, H, W, grads[k1], grads[b1], accumulate=a)
+                with ops.aside():
+                    ops.wgrad(P.r1_wgrad, xs, [Src(dR)], TN, H, W, grads[k1], grads[b1], accumulate=a)
             # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
             if P.r1_wino:
                 nm = P.r1_cols
@@ -778,7 +811,7 @@ class RefineNetEngine:
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
             for d in dirs:                                          # (the weight gradients read neither the stored gates nor the cell states)
                 st[d]['G'] = st[d]['C'] = None
-            in_flight = (st, feat, Gd) if defer else None          # what the weight-gradient launches still read: h, features, dgates
+            in_flight = (st, feat, Gd if defer else None, hold)    # what the weight-gradient launches still read: h, features, dgates, ...
             ctx.stages[s] = None
             return dfeat, in_flight
 
@@ -796,5 +829,6 @@ class RefineNetEngine:
                        dfeat_next, grads['in_block.conv.weight'], grads['in_block.conv.bias'], grads['in_block.prelu.weight'],
                        accumulate=False)
         ops.join(2 * Lr)                                          # the first stage's weight gradients (the last ones launched)
+        ops.rejoin()
         pending = None
         return grads

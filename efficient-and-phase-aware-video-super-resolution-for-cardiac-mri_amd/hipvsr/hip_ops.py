@@ -138,6 +138,30 @@ class HipOps:
             ev.record(st)
             cur.wait_event(ev)
 
+    # ---- a helper stream for work that nothing on the critical path waits for (weight gradients, the upsampler of a finished stage) -----
+    # aside(): the helper stream picks up behind everything the current stream has been given so far (so it may read what those
+    # launches produce) and the launches inside the block go to it; rejoin(): the current stream waits for everything the helper has
+    # been given.  Buffers the helper reads or writes must stay alive - and must not be rewritten by the current stream - until the
+    # next rejoin().  RNH_ASIDE=0: the block runs on the current stream (A/B measurements).
+    def aside(self):
+        if os.environ.get('RNH_ASIDE', '1') == '0':
+            import contextlib
+            return contextlib.nullcontext()
+        if getattr(self, '_helper', None) is None:
+            self._helper = torch.cuda.Stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._helper.wait_event(ev)
+        self._helper_used = True
+        return torch.cuda.stream(self._helper)
+
+    def rejoin(self):
+        if getattr(self, '_helper_used', False):
+            ev = torch.cuda.Event()
+            ev.record(self._helper)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._helper_used = False
+
     def _workspace(self, key, nfloats):
         """Scratch buffer ``key`` of the current stream, grown on demand.  A HIP graph captured through this object
         (hipvsr.graph) has the addresses of the buffers it used baked in: once a graph exists an outgrown buffer is
@@ -672,15 +696,19 @@ class HipOps:
     def uptail_xcorr_supported(self, C1, r, Co):
         return bool(self.lib.rnh_uptail_xcorr_supported(C1, r, Co))
 
-    def uptail_xcorr(self, y1, d_o, r):
-        """M (ND*ND, C1, 3, 3) and S (ND*ND) of the collapsed tail straight from the conv input and d_o (Co == 1)."""
+    def uptail_xcorr(self, y1, d_o, r, out=None):
+        """M (ND*ND, C1, 3, 3) and S (ND*ND) of the collapsed tail straight from the conv input and d_o (Co == 1); out = (M, S) allocated
+        by the caller (a caller that launches this on the helper stream allocates on its own stream)."""
         self._chk(d_o)
         self._chk(y1, mixed=True)
         B, Hm, Wm, C1 = y1.shape
         if tuple(d_o.shape) != (B, Hm * r, Wm * r, 1):
             raise L.HipKernelError('uptail_xcorr: shapes')
         nd2 = (r + 2) * (r + 2)
-        M, S = self.empty(nd2, C1, 3, 3), self.empty(nd2)
+        M, S = out if out is not None else (self.empty(nd2, C1, 3, 3), self.empty(nd2))
+        if tuple(M.shape) != (nd2, C1, 3, 3) or tuple(S.shape) != (nd2,):
+            raise L.HipKernelError('uptail_xcorr: out shapes')
+        self._chk(M, S)
         ws = self._workspace('uptail_xcorr', self.lib.rnh_uptail_xcorr_ws_floats(B, Hm, Wm, C1, r))
         fn, name = (self.lib.rnh_uptail_xcorr_bf16, 'rnh_uptail_xcorr_bf16') if y1.dtype == torch.bfloat16 else \
             (self.lib.rnh_uptail_xcorr, 'rnh_uptail_xcorr')

@@ -67,6 +67,13 @@ class TorchOps:
         import contextlib
         return contextlib.nullcontext()
 
+    def aside(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def rejoin(self):
+        pass
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.full(shape, float('nan'), dtype=dtype, device=self.device)   # poison: catches unwritten reads
 
@@ -331,7 +338,7 @@ class TorchOps:
     def uptail_xcorr_supported(self, C1, r, Co):
         return Co == 1 and r in (2, 3) and C1 % 64 == 0
 
-    def uptail_xcorr(self, y1, d_o, r):
+    def uptail_xcorr(self, y1, d_o, r, out=None):
         nd2 = (r + 2) * (r + 2)
         D = self.uptail_expand(d_o, r)[..., :nd2]                                        # (B, Hm, Wm, ND*ND)
         ypad = F.pad(y1.float(), (0, 0, 1, 1, 1, 1))
@@ -340,6 +347,10 @@ class TorchOps:
         for ty in range(3):
             for tx in range(3):
                 M[:, :, ty, tx] = torch.einsum('bhwd,bhwc->dc', D, ypad[:, ty:ty + Hm, tx:tx + Wm])
+        if out is not None:
+            out[0].copy_(M)
+            out[1].copy_(D.sum(dim=(0, 1, 2)))
+            return out
         return M, D.sum(dim=(0, 1, 2))
 
     def uptail_expand(self, d_o, r, Dc=None):

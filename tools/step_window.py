@@ -15,7 +15,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else len(ends) - 2
 lo, hi = ends[k], ends[k + 1]
 win = [(max(s, lo), min(e, hi), n) for s, e, n in rows if e > lo and s < hi]
 ev = sorted([(s, 1, i) for i, (s, e, n) in enumerate(win)] + [(e, 0, i) for i, (s, e, n) in enumerate(win)])
-active, hist, share = set(), collections.Counter(), collections.Counter()
+active, hist, share, alone = set(), collections.Counter(), collections.Counter(), collections.Counter()
 gaps, prev, last_end_name = [], lo, 'step start'
 for t, kind, i in ev:
     dt = t - prev
@@ -23,6 +23,8 @@ for t, kind, i in ev:
         hist[min(len(active), 6)] += dt
         for j in active:
             share[win[j][2]] += dt / len(active)
+        if len(active) == 1:
+            alone[win[next(iter(active))][2]] += dt
         if not active:
             gaps.append((dt, last_end_name, win[i][2]))
     prev = t
@@ -48,3 +50,6 @@ for (a, b), v in bypair.most_common(10):
 print('share of the window per kernel:')
 for n, v in share.most_common(12):
     print(f'   {100 * v / span:6.2f} %  {n}')
+print('time with the chip to itself, per kernel (ms, % of the window):')
+for n, v in alone.most_common(25):
+    print(f'   {v / 1e6:7.2f} ms {100 * v / span:6.2f} %  {n}')
