@@ -429,7 +429,7 @@ class RefineNetEngine:
             for u in (P.up[:-1] if tail_u is not None else P.up) if nb else []:
                 hh, ww = hh * u['r'], ww * u['r']
                 Yb.append(ops.empty(nb * TN, hh, ww, C, dtype=act if tail_bf16 else f32))
-            with ops.aside():
+            with ops.aside('up_fwd'):
                 for u, Y in zip(P.up, Yb):
                     ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, u['r']))
                     Ys.append(Y)
@@ -540,7 +540,7 @@ class RefineNetEngine:
             else:
                 D = ops.uptail_expand(dO, rt, P.tail_dc)
             hold += [M, Sd, D, dO]
-            with ops.aside():                            # the tail's weight gradients: cross-correlation (or the expanded GEMM) + contraction
+            with ops.aside('tail_w'):                    # the tail's weight gradients: cross-correlation (or the expanded GEMM) + contraction
                 if D is None:
                     ops.uptail_xcorr(xin, dO, rt, out=(M, Sd))
                 else:
@@ -557,7 +557,7 @@ class RefineNetEngine:
                 a = acc(u['wgrad'].wkey)
                 acc(u['wgrad'].bkey)
                 hold.append(dcur)
-                with ops.aside():
+                with ops.aside('up_w'):
                     ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
                               accumulate=a)
                 dnext = ops.empty(3 * TN, h_in, w_in, C, dtype=act)
@@ -602,7 +602,7 @@ class RefineNetEngine:
                     E = ops.xcol_gather_m(dR1p[hw * N:(hw + T) * N], N, w, 2 * Cl, act)
                     dbx = ops.zeros(8)                       # (zeros: the launch below may run in accumulate mode)
                     hold += [E, dbx]
-                with ops.aside():                            # the refine block's weight gradients (behind conv2's data gradient above)
+                with ops.aside('refine_w'):                  # the refine block's weight gradients (behind conv2's data gradient above)
                     if P.r2_wino and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0':
                         ops.wgrad(P.r2_wgrad_h, [Src(st['R1'], nch=2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], grads[P.r2_wgrad.bkey],
                                   accumulate=a)
@@ -643,7 +643,7 @@ class RefineNetEngine:
                 ops.add(gsrc[hw * N:(hw + T) * N], dR)
                 a = acc(k1)
                 acc(b1)
-                with ops.aside():
+                with ops.aside('refine_w'):
                     ops.wgrad(P.r1_wgrad, xs, [Src(dR)], TN, H, W, grads[k1], grads[b1], accumulate=a)
             # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
             if P.r1_wino:

@@ -142,9 +142,15 @@ class HipOps:
     # aside(): the helper stream picks up behind everything the current stream has been given so far (so it may read what those
     # launches produce) and the launches inside the block go to it; rejoin(): the current stream waits for everything the helper has
     # been given.  Buffers the helper reads or writes must stay alive - and must not be rewritten by the current stream - until the
-    # next rejoin().  RNH_ASIDE=0: the block runs on the current stream (A/B measurements).
-    def aside(self):
-        if os.environ.get('RNH_ASIDE', '1') == '0':
+    # next rejoin().  RNH_ASIDE=0: the block runs on the current stream (A/B measurements).  Under HIP-graph capture the block also stays on
+    # the current stream: a captured training step with this extra branch reproduced the eager step's gradients only intermittently (2 of
+    # 3 runs of tools/probes/graph_vs_eager.py differed in refine conv1's weight gradient by ~1 %, any ONE of the four blocks taken off
+    # the helper made the runs agree again, and the eager step - whose launches and dependencies are the same - is bit-identical with
+    # the helper delayed by 2 ms per block and without it, tests/test_parity_r04.py).  Cause not found; it joins the graph-replay flake of
+    # round 1 as unexplained, and the captured step keeps the shape that has replayed exactly since round 2.
+    def aside(self, tag=''):
+        if os.environ.get('RNH_ASIDE', '1') == '0' or (tag and tag in os.environ.get('RNH_ASIDE_OFF', '').split(',')) or \
+                torch.cuda.is_current_stream_capturing():
             import contextlib
             return contextlib.nullcontext()
         if getattr(self, '_helper', None) is None:
@@ -153,6 +159,9 @@ class HipOps:
         ev.record(torch.cuda.current_stream(self.device))
         self._helper.wait_event(ev)
         self._helper_used = True
+        if os.environ.get('RNH_ASIDE_DELAY'):                 # race detector (tests): the helper starts late by that many spin cycles, so a
+            with torch.cuda.stream(self._helper):             # launch elsewhere that does not wait for it - or rewrites what it reads - shows
+                torch.cuda._sleep(int(os.environ['RNH_ASIDE_DELAY']))
         return torch.cuda.stream(self._helper)
 
     def rejoin(self):

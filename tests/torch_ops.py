@@ -67,7 +67,7 @@ class TorchOps:
         import contextlib
         return contextlib.nullcontext()
 
-    def aside(self):
+    def aside(self, tag=''):
         import contextlib
         return contextlib.nullcontext()
 

@@ -1,0 +1,45 @@
+"""Debug probe: tests/test_predictor.py::test_graphed_training_steps_equal_eager_bit_for_bit with diagnostics - which parameters differ after
+which step, under RNH_ASIDE / RNH_DEFER_WGRAD settings.  usage: graph_vs_eager.py [f32|bf16]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd')):
+    sys.path.insert(0, p)
+import torch
+from oracle import refinenet_oracle as orc
+from hipvsr.step_tail import FlatAdam
+from src.model.nets import RefineNet
+from src.runner.trainers import AcdcVSRRefineNetTrainer
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+dev = torch.device('cuda:0')
+cfg = orc.Config(in_channels=1, out_channels=1, num_features=[16, 16], num_stages=2, refine_window_size=5, upscale_factor=4,
+                 update_memory=True, num_updated_frames=2, positional_encoding=True)
+sd = orc.init_state_dict(cfg, seed=8)
+g = torch.Generator('cpu').manual_seed(5)
+batches = []
+for k in range(6):
+    n = 4 if k % 3 != 2 else 2
+    batches.append(([torch.randn(n, 1, 16, 16, generator=g).to(dev) for _ in range(7)], [torch.randn(n, 1, 64, 64, generator=g).to(dev) for _ in range(3)],
+                    (torch.rand(n, 7, 1, generator=g) * 2 - 1).to(dev)))
+runs = {}
+for graph in (False, True, 'eager2', 'delayed'):
+    os.environ.pop('RNH_ASIDE_DELAY', None)
+    if graph == 'delayed':
+        os.environ['RNH_ASIDE_DELAY'] = '4000000'
+    net = RefineNet(**cfg)
+    net.load_state_dict(sd)
+    net = net.to(dev).set_compute_dtype(dtype).train()
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.net, tr.loss_fns, tr.metric_fns, tr.graph, tr._graphed = net, [torch.nn.L1Loss()], [], graph is True, None
+    tr.loss_weights = torch.tensor([1.0], device=dev)
+    tr.optimizer = FlatAdam(net.parameters(), lr=1e-3)
+    hist = []
+    for xs, ys, pc in batches:
+        outs, loss, _ = tr.train_step(xs, ys, pc)
+        torch.cuda.synchronize()
+        hist.append((float(loss.detach()), {k: p.grad.detach().clone() if p.grad is not None else None for k, p in net.named_parameters()}))
+    runs[graph] = hist
+for other in (True, 'eager2', 'delayed'):
+    print('eager vs', other)
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(runs[False], runs[other])):
+        bad = [(k, float((ga[k] - gb[k]).abs().max()), float(ga[k].abs().max())) for k in ga if ga[k] is not None and not torch.equal(ga[k], gb[k])]
+        print(' step', i, 'loss equal', la == lb, 'differing gradients:', bad)
