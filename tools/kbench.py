@@ -88,7 +88,26 @@ else:
 if P.xcol:
     timeit('refine1.fwd.xcol', lambda: ops.refine_xcol_fwd([Hf, Hb, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, 5, 64), 2.0 * nwin * N * H * W * 645 * 9, 3)
 Rr = ops.empty(nwin * N, H, W, 64)
-timeit('refine2.fwd', lambda: ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)]), 2.0 * nwin * N * H * W * 64 * 129 * 9, 3)
+def r2_fwd():                                       # as the engine runs it: 128 hidden-state channels in Winograd form + the phase channel
+    if P.r2_wino:
+        ops.conv(P.r2_fwd_h, [Src(R1, nch=128)], nwin * N, H, W, dsts=[Dst(Rr, 64)])
+        ops.conv(P.r2_fwd_x, [Src(R1, c0=128, nch=P.C1p - 128)], nwin * N, H, W, dsts=[Dst(Rr, 64, accumulate=True)])
+    else:
+        ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)])
+
+
+timeit('refine2.fwd', r2_fwd, 2.0 * nwin * N * H * W * 64 * 129 * 9, 3)
+dRr = R(TN, H, W, 64)
+dw2_, db2_ = ops.empty(64, 129, 3, 3), ops.empty(64)
+def r2_wgrad():
+    if P.r2_wino:
+        ops.wgrad(P.r2_wgrad_h, [Src(R1, nch=128)], [Src(dRr)], TN, H, W, dw2_, db2_)
+        ops.wgrad(P.r2_wgrad_x, [Src(R1, c0=128, nch=P.C1p - 128)], [Src(dRr)], TN, H, W, dw2_, None)
+    else:
+        ops.wgrad(P.r2_wgrad, [Src(R1)], [Src(dRr)], TN, H, W, dw2_, db2_)
+
+
+timeit('refine2.wgrad', r2_wgrad, 2.0 * TN * H * W * 64 * 129 * 9, 3)
 dR1p = R((T + 4) * N, H, W, P.C1p)
 xs1 = []
 for j in range(5):
