@@ -289,13 +289,9 @@ class RefineNetEngine:
 
         aside_keep = []
 
-        def run_stage(s, feat, start=None):
-            """Stage s of the forward; returns the features the next stage starts from and `start` for that stage.  A function of its own so that
-            the stage's transients die with its locals before the next stage allocates.
-            start = (fork event, event of the supervised frames' features) or None: the previous stage recorded the first event on the main
-            stream when the features of the frames on both sides of the supervised ones were complete - the ConvLSTM chains start from
-            there (forward from frame 0, backward from frame F - 1), beside the previous stage's refine convolutions over the supervised
-            windows, upsampler and feature update, and wait for the second event in front of the first supervised frame they meet."""
+        def run_stage(s, feat):
+            """Stage s of the forward; returns the features the next stage starts from.  A function of its own so that the stage's transients die
+            with its locals before the next stage allocates."""
             st = dict(feat=feat)
             # ---- bidirectional ConvLSTM over the frames (refine_net.py:82-93) ----------------------------
             # One cell launch (N images) fills the chip for well under a millisecond, so its ramp-up and tail matter.
@@ -317,7 +313,7 @@ class RefineNetEngine:
                 st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), act) for l, hd in enumerate(nf)],
                              C=[FrameStore(ops, N, lo_d, hi_d, keep, (H, W, hd), f32, ring=2, step=1 if fwd else -1) for hd in nf],
                              G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and s >= n_rc else None)
-            ops.fork(2 * Lr, after=start[0] if start else None)
+            ops.fork(2 * Lr)
             for idx in range(F_s):
                 for di, d in enumerate(dirs):
                     k = idx if d == 'forward' else F - 1 - idx
@@ -330,8 +326,6 @@ class RefineNetEngine:
                             if below is not None:
                                 ops.wait(below)
                             pl = P.lstm[(d, l)]
-                            if l == 0 and start and U <= k < U + T:
-                                ops.wait(start[1])              # the supervised frames' features come last (see above)
                             xin = feat if l == 0 else Hb[l - 1]
                             srcs = [xin.src(k)]
                             if cfg.memory:
@@ -368,34 +362,16 @@ class RefineNetEngine:
                     if P.pos:
                         out.append(Src(P4, img_off=(a + j) * N))
                 return out
-            # The feature update (refine_net.py:118-133) writes the next stage's features piece by piece, each behind the refine windows it needs,
-            # so that the next stage's ConvLSTM chains can start before this stage is done (run_stage's `start`): with gradients the windows
-            # come in three segments - in front of the supervised frames, behind them, and the supervised ones LAST.
-            update = S > 1 and s < S - 1
-            nfeat = FrameStore(ops, N, 0, F, sup, (H, W, C), act) if update else None
-            nxt, late = None, []                                    # `late`: main-stream buffers still in use after the fork event
-
-            def feat_update(lo_r, hi_r, other):
-                for a, b in nfeat.pieces(lo_r, hi_r):
-                    ops.add(nfeat.frames(a, b), feat.frames(a, b), other(a, b))
-            if update:                                             # the frames at both ends take the hidden states themselves
-                feat_update(0, hw, lambda a, b: HF.frames(a, b))
-                feat_update(F - hw, F, lambda a, b: HB.frames(a, b))
             if P.pos:
                 # conv1's output R1 comes back in the backward for the T supervised windows only (conv2's weight gradient): they get
                 # a buffer of their own, the windows on both sides a transient one each
-                wsegs = [(w0, U - hw), (U - hw + T, w0 + nwin), (U - hw, U - hw + T)] if need_grad else [(w0, w0 + nwin)]
-                early = update and need_grad and os.environ.get('RNH_EARLY_START', '1') != '0'
-                for si, (a, b) in enumerate(wsegs):
-                    if early and si == 2:                          # everything but the supervised frames is in place: the next stage may start
-                        nxt = [ops.record(), None]
+                wsegs = [(w0, U - hw), (U - hw, U - hw + T), (U - hw + T, w0 + nwin)] if need_grad else [(w0, w0 + nwin)]
+                for a, b in wsegs:
                     if b <= a:
                         continue
                     nw = b - a
                     srcs = win_srcs(a)
                     R1 = ops.empty(nw * N, H, W, P.C1p, dtype=act)
-                    if nxt is not None:
-                        late.append(R1)
                     hfs, hbs, p4s = HF.frames(a, b + w - 1), HB.frames(a, b + w - 1), P4[a * N:(b + w - 1) * N]   # the source frames of these windows
                     if P.r1_wino:
                         ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
@@ -406,8 +382,6 @@ class RefineNetEngine:
                         ops.conv(P.r1_fwd_a, srcs, nw * N, H, W, dsts=[Dst(R1, 2 * Cl)])
                         nfr = nw + w - 1
                         Z5 = ops.empty(nfr * N, H, W, 8)
-                        if nxt is not None:
-                            late.append(Z5)
                         ops.conv(P.r1x_fwd, [HF.src(a), HB.src(a), Src(P4, img_off=a * N)], nfr * N, H, W, dsts=[Dst(Z5, 8)])
                         ops.xcol_combine_m(Z5, params[P.r1_fwd.bkey], R1, N, w, 2 * Cl)
                     elif P.r1_split:
@@ -426,14 +400,8 @@ class RefineNetEngine:
                     if need_grad and a == U - hw:
                         st['R1'] = R1                           # windows U-hw .. U-hw+T-1
                     del R1
-                    if update:                                  # the frames these windows refine (window v is frame v + hw)
-                        feat_update(a + hw, b + hw, lambda fa, fb: R[(fa - hw - w0) * N:(fb - hw - w0) * N])
-                if nxt is not None:
-                    nxt[1] = ops.record()                       # ... and now the supervised frames' features as well
             else:
                 ops.conv(P.r1_fwd, win_srcs(w0), nwin * N, H, W, dsts=[Dst(R, Cl)])
-                if update:
-                    feat_update(hw, F - hw, lambda fa, fb: R[(fa - hw) * N:(fb - hw) * N])
 
             # ---- three output groups through the upsampler (refine_net.py:100-113, :194-205) --------------
             fc = feat.frames(U, U + T)
@@ -481,17 +449,19 @@ class RefineNetEngine:
                 st['Sb'], st['Ys'] = Sb, Ys
                 ctx.stages.append(st)
 
-            if update:
+            # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
+            if S > 1 and s < S - 1:
+                nfeat = FrameStore(ops, N, 0, F, sup, (H, W, C), act)
+                for lo_r, hi_r, other in ((0, hw, lambda a, b: HF.frames(a, b)), (hw, F - hw, lambda a, b: R[(a - hw) * N:(b - hw) * N]),
+                                          (F - hw, F, lambda a, b: HB.frames(a, b))):
+                    for a, b in nfeat.pieces(lo_r, hi_r):
+                        ops.add(nfeat.frames(a, b), feat.frames(a, b), other(a, b))
                 feat.release()                                # (the stage's entry keeps the supervised frames alive)
                 feat = nfeat
-            if nxt is not None:                                  # the next stage's side streams may start before these launches have run: nothing
-                late.append(R)                                # they read or write may be freed (and handed to those streams) before the forward's
-                aside_keep.append(late)                       # last join
-            return feat, (tuple(nxt) if nxt else None)
+            return feat
 
-        start = None
         for s in range(S):
-            feat, start = run_stage(s, feat, start)
+            feat = run_stage(s, feat)
             self._mem(f'fwd stage {s}: end')
         ops.rejoin()                                              # the upsamplers of all stages have written their outputs
         aside_keep.clear()

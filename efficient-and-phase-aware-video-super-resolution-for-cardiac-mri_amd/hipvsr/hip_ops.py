@@ -103,25 +103,19 @@ class HipOps:
     # HIP streams: 'cell' = 2L streams, 'layer' = L streams (both directions of a layer share one: measured best at
     # BASELINE config 2, where every cell launch fills the chip and cross-stream event waits only cost latency),
     # 'dir' = 2, 'one' = 1.
-    lstm_streams = 'layer'                                    # the engine sets it per compute type (RefineNetEngine.__init__)
-
     def _side_index(self, i):
-        which = 'RNH_LSTM_STREAMS_BWD' if self._side is self._banks[1] else 'RNH_LSTM_STREAMS_FWD'
-        mode = os.environ.get(which) or os.environ.get('RNH_LSTM_STREAMS') or self.lstm_streams
+        mode = os.environ.get('RNH_LSTM_STREAMS', 'layer')
         half = max(self._fork_n // 2, 1)
         return {'cell': i, 'layer': i % half, 'dir': i // half, 'one': 0}[mode]
 
-    def fork(self, n, bank=0, after=None):
-        """The n logical side streams pick up behind the current stream's work so far - or behind `after`, an earlier record() of it."""
+    def fork(self, n, bank=0):
         self._side = self._banks[bank]
         self._fork_n = n
         n = 1 + max(self._side_index(i) for i in range(n))
         while len(self._side) < n:
             self._side.append(torch.cuda.Stream(self.device))
-        ev = after
-        if ev is None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
         for st in self._side[:n]:
             st.wait_event(ev)
 

@@ -51,7 +51,7 @@ class TorchOps:
         self.device = torch.device(device)
         self._w = {}
 
-    def fork(self, n, bank=0, after=None):
+    def fork(self, n, bank=0):
         pass
 
     def join(self, n):
