@@ -373,13 +373,6 @@ class RefineNetEngine:
                     srcs = win_srcs(a)
                     R1 = ops.empty(nw * N, H, W, P.C1p, dtype=act)
                     hfs, hbs, p4s = HF.frames(a, b + w - 1), HB.frames(a, b + w - 1), P4[a * N:(b + w - 1) * N]   # the source frames of these windows
-                    xb = None
-                    if P.xcol:
-                        # conv1's channel 2*Cl (side path: small HBM- / VALU-bound launches) beside the Winograd launch over the other 2*Cl
-                        # columns: they write disjoint columns of R1; rejoined in front of conv2
-                        xb = ops.refine_xcol_bufs([hfs, hbs, p4s], w, Cl)
-                        with ops.aside('xcol_fwd'):
-                            ops.refine_xcol_fwd([hfs, hbs, p4s], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl, bufs=xb)
                     if P.r1_wino:
                         ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                         ops.refine_phase_bias(R1, p4s, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
@@ -397,7 +390,7 @@ class RefineNetEngine:
                     else:
                         ops.conv(P.r1_fwd, srcs, nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                     if P.xcol:
-                        ops.rejoin()
+                        ops.refine_xcol_fwd([hfs, hbs, p4s], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
                     ro = (a - w0) * N
                     if P.r2_wino:
                         ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
@@ -641,11 +634,8 @@ class RefineNetEngine:
                         ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
                 if P.xcol:
                     lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
-                    xsrc = [HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]]
-                    xb = ops.refine_xcol_bufs(xsrc, w, Cl, wgrad=True)
-                    hold.append(xb)
-                    with ops.aside('refine_w'):
-                        ops.refine_xcol_wgrad(xsrc, dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w, Cl, a, bufs=xb)
+                    ops.refine_xcol_wgrad([HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]],
+                                          dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w, Cl, a)
                 gsrc = dR1p
                 st['R1'] = None
             else:

@@ -565,28 +565,18 @@ class HipOps:
     # ---- side path of refine conv1's odd output channel 2*cl (csrc/small_kernels.hip, xcol_*) -----------------
     _XCOL_SEGS = staticmethod(lambda cl: ((0, cl, cl), (cl, cl, cl), (2 * cl, 4, 1)))       # (c0, nch, nvalid) of h_fwd, h_bwd, phase
 
-    def refine_xcol_bufs(self, srcs, J, cl, wgrad=False):
-        """The temporaries of refine_xcol_fwd (wgrad: of refine_xcol_wgrad), allocated on the current stream: a caller that runs the side path
-        on the helper stream (ops.aside) allocates here first and holds them until it has rejoined."""
-        B, H, W = srcs[0].shape[:3]
-        segs = self._XCOL_SEGS(cl)
-        if wgrad:
-            return dict(E=self.empty(B, H, W, J), dwx=[self.empty(J, nch, 3, 3) for _, nch, _ in segs], dbx=[self.empty(J) for _ in segs])
-        return dict(zero=self.zeros(J), wx=[self.empty(J, nch, 3, 3) for _, nch, _ in segs], z=[self.empty(B, H, W, J) for _ in segs])
-
-    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl, bufs=None):
+    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl):
         """R1[window i][..., 2*cl] = conv1 channel 2*cl over the J frame slots of srcs = (h_fwd, h_bwd, phase plane)."""
         self._chk(w1, b1, R1, *srcs)
         co, cs, Cin = 2 * cl, 2 * cl + 1, w1.shape[1]
         nwin, H, W, C = R1.shape[0] // N, R1.shape[1], R1.shape[2], R1.shape[3]
-        bufs = bufs or self.refine_xcol_bufs(srcs, J, cl)
-        zero, zs = bufs['zero'], []
-        for k, (s, (c0, nch, nv)) in enumerate(zip(srcs, self._XCOL_SEGS(cl))):
+        zero, zs = self.zeros(J), []
+        for s, (c0, nch, nv) in zip(srcs, self._XCOL_SEGS(cl)):
             if s.shape[0] != (nwin + J - 1) * N or s.shape[3] != nch:
                 raise L.HipKernelError('refine_xcol_fwd: source shape')
-            wx = bufs['wx'][k]
+            wx = self.empty(J, nch, 3, 3)
             L.check(self.lib.rnh_xcol_pack(_ptr(w1), _ptr(wx), Cin, co, J, cs, c0, nch, nv, self._stream()), 'rnh_xcol_pack')
-            zs.append(self.outconv_fwd(s, wx, zero, out=bufs['z'][k]))
+            zs.append(self.outconv_fwd(s, wx, zero))
         L.check(self.lib.rnh_xcol_combine(_ptr(zs[0]), _ptr(zs[1]), _ptr(zs[2]), b1.data_ptr() + 4 * co, _ptr(R1), H * W, N, nwin, J, C, co,
                                           self._stream()), 'rnh_xcol_combine')
 
@@ -647,21 +637,18 @@ class HipOps:
         L.check(self.lib.rnh_phase_bias_add(_ptr(R1), _ptr(P4), _ptr(w1), _ptr(ws), H, W, N, nwin, J, w1.shape[1], 2 * cl + 1, 2 * cl, C,
                                             ncols, self._stream()), 'rnh_phase_bias_add')
 
-    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate, bufs=None):
+    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
         """Weight / bias gradient of conv1's channel 2*cl: srcs = the (nwin + J - 1)*N source frames of (h_fwd, h_bwd,
         phase plane), dy = (nwin*N, H, W, C1p) gradient of conv1's output."""
         self._chk(dy, dw1, db1, *srcs)
         co, cs, Cin = 2 * cl, 2 * cl + 1, dw1.shape[1]
         nwin, H, W, C = dy.shape[0] // N, dy.shape[1], dy.shape[2], dy.shape[3]
-        bufs = bufs or self.refine_xcol_bufs(srcs, J, cl, wgrad=True)
-        E = bufs['E']
-        if tuple(E.shape) != ((nwin + J - 1) * N, H, W, J):
-            raise L.HipKernelError('refine_xcol_wgrad: buffer shape')
+        E = self.empty((nwin + J - 1) * N, H, W, J)
         L.check(self.lib.rnh_xcol_gather(_ptr(dy), _ptr(E), H * W, N, nwin, J, C, co, self._stream()), 'rnh_xcol_gather')
         for k, (s, (c0, nch, nv)) in enumerate(zip(srcs, self._XCOL_SEGS(cl))):
             if s.shape[0] != (nwin + J - 1) * N or s.shape[3] != nch:
                 raise L.HipKernelError('refine_xcol_wgrad: source shape')
-            dwx, dbx = bufs['dwx'][k], bufs['dbx'][k]
+            dwx, dbx = self.empty(J, nch, 3, 3), self.empty(J)
             self.outconv_wgrad(s, E, dwx, dbx)
             L.check(self.lib.rnh_xcol_unpack(_ptr(dwx), _ptr(dbx) if k == 0 else None, _ptr(dw1), _ptr(db1), Cin, co, J, cs, c0, nch, nv,
                                              int(accumulate), self._stream()), 'rnh_xcol_unpack')

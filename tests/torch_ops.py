@@ -238,10 +238,7 @@ class TorchOps:
             feats.append(torch.cat(parts, dim=-1).permute(0, 3, 1, 2))
         return feats
 
-    def refine_xcol_bufs(self, srcs, J, cl, wgrad=False):
-        return None
-
-    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl, bufs=None):
+    def refine_xcol_fwd(self, srcs, w1, b1, R1, N, J, cl):
         co, nwin = 2 * cl, R1.shape[0] // N
         for i, f in enumerate(self._xcol_windows(srcs, N, J, nwin)):
             R1[i * N:(i + 1) * N, ..., co] = F.conv2d(f, w1[co:co + 1], b1[co:co + 1], padding=1)[:, 0]
@@ -254,7 +251,7 @@ class TorchOps:
             wp = w1[:ncols, [j * (2 * cl + 1) + 2 * cl for j in range(J)]]
             R1[i * N:(i + 1) * N, ..., :ncols] += F.conv2d(x, wp, None, padding=1).permute(0, 2, 3, 1)
 
-    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate, bufs=None):
+    def refine_xcol_wgrad(self, srcs, dy, dw1, db1, N, J, cl, accumulate):
         co, nwin = 2 * cl, dy.shape[0] // N
         w0 = torch.zeros(1, dw1.shape[1], 3, 3, device=self.device, requires_grad=True)
         b0 = torch.zeros(1, device=self.device, requires_grad=True)
