@@ -299,7 +299,7 @@ def run_case(args, dtype, dev, world, rank):
         out = {
             'metric': f'cine-frames/sec fwd+bwd, x{args.scale} SR {args.size}->{args.scale * args.size} T={args.frames}', 'value': round(n_global * args.frames * args.steps / dt, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
-            'ms_per_step_median': round(median_ms, 2),
+            'ms_per_step_median': round(median_ms, 2), 'ms_per_step_min_max': [round(per_step[0], 2), round(per_step[-1], 2)],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': f'RefineNet x{args.scale} training step (fwd + deep-supervision L1 + bwd + grad all-reduce + Adam), '
                                    f'N={args.batch}/GPU, T={args.frames} (F={args.frames + 12}), {args.size}x{args.size}->'
