@@ -830,5 +830,6 @@ class RefineNetEngine:
                        accumulate=False)
         ops.join(2 * Lr)                                          # the first stage's weight gradients (the last ones launched)
         ops.rejoin()
+        ops.fence()                                               # (one sink for a captured graph: see HipOps.fence)
         pending = None
         return grads

@@ -150,7 +150,7 @@ class HipOps:
     # round 1 as unexplained, and the captured step keeps the shape that has replayed exactly since round 2.
     def aside(self, tag=''):
         if os.environ.get('RNH_ASIDE', '1') == '0' or (tag and tag in os.environ.get('RNH_ASIDE_OFF', '').split(',')) or \
-                torch.cuda.is_current_stream_capturing():
+                (torch.cuda.is_current_stream_capturing() and os.environ.get('RNH_ASIDE_CAPTURE') != '1'):        # (=1: investigation only)
             import contextlib
             return contextlib.nullcontext()
         if getattr(self, '_helper', None) is None:
@@ -170,6 +170,15 @@ class HipOps:
             ev.record(self._helper)
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._helper_used = False
+
+    def fence(self):
+        """One trivial launch on the current stream behind everything it has waited for.  A stream that joins side streams and then launches
+        nothing leaves their last launches as additional SINK nodes of a captured HIP graph; the replays of such a graph did not always
+        hold back the launching stream's later work (the optimizer step) until every sink had finished (ROCm 7.2; tools/probes/graph_dot.py)."""
+        if getattr(self, '_fence_buf', None) is None:
+            self._fence_buf = torch.zeros(8, dtype=torch.float32, device=self.device)
+        b = self._fence_buf
+        L.check(self.lib.rnh_ew_add(_ptr(b[4:]), _ptr(b[:4]), None, None, 4, 0, self._stream()), 'rnh_ew_add(fence)')
 
     def _workspace(self, key, nfloats):
         """Scratch buffer ``key`` of the current stream, grown on demand.  A HIP graph captured through this object

@@ -74,6 +74,9 @@ class TorchOps:
     def rejoin(self):
         pass
 
+    def fence(self):
+        pass
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.full(shape, float('nan'), dtype=dtype, device=self.device)   # poison: catches unwritten reads
 
