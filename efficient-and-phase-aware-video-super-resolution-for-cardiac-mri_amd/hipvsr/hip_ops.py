@@ -55,6 +55,7 @@ class HipOps:
         # hip::Stream::EndCapture).  The 'one' mapping of RNH_LSTM_STREAMS (a stream waiting on its own event) has the
         # same problem and is for eager measurements only.
         self._banks = ([], [])
+        self._helper, self._helper_used, self._fence_buf = None, False, None      # aside() / rejoin() / fence()
         self._side = self._banks[0]
         self._fork_n = 2
         self._zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)      # what masked wgrad lanes read
@@ -155,7 +156,7 @@ class HipOps:
                 (torch.cuda.is_current_stream_capturing() and os.environ.get('RNH_ASIDE_CAPTURE') != '1'):        # (=1: investigation only)
             import contextlib
             return contextlib.nullcontext()
-        if getattr(self, '_helper', None) is None:
+        if self._helper is None:
             self._helper = torch.cuda.Stream(self.device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
@@ -167,7 +168,7 @@ class HipOps:
         return torch.cuda.stream(self._helper)
 
     def rejoin(self):
-        if getattr(self, '_helper_used', False):
+        if self._helper_used:
             ev = torch.cuda.Event()
             ev.record(self._helper)
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -177,7 +178,7 @@ class HipOps:
         """One trivial launch on the current stream behind everything it has waited for.  A stream that joins side streams and then launches
         nothing leaves their last launches as additional SINK nodes of a captured HIP graph; the replays of such a graph did not always
         hold back the launching stream's later work (the optimizer step) until every sink had finished (ROCm 7.2; tools/probes/graph_dot.py)."""
-        if getattr(self, '_fence_buf', None) is None:
+        if self._fence_buf is None:
             self._fence_buf = torch.zeros(8, dtype=torch.float32, device=self.device)
         b = self._fence_buf
         L.check(self.lib.rnh_ew_add(_ptr(b[4:]), _ptr(b[:4]), None, None, 4, 0, self._stream()), 'rnh_ew_add(fence)')
