@@ -235,56 +235,80 @@ constexpr int OC_MAX = 8;
 constexpr int OT = 16;                  // 16x16 output pixels per block
 constexpr int OROW = 20;                // 16 channels + 4 pad floats per halo pixel (conflict-free ds_read_b128)
 
-__global__ void __launch_bounds__(256) outconv_fwd_kernel(const float *x, const float *w, const float *bias, float *y, int B,
-                                                          int H, int W, int Cin, int Cout, int TX, int TY) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *halo = sm;                                   // [(OT+2)*(OT+2)][OROW]
-    float *swt = sm + (OT + 2) * (OT + 2) * OROW;       // [co][tap][Cin16] (Cin padded to 16)
-    const int Cp = (Cin + 15) & ~15;
-    for (int e = threadIdx.x; e < Cout * 9 * Cp; e += blockDim.x) {
-        const int ci = e % Cp, r = e / Cp, tap = r % 9, co = r / 9;
-        swt[e] = ci < Cin ? w[(co * Cin + ci) * 9 + tap] : 0.f;
-    }
+// y[p][co] = bias[co] + sum_{ci,t} x[p + t][ci] * w[co * wco + ci * wci + t]  (FLIP: tap 8 - t - a data gradient read as a convolution).
+// thread = one pixel of a 16 x 16 tile, all COUT outputs.  The 18 x 18 halo of a 16-channel chunk sits in LDS, double-buffered: the
+// next chunk travels global -> registers under the FMAs of this one, one barrier per chunk.  The weights never touch LDS: their
+// addresses are wave-uniform, so they arrive through the scalar cache as SGPR operands of the FMAs (the round-1 kernel read every
+// weight as a broadcast float4 from LDS - five of its six LDS reads per 20 FMAs - and was LDS-bound at 1.5 TB/s of input).
+// Output pixel stride ldy >= COUT + yzero; channels COUT .. COUT + yzero - 1 are written as zeros.
+template <int COUT, bool FLIP>
+__global__ void __launch_bounds__(256) outconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ y, int B, int H, int W, int Cin, int TX, int TY, int wco, int wci,
+                                                          int ldy, int yzero) {
+    constexpr int HP = (OT + 2) * (OT + 2), NLD = (HP * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float halo[2][HP * OROW];
     const int tile = blockIdx.x;
     const int b = tile / (TX * TY), tr = tile - b * TX * TY, ty = tr / TX, tx = tr - ty * TX;
     const int y0 = ty * OT, x0 = tx * OT;
     const int ly = threadIdx.x / OT, lx = threadIdx.x % OT;
-    float acc[OC_MAX];
+    const float *xb = x + (long)b * H * W * Cin;
+    // staging items e = tid + 256 k: (halo pixel e >> 2, channel quad e & 3); offset inside the image or -1 (outside: zero padding)
+    int soff[NLD];
 #pragma unroll
-    for (int co = 0; co < OC_MAX; ++co) acc[co] = co < Cout ? bias[co] : 0.f;
-    for (int c0 = 0; c0 < Cin; c0 += 16) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < (OT + 2) * (OT + 2) * 4; e += blockDim.x) {
-            const int q = e & 3, hp = e >> 2, hy = hp / (OT + 2), hx = hp - hy * (OT + 2);
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c0 + q * 4 < Cin)
-                v = rnh_ld4(x + (((long)b * H + gy) * W + gx) * Cin + c0 + q * 4);
-            rnh_st4(halo + hp * OROW + q * 4, v);
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k, q = e & 3, hp = e >> 2, hy = hp / (OT + 2), hx = hp - hy * (OT + 2);
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        soff[k] = (hp < HP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (gy * W + gx) * Cin + q * 4 : -1;
+    }
+    float4 pre[NLD];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int q = (threadIdx.x + 256 * k) & 3;
+            pre[k] = (soff[k] >= 0 && c0 + q * 4 < Cin) ? rnh_ld4(xb + soff[k] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+    };
+    auto park = [&](int buf) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int hp = (ly + tap / 3) * (OT + 2) + lx + tap % 3;
+        for (int k = 0; k < NLD; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e < HP * 4) rnh_st4(&halo[buf][(e >> 2) * OROW + (e & 3) * 4], pre[k]);
+        }
+    };
+    float acc[COUT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 xv = rnh_ld4(halo + hp * OROW + q * 4);
+    for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < Cin; c0 += 16, cur ^= 1) {
+        const bool more = c0 + 16 < Cin;
+        if (more) fetch(c0 + 16);
+        const float *hb = halo[cur] + (ly * (OT + 2) + lx) * OROW;
+        const int nch = min(16, Cin - c0);
+        // (channel by channel: the 9 x COUT weights of one input channel are all the SGPRs the loop keeps alive)
+#pragma unroll 2
+        for (int cc = 0; cc < nch; ++cc) {
+            float xs[9];
 #pragma unroll
-                for (int co = 0; co < OC_MAX; ++co) {
-                    if (co < Cout) {
-                        const float4 wv = rnh_ld4(swt + (co * 9 + tap) * Cp + c0 + q * 4);
-                        acc[co] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
-                    }
-                }
+            for (int t = 0; t < 9; ++t) xs[t] = hb[((t / 3) * (OT + 2) + t % 3) * OROW + cc];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float *wp = w + (long)co * wco + (long)(c0 + cc) * wci;              // wave-uniform: scalar loads
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[co] = __builtin_fmaf(xs[t], wp[FLIP ? 8 - t : t], acc[co]);
             }
         }
+        if (more) park(cur ^ 1);
+        __syncthreads();
     }
     const int gy = y0 + ly, gx = x0 + lx;
     if (gy < H && gx < W) {
-        float *o = y + (((long)b * H + gy) * W + gx) * Cout;
+        float *o = y + (((long)b * H + gy) * W + gx) * ldy;
 #pragma unroll
-        for (int co = 0; co < OC_MAX; ++co)
-            if (co < Cout) o[co] = acc[co];
+        for (int co = 0; co < COUT; ++co) o[co] = acc[co];
+        for (int z = 0; z < yzero; ++z) o[COUT + z] = 0.f;
     }
 }
 
@@ -906,19 +930,45 @@ extern "C" int rnh_inconv_prelu_bwd(const float *x, const float *w, const float 
     return 0;
 }
 
+template <bool FLIP>
+static int launch_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout, int wco,
+                              int wci, int ldy, int yzero, hipStream_t st) {
+    const int TX = (W + OT - 1) / OT, TY = (H + OT - 1) / OT;
+    const dim3 grid((unsigned)(B * TX * TY)), block(256);
+#define RNH_OC(n)                                                                                                                    \
+    case n:                                                                                                                          \
+        hipLaunchKernelGGL((outconv_fwd_kernel<n, FLIP>), grid, block, 0, st, x, w, bias, y, B, H, W, Cin, TX, TY, wco, wci, ldy, yzero); \
+        break;
+    switch (Cout) {
+        RNH_OC(1) RNH_OC(2) RNH_OC(3) RNH_OC(4) RNH_OC(5) RNH_OC(6) RNH_OC(7) RNH_OC(8)
+    }
+#undef RNH_OC
+    return 0;
+}
+
+static int outconv_fwd_checked(const char *who, const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                               int Cout, int wco, int wci, int flip, int ldy, int yzero, void *stream) {
+    if (!x || !w || !y || B < 1 || H < 1 || W < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "%s: bad arguments", who);
+    if (Cin & 3) RNH_FAIL(RNH_E_ALIGN, "%s: Cin must be a multiple of 4", who);
+    if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "%s: Cout must be 1..%d", who, OC_MAX);
+    if (yzero < 0 || ldy < Cout + yzero) RNH_FAIL(RNH_E_ARG, "%s: output pixel stride %d < %d channels", who, ldy, Cout + yzero);
+    if ((long)H * W * Cin >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "%s: image too large for 32-bit offsets", who);
+    if (flip) launch_outconv_fwd<true>(x, w, bias, y, B, H, W, Cin, Cout, wco, wci, ldy, yzero, (hipStream_t)stream);
+    else launch_outconv_fwd<false>(x, w, bias, y, B, H, W, Cin, Cout, wco, wci, ldy, yzero, (hipStream_t)stream);
+    RNH_CHECK_LAUNCH(who);
+    return 0;
+}
+
 extern "C" int rnh_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
                                void *stream) {
-    if (!x || !w || !bias || !y || B < 1 || H < 1 || W < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "rnh_outconv_fwd: bad arguments");
-    if (Cin & 3) RNH_FAIL(RNH_E_ALIGN, "rnh_outconv_fwd: Cin must be a multiple of 4");
-    if (Cout < 1 || Cout > OC_MAX) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_fwd: Cout must be 1..%d", OC_MAX);
-    const int Cp = (Cin + 15) & ~15;
-    const size_t shm = ((size_t)(OT + 2) * (OT + 2) * OROW + (size_t)Cout * 9 * Cp) * sizeof(float);
-    if (shm > 64000) RNH_FAIL(RNH_E_RANGE, "rnh_outconv_fwd: Cin too large");
-    const int TX = (W + OT - 1) / OT, TY = (H + OT - 1) / OT;
-    hipLaunchKernelGGL(outconv_fwd_kernel, dim3((unsigned)(B * TX * TY)), dim3(256), shm, (hipStream_t)stream, x, w, bias, y, B, H,
-                       W, Cin, Cout, TX, TY);
-    RNH_CHECK_LAUNCH("rnh_outconv_fwd");
-    return 0;
+    if (!bias) RNH_FAIL(RNH_E_ARG, "rnh_outconv_fwd: bad arguments");
+    return outconv_fwd_checked("rnh_outconv_fwd", x, w, bias, y, B, H, W, Cin, Cout, Cin * 9, 9, 0, Cout, 0, stream);
+}
+
+extern "C" int rnh_outconv_fwd_ld(const float *x, const float *w, int64_t wco, int64_t wci, int flip, const float *bias, float *y, int ldy,
+                                  int yzero, int B, int H, int W, int Cin, int Cout, void *stream) {
+    if (wco < 0 || wci < 9 || wco * Cout >= (1L << 31) || wci * Cin >= (1L << 31)) RNH_FAIL(RNH_E_ARG, "rnh_outconv_fwd_ld: weight strides");
+    return outconv_fwd_checked("rnh_outconv_fwd_ld", x, w, bias, y, B, H, W, Cin, Cout, (int)wco, (int)wci, flip, ldy, yzero, stream);
 }
 
 extern "C" int rnh_outconv_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout, void *stream) {

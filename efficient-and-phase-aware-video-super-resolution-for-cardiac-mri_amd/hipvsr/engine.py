@@ -393,8 +393,10 @@ class RefineNetEngine:
                         ops.refine_xcol_fwd([hfs, hbs, p4s], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, w, Cl)
                     ro = (a - w0) * N
                     if P.r2_wino:
-                        ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
-                        ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, accumulate=True, img_off=ro)])
+                        # (the small launch stores, the Winograd launch accumulates: the read-modify-write of R then rides in the
+                        # MFMA-bound kernel instead of doubling the traffic of the HBM-bound one; a + b = b + a, the bits are the same)
+                        ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
+                        ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, accumulate=True, img_off=ro)])
                     else:
                         ops.conv(P.r2_fwd, [Src(R1)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
                     if need_grad and a == U - hw:
@@ -586,7 +588,8 @@ class RefineNetEngine:
                 dR1p = ops.halo_buffer('dR1p', ((T + 2 * hw) * N, H, W, P.C1p), act, hw * N, (hw + T) * N)
                 if P.r2_wino:
                     ops.conv(P.r2_dgrad_h, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
-                    ops.conv(P.r2_dgrad_x, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])
+                    # (the one real column of the rest: a 9-tap, Cl-channel stencil, HBM-bound - not a 64-column GEMM launch)
+                    ops.conv_to_column(dR, params[P.r2_fwd.wkey], 2 * Cl, dR1p[hw * N:(hw + T) * N], 2 * Cl, yzero=P.C1p - P.C1)
                 elif P.r1_split:
                     ops.conv(P.r2_dgrad_a, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
                     ops.conv(P.r2_dgrad_b, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 2 * Cl, c0=2 * Cl, img_off=hw * N)])

@@ -558,6 +558,16 @@ class HipOps:
                 'rnh_outconv_fwd')
         return y
 
+    def conv_to_column(self, x, w, col, out, c0, yzero=0):
+        """out[..., c0] = the data gradient of a 3x3 convolution with OIHW weights ``w`` (O = x's channels) w.r.t. its input channel ``col``:
+        sum_{o, t} x[p - t][o] w[o][col][t]; channels c0+1 .. c0+yzero of ``out`` := 0.  One HBM-bound launch of rnh_outconv_fwd_ld."""
+        self._chk(x, w, out)
+        B, H, W, Cin = x.shape
+        if w.shape[0] != Cin or tuple(w.shape[2:]) != (3, 3) or tuple(out.shape[:3]) != (B, H, W) or c0 + 1 + yzero > out.shape[3]:
+            raise L.HipKernelError('conv_to_column: shapes')
+        L.check(self.lib.rnh_outconv_fwd_ld(_ptr(x), w.data_ptr() + 4 * 9 * col, 0, w.shape[1] * 9, 1, None, out.data_ptr() + 4 * c0,
+                                            out.shape[3], yzero, B, H, W, Cin, 1, self._stream()), 'rnh_outconv_fwd_ld')
+
     def outconv_dgrad(self, dy, w):
         self._chk(dy, w)
         B, H, W, Cout = dy.shape

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
-ABI_VERSION = 2          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
+ABI_VERSION = 3          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -25,7 +25,7 @@ LOSS_L1, LOSS_CHARBONNIER = 0, 1
 LOSS_BLOCKS = 64
 
 EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_reduce', 'rnh_inconv_prelu_fwd',
-           'rnh_inconv_prelu_bwd', 'rnh_inconv_bwd_ws_floats', 'rnh_outconv_fwd', 'rnh_outconv_dgrad',
+           'rnh_inconv_prelu_bwd', 'rnh_inconv_bwd_ws_floats', 'rnh_outconv_fwd', 'rnh_outconv_fwd_ld', 'rnh_outconv_dgrad',
            'rnh_outconv_wgrad', 'rnh_outconv_wgrad_ws_floats', 'rnh_lstm_gates_bwd', 'rnh_loss_fwd_bwd', 'rnh_loss_total', 'rnh_ew_add',
            'rnh_phase_plane', 'rnh_last_error', 'rnh_abi_version', 'rnh_struct_sizes', 'rnh_uptail_compose',
            'rnh_uptail_dgrad', 'rnh_uptail_expand', 'rnh_uptail_wcontract', 'rnh_uptail_fwd', 'rnh_uptail_fwd_ws_floats',
@@ -141,6 +141,7 @@ def load():
     lib.rnh_inconv_bwd_ws_floats.argtypes = [i32, i32]
     lib.rnh_inconv_bwd_ws_floats.restype = i64
     lib.rnh_outconv_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_outconv_fwd_ld.argtypes = [vp, vp, i64, i64, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_outconv_dgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_outconv_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_outconv_wgrad_ws_floats.argtypes = [i32, i32]

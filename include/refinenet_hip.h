@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 2       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract */
+#define RNH_ABI_VERSION 3       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -215,6 +215,13 @@ int64_t rnh_inconv_bwd_ws_floats(int Cin, int Cout);
  * convolution, x NHWC [B][H][W][Cin], y NHWC [B][H][W][Cout]. */
 int rnh_outconv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
                     int Cout, void *stream);
+/* The same kernel with explicit weight and output strides (since ABI 3): weight element (co, ci, tap) = w[co*wco + ci*wci + tap]
+ * (flip != 0: tap 8 - tap, i.e. a data gradient read as a convolution), bias may be null, output pixel stride ldy floats with
+ * the Cout results at y[p*ldy .. ] and `yzero` zero channels behind them.  Replaces the 64-column GEMM launch that produced the one
+ * real column of conv2's data gradient w.r.t. conv1's channel 128 (autograd of refine_net.py:152; w = conv2.weight + 128*9,
+ * wci = 129*9, flip = 1, Cout = 1). */
+int rnh_outconv_fwd_ld(const float *x, const float *w, int64_t wco, int64_t wci, int flip, const float *bias, float *y, int ldy,
+                       int yzero, int B, int H, int W, int Cin, int Cout, void *stream);
 /* Its data gradient dx[p][ci] = sum_{t,co} dy[p-t][co] w[co][ci][t] ... */
 int rnh_outconv_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout,
                       void *stream);

@@ -368,3 +368,50 @@ def test_helper_stream_changes_no_bit_even_when_it_runs_late(dtype, nf, monkeypa
             assert la == lb, (mode, i, la, lb)
             for k in ga:
                 assert torch.equal(ga[k], gb[k]), (mode, 'step', i, k, float((ga[k] - gb[k]).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the small direct convolution (rnh_outconv_fwd: weights through the scalar cache, double-buffered halo) and its strided form
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 1, 1, 4, 1), (2, 3, 17, 4, 5), (1, 16, 16, 64, 5), (2, 37, 9, 20, 3), (1, 40, 33, 64, 8),
+                                            (3, 18, 50, 36, 2), (1, 33, 31, 132, 5)])
+def test_small_direct_convolution_vs_float64(B, H, W, Cin, Cout):
+    """rnh_outconv_fwd (reference refine_net.py:201 / the per-frame form of conv1's channel 128, :149) against float64 F.conv2d: channel counts
+    that are not multiples of the 16-channel chunk, one and several chunks, tile tails, single pixels."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(B * 1000 + H * 10 + Cin)
+    x, w, b = torch.randn(B, H, W, Cin, generator=g), torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, torch.randn(Cout, generator=g)
+    y = ops.outconv_fwd(x.to(dev), w.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    err = float((y.cpu().double() - ref).abs().max())
+    assert err <= 2e-6 * float(ref.abs().max()) + 1e-6, err
+
+
+@pytest.mark.parametrize('B,H,W,Cin', [(1, 1, 1, 64), (2, 5, 19, 64), (1, 37, 50, 64), (2, 16, 16, 16), (7, 128, 128, 64)])
+def test_data_gradient_column_vs_float64(B, H, W, Cin):
+    """rnh_outconv_fwd_ld as the engine uses it: conv2's data gradient w.r.t. conv1's channel 128 (autograd of refine_net.py:152) written
+    into channel 128 of the 132-channel gradient tensor, pad channels zeroed, the 128 columns in front untouched."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    dev = _dev()
+    ops = HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(B * 1000 + H * 10 + W)
+    col, C1, C1p = 2 * Cin, 2 * Cin + 1, 2 * Cin + 4
+    dR, w2 = torch.randn(B, H, W, Cin, generator=g), torch.randn(Cin, C1, 3, 3, generator=g) * 0.1
+    out = torch.full((B + 2, H, W, C1p), float('nan'))
+    out[..., :col] = 3.0
+    od = out.to(dev)
+    ops.conv_to_column(dR.to(dev), w2.to(dev), col, od[1:B + 1], col, yzero=C1p - C1)
+    torch.cuda.synchronize()
+    x = dR.permute(0, 3, 1, 2).double()
+    ref = F.conv_transpose2d(x, w2[:, col:col + 1].double(), padding=1)[:, 0]
+    got = od.cpu()
+    err = float((got[1:B + 1, ..., col].double() - ref).abs().max())
+    assert err <= 2e-6 * float(ref.abs().max()) + 1e-6, err
+    assert float(got[1:B + 1, ..., col + 1:].abs().max()) == 0.0
+    assert bool((got[1:B + 1, ..., :col] == 3.0).all()) and bool(torch.isnan(got[0]).sum() == got[0][..., col:].numel())
+    assert bool(torch.isnan(got[B + 1][..., col:]).all())

@@ -284,6 +284,12 @@ class TorchOps:
             else:
                 dw1[:ncols, j * cs + c0] = g[:, j]
 
+    def conv_to_column(self, x, w, col, out, c0, yzero=0):
+        d = F.conv_transpose2d(x.permute(0, 3, 1, 2), w[:, col:col + 1], padding=1).permute(0, 2, 3, 1)
+        out[..., c0:c0 + 1] = d
+        if yzero:
+            out[..., c0 + 1:c0 + 1 + yzero] = 0
+
     def refine_xcol_dgrad(self, g, w1, dHf, dHb, N, J, cl):
         T = dHf.shape[0] // N
         cs, c = 2 * cl + 1, 2 * cl

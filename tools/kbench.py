@@ -90,8 +90,8 @@ if P.xcol:
 Rr = ops.empty(nwin * N, H, W, 64)
 def r2_fwd():                                       # as the engine runs it: 128 hidden-state channels in Winograd form + the phase channel
     if P.r2_wino:
-        ops.conv(P.r2_fwd_h, [Src(R1, nch=128)], nwin * N, H, W, dsts=[Dst(Rr, 64)])
-        ops.conv(P.r2_fwd_x, [Src(R1, c0=128, nch=P.C1p - 128)], nwin * N, H, W, dsts=[Dst(Rr, 64, accumulate=True)])
+        ops.conv(P.r2_fwd_x, [Src(R1, c0=128, nch=P.C1p - 128)], nwin * N, H, W, dsts=[Dst(Rr, 64)])
+        ops.conv(P.r2_fwd_h, [Src(R1, nch=128)], nwin * N, H, W, dsts=[Dst(Rr, 64, accumulate=True)])
     else:
         ops.conv(P.r2_fwd, [Src(R1)], nwin * N, H, W, dsts=[Dst(Rr, 64)])
 
@@ -109,6 +109,10 @@ def r2_wgrad():
 
 timeit('refine2.wgrad', r2_wgrad, 2.0 * TN * H * W * 64 * 129 * 9, 3)
 dR1p = R((T + 4) * N, H, W, P.C1p)
+if P.r2_wino:
+    timeit('refine2.dgrad.h(wino)', lambda: ops.conv(P.r2_dgrad_h, [Src(dRr)], TN, H, W, dsts=[Dst(dR1p, 128, img_off=2 * N)]), 2.0 * TN * H * W * 64 * 128 * 9, 3)
+    timeit('refine2.dgrad.x(gemm)', lambda: ops.conv(P.r2_dgrad_x, [Src(dRr)], TN, H, W, dsts=[Dst(dR1p, P.C1p - 128, c0=128, img_off=2 * N)]), 2.0 * TN * H * W * 64 * 9, 3)
+    timeit('refine2.dgrad.x(column)', lambda: ops.conv_to_column(dRr, params[P.r2_fwd.wkey], 128, dR1p[2 * N:(2 + T) * N], 128, yzero=P.C1p - 129), 2.0 * TN * H * W * 64 * 9, 3)
 xs1 = []
 for j in range(5):
     xs1 += [Src(Hf, img_off=(4 + j) * N), Src(Hb, img_off=(4 + j) * N), Src(P4, img_off=(4 + j) * N)]
