@@ -13,8 +13,9 @@
 // instructions per MFMA, LDS busy ~80 % of the MFMA time - 0.31 of the bf16 peak.)
 //
 //   * work item = (image, 32-pixel column strip, range of RPI rows); per image row y one barrier-separated step;
-//   * the x shift of a tap is a shift of the pixel ROW address of the transposed read - free, no alignment constraint, no
-//     funnel shifts; the y shift is a choice of row slot: a step takes TWO output rows (36 MFMAs per wave between two
+//   * the x shift of a tap is a shift of the pixel ROW address of the transposed read - no alignment constraint (the register-staged
+//     kernel reads one fragment per shift; the LDS-DMA kernel, which is LDS-bandwidth-bound, reads 12 pixels once and makes the three
+//     shifted fragments in registers: 3 reads + 4 v_alignbit instead of 6 reads); the y shift is a choice of row slot: a step takes TWO output rows (36 MFMAs per wave between two
 //     barriers), input rows live in a ring of 6 slots, rows y + 3, y + 4 are loaded while rows y, y + 1 are being multiplied, so
 //     each input row is staged once per strip and serves the three dy taps of three output rows;
 //   * image layout: pixel row pitch 128 B = four 32-byte chunks of 16 channels; chunk c of pixel row r sits at c ^ (r & 2): the
@@ -374,11 +375,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
 
     // ---- transposed fragment reads (see the register-staged kernel): per-lane byte offsets inside a row image for the three x shifts
     const int gq = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
-    int xo[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const int prow = 8 * kh + tq + dx;                       // (+ 16 ks + 4 sr: multiples of 4 leave bit 1 alone)
-        xo[dx] = prow * 128 + 32 * ((2 * rb + gq) ^ (prow & 2)) + 8 * tp;
+    int xo[1];
+    {
+        const int prow = 8 * kh + tq;                            // (+ 16 ks + 4 sr: multiples of 4 leave bit 1 alone)
+        xo[0] = prow * 128 + 32 * ((2 * rb + gq) ^ (prow & 2)) + 8 * tp;
     }
     const int yo = (8 * kh + tq) * 128 + 32 * ((2 * cb + gq) ^ (tq & 2)) + 8 * tp;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
@@ -427,19 +427,17 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
             }
             // input fragments: group g = (input row ri, k step ks), three x shifts x two reads; group g + 1 is requested before
             // group g is multiplied
-            u32x2 xf[2][3][2];
+            u32x2 xf[2][3];                                      // pixels 8 kh + 0..3, 4..7, 8..11 of the lane's channel
             auto xreads = [&](int set, int ri, int ks) {
-                const unsigned base = lds0 + xs_off(y - 1 + ri);
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const unsigned a_ = base + xo[dx];
-                    if (ks == 0) {
-                        RNH_TR(xf[set][dx][0], a_, 0);
-                        RNH_TR(xf[set][dx][1], a_, 512);
-                    } else {
-                        RNH_TR(xf[set][dx][0], a_, 2048);
-                        RNH_TR(xf[set][dx][1], a_, 2560);
-                    }
+                const unsigned a_ = lds0 + xs_off(y - 1 + ri) + xo[0];
+                if (ks == 0) {
+                    RNH_TR(xf[set][0], a_, 0);
+                    RNH_TR(xf[set][1], a_, 512);
+                    RNH_TR(xf[set][2], a_, 1024);
+                } else {
+                    RNH_TR(xf[set][0], a_, 2048);
+                    RNH_TR(xf[set][1], a_, 2560);
+                    RNH_TR(xf[set][2], a_, 3072);
                 }
             };
             xreads(0, 0, 0);
@@ -449,11 +447,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
                 const int ri = g >> 1, ks = g & 1, set = g & 1;
                 if (g + 1 < 8) {
                     xreads(set ^ 1, (g + 1) >> 1, (g + 1) & 1);
-                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xf[set][0][0]), "+v"(xf[set][0][1]), "+v"(xf[set][1][0]), "+v"(xf[set][1][1]),
-                                 "+v"(xf[set][2][0]), "+v"(xf[set][2][1]));
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0][0]), "+v"(xf[set][0][1]), "+v"(xf[set][1][0]), "+v"(xf[set][1][1]),
-                                 "+v"(xf[set][2][0]), "+v"(xf[set][2][1]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
                 }
                 if (g == 0) {                                    // (the gradient reads are older than group 0's: they have landed too)
 #pragma unroll
@@ -469,10 +465,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
 #pragma unroll
                     for (int o = 0; o < 2; ++o) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[o][g], bacc, 0, 0, 0);
                 }
+                // the three x shifts of the 12 pixels in registers: dword i = pixels (2i, 2i + 1); shift 1 = four funnel shifts
+                const unsigned d0 = xf[set][0].x, d1 = xf[set][0].y, d2 = xf[set][1].x, d3 = xf[set][1].y, d4 = xf[set][2].x;
                 bf16x8 f[3];
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    f[dx] = __builtin_bit_cast(bf16x8, make_uint4(xf[set][dx][0].x, xf[set][dx][0].y, xf[set][dx][1].x, xf[set][dx][1].y));
+                f[0] = __builtin_bit_cast(bf16x8, make_uint4(d0, d1, d2, d3));
+                f[1] = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                                             __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)));
+                f[2] = __builtin_bit_cast(bf16x8, make_uint4(d1, d2, d3, d4));
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int dy = ri - o;                       // input row y - 1 + ri feeds output row y + o through tap row dy
