@@ -312,6 +312,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];      // zero-initialised: the source of every masked piece
 
+// Diagnostic ablations of the LDS-DMA kernel (never defined in the product build; results are wrong, only the time is of interest):
+// -DRNH_DEXP=<mask>  1: no row requests inside the step loop (and no waits for them), 2: fragments read once per run, 4: no barrier in the loop
+#ifndef RNH_DEXP
+#define RNH_DEXP 0
+#endif
+// x fragments of the three taps of a row: RNH_WXF 0 = one transposed read pair per shift (6 reads), 1 (product) = 12 pixels read once, the
+// shifts in registers (3 reads + 8 VALU).  Same box, ConvLSTM launch: 563-647 us against 529-546; a 4-read form measured like the 3-read one.
+#ifndef RNH_WXF
+#define RNH_WXF 1
+#endif
 constexpr int DNX = 10, DNY = 8;
 constexpr int DSMEM = DNX * XS_BYTES + DNY * YS_BYTES;                    // 76 288 B
 
@@ -348,37 +358,62 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
     const bool want_bias = P.bslab != nullptr && rt == 0 && rb == 0;
     const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
-    // ---- DMA: one piece per thread into the row image at byte 16 tid (+ pixels 32, 33 of an input row by the first 16 lanes of wave 0)
-    auto piece_src = [&](const Grp &g, int b, int y, int x) -> gptr_t {
-        const bool ok = g.ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        const char *q = g.ptr + (long)(b + g.img_off) * g.img_stride + (long)(ok ? y : 0) * g.row_stride + (long)(ok ? x : 0) * g.pix_stride;
-        return (gptr_t)(ok ? q : reinterpret_cast<const char *>(g_zero_page));
+    // ---- DMA: one piece per thread into the row image at byte 16 tid (+ pixels 32, 33 of an input row by the first 16 lanes of wave 0).
+    // Address generation was the larger part of this kernel's instruction stream (round 4: 290 of 430 instructions per step, 64-bit
+    // multiplies and a modulo per request): a run's requests go out in increasing row order, so every piece has a RUNNING row pointer
+    // (image, x position and its validity folded in once per run), a request selects that pointer or the zero page and advances it by
+    // the row stride; ring slots are running scalar counters.  ConvLSTM launch 580 -> 505 us.
+    const unsigned long long zp = (unsigned long long)g_zero_page;
+    unsigned long long xp = zp, xp2 = zp, yp = zp;               // main piece, halo piece (wave 0, lanes 0..15), gradient piece
+    bool xok = false, xok2 = false, yok = false;
+    int xrow = 0, yrow = 0, yb = 0;                              // the rows the running pointers stand at; end of the run's gradient rows
+    const unsigned long long xrs = (unsigned long long)gx.row_stride, yrs = (unsigned long long)gy.row_stride;
+    auto set_run = [&](int b, int x0, int ya) {
+        const int xc = x0 + pxt - 1, xc2 = x0 + 31 + pxt, yc = x0 + pxt;
+        xok = gx.ok && (unsigned)xc < (unsigned)W;
+        xok2 = gx.ok && (unsigned)xc2 < (unsigned)W;
+        yok = gy.ok && (unsigned)yc < (unsigned)W;
+        const char *xi = gx.ptr + (long)(b + gx.img_off) * gx.img_stride + (long)(ya - 1) * gx.row_stride;
+        xp = (unsigned long long)(xi + (long)(xok ? xc : 0) * gx.pix_stride);
+        xp2 = (unsigned long long)(xi + (long)(xok2 ? xc2 : 0) * gx.pix_stride);
+        yp = (unsigned long long)(gy.ptr + (long)(b + gy.img_off) * gy.img_stride + (long)ya * gy.row_stride + (long)(yok ? yc : 0) * gy.pix_stride);
+        xrow = ya - 1;
+        yrow = ya;
     };
-    auto xs_off = [&](int r) { return ((r + 11) % DNX) * XS_BYTES; };          // input row r >= -1
-    auto ys_off = [&](int r) { return DNX * XS_BYTES + (r & (DNY - 1)) * YS_BYTES; };
-    int b = 0, x0 = 0, yb = 0;
-    auto dma_x = [&](int r) {
-        __builtin_amdgcn_global_load_lds(piece_src(gx, b, r, x0 + pxt - 1), (lptr_t)(smem + xs_off(r) + wave * 1024), 16, 0, 0);
+    // slot of input row r0 + j given the slot s0 of row r0 (j < DNX)
+    auto wrap = [&](int s0, int j) { const int t = s0 + j; return t >= DNX ? t - DNX : t; };
+    auto dma_x = [&](int slot) {                                 // the next input row (xrow) of the run
+        const bool rin = (unsigned)xrow < (unsigned)H;
+        __builtin_amdgcn_global_load_lds((gptr_t)((xok && rin) ? xp : zp), (lptr_t)(smem + slot * XS_BYTES + wave * 1024), 16, 0, 0);
         if (wave == 0) {
-            if (lane < 16) __builtin_amdgcn_global_load_lds(piece_src(gx, b, r, x0 + 31 + pxt), (lptr_t)(smem + xs_off(r) + 32 * 128), 16, 0, 0);
+            if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)((xok2 && rin) ? xp2 : zp), (lptr_t)(smem + slot * XS_BYTES + 32 * 128), 16, 0, 0);
+            xp2 += xrs;
         }
+        xp += xrs;
+        ++xrow;
     };
-    auto dma_y = [&](int r) {
-        __builtin_amdgcn_global_load_lds(piece_src(gy, b, r < yb ? r : -1, x0 + pxt), (lptr_t)(smem + ys_off(r) + wave * 1024), 16, 0, 0);
+    auto ys_off = [&](int r) { return DNX * XS_BYTES + (r & (DNY - 1)) * YS_BYTES; };
+    auto dma_y = [&]() {                                         // the next gradient row (yrow); rows of other items (>= yb) come from the zero page
+        const bool rin = (unsigned)yrow < (unsigned)yb;
+        __builtin_amdgcn_global_load_lds((gptr_t)((yok && rin) ? yp : zp), (lptr_t)(smem + ys_off(yrow) + wave * 1024), 16, 0, 0);
+        yp += yrs;
+        ++yrow;
     };
-    auto group = [&](int y) {                                    // what step y needs beyond step y - 2: 6 requests in wave 0, 4 elsewhere
-        dma_x(y + 1);
-        dma_x(y + 2);
-        dma_y(y);
-        dma_y(y + 1);
+    // what step y needs beyond step y - 2 (6 requests in wave 0, 4 elsewhere): input rows y + 1, y + 2 into the slots s, s + 1; gradient rows y, y + 1
+    auto group = [&](int s) {
+        dma_x(s);
+        dma_x(wrap(s, 1));
+        dma_y();
+        dma_y();
     };
 
     // ---- transposed fragment reads (see the register-staged kernel): per-lane byte offsets inside a row image for the three x shifts
     const int gq = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
-    int xo[1];
-    {
-        const int prow = 8 * kh + tq;                            // (+ 16 ks + 4 sr: multiples of 4 leave bit 1 alone)
-        xo[0] = prow * 128 + 32 * ((2 * rb + gq) ^ (prow & 2)) + 8 * tp;
+    int xo[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int prow = 8 * kh + tq + dx;                       // (+ 16 ks + 4 sr: multiples of 4 leave bit 1 alone)
+        xo[dx] = prow * 128 + 32 * ((2 * rb + gq) ^ (prow & 2)) + 8 * tp;
     }
     const int yo = (8 * kh + tq) * 128 + 32 * ((2 * cb + gq) ^ (tq & 2)) + 8 * tp;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
@@ -397,28 +432,34 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
         const int st0 = (int)(sc - strip * spr);
         const int nst = (int)((s1 - sc) < (long)(spr - st0) ? (s1 - sc) : (long)(spr - st0));
         sc += nst;
-        b = (int)(strip / nseg);
-        x0 = (int)(strip - (long)b * nseg) * WT;
+        const int b = (int)(strip / nseg), x0 = (int)(strip - (long)b * nseg) * WT;
         const int ya = 2 * st0;
         yb = ya + 2 * nst < H ? ya + 2 * nst : H;
+        set_run(b, x0, ya);
         // everything the previous item left in flight has landed and has been read before its slots are requested again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        dma_x(ya - 1);
-        dma_x(ya);
-        group(ya);
-        group(ya + 2);
-        group(ya + 4);
+        int sm1 = 0;                                             // slot of input row y - 1 (every run starts its ring at slot 0)
+        dma_x(0);                                                // rows ya - 1, ya
+        dma_x(1);
+        group(2);                                                // steps ya, ya + 2, ya + 4
+        group(4);
+        group(6);
+        u32x2 yb4[2][2][2];
+        u32x2 xf[2][RNH_WXF ? 3 : 6];                            // RNH_WXF 1: pixels 8 kh + 0..3, 4..7, 8..11 of the lane's channel
         for (int y = ya; y < yb; y += 2) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                        // step y's rows are in LDS for every wave; step y - 2 has been read by all
-            group(y + 6);                                        // into the slots of input rows y - 3, y - 2 / gradient rows y - 2, y - 1
+            if constexpr (!(RNH_DEXP & 1)) {
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+            if constexpr (!(RNH_DEXP & 4)) __builtin_amdgcn_s_barrier();      // step y's rows are in LDS for every wave; step y - 2 has been read by all
+            if constexpr (!(RNH_DEXP & 1)) group(wrap(sm1, 8));  // step y + 6's rows into the slots of input rows y - 3, y - 2 / gradient rows y - 2, y - 1
 
             // gradient fragments of the two output rows [row][k step]: 8 reads
-            u32x2 yb4[2][2][2];
+            const bool rd = !(RNH_DEXP & 2) || y == ya;
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
+                if (!rd) break;
                 const unsigned ya_ = lds0 + ys_off(y + o) + yo;
                 RNH_TR(yb4[o][0][0], ya_, 0);
                 RNH_TR(yb4[o][0][1], ya_, 512);
@@ -427,9 +468,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
             }
             // input fragments: group g = (input row ri, k step ks), three x shifts x two reads; group g + 1 is requested before
             // group g is multiplied
-            u32x2 xf[2][3];                                      // pixels 8 kh + 0..3, 4..7, 8..11 of the lane's channel
             auto xreads = [&](int set, int ri, int ks) {
-                const unsigned a_ = lds0 + xs_off(y - 1 + ri) + xo[0];
+                if (!rd) return;
+                const unsigned base = lds0 + wrap(sm1, ri) * XS_BYTES;
+#if RNH_WXF == 0
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const unsigned a_ = base + xo[dx];
+                    if (ks == 0) {
+                        RNH_TR(xf[set][2 * dx], a_, 0);
+                        RNH_TR(xf[set][2 * dx + 1], a_, 512);
+                    } else {
+                        RNH_TR(xf[set][2 * dx], a_, 2048);
+                        RNH_TR(xf[set][2 * dx + 1], a_, 2560);
+                    }
+                }
+#else
+                const unsigned a_ = base + xo[0];
                 if (ks == 0) {
                     RNH_TR(xf[set][0], a_, 0);
                     RNH_TR(xf[set][1], a_, 512);
@@ -439,18 +494,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
                     RNH_TR(xf[set][1], a_, 2560);
                     RNH_TR(xf[set][2], a_, 3072);
                 }
+#endif
             };
             xreads(0, 0, 0);
             bf16x8 bfr[2][2];
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int ri = g >> 1, ks = g & 1, set = g & 1;
-                if (g + 1 < 8) {
-                    xreads(set ^ 1, (g + 1) >> 1, (g + 1) & 1);
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
-                }
+                if (g + 1 < 8) xreads(set ^ 1, (g + 1) >> 1, (g + 1) & 1);
+#if RNH_WXF == 0
+                if (g + 1 < 8) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]), "+v"(xf[set][3]), "+v"(xf[set][4]), "+v"(xf[set][5]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]), "+v"(xf[set][3]), "+v"(xf[set][4]), "+v"(xf[set][5]));
+#else
+                if (g + 1 < 8) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[set][0]), "+v"(xf[set][1]), "+v"(xf[set][2]));
+#endif
                 if (g == 0) {                                    // (the gradient reads are older than group 0's: they have landed too)
 #pragma unroll
                     for (int o = 0; o < 2; ++o)
@@ -465,13 +523,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
 #pragma unroll
                     for (int o = 0; o < 2; ++o) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[o][g], bacc, 0, 0, 0);
                 }
-                // the three x shifts of the 12 pixels in registers: dword i = pixels (2i, 2i + 1); shift 1 = four funnel shifts
-                const unsigned d0 = xf[set][0].x, d1 = xf[set][0].y, d2 = xf[set][1].x, d3 = xf[set][1].y, d4 = xf[set][2].x;
                 bf16x8 f[3];
-                f[0] = __builtin_bit_cast(bf16x8, make_uint4(d0, d1, d2, d3));
-                f[1] = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
-                                                             __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)));
-                f[2] = __builtin_bit_cast(bf16x8, make_uint4(d1, d2, d3, d4));
+#if RNH_WXF == 0
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    f[dx] = __builtin_bit_cast(bf16x8, make_uint4(xf[set][2 * dx].x, xf[set][2 * dx].y, xf[set][2 * dx + 1].x, xf[set][2 * dx + 1].y));
+#else
+                {
+                    // the three x shifts of the 12 pixels in registers: dword i = pixels (2i, 2i + 1); shift 1 = four funnel shifts
+                    const unsigned d0 = xf[set][0].x, d1 = xf[set][0].y, d2 = xf[set][1].x, d3 = xf[set][1].y, d4 = xf[set][2].x;
+                    f[0] = __builtin_bit_cast(bf16x8, make_uint4(d0, d1, d2, d3));
+                    f[1] = __builtin_bit_cast(bf16x8, make_uint4(__builtin_amdgcn_alignbit(d1, d0, 16), __builtin_amdgcn_alignbit(d2, d1, 16),
+                                                                 __builtin_amdgcn_alignbit(d3, d2, 16), __builtin_amdgcn_alignbit(d4, d3, 16)));
+                    f[2] = __builtin_bit_cast(bf16x8, make_uint4(d1, d2, d3, d4));
+                }
+#endif
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int dy = ri - o;                       // input row y - 1 + ri feeds output row y + o through tap row dy
@@ -482,6 +548,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            sm1 = wrap(sm1, 2);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the workgroup has gone
