@@ -155,20 +155,39 @@ def test_lds_dma_weight_gradient_kernel_keeps_its_pipeline(tmp_path):
     assert counted == [0, 0, 8, 12], waits
     mf = [i for i, ln in enumerate(lines) if ln.startswith('v_mfma')]
     assert len(mf) == 40                                          # 36 per step + 4 for the bias gradient
+    # (c) as a simulation of the LDS queue: a fragment read is in flight from its issue until an s_waitcnt lgkmcnt(N) leaves at most N
+    # younger LDS operations outstanding (LDS returns in order); until then NO other instruction may name one of its target registers.
+    # (Since round 4 the kernel builds the shifted fragments in registers - v_perm / v_mov on read targets - which is fine behind the wait.)
     first_tr = min(i for i, ln in enumerate(lines) if TR_RE.match(ln))
-    targets = set()
-    for ln in lines:
+    reg_re = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+
+    def named(ln):
+        out = set()
+        for a, b, c in reg_re.findall(ln):
+            out.update(range(int(a), int(b) + 1) if a else [int(c)])
+        return out
+
+    flight, bad, nread = [], [], 0
+    for ln in lines[first_tr:mf[-1] + 1]:
         m = TR_RE.match(ln)
         if m:
-            targets.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    bad = []
-    for ln in lines[first_tr:mf[-1] + 1]:
-        m = MOVE_RE.match(ln) or SPILL_RE.match(ln)
-        if m and any(r in targets for r in _regs(m)):
+            flight.append(set(range(int(m.group(1)), int(m.group(2)) + 1)))
+            nread += 1
+            continue
+        w = re.search(r'lgkmcnt\((\d+)\)', ln) if ln.startswith('s_waitcnt') else None
+        if w:
+            flight = flight[len(flight) - int(w.group(1)):] if int(w.group(1)) < len(flight) else flight
+            if int(w.group(1)) == 0:
+                flight = []
+            continue
+        if ln.startswith('ds_') or ln.startswith('s_load'):
+            bad.append('another lgkmcnt operation inside the counted window: ' + ln)
+        pending = set().union(*flight) if flight else set()
+        if pending & named(ln):
             bad.append(ln)
-        if ln.startswith('scratch_'):
+        if ln.startswith('scratch_') or SPILL_RE.match(ln):
             bad.append(ln)
-    assert not bad, bad[:8]
+    assert nread >= 30 and not bad, bad[:8]
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
