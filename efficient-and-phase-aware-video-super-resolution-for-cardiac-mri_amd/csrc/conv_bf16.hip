@@ -232,18 +232,24 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const __amdgpu_buffer_rsrc_t wrs = bdesc(P.wp);
     const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
     const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
-    const int nslabs = P.nchunks * NTAPS;
     constexpr int RING = NTAPS == 1 ? 1 : (KC == 32 ? 6 : 3), AHEAD = RING - 1;
     constexpr int NSTEP = NTAPS * KS;                            // (tap, k step) pairs per chunk; NSTEP % RING == 0: the set of a step is static
     static_assert(NTAPS == 1 || NSTEP % RING == 0, "the fragment ring must divide the steps of a chunk");
     uint4 bq[RING][NB];
-    // fragments of step g = chunk * NSTEP + tap * KS + ks of the launch: slab (16-channel chunk KS * chunk + ks, tap); beyond the end: zeros, unused
-    auto bload = [&](int g, int set) {
-        const int c = g / NSTEP, r = g - c * NSTEP, tap = r / KS, ks = r - tap * KS;
-        const bool ok = g < nslabs;
-        const int base = ((KS * c + ks) * NTAPS + tap) * slab;
+    const int nch = P.nchunks / KS;
+    // fragments of step sa of chunk c (sa >= NSTEP: of the chunks behind it): slab (16-channel chunk KS * chunk + ks, tap).  sa is a compile-time
+    // constant at every call site, so tap, k step and chunk increment are too: the slab's byte offset is ONE scalar multiply-add and goes into the
+    // load's scalar offset, the per-lane offsets never change (round 4; until then a division by NSTEP per step - 14 SALU + 4 VALU instructions
+    // in front of every 8 MFMAs).  Behind the last chunk the fragments are never used: the last chunk's are read again.
+    int wvo[NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bq[set][n] = bld16(wrs, ok ? base + wlane + n * 32 * 32 : -1);
+    for (int n = 0; n < NB; ++n) wvo[n] = wlane + n * 32 * 32;
+    auto bload = [&](int c, int sa, int set) {
+        const int q = sa / NSTEP, r = sa - q * NSTEP, tap = r / KS, ks = r - tap * KS;
+        const int cc = c + q < nch ? c + q : nch - 1;
+        const int base = (cc * KS + ks) * NTAPS * slab + tap * slab;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bq[set][n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[n], base, 0));
     };
 
     f32x16 acc[MB][NB];
@@ -253,7 +259,6 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
-    const int nch = P.nchunks / KS;
 
     // One chunk.  The halo of chunk c + 1 sits in registers since step 2 KS of chunk c - 1 (a whole chunk of MFMAs ago, so the
     // wait in store_chunk costs nothing); at step 2 KS it goes to the other LDS buffer - nobody reads that one before the
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             if (step + 1 < NSTEP && !(RNH_EXP & 2)) afrags(step + 1, (step + 1) & 1);
-            if constexpr (NTAPS == 9 && !(RNH_EXP & 1)) bload(c * NSTEP + step + AHEAD, (step + AHEAD) % RING);      // AHEAD steps ahead
+            if constexpr (NTAPS == 9 && !(RNH_EXP & 1)) bload(c, step + AHEAD, (step + AHEAD) % RING);      // AHEAD steps ahead
             if (step == (NTAPS == 9 ? 2 * KS : 0) && !(RNH_EXP & 4)) {
                 if (c + 1 < nch) store_chunk(buf ^ 1);
                 if (c + 2 < nch) load_chunk();
@@ -282,17 +287,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 for (int n = 0; n < NB; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (step & 1)][m],
                                                                         __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
-            if constexpr (NTAPS == 1) bload(c + 1, 0);
+            if constexpr (NTAPS == 1) bload(c + 1, 0, 0);
             if constexpr (NTAPS == 9) __builtin_amdgcn_sched_barrier(0);     // pin the issue order: hipcc otherwise sinks the weight loads to their first use
         }
     };
 
     // ---- K loop: double-buffered halo, one barrier per chunk ------------------------------------------------------------
     BSTAMP(0);
-    bload(0, 0);
+    bload(0, 0, 0);
     if constexpr (NTAPS == 9) {
 #pragma unroll
-        for (int g = 1; g < AHEAD; ++g) bload(g, g);
+        for (int g = 1; g < AHEAD; ++g) bload(0, g, g);
     }
     load_chunk();
     store_chunk(0);
