@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
                          : "i"(KEEP));
     };
     int voa[MI][2];                                   // byte offsets of the next step's A pieces (or -1: zeros)
-    bool fm_cur = false, fm_prev = false;             // a fully out-of-range A load among this / the previous step's loads
+    bool fm_cur = false, fm_prev = false;             // an A load with out-of-range lanes among this / the previous step's loads
     auto next_offsets = [&]() {
         int dy = 0, dx = 0;
         if (P.ntaps == 9) {
@@ -322,16 +322,18 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             voa[i][0] = (v && cc < anch) ? o : -1;
             voa[i][1] = (v && cc + 8 < anch) ? o + 32 : -1;
         }
-        // A load whose 64 lanes are ALL out of range never goes to memory and returns at once - ahead of older loads
-        // that are still in flight - so the counted waits below (which assume in-order return) would let an MFMA read
-        // a register before its data has landed (seen as wrong workgroups on border rows, about one in 10^5, and
-        // wholesale with 4-channel sources, where the second 16-byte piece is always absent).  Such loads are rare
-        // (image border rows, short channel tails): while one may be among the younger loads, wait for everything.
+        // Loads with out-of-range lanes do not keep their place in the return order: a load whose 64 lanes are ALL out of range never goes
+        // to memory and returns at once, ahead of older loads still in flight (round 1: wrong workgroups on border rows, about one in 10^5,
+        // wholesale with 4-channel sources) - and a PARTLY masked load can overtake older ones too when memory is busy (round 4: with a
+        // weight-gradient kernel streaming on another stream, one 32 x 32 training step in 60 came out with a few image rows of this
+        // kernel's output computed from registers whose loads had not landed; tools/probes/flake_width16.py, profiles/r04_ab_*).  The
+        // counted waits below assume in-order return, so: while a load with ANY masked lane may be among the younger loads, wait for
+        // everything.  (Border pixels and channel tails only; the waves of the image interior keep the counted waits.)
         fm_prev = fm_cur;
         fm_cur = false;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            fm_cur |= __builtin_amdgcn_ballot_w64(voa[i][0] != -1) == 0 || __builtin_amdgcn_ballot_w64(voa[i][1] != -1) == 0;
+            fm_cur |= __builtin_amdgcn_ballot_w64(voa[i][0] == -1) != 0 || __builtin_amdgcn_ballot_w64(voa[i][1] == -1) != 0;
     };
     auto drain_if_unordered = [&]() {
         if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

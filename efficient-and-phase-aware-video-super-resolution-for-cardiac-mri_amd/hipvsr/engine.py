@@ -192,6 +192,14 @@ class RefineNetEngine:
         if os.environ.get('RNH_MEMLOG') == '1' and hasattr(self.ops, 'mem_allocated'):
             self.__dict__.setdefault('memlog', []).append((label, self.ops.mem_allocated()))
 
+    def _sum(self, label, t):
+        """RNH_DBGSUM=1 (race hunting, tools/probes/flake_width16.py): (label, float64 sum of t as a device scalar) in self.dbgsum - launched
+        on the current stream right where the engine stands, no synchronisation."""
+        if os.environ.get('RNH_DBGSUM') == '1' and t is not None:
+            self.__dict__.setdefault('dbgsum', []).append((label, t.detach().double().sum()))
+        if os.environ.get('RNH_DBGKEEP') == '1' and t is not None:          # the tensor itself stays alive (no launch): inspected after the step
+            self.__dict__.setdefault('dbgkeep', []).append((label, t))
+
     def recompute_stages(self, N, H, W, F):
         """How many stages (the first n of S) recompute their ConvLSTM gates in the backward - one more cell launch per cell and supervised
         frame of those stages - instead of reading gates the forward stored.  'store': 0, 'recompute': all, an integer: that many,
@@ -575,6 +583,8 @@ class RefineNetEngine:
                 ops.add(dR, dfeat_next, accumulate=True)
             st['Sb'] = st['Ys'] = None
             self._mem(f'bwd stage {s}: upsampler done')
+            self._sum(f'bwd {s} dS', dS)
+            self._sum(f'bwd {s} dfeat0', dfeat)
 
             # ---- refine block backward on the T supervised windows --------------------------------------------
             xs = []
@@ -663,6 +673,9 @@ class RefineNetEngine:
                          dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
 
             self._mem(f'bwd stage {s}: refine done')
+            self._sum(f'bwd {s} gsrc', gsrc)
+            self._sum(f'bwd {s} dHf', dHf)
+            self._sum(f'bwd {s} dHb', dHb)
             # ---- ConvLSTM back-propagation through time over the supervised frames ----------------------------
             # Same wavefront as the forward, reversed: cell (d, l, k) needs the input gradient of (d, l+1, k) (an
             # event) and the state gradients of its own next-processed frame (stream order).  Buffers that cross
@@ -811,7 +824,10 @@ class RefineNetEngine:
             else:
                 ops.join(2 * Lr)
             self._mem(f'bwd stage {s}: BPTT done')
+            self._sum(f'bwd {s} dfeat_fwd', dfeat_d['forward'])
+            self._sum(f'bwd {s} dfeat_bwd', dfeat_d['backward'])
             ops.add(dfeat, dfeat_d['forward'], dfeat_d['backward'], accumulate=True)
+            self._sum(f'bwd {s} dfeat', dfeat)
             for d in dirs:                                          # (the weight gradients read neither the stored gates nor the cell states)
                 st[d]['G'] = st[d]['C'] = None
             in_flight = (st, feat, Gd if defer else None, hold)    # what the weight-gradient launches still read: h, features, dgates, ...

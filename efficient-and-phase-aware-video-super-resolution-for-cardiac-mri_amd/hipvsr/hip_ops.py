@@ -192,9 +192,25 @@ class HipOps:
         if t is None or t.numel() < nfloats:
             if t is not None and self.graph_captures:
                 self._ws_retired.append(t)
-            t = self.empty(int(nfloats))
+            if os.environ.get('RNH_WS_GUARD') == '1':         # debugging aid: 256 KiB of sentinel behind (and in front of) every scratch buffer
+                g = 65536
+                full = self.empty(int(nfloats) + 2 * g)
+                full.fill_(-12345.0)
+                self.__dict__.setdefault('_ws_guard', {})[key] = (full, g, int(nfloats))
+                t = full[g:g + int(nfloats)]
+            else:
+                t = self.empty(int(nfloats))
             self._ws[key] = t
         return t
+
+    def check_ws_guards(self):
+        """RNH_WS_GUARD=1: names of the scratch buffers whose guard bands have been written to (device sync)."""
+        bad = []
+        for key, (full, g, n) in getattr(self, '_ws_guard', {}).items():
+            lo, hi = full[:g], full[g + n:]
+            if bool((lo != -12345.0).any()) or bool((hi != -12345.0).any()):
+                bad.append((key, int((lo != -12345.0).sum()), int((hi != -12345.0).sum()), n))
+        return bad
 
     def halo_buffer(self, key, shape, dtype, lo, hi):
         """A buffer of ``shape`` whose leading-dimension slices outside [lo, hi) are zero and stay zero: allocated and zeroed
