@@ -197,11 +197,6 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     [[maybe_unused]] uint4 rh[KC == 16 ? A_ITERS : 1];           // second halves of fp32 pieces (16-channel chunks only)
     int ra_f32 = 0;
     int si = 0, cc = 0;
-    // Pieces outside the image (zero padding) and absent channels: the loads go to a VALID address (the first pixel of the source) and the
-    // piece is zeroed when it is written to LDS.  An out-of-range offset would give the zeros for free, but a load with out-of-range lanes
-    // does not keep its place in the return order (csrc/conv_igemm.hip, round 4), and every vmcnt wait hipcc counts for the weight
-    // fragments assumes it does.  `left_ld`: the channels left in the source when the chunk in registers was requested.
-    int left_ld = 0;
     auto load_chunk = [&]() {
         const rnh_msrc_t &S = P.src[si];
         const int es = (KC == 32 || S.dtype == RNH_DT_BF16) ? 2 : 4;
@@ -209,15 +204,14 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                            ((((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x) * S.C + S.c0 + cc * KC) * es;
         const __amdgpu_buffer_rsrc_t rs = bdesc(base);
         const int pstride = S.C * es, left = S.nch - cc * KC;
-        left_ld = left;
         if constexpr (KC == 16) ra_f32 = S.dtype != RNH_DT_BF16;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int ch = ahalf[i] * 8;
             const bool ok = apix[i] >= 0 && ch < left;
             const int off = apix[i] * pstride + ch * es;
-            ra[i] = bld16(rs, ok ? off : 0);
-            if constexpr (KC == 16) rh[i] = bld16(rs, ok && ra_f32 && ch + 4 < left ? off + 16 : 0);
+            ra[i] = bld16(rs, ok ? off : -1);
+            if constexpr (KC == 16) rh[i] = bld16(rs, ok && ra_f32 && ch + 4 < left ? off + 16 : -1);
         }
         if (++cc * KC >= S.nch) {
             cc = 0;
@@ -228,19 +222,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         unsigned char *Ab = smem + buf * A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int ch = ahalf[i] * 8;
             uint4 v = ra[i];
-            if constexpr (KC == 16) {
-                uint4 h = rh[i];
-                if (!(ch + 4 < left_ld)) h = make_uint4(0u, 0u, 0u, 0u);
-                v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, h)) : ra[i];
-            }
-            if (alds[i] >= 0) {
-                *reinterpret_cast<uint4 *>(Ab + alds[i]) = v;
-                // (a second, exec-masked store for the few lanes of padding - LDS stores of a wave execute in order - instead of four
-                // selects per piece in every lane; whole waves of interior pixels skip it)
-                if (apix[i] < 0 || ch >= left_ld) *reinterpret_cast<uint4 *>(Ab + alds[i]) = make_uint4(0u, 0u, 0u, 0u);
-            }
+            if constexpr (KC == 16) v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
+            if (alds[i] >= 0) *reinterpret_cast<uint4 *>(Ab + alds[i]) = v;
         }
     };
 
