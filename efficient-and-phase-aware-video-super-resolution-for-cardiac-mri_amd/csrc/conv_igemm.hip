@@ -322,13 +322,15 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             voa[i][0] = (v && cc < anch) ? o : -1;
             voa[i][1] = (v && cc + 8 < anch) ? o + 32 : -1;
         }
-        // Loads with out-of-range lanes do not keep their place in the return order: a load whose 64 lanes are ALL out of range never goes
-        // to memory and returns at once, ahead of older loads still in flight (round 1: wrong workgroups on border rows, about one in 10^5,
-        // wholesale with 4-channel sources) - and a PARTLY masked load can overtake older ones too when memory is busy (round 4: with a
-        // weight-gradient kernel streaming on another stream, one 32 x 32 training step in 60 came out with a few image rows of this
-        // kernel's output computed from registers whose loads had not landed; tools/probes/flake_width16.py, profiles/r04_ab_*).  The
-        // counted waits below assume in-order return, so: while a load with ANY masked lane may be among the younger loads, wait for
-        // everything.  (Border pixels and channel tails only; the waves of the image interior keep the counted waits.)
+        // The counted waits of this loop (vmcnt(L/2): the younger half-step of loads stays in flight) are NOT used any more (round 4).
+        // History: a load whose 64 lanes are ALL out of range seemed to overtake older loads (round 1: wrong workgroups on border rows, one in
+        // 10^5, wholesale with 4-channel sources), so the loop drained when such a load was among the younger ones.  Round 4: with a weight-
+        // gradient kernel streaming on another stream, one training step in 60 of the width-16 net (32 x 32) and one in 60 at 128 x 128 came
+        // out with the tiles of a whole XCD computed from operands that had not landed - draining whenever ANY lane is masked cured 32 x 32
+        // and 64 x 64 (0 in 1500) but not 128 x 128 (16 in 1000), i.e. interior waves with the plain counted waits fail too.  A probe
+        // (tools/probes/oob_order.hip) finds buffer loads with out-of-range lanes returning IN order, so the cause is not understood;
+        // with a full drain in front of every half step the kernel is exact in 3000 steps at all three sizes (tools/probes/flake_width16.py,
+        // profiles/r04_ab_*).  -DRNH_IGEMM_COUNTED restores the old waits for investigation.
         fm_prev = fm_cur;
         fm_cur = false;
 #pragma unroll
@@ -336,7 +338,11 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             fm_cur |= __builtin_amdgcn_ballot_w64(voa[i][0] == -1) != 0 || __builtin_amdgcn_ballot_w64(voa[i][1] == -1) != 0;
     };
     auto drain_if_unordered = [&]() {
+#ifdef RNH_IGEMM_COUNTED                              // diagnostic build: the counted waits of rounds 1-3 wherever no lane is masked
         if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     };
     auto issue_a = [&](Frag &FL, int q) {
 #pragma unroll
