@@ -415,3 +415,36 @@ def test_data_gradient_column_vs_float64(B, H, W, Cin):
     assert float(got[1:B + 1, ..., col + 1:].abs().max()) == 0.0
     assert bool((got[1:B + 1, ..., :col] == 3.0).all()) and bool(torch.isnan(got[0]).sum() == got[0][..., col:].numel())
     assert bool(torch.isnan(got[B + 1][..., col:]).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cold training steps beside a streaming kernel (the race of DESIGN.md section 4d (e))
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype,width,size,reps', [('f32', 16, 32, 160), ('f32', 16, 128, 120), ('bf16', 16, 32, 80)])
+def test_cold_training_steps_repeat_bit_for_bit_beside_the_helper_stream(dtype, width, size, reps, monkeypatch):
+    """One training step of a FRESH net (new engine, streams, scratch buffers) per repetition, every loss and gradient bitwise equal to the first
+    repetition's.  RNH_POISON fills every new buffer on its stream (timing noise, and NaN wherever something unwritten is read); the weight gradients
+    stream on the helper stream meanwhile.  With the direct implicit-GEMM kernel's counted waits of rounds 1-3 1.2-2 % of these steps came out
+    wrong at either size (tools/probes/flake_width16.py, profiles/r04_ab_*): 160 / 120 repetitions miss that with probability < 10 %."""
+    monkeypatch.setenv('RNH_POISON', '1')
+    monkeypatch.setenv('RNH_ASIDE_OFF', 'up_fwd')
+    cfg = orc.Config(in_channels=1, out_channels=1, num_features=[width, width], num_stages=3, refine_window_size=5, upscale_factor=4,
+                     update_memory=True, num_updated_frames=2, positional_encoding=True)
+    sd = orc.init_state_dict(cfg, seed=8)
+    dev = _dev()
+    inputs, targets, pos = orc.synthetic_batch(cfg, 2, 3, size, size, seed=90)
+    first, wrong = None, []
+    for r in range(reps):
+        net = _net(cfg, sd, dtype).train()
+        tr = _train_trainer(net, 1e-3)
+        _, loss, _ = tr.train_step([x.to(dev) for x in inputs], [t.to(dev) for t in targets], pos.to(dev))
+        torch.cuda.synchronize()
+        cur = {'loss': loss.detach().clone()}
+        cur.update({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        assert all(bool(torch.isfinite(v).all()) for v in cur.values()), (r, 'non-finite')
+        if first is None:
+            first = cur
+        elif any(not torch.equal(cur[k], first[k]) for k in cur):
+            wrong.append((r, [k for k in cur if not torch.equal(cur[k], first[k])][:4]))
+        del net, tr
+    assert not wrong, (len(wrong), 'of', reps, wrong[:3])
