@@ -337,10 +337,12 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         for (int i = 0; i < MI; ++i)
             fm_cur |= __builtin_amdgcn_ballot_w64(voa[i][0] == -1) != 0 || __builtin_amdgcn_ballot_w64(voa[i][1] == -1) != 0;
     };
-    auto drain_if_unordered = [&]() {
-#ifdef RNH_IGEMM_COUNTED                              // diagnostic build: the counted waits of rounds 1-3 wherever no lane is masked
-        if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto drain_if_unordered = [&](int q) {
+#ifdef RNH_IGEMM_COUNTED                              // diagnostic builds: 1 = the counted waits of rounds 1-3 wherever no lane is masked; 2 / 3 = full drain in
+        if (fm_cur || fm_prev || (RNH_IGEMM_COUNTED == 2 && q == 0) || (RNH_IGEMM_COUNTED == 3 && q == 1))      // front of the first / second half step only
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
+        (void)q;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     };
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         if constexpr (ISSUE) next_offsets();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            drain_if_unordered();
+            drain_if_unordered(q);
             if (q == 0 || !ISSUE) {
                 if (q == 0) wait_half(FC, 0, std::integral_constant<int, LH>());
                 else wait_half(FC, 1, std::integral_constant<int, 0>());
