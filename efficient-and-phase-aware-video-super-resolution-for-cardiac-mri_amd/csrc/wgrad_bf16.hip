@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const rnh_wgrad_bf16
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];      // zero-initialised: the source of every masked piece
 
 // Diagnostic ablations of the LDS-DMA kernel (never defined in the product build; results are wrong, only the time is of interest):
-// -DRNH_DEXP=<mask>  1: no row requests inside the step loop (and no waits for them), 2: fragments read once per run, 4: no barrier in the loop
+// -DRNH_DEXP=<mask>  1: no row requests inside the step loop (and no waits for them), 2: fragments read once per run, 4: no barrier in the loop,
+//                    8: the requests are issued but never waited for
 #ifndef RNH_DEXP
 #define RNH_DEXP 0
 #endif
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
         u32x2 yb4[2][2][2];
         u32x2 xf[2][RNH_WXF ? 3 : 6];                            // RNH_WXF 1: pixels 8 kh + 0..3, 4..7, 8..11 of the lane's channel
         for (int y = ya; y < yb; y += 2) {
-            if constexpr (!(RNH_DEXP & 1)) {
+            if constexpr (!(RNH_DEXP & 1) && !(RNH_DEXP & 8)) {                      // (8: requests go out, nobody waits for them)
                 if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
