@@ -248,6 +248,15 @@ def run_case(args, dtype, dev, world, rank):
     from hipvsr import dp
     from hipvsr.step_tail import FlatAdam
     from src.runner.trainers import AcdcVSRRefineNetTrainer
+    if os.environ.get('BENCH_DUMMY_STREAMS'):        # diagnosis: advance torch's stream pool as an earlier case in the same process would have
+        _dummy = [torch.cuda.Stream(dev) for _ in range(int(os.environ['BENCH_DUMMY_STREAMS']))]
+    if os.environ.get('BENCH_DUMMY_ALLOC_GB'):       # diagnosis: the memory history an earlier case in the same process would have left
+        _blocks = [torch.empty(1 << 30, dtype=torch.uint8, device=dev) for _ in range(int(os.environ['BENCH_DUMMY_ALLOC_GB']))]
+        for _b in _blocks:
+            _b.fill_(1)
+        torch.cuda.synchronize()
+        del _blocks, _b
+        torch.cuda.empty_cache()
     net = make_net(dev, seed=0, scale=args.scale)
     net.set_compute_dtype(dtype)
     dp.broadcast_parameters(net)
@@ -271,11 +280,16 @@ def run_case(args, dtype, dev, world, rank):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step times (no host sync inside the region)
     t0 = time.perf_counter()
     marks[0].record()
+    host = []
     for i in range(args.steps):
+        h0 = time.perf_counter()
         _, loss, _ = tr.train_step(inputs, targets, pos)
         marks[i + 1].record()
+        host.append(time.perf_counter() - h0)
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get('BENCH_EACH_STEP'):            # diagnosis: the steps in order, to stderr
+        print(dtype, 'per-step ms:', [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)], 'wall', round((time.perf_counter() - t0) * 1e3, 1), 'host enqueue ms per step:', [round(h * 1e3, 1) for h in host], file=sys.stderr, flush=True)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -443,7 +457,7 @@ def main(argv=None):
         sec = run_case(args, 'bf16', dev, world, rank)
     if rank == 0:
         if sec is not None:
-            out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median',
+            out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'ms_per_step_min_max',
                                                     'dtype', 'data', 'config', 'roofline')}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

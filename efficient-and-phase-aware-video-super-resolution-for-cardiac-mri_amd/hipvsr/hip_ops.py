@@ -33,6 +33,22 @@ def packed_view(tensors, device=None):
     return torch.stack([t.to(dev, torch.float32) for t in tensors], dim=0)
 
 
+# Side streams are a per-process resource: every HipOps instance of a device uses the SAME ones (role by role: LSTM bank and index, the
+# helper).  A second engine in the same process - bench.py's bf16 case behind its fp32 case, a predictor beside a trainer - that made
+# streams of its own ran its step 5 % slower than the same step in a fresh process (86.3 against 82.1 ms, single kernels equally fast:
+# the later streams share hardware queues less favourably); with shared streams it does not.  Engines of one process issue their work from
+# the same current stream and order every use of a side stream by events, so sharing them changes no dependency.
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    key = (str(device), role)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
 class HipOps:
     name = 'hip'
 
@@ -114,7 +130,8 @@ class HipOps:
         self._fork_n = n
         n = 1 + max(self._side_index(i) for i in range(n))
         while len(self._side) < n:
-            self._side.append(torch.cuda.Stream(self.device))
+            self._side.append(_shared_stream(self.device, ('lstm', bank, len(self._side))) if os.environ.get('RNH_SHARED_STREAMS', '1') != '0'
+                              else torch.cuda.Stream(self.device))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         for st in self._side[:n]:
@@ -157,7 +174,7 @@ class HipOps:
             import contextlib
             return contextlib.nullcontext()
         if self._helper is None:
-            self._helper = torch.cuda.Stream(self.device)
+            self._helper = _shared_stream(self.device, ('helper', 0)) if os.environ.get('RNH_SHARED_STREAMS', '1') != '0' else torch.cuda.Stream(self.device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._helper.wait_event(ev)
