@@ -79,6 +79,14 @@ class HipOps:
         self.direct = (os.environ.get('RNH_DIRECT', '1') != '0') if direct is None else bool(direct)
         self.direct_ps = os.environ.get('RNH_DIRECT_PS', '1') != '0'
         self.wino_wgrad = os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0'
+        # experiment (DESIGN 4d c): the order in which the side streams are first USED decides which of them share a hardware queue (ROCm binds
+        # a stream to one of GPU_MAX_HW_QUEUES = 4 queues); RNH_STREAM_TOUCH="H,F0,F1,F2,B0,B1,B2" submits one trivial launch on each, in that order
+        if os.environ.get('RNH_STREAM_TOUCH'):
+            for role in os.environ['RNH_STREAM_TOUCH'].split(','):
+                st = _shared_stream(self.device, ('helper', 0)) if role == 'H' else _shared_stream(self.device, ('lstm', 0 if role[0] == 'F' else 1, int(role[1])))
+                with torch.cuda.stream(st):
+                    self._zero_page.add_(0)
+            torch.cuda.synchronize(self.device)
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, *shape, dtype=torch.float32):
