@@ -322,28 +322,21 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             voa[i][0] = (v && cc < anch) ? o : -1;
             voa[i][1] = (v && cc + 8 < anch) ? o + 32 : -1;
         }
-        // The counted waits of this loop (vmcnt(L/2): the younger half-step of loads stays in flight) are NOT used any more (round 4).
-        // History: a load whose 64 lanes are ALL out of range seemed to overtake older loads (round 1: wrong workgroups on border rows, one in
-        // 10^5, wholesale with 4-channel sources), so the loop drained when such a load was among the younger ones.  Round 4: with a weight-
-        // gradient kernel streaming on another stream, one training step in 60 of the width-16 net (32 x 32) and one in 60 at 128 x 128 came
-        // out with the tiles of a whole XCD computed from operands that had not landed - draining whenever ANY lane is masked cured 32 x 32
-        // and 64 x 64 (0 in 1500) but not 128 x 128 (16 in 1000), i.e. interior waves with the plain counted waits fail too.  A probe
-        // (tools/probes/oob_order.hip) finds buffer loads with out-of-range lanes returning IN order, so the cause is not understood;
-        // with a full drain in front of every half step the kernel is exact in 3000 steps at all three sizes (tools/probes/flake_width16.py,
-        // profiles/r04_ab_*).  -DRNH_IGEMM_COUNTED restores the old waits for investigation.
+        // Loads with masked lanes: round 1 saw a load whose 64 lanes are ALL out of range return ahead of older loads (wrong workgroups on border
+        // rows, wholesale with 4-channel sources) and drained while one was among the younger loads; round 4 widened that to ANY masked lane while
+        // hunting the wrong steps that turned out to be the copied tail registers described at the K loop below.  tools/probes/oob_order.hip finds
+        // out-of-range loads in order on this hardware, so the drain may be unnecessary; it only costs the waves of the image border, and stays.
         fm_prev = fm_cur;
         fm_cur = false;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             fm_cur |= __builtin_amdgcn_ballot_w64(voa[i][0] == -1) != 0 || __builtin_amdgcn_ballot_w64(voa[i][1] == -1) != 0;
     };
-    auto drain_if_unordered = [&](int q) {
-#ifdef RNH_IGEMM_COUNTED                              // diagnostic builds: 1 = the counted waits of rounds 1-3 wherever no lane is masked; 2 / 3 = full drain in
-        if (fm_cur || fm_prev || (RNH_IGEMM_COUNTED == 2 && q == 0) || (RNH_IGEMM_COUNTED == 3 && q == 1))      // front of the first / second half step only
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        (void)q;
+    auto drain_if_unordered = [&]() {
+#ifdef RNH_IGEMM_DRAIN_ALL                            // diagnostic build: a full drain in front of every half step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     };
     auto issue_a = [&](Frag &FL, int q) {
@@ -369,7 +362,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         if constexpr (ISSUE) next_offsets();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            drain_if_unordered(q);
+            drain_if_unordered();
             if (q == 0 || !ISSUE) {
                 if (q == 0) wait_half(FC, 0, std::integral_constant<int, LH>());
                 else wait_half(FC, 1, std::integral_constant<int, 0>());
@@ -393,24 +386,34 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         Frag F0, F1;
         const int nk = P.nk;
         int ks = 0;
+        // The tile ALWAYS ends with the same code: "multiply F0, load nothing".  (Until round 4 there were two tails - one step left: multiply F0;
+        // two left: multiply F0 loading F1, then multiply F1 - which end in the same code on different registers; hipcc folded them into ONE
+        // block behind copies of F0 / F1: v_mov of registers whose loads may still be in flight, in FRONT of the counted wait.  The last K step of
+        // a tile then multiplied stale operands whenever its loads took longer than one step: round 4's "race", DESIGN.md 4d (e) - only under
+        // cross-stream memory load, a whole XCD's tiles at a time.)  The parity is settled at the START instead: with an even number of K
+        // steps the first one goes through F1.  tests/test_isa_guards.py checks that no load target is copied anywhere in this loop.
         next_offsets();                               // K step 0
-        issue_a(F0, 0);
-        issue_b(F0, 0, 0, 0, NI);
-        issue_a(F0, 1);
-        issue_b(F0, 1, 0, 0, NI);
-        for (; ks + 2 < nk; ks += 2) {
+        if (nk & 1) {
+            issue_a(F0, 0);
+            issue_b(F0, 0, 0, 0, NI);
+            issue_a(F0, 1);
+            issue_b(F0, 1, 0, 0, NI);
+        } else {
+            issue_a(F1, 0);
+            issue_b(F1, 0, 0, 0, NI);
+            issue_a(F1, 1);
+            issue_b(F1, 1, 0, 0, NI);
+            advance();
+            step(F0, F1, 1, std::true_type());
+            ks = 1;
+        }
+        for (; ks + 2 < nk; ks += 2) {                // an even number of steps is left behind step ks, which is in F0
             advance();
             step(F1, F0, ks + 1, std::true_type());
             advance();
             step(F0, F1, ks + 2, std::true_type());
         }
-        if (ks + 2 == nk) {
-            advance();
-            step(F1, F0, ks + 1, std::true_type());
-            step(F0, F1, 0, std::false_type());
-        } else {
-            step(F1, F0, 0, std::false_type());
-        }
+        step(F1, F0, 0, std::false_type());
     }
     }
 

@@ -134,6 +134,41 @@ def test_no_copies_of_async_load_targets(tmp_path, src, pattern, nmin):
     assert seen >= nmin
 
 
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
+def test_direct_implicit_gemm_never_copies_a_load_target(tmp_path):
+    """conv_igemm_kernel<..., DIRECT> (csrc/conv_igemm.hip) loads its MFMA operands straight into registers one K step ahead and waits for them
+    with counted s_waitcnt vmcnt(N).  Until round 4 the K loop had two tails that hipcc folded into one block behind v_mov copies of the operand
+    registers - copies of registers whose loads could still be in flight, in front of the wait: under cross-stream memory load the last K step of
+    a tile multiplied stale operands (DESIGN.md 4d (e); on the GPU: tests/test_parity_r04.py::test_cold_training_steps_repeat_bit_for_bit_beside_
+    the_helper_stream).  Static check of every DIRECT instantiation: between the first operand load and the last MFMA no move reads a register that
+    a buffer_load_dwordx4 of the kernel writes."""
+    text = _asm(os.path.join(CSRC, 'conv_igemm.hip'), str(tmp_path))
+    reg_re = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+    seen = 0
+    for name, lines in _kernels(text, 'conv_igemm_kernel'):
+        if 'Lb1EEE' not in name:                       # the LDS-staged variant: its loads are consumed behind a full wait and a barrier
+            continue
+        seen += 1
+        targets = set()
+        for ln in lines:
+            m = re.match(r'buffer_load_dwordx4\s+v\[(\d+):(\d+)\]', ln)
+            if m:
+                targets.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        first = min(i for i, ln in enumerate(lines) if ln.startswith('buffer_load_dwordx4'))
+        last = max(i for i, ln in enumerate(lines) if ln.startswith('v_mfma'))
+        bad = []
+        for ln in lines[first:last + 1]:
+            if ln.startswith(('v_mov_b32', 'v_mov_b64', 'v_pk_mov_b32', 'v_accvgpr_write_b32')) or ln.startswith('scratch_store'):
+                ops_ = ln.split(None, 1)[1].split(',', 1)
+                src = set()
+                for a, b, c in reg_re.findall(ops_[1] if len(ops_) > 1 else ''):
+                    src.update(range(int(a), int(b) + 1) if a else [int(c)])
+                if src & targets:
+                    bad.append(ln)
+        assert not bad, (name, len(bad), bad[:4])
+    assert seen >= 9
+
+
 TR_RE = re.compile(r'ds_read_b64_tr_b16\s+v\[(\d+):(\d+)\]')
 
 

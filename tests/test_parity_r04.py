@@ -424,8 +424,9 @@ def test_data_gradient_column_vs_float64(B, H, W, Cin):
 def test_cold_training_steps_repeat_bit_for_bit_beside_the_helper_stream(dtype, width, size, reps, monkeypatch):
     """One training step of a FRESH net (new engine, streams, scratch buffers) per repetition, every loss and gradient bitwise equal to the first
     repetition's.  RNH_POISON fills every new buffer on its stream (timing noise, and NaN wherever something unwritten is read); the weight gradients
-    stream on the helper stream meanwhile.  With the direct implicit-GEMM kernel's counted waits of rounds 1-3 1.2-2 % of these steps came out
-    wrong at either size (tools/probes/flake_width16.py, profiles/r04_ab_*): 160 / 120 repetitions miss that with probability < 10 %."""
+    stream on the helper stream meanwhile.  With the direct implicit-GEMM kernel of rounds 1-3 (two loop tails that hipcc folded behind copies of
+    operand registers whose loads were still in flight) 1.2-2 % of these steps came out wrong at either size
+    (tools/probes/flake_width16.py, profiles/r04_ab_*): 160 / 120 repetitions miss that with probability < 10 %."""
     monkeypatch.setenv('RNH_POISON', '1')
     monkeypatch.setenv('RNH_ASIDE_OFF', 'up_fwd')
     cfg = orc.Config(in_channels=1, out_channels=1, num_features=[width, width], num_stages=3, refine_window_size=5, upscale_factor=4,
