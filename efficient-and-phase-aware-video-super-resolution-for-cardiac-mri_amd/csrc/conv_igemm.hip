@@ -325,7 +325,9 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         // Loads with masked lanes: round 1 saw a load whose 64 lanes are ALL out of range return ahead of older loads (wrong workgroups on border
         // rows, wholesale with 4-channel sources) and drained while one was among the younger loads; round 4 widened that to ANY masked lane while
         // hunting the wrong steps that turned out to be the copied tail registers described at the K loop below.  tools/probes/oob_order.hip finds
-        // out-of-range loads in order on this hardware, so the drain may be unnecessary; it only costs the waves of the image border, and stays.
+        // out-of-range loads in order on this hardware, and a build without this drain (-DRNH_IGEMM_NO_MASK_DRAIN) is exact in 3000 cold steps and
+        // passes the 174 parity tests (profiles/r04_at_*): round 1's wrong workgroups were most likely the tail copies too.  The drain only costs the
+        // waves of the image border; it stays until more boxes have seen the build without it.
         fm_prev = fm_cur;
         fm_cur = false;
 #pragma unroll
@@ -335,6 +337,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
     auto drain_if_unordered = [&]() {
 #ifdef RNH_IGEMM_DRAIN_ALL                            // diagnostic build: a full drain in front of every half step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif defined(RNH_IGEMM_NO_MASK_DRAIN)                 // diagnostic build: counted waits everywhere, also with masked lanes among the younger loads
 #else
         if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
