@@ -168,17 +168,15 @@ class HipOps:
     # aside(): the helper stream picks up behind everything the current stream has been given so far (so it may read what those
     # launches produce) and the launches inside the block go to it; rejoin(): the current stream waits for everything the helper has
     # been given.  Buffers the helper reads or writes must stay alive - and must not be rewritten by the current stream - until the
-    # next rejoin().  RNH_ASIDE=0: the block runs on the current stream (A/B measurements).  Under HIP-graph capture the block also stays on
-    # the current stream: a captured training step with this extra branch reproduced the eager step's gradients only intermittently - on
-    # some boxes (5 of 12 runs of the graph-vs-eager test on one MI355X, 0 of 80 on another, same code); a replay then differs from the eager
-    # step by ~1 % in the gradients downstream of refine conv1's gradient planes.  The captured graph was dumped (hipGraphDebugDotPrint,
-    # tools/probes/graph_dot.py): every edge the streams' events imply is there; the eager step - same launches, same dependencies - is
-    # bit-identical with the helper delayed by 2 ms per block and without it (tests/test_parity_r04.py), and repeatable over 60 steps at
-    # config 2.  Cause not found (RNH_ASIDE_CAPTURE=1 re-enables it for investigation); the captured step keeps the shape that has replayed
-    # exactly since round 2, plus fence() below.
+    # next rejoin().  RNH_ASIDE=0: the block runs on the current stream (A/B measurements).  Under HIP-graph capture the helper is an ordinary
+    # branch of the captured graph (it allocates nothing).  History: mid-round 4 a captured training step with this branch reproduced the eager
+    # gradients only intermittently on some boxes (5 of 12 runs on one MI355X, 0 of 80 on another; ~1 % off downstream of refine conv1's gradient
+    # planes) and the branch was kept out of captures; the cause turned out to be the direct implicit-GEMM kernel's folded loop tails (stale operand
+    # copies under cross-stream memory load, DESIGN.md 4d e) - with that fixed, 58 of 58 graph-vs-eager runs on four boxes agree bit for bit.
+    # RNH_ASIDE_CAPTURE=0 keeps the blocks on the capturing stream.
     def aside(self, tag=''):
         if os.environ.get('RNH_ASIDE', '1') == '0' or (tag and tag in os.environ.get('RNH_ASIDE_OFF', '').split(',')) or \
-                (torch.cuda.is_current_stream_capturing() and os.environ.get('RNH_ASIDE_CAPTURE') != '1'):        # (=1: investigation only)
+                (torch.cuda.is_current_stream_capturing() and os.environ.get('RNH_ASIDE_CAPTURE', '1') == '0'):
             import contextlib
             return contextlib.nullcontext()
         if self._helper is None:
