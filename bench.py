@@ -27,6 +27,9 @@ size, steps and warm-up, timed the same way in the same process right after the 
 kernel source (sha256 of csrc/conv_wino.hip / csrc/conv_bf16.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
+Diagnosis (environment, no effect on the numbers' definition): BENCH_EACH_STEP=1 prints every timed step's HIP-event time and host enqueue time to stderr;
+BENCH_DUMMY_STREAMS=<n> / BENCH_DUMMY_ALLOC_GB=<n> give a case the stream-pool position / allocator history an earlier case of the same process would have left
+(how the 5 % penalty of the second engine of a process was traced to its side streams, DESIGN.md 4d c).
 """
 import argparse
 import json
