@@ -79,7 +79,7 @@ class HipOps:
         self.direct = (os.environ.get('RNH_DIRECT', '1') != '0') if direct is None else bool(direct)
         self.direct_ps = os.environ.get('RNH_DIRECT_PS', '1') != '0'
         self.wino_wgrad = os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0'
-        # experiment (DESIGN 4d c): the order in which the side streams are first USED decides which of them share a hardware queue (ROCm binds
+        # experiment (DESIGN 4d d): the order in which the side streams are first USED decides which of them share a hardware queue (ROCm binds
         # a stream to one of GPU_MAX_HW_QUEUES = 4 queues); RNH_STREAM_TOUCH="H,F0,F1,F2,B0,B1,B2" submits one trivial launch on each, in that order
         if os.environ.get('RNH_STREAM_TOUCH'):
             for role in os.environ['RNH_STREAM_TOUCH'].split(','):
