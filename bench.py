@@ -452,7 +452,24 @@ def main(argv=None):
     dev = torch.device(f'cuda:{local}')
     torch.cuda.set_device(dev)
     if 'RANK' in os.environ:                      # launched by torchrun (also with one rank): RCCL process group
-        dist.init_process_group('nccl', device_id=dev)
+        # librccl prints a five-line banner (versions, host, library path) to STDOUT when its first communicator is made; rank 0's stdout is
+        # the ONE JSON line of the contract, so the communicator is made here, with fd 1 pointed at stderr meanwhile
+        if os.environ.get('BENCH_TOUCH_FIRST', '1') != '0':
+            # the engine's side streams are used once, in the order a step first uses them, BEFORE RCCL makes its stream: which streams share a
+            # hardware queue is decided by first use (DESIGN.md 4d d), and this keeps the pairing of the single-process run
+            from hipvsr.hip_ops import touch_side_streams
+            touch_side_streams(dev)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     out = run_case(args, args.dtype, dev, world, rank)
     sec = None

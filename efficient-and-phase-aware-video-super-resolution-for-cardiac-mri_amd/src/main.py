@@ -121,6 +121,8 @@ def main(args):
     if world > 1:
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
+            from hipvsr.hip_ops import touch_side_streams
+            touch_side_streams(f'cuda:{local_rank}')              # before RCCL makes its stream: hardware-queue pairing as in the single-GPU run
             torch.distributed.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
         else:
             torch.distributed.init_process_group('gloo')
