@@ -365,39 +365,50 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_dma_kernel(const rnh_wgrad_
     // (image, x position and its validity folded in once per run), a request selects that pointer or the zero page and advances it by
     // the row stride; ring slots are running scalar counters.  ConvLSTM launch 580 -> 505 us.
     const unsigned long long zp = (unsigned long long)g_zero_page;
-    unsigned long long xp = zp, xp2 = zp, yp = zp;               // main piece, halo piece (wave 0, lanes 0..15), gradient piece
-    bool xok = false, xok2 = false, yok = false;
+    // per run: the running pointer of a piece IS the zero page (and its row stride 0) where the piece's column is outside the image or the channel group is
+    // padding; rows outside the image are a wave-uniform condition: a branch between two requests, no select
+    unsigned long long xp = zp, xp2 = zp, yp = zp, xst = 0, xst2 = 0, yst = 0;
     int xrow = 0, yrow = 0, yb = 0;                              // the rows the running pointers stand at; end of the run's gradient rows
-    const unsigned long long xrs = (unsigned long long)gx.row_stride, yrs = (unsigned long long)gy.row_stride;
     auto set_run = [&](int b, int x0, int ya) {
         const int xc = x0 + pxt - 1, xc2 = x0 + 31 + pxt, yc = x0 + pxt;
-        xok = gx.ok && (unsigned)xc < (unsigned)W;
-        xok2 = gx.ok && (unsigned)xc2 < (unsigned)W;
-        yok = gy.ok && (unsigned)yc < (unsigned)W;
+        const bool xok = gx.ok && (unsigned)xc < (unsigned)W, xok2 = gx.ok && (unsigned)xc2 < (unsigned)W, yok = gy.ok && (unsigned)yc < (unsigned)W;
         const char *xi = gx.ptr + (long)(b + gx.img_off) * gx.img_stride + (long)(ya - 1) * gx.row_stride;
-        xp = (unsigned long long)(xi + (long)(xok ? xc : 0) * gx.pix_stride);
-        xp2 = (unsigned long long)(xi + (long)(xok2 ? xc2 : 0) * gx.pix_stride);
-        yp = (unsigned long long)(gy.ptr + (long)(b + gy.img_off) * gy.img_stride + (long)ya * gy.row_stride + (long)(yok ? yc : 0) * gy.pix_stride);
+        xp = xok ? (unsigned long long)(xi + (long)xc * gx.pix_stride) : zp;
+        xp2 = xok2 ? (unsigned long long)(xi + (long)xc2 * gx.pix_stride) : zp;
+        yp = yok ? (unsigned long long)(gy.ptr + (long)(b + gy.img_off) * gy.img_stride + (long)ya * gy.row_stride + (long)yc * gy.pix_stride) : zp;
+        xst = xok ? (unsigned long long)gx.row_stride : 0;
+        xst2 = xok2 ? (unsigned long long)gx.row_stride : 0;
+        yst = yok ? (unsigned long long)gy.row_stride : 0;
         xrow = ya - 1;
         yrow = ya;
     };
     // slot of input row r0 + j given the slot s0 of row r0 (j < DNX)
     auto wrap = [&](int s0, int j) { const int t = s0 + j; return t >= DNX ? t - DNX : t; };
     auto dma_x = [&](int slot) {                                 // the next input row (xrow) of the run
-        const bool rin = (unsigned)xrow < (unsigned)H;
-        __builtin_amdgcn_global_load_lds((gptr_t)((xok && rin) ? xp : zp), (lptr_t)(smem + slot * XS_BYTES + wave * 1024), 16, 0, 0);
-        if (wave == 0) {
-            if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)((xok2 && rin) ? xp2 : zp), (lptr_t)(smem + slot * XS_BYTES + 32 * 128), 16, 0, 0);
-            xp2 += xrs;
+        const bool rin = (unsigned)xrow < (unsigned)H;           // wave-uniform
+        lptr_t l0 = (lptr_t)(smem + slot * XS_BYTES + wave * 1024), l1 = (lptr_t)(smem + slot * XS_BYTES + 32 * 128);
+        if (rin) {
+            __builtin_amdgcn_global_load_lds((gptr_t)xp, l0, 16, 0, 0);
+            if (wave == 0) {
+                if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)xp2, l1, 16, 0, 0);
+            }
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)zp, l0, 16, 0, 0);
+            if (wave == 0) {
+                if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)zp, l1, 16, 0, 0);
+            }
         }
-        xp += xrs;
+        if (wave == 0) xp2 += xst2;
+        xp += xst;
         ++xrow;
     };
     auto ys_off = [&](int r) { return DNX * XS_BYTES + (r & (DNY - 1)) * YS_BYTES; };
     auto dma_y = [&]() {                                         // the next gradient row (yrow); rows of other items (>= yb) come from the zero page
-        const bool rin = (unsigned)yrow < (unsigned)yb;
-        __builtin_amdgcn_global_load_lds((gptr_t)((yok && rin) ? yp : zp), (lptr_t)(smem + ys_off(yrow) + wave * 1024), 16, 0, 0);
-        yp += yrs;
+        const bool rin = (unsigned)yrow < (unsigned)yb;          // wave-uniform
+        lptr_t l0 = (lptr_t)(smem + ys_off(yrow) + wave * 1024);
+        if (rin) __builtin_amdgcn_global_load_lds((gptr_t)yp, l0, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)zp, l0, 16, 0, 0);
+        yp += yst;
         ++yrow;
     };
     // what step y needs beyond step y - 2 (6 requests in wave 0, 4 elsewhere): input rows y + 1, y + 2 into the slots s, s + 1; gradient rows y, y + 1
