@@ -116,7 +116,7 @@ def synthetic_batch(dev, n, t, h, w, seed, u=6, s=4):
     return inputs, targets, pos
 
 
-def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
+def lstm_kernel_roofline(net, dev, n, h, w, reps=200, warm=50):
     """Average duration of ONE ConvLSTM-cell launch (rnh_conv_wino with the LSTM epilogue in the fp32 path, rnh_conv_bf16 in the
     bf16-storage path) at the benchmark shape, by HIP events on the stream the kernels run on (torch's current stream)."""
     from hipvsr.plans import Src
@@ -132,8 +132,8 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=20):
 
     def launch():
         ops.conv(pl['full'], [Src(x), Src(hp)], n, h, w, lstm=dict(hd=hd, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
-    for _ in range(3):
-        launch()
+    for _ in range(warm):                                  # (50 launches = 16 ms: the clocks have settled; with 3 the 20 timed launches that followed came
+        launch()                                           #  out anywhere between 0.325 and 0.346 ms on the same tree - the profiler's 403-launch average is 0.325)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
