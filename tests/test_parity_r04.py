@@ -449,3 +449,27 @@ def test_cold_training_steps_repeat_bit_for_bit_beside_the_helper_stream(dtype, 
             wrong.append((r, [k for k in cur if not torch.equal(cur[k], first[k])][:4]))
         del net, tr
     assert not wrong, (len(wrong), 'of', reps, wrong[:3])
+
+
+def test_engines_of_a_process_share_their_side_streams():
+    """Two HipOps instances of one device use the SAME side streams, role by role (DESIGN.md 4d c: a second engine with streams of its own ran
+    its step 5 % slower - hardware-queue pairing), and touch_side_streams() names exactly those."""
+    from hipvsr import hip_ops as ho
+    dev = _dev()
+    a, b = ho.HipOps(dev), ho.HipOps(dev)
+    for ops in (a, b):
+        ops.fork(6, bank=0)
+        ops.join(6)
+        ops.fork(6, bank=1)
+        ops.join(6)
+        with ops.aside('up_w'):
+            pass
+        ops.rejoin()
+    assert [s.cuda_stream for s in a._banks[0]] == [s.cuda_stream for s in b._banks[0]] and len(a._banks[0]) == 3
+    assert [s.cuda_stream for s in a._banks[1]] == [s.cuda_stream for s in b._banks[1]]
+    assert a._helper.cuda_stream == b._helper.cuda_stream
+    assert len({s.cuda_stream for s in a._banks[0] + a._banks[1] + [a._helper]}) == 7          # seven distinct streams
+    ho.touch_side_streams(dev)
+    assert ho._shared_stream(dev, ('helper', 0)).cuda_stream == a._helper.cuda_stream
+    assert ho._shared_stream(dev, ('lstm', 1, 2)).cuda_stream == a._banks[1][2].cuda_stream
+    torch.cuda.synchronize()
