@@ -436,6 +436,48 @@ def test_bf16_module_vs_fp32_oracle(name, n, t, h, w):
           f'worst relative L2 error of an output {worst:.2e}, of a gradient {gw:.2e}')
 
 
+def test_bf16_bench_launch_geometry_n8_equals_replicated_n2():
+    """The bf16 twin of tests/test_hip_parity.py::test_bench_launch_geometry_n8_equals_replicated_n2 - the exact launch
+    geometry of `bench.py`'s `secondary` line and of BASELINE config 3 per GPU (N = 8, T = 7, 128x128, bf16 storage): a
+    batch made of four copies of the N = 2 batch that test_bf16_module_vs_fp32_oracle checks against the oracle.  Samples
+    are independent bit for bit (quirk Q8; every tile of a bf16 launch belongs to one image), so each of the 8 samples of
+    each of the 63 outputs equals its N = 2 twin exactly - which pins the 2048-workgroup cell launches, the 45-window refine
+    launches and the 168-image upsampler launches.  Backward: the loss is a mean over samples, so every per-sample activation
+    gradient is the N = 2 one times 1/4 - a power of two, exact in bf16 - and the parameter gradients are equal up to the
+    summation order of the fp32 accumulators, which depends on N through the weight gradients' split counts
+    (hipvsr/plans.py WgradPlan.nsplit_bf16): the fp32 contract's criterion (elementwise 1e-5 + 1e-3 |g|, L2 1e-3) holds between
+    the two bf16 runs."""
+    cfg = orc.exp1_x4_config()
+    sd = orc.init_state_dict(cfg, seed=77)
+    inputs, targets, pos = orc.synthetic_batch(cfg, 2, 7, 128, 128, seed=78)     # the batch of test_bf16_module_vs_fp32_oracle[config 2 / 3]
+    net2, _, outs2, loss2 = _module_step(dict(cfg), sd, inputs, targets, pos, 'bf16')
+    g2 = {k: p.grad.detach().cpu().clone() for k, p in net2.named_parameters() if p.grad is not None}
+    o2 = [[o.detach().clone() for o in grp] for grp in outs2]
+    del net2, outs2
+    rep = lambda t: torch.cat([t] * 4, 0)                                   # noqa: E731
+    net8, _, outs8, loss8 = _module_step(dict(cfg), sd, [rep(x) for x in inputs], [rep(t) for t in targets], rep(pos), 'bf16')
+    assert net8._engine().bf16
+    assert len(outs8) == 9 and all(len(grp) == 7 for grp in outs8)
+    for ga, gb in zip(outs8, o2):
+        for a, b in zip(ga, gb):
+            assert tuple(a.shape) == (8, 1, 512, 512)
+            for q in range(4):
+                assert torch.equal(a[2 * q:2 * q + 2], b), q
+    assert abs(float(loss8) - float(loss2)) <= 1e-6 * abs(float(loss2))
+    worst = 0.0
+    for k, p in net8.named_parameters():
+        if k not in g2:
+            assert p.grad is None, k
+            continue
+        a, b = p.grad.detach().cpu().double(), g2[k].double()
+        d = (a - b).abs()
+        assert float((d - (1e-5 + 1e-3 * b.abs())).max()) <= 0, (k, float(d.max()), float(b.abs().max()))
+        rel = float(d.norm()) / float(b.norm())
+        worst = max(worst, rel)
+        assert rel <= 1e-3, (k, rel)
+    print(f'bf16 N=8 bench geometry: 63 outputs bit-identical per sample to the N=2 run; worst relative L2 difference of a gradient {worst:.2e}')
+
+
 G1_CASES = [f'x{s}_pos{p}_mem{m}' for s in (2, 3, 4) for p in (1, 0) for m in (1, 0)] + ['x8_pos1_mem1']
 
 
