@@ -117,16 +117,36 @@ __device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
 // Diagnostic ablations (tools/bf16_ablate.sh; never defined in the product build): -DRNH_EXP=<mask> removes one cost of the main
 // loop at a time - results are WRONG, only the launch time is of interest.  1: weight fragments loaded once, 2: halo fragments read
 // once per chunk, 4: no halo staging after the prologue, 8: no barrier in the loop, 16: epilogue skipped; 32 / 64 / 128 keep the
-// results: column-tile-major block order, second workgroup of a CU delayed by ~6 / ~12 us
+// results: column-tile-major block order, second workgroup of a CU delayed by ~6 / ~12 us; 256: one workgroup per CU (LDS padded)
 #ifndef RNH_EXP
 #define RNH_EXP 0
+#endif
+
+// (experiment, tools/experiments/r05_prio.sh: s_setprio RNH_PRIO for the main loop, RNH_PRIO_EPI for the epilogue - every combination of
+// 0..3 measured within noise of no s_setprio at all, profiles/r05_d_setprio.txt; the product build issues none)
+#if defined(RNH_PRIO) || defined(RNH_PRIO_EPI)
+#ifndef RNH_PRIO
+#define RNH_PRIO 0
+#endif
+#ifndef RNH_PRIO_EPI
+#define RNH_PRIO_EPI 0
+#endif
+#define RNH_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define RNH_SETPRIO(x)
 #endif
 
 #ifdef RNH_STAMPS
 __device__ unsigned long long g_bf16_stamps[64];
 #define BSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_bf16_stamps[i] = __builtin_readcyclecounter(); } while (0)
+// per-workgroup trace (tools/bf16_wgtrace.py): wall clock (100 MHz) and shader cycles at the start / park / end of every workgroup, and where it ran
+__device__ unsigned long long g_bf16_wgtrace[8 * 4096];
+#define WGTRACE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_bf16_wgtrace[8 * blockIdx.x + 2 * (slot)] = __builtin_amdgcn_s_memrealtime(); \
+        g_bf16_wgtrace[8 * blockIdx.x + 2 * (slot) + 1] = __builtin_amdgcn_s_memtime(); \
+        if ((slot) == 0) g_bf16_wgtrace[8 * blockIdx.x + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); } } while (0)
 #else
 #define BSTAMP(i)
+#define WGTRACE(slot)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -154,10 +174,11 @@ struct GeoD {
     static constexpr int PPP = 2 * KS;                          // 16-byte pieces per halo pixel
     static constexpr int A_BYTES = HP * APITCH, A_PIECES = PPP * HP, A_ITERS = (A_PIECES + 255) / 256;
     static constexpr int OPITCH = NCOLS + 4;                    // floats per parked pixel
-    static constexpr int PXR = NCOLS == 128 ? 128 : 256;        // pixels parked per epilogue round
-    static constexpr int OUT_BYTES = PXR * OPITCH * 4;
-    static constexpr int SMEM = 2 * A_BYTES > OUT_BYTES ? 2 * A_BYTES : OUT_BYTES;
-    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
+    static constexpr int PXR = 2 * TW;                          // pixels parked per epilogue round: one 32-pixel row block of each pixel half
+    static constexpr int OUT_BYTES = 2 * PXR * OPITCH * 4;      // two park images
+    static constexpr int SMEM0 = 2 * A_BYTES > OUT_BYTES ? 2 * A_BYTES : OUT_BYTES;
+    static constexpr int SMEM = (RNH_EXP & 256) ? 100 * 1024 : SMEM0;      // (experiment 256: ONE workgroup per CU)
+    static_assert(2 * SMEM0 <= 160 * 1024, "two workgroups per CU");
 };
 
 template <int EPI, int NCOLS, int NTAPS, int KC = 16>
@@ -294,6 +315,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
 
     // ---- K loop: double-buffered halo, one barrier per chunk ------------------------------------------------------------
     BSTAMP(0);
+    WGTRACE(0);
+    RNH_SETPRIO(RNH_PRIO);
     bload(0, 0, 0);
     if constexpr (NTAPS == 9) {
 #pragma unroll
@@ -310,7 +333,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         BSTAMP(10 + 3 * (c & 15));
         if (!(RNH_EXP & 8)) __syncthreads();
     }
+    RNH_SETPRIO(RNH_PRIO_EPI);
     BSTAMP(1);
+    WGTRACE(1);
     if (RNH_EXP & 16) {                                         // keep the accumulators alive, skip the epilogue
         float s = 0.f;
 #pragma unroll
@@ -323,106 +348,132 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         return;
     }
 
-    // ---- epilogue: the accumulators (+ bias) are parked as an fp32 [pixel][column] tile, PXR pixels at a time (128-column
-    // tiles: the two pixel halves in turn, parked by the two waves that own them; 64-column tiles: all 256 at once), and
-    // all 256 threads finish 8 columns of a pixel per step with whole-row 16-byte accesses ------------------------------
-    float *ot = reinterpret_cast<float *>(smem);
-    constexpr int PXR = G::PXR, ROUNDS = TH * TW / PXR;
-    // ConvLSTM: the previous cell state of ALL the thread's items (ROUNDS x PXR / 64 pixels x 8 channels, fp32) is requested
-    // here, before the accumulators are parked, as unconditional asm loads from clamped (always valid) addresses; left to
-    // hipcc each load sat right in front of its use, one exposed memory round trip per item - 10 k of the 16 k cycles of the
-    // finishing phase (tools/bf16_stamps.py).  No previous state: any valid address, zeros behind the wait.
-    constexpr int NIT = EPI == RNH_EPI_LSTM ? ROUNDS * (PXR / 64) : 1;
+    // ---- epilogue (round 5 form): MB = 4 rounds, one accumulator row block of EVERY wave per round.  Round r parks tile rows r and
+    // 4 + r (64 pixels x NCOLS columns, + bias) as an fp32 [pixel][column] image, then all 256 threads finish 8 columns of a pixel
+    // per item with whole-row 16-byte accesses.  Two such images: the block of round r + 1 is parked BEFORE the items of round r
+    // are read, so a round costs one barrier, every wave parks and finishes the same amount in every round, and a wave's LDS
+    // writes run beside its LDS reads.  (Until round 4: two rounds of 128 pixels, parked by the two waves that own that pixel half
+    // while the other two waited at the barrier, two barriers per round - per-workgroup traces, tools/bf16_wgtrace.py, showed the
+    // finishing phase at 38 % of a workgroup's lifetime; the values parked and the arithmetic of an item are unchanged, so are
+    // the results, bit for bit.)
+    float *const ot0 = reinterpret_cast<float *>(smem);
+    constexpr int PXR = G::PXR, ROUNDS = MB, OBUF = PXR * G::OPITCH;
+    static_assert(PXR == 2 * TW && TH == 2 * MB, "a round = one row block of the two pixel halves");
+    // ConvLSTM: the previous cell state of ALL the thread's items (one per round: 8 channels, fp32) is requested here, before the
+    // accumulators are parked, as unconditional asm loads from clamped (always valid) addresses; left to hipcc each load sat
+    // right in front of its use, one exposed memory round trip per item (tools/bf16_stamps.py, round 3).  No previous state: any
+    // valid address, zeros behind the wait.
+    constexpr int NIT = EPI == RNH_EPI_LSTM ? ROUNDS : 1;
     typedef float f32x4q __attribute__((ext_vector_type(4)));       // (a plain vector type: HIP's float4 struct would be passed to the asm through memory)
     [[maybe_unused]] f32x4q cpq[NIT][2];
     if constexpr (EPI == RNH_EPI_LSTM) {
         const int hd = P.hd, hcl = min(nt * 32 + (tid & 3) * 8, hd - 8);
         const float *csrc = P.c_prev ? P.c_prev : P.c_out;
+        const int px = tid >> 2;
 #pragma unroll
         for (int q = 0; q < NIT; ++q) {
-            const int r = q / (PXR / 64), px = (tid >> 2) + 64 * (q % (PXR / 64));
-            const int y = min(y0 + r * (PXR / TW) + px / TW, H - 1), x = min(x0 + (px & (TW - 1)), W - 1);
+            const int y = min(y0 + (px >> 5) * MB + q, H - 1), x = min(x0 + (px & (TW - 1)), W - 1);
             const float *p = csrc + (((long)img * H + y) * W + x) * hd + hcl;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cpq[q][0]) : "v"(p) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cpq[q][1]) : "v"(p) : "memory");
         }
     }
+    float bv[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bv[n] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31] : 0.f;
+    auto park = [&](int m, float *ob) {                             // row block m of this wave -> pixels 32 ph .. 32 ph + 31 of the image
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = chalf * (NCOLS / 2) + n * 32 + l31;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ob[(ph * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc[m][n][v] + bv[n];
+        }
+    };
+    park(0, ot0);
+    __syncthreads();
+    BSTAMP(2);
+    if constexpr (EPI == RNH_EPI_LSTM) {
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpq[q][0]), "+v"(cpq[q][1]));
+    }
+
+    // per-thread constants of the items (the same in every round)
+    [[maybe_unused]] bool live = false;
+    [[maybe_unused]] void *dptr = nullptr;
+    [[maybe_unused]] int ddt = 0, dacc = 0, ps_r = 1, ps_i = 0, ps_j = 0;
+    [[maybe_unused]] long dimg = 0, dch = 0, dC = 0;                 // element = ((img' * H + y) * W' + x') * dC + dch with the strides below
+    constexpr int G8 = NCOLS / 8;
+    if constexpr (EPI == RNH_EPI_PS) {
+        const int n0 = nt * NCOLS + (tid % G8) * 8, rr = P.ps_r, cq = P.ps_cq;
+        live = n0 < cq * rr * rr;
+        const int sub = n0 / cq;
+        ps_r = rr, ps_i = sub / rr, ps_j = sub - (sub / rr) * rr;
+        dptr = P.dst[0].ptr, ddt = P.dst[0].dtype, dC = cq, dch = n0 - sub * cq, dimg = img;
+    } else if constexpr (EPI == RNH_EPI_STORE) {
+        const int n0 = nt * NCOLS + (tid % G8) * 8;
+        int seg = -1, cbase = 0;
+        for (int d = 0; d < P.ndst; ++d) {
+            if (seg < 0 && n0 < cbase + P.dst[d].ncols) seg = d;
+            if (seg < 0) cbase += P.dst[d].ncols;
+        }
+        live = seg >= 0;
+        const rnh_mdst_t &D = P.dst[live ? seg : 0];
+        dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
+    }
+
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        if (r > 0) __syncthreads();                             // the previous round has been read
-        if (ROUNDS == 1 || ph == r) {
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const int col = chalf * (NCOLS / 2) + n * 32 + l31;
-                const float bv = P.bias ? P.bias[nt * NCOLS + col] : 0.f;
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int px = (ROUNDS == 1 ? MB * ph + m : m) * TW + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                        ot[px * G::OPITCH + col] = acc[m][n][v] + bv;
-                    }
-            }
-        }
-        __syncthreads();
-        if (r == 0) BSTAMP(2);
+        const float *ot = ot0 + (r & 1) * OBUF;
+        BSTAMP(40 + 4 * r);
+        if (r + 1 < ROUNDS) park(r + 1, ot0 + ((r + 1) & 1) * OBUF);   // (its image was last read in round r - 1, in front of the last barrier)
+        BSTAMP(41 + 4 * r);
+        // pixel p of the image = tile row (p >> 5) * MB + r, column p & 31
         if constexpr (EPI == RNH_EPI_LSTM) {
-            if (r == 0) {
-#pragma unroll
-                for (int q = 0; q < NIT; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cpq[q][0]), "+v"(cpq[q][1]));
-            }
-        }
-        const int ybase = y0 + r * (PXR / TW);
-        if constexpr (EPI == RNH_EPI_LSTM) {
-            // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap).  A thread's 8 channels
-            // are the same in every step (256 % 4 == 0): everything but the pixel is hoisted out of the loop
+            // column = gate * 32 + j of the tile's 32 hidden channels nt * 32 + j (plans.lstm_colmap).  One item per thread and round:
+            // pixel tid >> 2, channels 8 (tid & 3) ..
             const int hd = P.hd, j0 = (tid & 3) * 8, hc = nt * 32 + j0;
             const float *cprev = P.c_prev;
             float *cout = P.c_out;
             void *hout = P.h_out, *gout = P.gates_out;
             const int hdt = P.h_dtype, gdt = P.gates_dtype;
-            if (hc < hd) {
+            const int px = tid >> 2;
+            const int y = y0 + (px >> 5) * MB + r, x = x0 + (px & (TW - 1));
+            if (hc < hd && y < H && x < W) {
+                const float *o = ot + px * G::OPITCH + j0;
+                const long pe = ((long)img * H + y) * W + x;
+                float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
+                const f32x4q ca = cpq[r][0], cb = cpq[r][1];
+                cp[0] = ca.x; cp[1] = ca.y; cp[2] = ca.z; cp[3] = ca.w; cp[4] = cb.x; cp[5] = cb.y; cp[6] = cb.z; cp[7] = cb.w;
+                if (!cprev) {
 #pragma unroll
-                for (int k = 0; k < PXR / 64; ++k) {
-                    const int px = (tid >> 2) + 64 * k;
-                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
-                    if (y >= H || x >= W) continue;
-                    const float *o = ot + px * G::OPITCH + j0;
-                    const long pe = ((long)img * H + y) * W + x;
-                    float cp[8], cn[8], hn[8], gi[8], gf[8], go[8], gg[8];
-                    const f32x4q ca = cpq[r * (PXR / 64) + k][0], cb = cpq[r * (PXR / 64) + k][1];
-                    cp[0] = ca.x; cp[1] = ca.y; cp[2] = ca.z; cp[3] = ca.w; cp[4] = cb.x; cp[5] = cb.y; cp[6] = cb.z; cp[7] = cb.w;
-                    if (!cprev) {
+                    for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+                }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        gi[e] = b_sigmoid(o[e]);
-                        gf[e] = b_sigmoid(o[32 + e]);
-                        go[e] = b_sigmoid(o[64 + e]);
-                        gg[e] = b_tanh_fast(o[96 + e]);
-                        cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-                        hn[e] = go[e] * b_tanh_fast(cn[e]);
-                    }
-                    store8(cout, RNH_DT_F32, pe * hd + hc, cn);
-                    store8(hout, hdt, pe * hd + hc, hn);
-                    if (gout) {
-                        store8(gout, gdt, pe * 4 * hd + hc, gi);
-                        store8(gout, gdt, pe * 4 * hd + hd + hc, gf);
-                        store8(gout, gdt, pe * 4 * hd + 2 * hd + hc, go);
-                        store8(gout, gdt, pe * 4 * hd + 3 * hd + hc, gg);
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    gi[e] = b_sigmoid(o[e]);
+                    gf[e] = b_sigmoid(o[32 + e]);
+                    go[e] = b_sigmoid(o[64 + e]);
+                    gg[e] = b_tanh_fast(o[96 + e]);
+                    cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+                    hn[e] = go[e] * b_tanh_fast(cn[e]);
+                }
+                store8(cout, RNH_DT_F32, pe * hd + hc, cn);
+                store8(hout, hdt, pe * hd + hc, hn);
+                if (gout) {
+                    store8(gout, gdt, pe * 4 * hd + hc, gi);
+                    store8(gout, gdt, pe * 4 * hd + hd + hc, gf);
+                    store8(gout, gdt, pe * 4 * hd + 2 * hd + hc, go);
+                    store8(gout, gdt, pe * 4 * hd + 3 * hd + hc, gg);
                 }
             }
         } else if constexpr (EPI == RNH_EPI_LSTM_BWD) {
             // Data gradient of a ConvLSTM cell + gate backward of the frame its chain processes next (include/refinenet_hip.h).  The parked
-            // tile holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
+            // image holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
             const rnh_mdst_t &D = P.dst[0];
             const int ncx = D.ncols, ncx8 = ncx >> 3, hd = P.hd, hd8 = hd >> 3;
             for (int it = tid; it < PXR * ncx8; it += 256) {        // items (pixel, 8 columns of the input gradient)
                 const int px = it / ncx8, c8 = it - px * ncx8;
-                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                const int y = y0 + (px >> 5) * MB + r, x = x0 + (px & (TW - 1));
                 if (y >= H || x >= W) continue;
                 const float *o = ot + px * G::OPITCH + c8 * 8;
                 float f[8];
@@ -446,7 +497,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             const int hdt = P.bw_dh_dtype, gdt = P.gates_dtype, dgdt = P.bw_dgates_dtype, rdt = P.bw_rec_dtype;
             for (int it = tid; it < PXR * hd8; it += 256) {
                 const int px = it / hd8, g = it - px * hd8;
-                const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                const int y = y0 + (px >> 5) * MB + r, x = x0 + (px & (TW - 1));
                 if (y >= H || x >= W) continue;
                 const long p = ((long)img * H + y) * W + x;
                 const long o = p * hd + g * 8, og = p * 4 * hd + g * 8;
@@ -485,34 +536,12 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 if (dcprev) store8(dcprev, RNH_DT_F32, o, dcp);
             }
         } else {
-            // a thread's 8 columns are the same in every step (256 % G8 == 0): destination segment / sub-pixel once per thread
-            constexpr int G8 = NCOLS / 8;
-            const int c8 = tid % G8, n0 = nt * NCOLS + c8 * 8;
-            bool live;
-            void *dptr;
-            int ddt, dacc = 0;
-            long dimg = 0, dpix = 0, dch = 0, dC = 0;                // element = ((img' * H + y) * W' + x') * dC + dch with the strides below
-            int ps_r = 1, ps_i = 0, ps_j = 0;
-            if constexpr (EPI == RNH_EPI_PS) {
-                const int rr = P.ps_r, cq = P.ps_cq;
-                live = n0 < cq * rr * rr;
-                const int sub = n0 / cq;
-                ps_r = rr, ps_i = sub / rr, ps_j = sub - (sub / rr) * rr;
-                dptr = P.dst[0].ptr, ddt = P.dst[0].dtype, dC = cq, dch = n0 - sub * cq, dimg = img;
-            } else {
-                int seg = -1, cbase = 0;
-                for (int d = 0; d < P.ndst; ++d) {
-                    if (seg < 0 && n0 < cbase + P.dst[d].ncols) seg = d;
-                    if (seg < 0) cbase += P.dst[d].ncols;
-                }
-                live = seg >= 0;
-                const rnh_mdst_t &D = P.dst[live ? seg : 0];
-                dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
-            }
-            (void)dpix;
+            // a thread's 8 columns are the same in every item (256 % G8 == 0): destination segment / sub-pixel found once, above
             if (live) {
+                const int c8 = tid % G8;
+#pragma unroll
                 for (int px = tid / G8; px < PXR; px += 256 / G8) {
-                    const int y = ybase + px / TW, x = x0 + (px & (TW - 1));
+                    const int y = y0 + (px >> 5) * MB + r, x = x0 + (px & (TW - 1));
                     if (y >= H || x >= W) continue;
                     const float *o = ot + px * G::OPITCH + c8 * 8;
                     float f[8];
@@ -529,8 +558,12 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 }
             }
         }
+        BSTAMP(42 + 4 * r);
+        if (r + 1 < ROUNDS) __syncthreads();                        // image (r + 1) & 1 is written, image r & 1 is read
+        BSTAMP(43 + 4 * r);
     }
     BSTAMP(3);
+    WGTRACE(2);
 }
 
 inline int bgrid_for(long n, int cap = 8192) {
@@ -555,6 +588,9 @@ int rnh_check_msrc(const rnh_msrc_t &s, const char *who) { return check_msrc(s, 
 #ifdef RNH_STAMPS
 extern "C" int rnh_debug_bf16_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_stamps), sizeof(g_bf16_stamps));
+}
+extern "C" int rnh_debug_bf16_wgtrace(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bf16_wgtrace), sizeof(g_bf16_wgtrace));
 }
 #endif
 

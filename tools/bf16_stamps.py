@@ -6,7 +6,7 @@ PKG = os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-c
 sys.path[:0] = [ROOT, PKG]
 import torch
 from hipvsr import lib as L
-L.LIB_PATH = os.path.join(PKG, 'hipvsr', 'lib_stamps.so')
+L.LIB_PATH = os.environ.get('RNH_LIB', os.path.join(PKG, 'hipvsr', 'lib_stamps.so'))
 from hipvsr.hip_ops import HipOps
 from hipvsr.plans import Dst, NetPlans, Src
 from hipvsr.spec import NetConfig, state_dict_spec
@@ -42,3 +42,5 @@ for c in range(min(nch, 16)):
     a, b, d = z[8 + 3 * c], z[9 + 3 * c], z[10 + 3 * c]
     nxt = z[8 + 3 * (c + 1)] if c + 1 < nch else z[1]
     print(f'  chunk {c}: phase A {b - a:6d}  phase B {d - b:6d}  phase C {nxt - d:6d}   (variant D: compute / store / barrier; variant L: store+barrier / compute / barrier)')
+print('epilogue rounds (park next / items / barrier):', [(z[41 + 4 * r] - z[40 + 4 * r], z[42 + 4 * r] - z[41 + 4 * r], z[43 + 4 * r] - z[42 + 4 * r]) for r in range(4)],
+      'first park + barrier + c_prev wait:', z[40] - z[1])
