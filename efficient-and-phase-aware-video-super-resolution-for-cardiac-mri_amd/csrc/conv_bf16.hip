@@ -117,7 +117,7 @@ __device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
 // Diagnostic ablations (tools/bf16_ablate.sh; never defined in the product build): -DRNH_EXP=<mask> removes one cost of the main
 // loop at a time - results are WRONG, only the launch time is of interest.  1: weight fragments loaded once, 2: halo fragments read
 // once per chunk, 4: no halo staging after the prologue, 8: no barrier in the loop, 16: epilogue skipped; 32 / 64 / 128 keep the
-// results: column-tile-major block order, second workgroup of a CU delayed by ~6 / ~12 us; 256: one workgroup per CU (LDS padded)
+// results: column-tile-major block order, second workgroup of a CU delayed by ~6 / ~12 us; 256: one workgroup per CU (LDS padded); 512: the generic item loop of the LSTM-backward epilogue instead of the prefetching one
 #ifndef RNH_EXP
 #define RNH_EXP 0
 #endif
@@ -378,6 +378,43 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cpq[q][1]) : "v"(p) : "memory");
         }
     }
+    // ConvLSTM backward, the shape the bf16 engine launches (hd = 64 hidden channels, 64 input-gradient columns, bf16 dh / gates): a thread has
+    // exactly two gate items per round - pixels (tid >> 3) and (tid >> 3) + 32 of the image, channels 8 (tid & 7) .. - and their eleven 16-byte
+    // operands (dh, dc_next, c_prev, c_next, the four gates) are requested a ROUND AHEAD as unconditional asm loads from clamped addresses, like
+    // the forward cell's previous state above: in the generic loop below every item issued its loads right in front of their use, eleven
+    // exposed round trips per item with two waves per SIMD to hide them (125 us per launch at config 2's size against 78 + 60 for the two
+    // separate launches that move 20 % more bytes).  Values and arithmetic are those of the generic loop, bit for bit.
+    typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+    struct BwItem { u32x4q dh, g[4]; f32x4q dc[2], cp[2], cn[2]; };
+    [[maybe_unused]] BwItem bwq[EPI == RNH_EPI_LSTM_BWD ? 2 : 1];
+    [[maybe_unused]] bool bw_fast = false;
+    [[maybe_unused]] auto bw_issue = [&](int r) {
+        const int g = tid & 7;
+        const char *dhp = reinterpret_cast<const char *>(P.bw_dh), *gp = reinterpret_cast<const char *>(P.bw_gates);
+        const float *cnext = P.bw_c_next, *dcn = P.bw_dc_next ? P.bw_dc_next : cnext, *cprev = P.bw_c_prev ? P.bw_c_prev : cnext;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int y = min(y0 + k * MB + r, H - 1), x = min(x0 + ((tid >> 3) & (TW - 1)), W - 1);
+            const long p = ((long)img * H + y) * W + x;
+            const long o = p * 64 + g * 8, og = p * 256 + g * 8;
+            const char *a_dh = dhp + o * 2, *a_g = gp + og * 2;
+            const float *a_dc = dcn + o, *a_cp = cprev + o, *a_cn = cnext + o;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bwq[k].dh) : "v"(a_dh) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bwq[k].dc[0]) : "v"(a_dc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bwq[k].dc[1]) : "v"(a_dc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bwq[k].cp[0]) : "v"(a_cp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bwq[k].cp[1]) : "v"(a_cp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bwq[k].cn[0]) : "v"(a_cn) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bwq[k].cn[1]) : "v"(a_cn) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bwq[k].g[0]) : "v"(a_g) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(bwq[k].g[1]) : "v"(a_g) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(bwq[k].g[2]) : "v"(a_g) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:384" : "=v"(bwq[k].g[3]) : "v"(a_g) : "memory");
+        }
+    };
+    if constexpr (EPI == RNH_EPI_LSTM_BWD) {
+        bw_fast = NCOLS == 128 && P.hd == 64 && P.dst[0].ncols == 64 && P.bw_dh_dtype == RNH_DT_BF16 && P.gates_dtype == RNH_DT_BF16 && !(RNH_EXP & 512);
+    }
     float bv[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) bv[n] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31] : 0.f;
@@ -390,6 +427,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         }
     };
     park(0, ot0);
+    if constexpr (EPI == RNH_EPI_LSTM_BWD) {                        // (behind the first park: 32 accumulator registers fewer are live beside the 88 of the operands)
+        if (bw_fast) bw_issue(0);
+    }
     __syncthreads();
     BSTAMP(2);
     if constexpr (EPI == RNH_EPI_LSTM) {
@@ -471,6 +511,84 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             // image holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
             const rnh_mdst_t &D = P.dst[0];
             const int ncx = D.ncols, ncx8 = ncx >> 3, hd = P.hd, hd8 = hd >> 3;
+            if (bw_fast) {
+                // the gate items of this round from the operands requested a round ago (bw_issue), then the requests of the next round, then the
+                // input-gradient items
+                const float *dcn = P.bw_dc_next, *cprev = P.bw_c_prev;
+                void *dgp = P.bw_dgates;
+                float *dcprev = P.bw_dc_prev;
+                const int dgdt = P.bw_dgates_dtype, rdt = P.bw_rec_dtype;
+                constexpr int gdt = RNH_DT_BF16;                    // (bw_fast)
+                const int g = tid & 7;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(bwq[k].dh), "+v"(bwq[k].g[0]), "+v"(bwq[k].g[1]), "+v"(bwq[k].g[2]), "+v"(bwq[k].g[3]), "+v"(bwq[k].dc[0]), "+v"(bwq[k].dc[1]),
+                                   "+v"(bwq[k].cp[0]), "+v"(bwq[k].cp[1]), "+v"(bwq[k].cn[0]), "+v"(bwq[k].cn[1]));
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int px = (tid >> 3) + 32 * k;
+                    const int y = y0 + k * MB + r, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const long p = ((long)img * H + y) * W + x;
+                    const long o = p * 64 + g * 8, og = p * 256 + g * 8;
+                    float vdh[8], vdc[8], vcp[8], vcn[8], gi[8], gf[8], go[8], gg[8];
+                    unpack8(__builtin_bit_cast(uint4, bwq[k].dh), vdh);
+                    unpack8(__builtin_bit_cast(uint4, bwq[k].g[0]), gi);
+                    unpack8(__builtin_bit_cast(uint4, bwq[k].g[1]), gf);
+                    unpack8(__builtin_bit_cast(uint4, bwq[k].g[2]), go);
+                    unpack8(__builtin_bit_cast(uint4, bwq[k].g[3]), gg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vdc[e] = bwq[k].dc[0][e], vdc[4 + e] = bwq[k].dc[1][e];
+                        vcp[e] = bwq[k].cp[0][e], vcp[4 + e] = bwq[k].cp[1][e];
+                        vcn[e] = bwq[k].cn[0][e], vcn[4 + e] = bwq[k].cn[1][e];
+                    }
+                    const float *rec = ot + px * G::OPITCH + ncx + g * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = rec[e];
+                        if (rdt == RNH_DT_BF16) t = (float)(__bf16)t;
+                        vdh[e] += t;
+                    }
+                    float di[8], df[8], dgo[8], dg[8], dcp[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float th = gdt == RNH_DT_BF16 ? b_tanh_fast(vcn[e]) : tanhf(vcn[e]);   // (as the forward cell's h' = o tanh(c'); gates_bwd_m_kernel alike)
+                        const float d_o = vdh[e] * th;
+                        const float dct = (dcn ? vdc[e] : 0.f) + vdh[e] * go[e] * (1.f - th * th);
+                        di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+                        df[e] = dct * (cprev ? vcp[e] : 0.f) * gf[e] * (1.f - gf[e]);
+                        dgo[e] = d_o * go[e] * (1.f - go[e]);
+                        dg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+                        dcp[e] = dct * gf[e];
+                    }
+                    store8(dgp, dgdt, og, di);
+                    store8(dgp, dgdt, og + 64, df);
+                    store8(dgp, dgdt, og + 128, dgo);
+                    store8(dgp, dgdt, og + 192, dg);
+                    if (dcprev) store8(dcprev, RNH_DT_F32, o, dcp);
+                }
+                if (r + 1 < ROUNDS) bw_issue(r + 1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {                       // items (pixel, 8 columns of the input gradient): the same pixels and column groups
+                    const int px = (tid >> 3) + 32 * k;
+                    const int y = y0 + k * MB + r, x = x0 + (px & (TW - 1));
+                    if (y >= H || x >= W) continue;
+                    const float *o = ot + px * G::OPITCH + g * 8;
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = o[e];
+                    const long e = ((((long)img + D.img_off) * H + y) * W + x) * D.C + D.c0 + g * 8;
+                    if (D.accumulate) {
+                        float old[8];
+                        load8(D.ptr, D.dtype, e, old);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] += old[q];
+                    }
+                    store8(D.ptr, D.dtype, e, f);
+                }
+            } else {
             for (int it = tid; it < PXR * ncx8; it += 256) {        // items (pixel, 8 columns of the input gradient)
                 const int px = it / ncx8, c8 = it - px * ncx8;
                 const int y = y0 + (px >> 5) * MB + r, x = x0 + (px & (TW - 1));
@@ -520,7 +638,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 float di[8], df[8], dgo[8], dg[8], dcp[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float th = tanhf(vcn[e]);
+                    const float th = gdt == RNH_DT_BF16 ? b_tanh_fast(vcn[e]) : tanhf(vcn[e]);   // (as the forward cell's h' = o tanh(c'); gates_bwd_m_kernel alike)
                     const float d_o = vdh[e] * th;
                     const float dct = (dcn ? vdc[e] : 0.f) + vdh[e] * go[e] * (1.f - th * th);
                     di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
@@ -534,6 +652,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 store8(dgp, dgdt, og + 2 * hd, dgo);
                 store8(dgp, dgdt, og + 3 * hd, dg);
                 if (dcprev) store8(dcprev, RNH_DT_F32, o, dcp);
+            }
             }
         } else {
             // a thread's 8 columns are the same in every item (256 % G8 == 0): destination segment / sub-pixel found once, above

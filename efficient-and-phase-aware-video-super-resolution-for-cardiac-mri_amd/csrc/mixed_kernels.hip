@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(256) gates_bwd_m_kernel(const void *dh, int hd
         float di[8], df[8], dgo[8], dg[8], dcp[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float th = tanhf(vcn[e]);
+            // bf16 gates = the bf16-storage path, whose forward cell computed h' = o tanh(c') with this form of tanh (conv_bf16.hip b_tanh_fast:
+            // one exp, one rcp, absolute error <= 2 ulp of 1); the fused epilogue of conv_bf16d_kernel<LSTM_BWD> computes the same expression
+            const float th = gdt == RNH_DT_BF16 ? __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * vcn[e])), -1.f) : tanhf(vcn[e]);
             const float d_o = vdh[e] * th;
             const float dct = (dcn ? vdc[e] : 0.f) + vdh[e] * go[e] * (1.f - th * th);
             di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
