@@ -121,6 +121,14 @@ __device__ __forceinline__ uint4 bld16(__amdgpu_buffer_rsrc_t r, int voff) {
 #ifndef RNH_EXP
 #define RNH_EXP 0
 #endif
+// RNH_M16 = 1 builds the 32-channel-chunk kernels on v_mfma_f32_16x16x32_bf16 with the halo brought in by LDS-DMA (the "M16" blocks below).
+// Measured in round 5 and NOT the product build: a bare loop of that MFMA shape sustains 2.07 PFLOP/s against 1.86 for 32x32x16 on this board
+// (tools/probes/mfma_bf16_shapes2.hip, profiles/r05_f_*: the chip holds 2.1 instead of 1.87 GHz under it), but inside this kernel the two forms
+// are equal - ConvLSTM cell 78.4-78.9 against 79.1-80.5 us, bf16 step 80.78 against 80.71 ms, the fused backward launch 5 % slower (profiles/r05_i_*,
+// r05_j_*): the launch is not bound by its main loop's matrix instructions.  Kept as an A/B build (124 bf16 tests green with it).
+#ifndef RNH_M16
+#define RNH_M16 0
+#endif
 
 // (experiment, tools/experiments/r05_prio.sh: s_setprio RNH_PRIO for the main loop, RNH_PRIO_EPI for the epilogue - every combination of
 // 0..3 measured within noise of no s_setprio at all, profiles/r05_d_setprio.txt; the product build issues none)
@@ -172,7 +180,17 @@ struct GeoD {
     static constexpr int KS = KC / 16;                          // MFMA k steps per tap
     static constexpr int APITCH = KC == 32 ? 80 : PITCH;        // bytes per halo pixel: data + 16 B pad (fragment reads conflict-free for both)
     static constexpr int PPP = 2 * KS;                          // 16-byte pieces per halo pixel
-    static constexpr int A_BYTES = HP * APITCH, A_PIECES = PPP * HP, A_ITERS = (A_PIECES + 255) / 256;
+    // KC == 32 (round 5): v_mfma_f32_16x16x32_bf16 - a lane supplies 8 channels of one of 16 pixels, the four 8-channel groups of the chunk sit in
+    // four lane groups.  The halo is stored as four PLANES [channel group][pixel][16 bytes] (plane stride a multiple of 256 bytes): the 16 lanes
+    // that a ds_read_b128 serves per LDS cycle (MI355X_MICROARCH.md, LDS table: {0-3, 12-15, 20-27}, ...) are 8 pixels of one plane and the 8
+    // pixels between them of the next plane = 16 different 16-byte bank groups.  (Pixel-major with any pitch cannot be conflict-free for this
+    // access: the second plane's slots would have to be the first's shifted by one.)  A plane is 64 consecutive pixels per wave-instruction of
+    // an LDS-DMA load (buffer_load_dwordx4 ... lds: LDS address = M0 + 16 lane), so the halo goes from memory to LDS without staging registers
+    // or ds_write: wave w fills plane w of the chunk, six instructions (tools/probes/lds_dma_oob.hip: lanes with an out-of-range offset write
+    // zeros - the zero padding and the 44 slots behind the 340 pixels cost no branch)
+    static constexpr bool M16 = KC == 32 && RNH_M16;
+    static constexpr int PLANE = (HP + 63) / 64 * 1024;          // whole LDS-DMA wave-instructions (64 slots of 16 bytes); a multiple of 256 bytes
+    static constexpr int A_BYTES = M16 ? 4 * PLANE : HP * APITCH, A_PIECES = PPP * HP, A_ITERS = (A_PIECES + 255) / 256;
     static constexpr int OPITCH = NCOLS + 4;                    // floats per parked pixel
     static constexpr int PXR = 2 * TW;                          // pixels parked per epilogue round: one 32-pixel row block of each pixel half
     static constexpr int OUT_BYTES = 2 * PXR * OPITCH * 4;      // two park images
@@ -186,11 +204,14 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     using G = GeoD<NCOLS, KC>;
     constexpr int TH = G::TH, NB = G::NB, MB = G::MB, A_BYTES = G::A_BYTES, A_PIECES = G::A_PIECES, A_ITERS = G::A_ITERS;
     constexpr int KS = G::KS, APITCH = G::APITCH, PPP = G::PPP;
+    constexpr bool M16 = G::M16;
+    constexpr int PLANE = G::PLANE, NB16 = NCOLS / 32;               // 16-column blocks of a wave (its NCOLS / 2 columns)
     static_assert(NTAPS % 3 == 0 || NTAPS == 1, "the fragment ring has three sets");
     static_assert(KC == 16 || (KC == 32 && NTAPS == 9), "32-channel chunks serve the 3x3 kernels");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
+    [[maybe_unused]] const int l15 = lane & 15, kg = lane >> 4;
     const int ph = wave & 1, chalf = wave >> 1;
     const int bid = rnh_xcd_remap(blockIdx.x, P.B * TYn * TXn * NT);
     // (RNH_EXP & 32, experiment: column-tile-major block order - the workgroups that run together stream the SAME weight fragments)
@@ -203,18 +224,33 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const int H = P.H, W = P.W;
     const int sc = P.src[0].scale, Hs = H * sc, Ws = W * sc;
 
-    int apix[A_ITERS], alds[A_ITERS], ahalf[A_ITERS];
+    // halo staging: piece p = tid + 256 i of the chunk's A_PIECES 16-byte pieces = (halo pixel p / PPP, 8-channel group p % PPP).  256 is a multiple of
+    // PPP, so the group is the same for every i and the pixel advances by 256 / PPP: one LDS address and one group per thread, the rest are constants
+    constexpr int A_BLOCKS = PLANE / 1024;                           // (M16) LDS-DMA instructions per plane
+    int apix[M16 ? A_BLOCKS : A_ITERS];
+    const int ahalf0 = tid % PPP;
+    const int alds0 = M16 ? ahalf0 * PLANE + (tid / PPP) * 16 : (tid / PPP) * APITCH + ahalf0 * 16;
+    constexpr int ALDS_STEP = (256 / PPP) * (M16 ? 16 : APITCH);
+    const bool alast = tid < A_PIECES - 256 * (A_ITERS - 1);         // the last round of pieces is a partial one
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        const int p = tid + 256 * i, px = p / PPP, hr = px / HPW, hc = px - hr * HPW;
-        const int y = y0 - 1 + hr, x = x0 - 1 + hc;
-        const bool in = p < A_PIECES && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        ahalf[i] = p % PPP;
-        alds[i] = p < A_PIECES ? px * APITCH + (p % PPP) * 16 : -1;
-        apix[i] = in ? (y * sc) * Ws + x * sc : -1;
+        for (int i = 0; i < A_BLOCKS; ++i) {                        // halo pixel 64 i + lane (the same in every wave; the wave picks the plane)
+            const int px = 64 * i + lane, hr = px / HPW, hc = px - hr * HPW;
+            const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+            const bool in = px < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            apix[i] = in ? (y * sc) * Ws + x * sc : -1;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int p = tid + 256 * i, px = p / PPP, hr = px / HPW, hc = px - hr * HPW;
+            const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+            const bool in = p < A_PIECES && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            apix[i] = in ? (y * sc) * Ws + x * sc : -1;
+        }
     }
 
-    uint4 ra[A_ITERS];
+    uint4 ra[M16 ? 1 : A_ITERS];
     [[maybe_unused]] uint4 rh[KC == 16 ? A_ITERS : 1];           // second halves of fp32 pieces (16-channel chunks only)
     int ra_f32 = 0;
     int si = 0, cc = 0;
@@ -228,7 +264,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         if constexpr (KC == 16) ra_f32 = S.dtype != RNH_DT_BF16;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int ch = ahalf[i] * 8;
+            const int ch = ahalf0 * 8;
             const bool ok = apix[i] >= 0 && ch < left;
             const int off = apix[i] * pstride + ch * es;
             ra[i] = bld16(rs, ok ? off : -1);
@@ -245,7 +281,37 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int i = 0; i < A_ITERS; ++i) {
             uint4 v = ra[i];
             if constexpr (KC == 16) v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
-            if (alds[i] >= 0) *reinterpret_cast<uint4 *>(Ab + alds[i]) = v;
+            if (i + 1 < A_ITERS || alast) *reinterpret_cast<uint4 *>(Ab + alds0 + i * ALDS_STEP) = v;
+        }
+    };
+
+    // (M16) the halo of the next 32-channel chunk of the source list, by LDS-DMA into halo buffer buf: wave w requests channel group w of every halo
+    // pixel.  Inline asm (hipcc would drain every ordinary load behind an LDS-DMA builtin with vmcnt(0): cdna_hip_programming.md, "Pipelining
+    // across barriers"); M0 is written in the statement that reads it.  The requests count in vmcnt like any load: the chunk loop waits for them with
+    // a COUNTED vmcnt that leaves the weight-fragment loads issued behind them in flight.
+    typedef int i32x4q __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] const unsigned smem_lds = (unsigned)(unsigned long long)(&smem[0]);
+    [[maybe_unused]] auto dma_chunk = [&](int buf) {
+        const rnh_msrc_t &S = P.src[si];
+        const char *base = reinterpret_cast<const char *>(S.ptr) +
+                           ((((long)(img + S.img_off) * Hs + S.sub_y) * Ws + S.sub_x) * S.C + S.c0 + cc * KC + wave * 8) * 2;
+        const unsigned long long u = (unsigned long long)base;
+        i32x4q rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+        rs[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+        rs[2] = 0x7fffffff;
+        rs[3] = 0x00020000;
+        const int pstride = S.C * 2;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(smem_lds + buf * A_BYTES + wave * PLANE);
+#pragma unroll
+        for (int i = 0; i < A_BLOCKS; ++i) {
+            const int voff = apix[i] >= 0 ? apix[i] * pstride : -1;
+            const unsigned ld = l0 + i * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ld), "v"(voff), "s"(rs) : "memory");
+        }
+        if (++cc * KC >= S.nch) {
+            cc = 0;
+            ++si;
         }
     };
 
@@ -253,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const __amdgpu_buffer_rsrc_t wrs = bdesc(P.wp);
     const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
     const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
-    constexpr int RING = NTAPS == 1 ? 1 : (KC == 32 ? 6 : 3), AHEAD = RING - 1;
+    constexpr int RING = NTAPS == 1 ? 1 : (M16 ? 1 : (KC == 32 ? 6 : 3)), AHEAD = RING - 1;
     constexpr int NSTEP = NTAPS * KS;                            // (tap, k step) pairs per chunk; NSTEP % RING == 0: the set of a step is static
     static_assert(NTAPS == 1 || NSTEP % RING == 0, "the fragment ring must divide the steps of a chunk");
     uint4 bq[RING][NB];
@@ -273,13 +339,65 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int n = 0; n < NB; ++n) bq[set][n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[n], base, 0));
     };
 
-    f32x16 acc[MB][NB];
+    f32x16 acc[M16 ? 1 : MB][M16 ? 1 : NB];
+    if constexpr (!M16) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
+                for (int v = 0; v < 16; ++v) acc[m][n][v] = 0.f;
+    }
+    // ---- the 16x16x32 form (KC == 32): accumulator block (b, j) = pixels 16 (b & 1) .. + 15 of tile row MB ph + (b >> 1) x columns 16 j .. + 15 of the
+    // wave's NCOLS / 2; a step = (tap, pair of tile rows): 4 A fragments (double-buffered), the tap's NB16 B fragments, 4 NB16 MFMAs.  The B
+    // fragment of (tap, 16 columns) comes out of the SAME packed weights: lane group kg reads the 16-byte half (kg & 1) of 16-channel slab
+    // 2 chunk + (kg >> 1) - its channels 8 kg .. 8 kg + 7 of the chunk, the ones A's lane group kg holds.  Ring of three taps, requested two taps
+    // (four steps, 64 MFMAs) ahead, across chunk boundaries.
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4m acc16[M16 ? 2 * MB : 1][M16 ? NB16 : 1];
+    [[maybe_unused]] uint4 bq16[M16 ? 3 : 1][M16 ? NB16 : 1];
+    [[maybe_unused]] int wvo16 = 0;                                  // per-lane byte offset of the first 16-column block; block j is 512 j bytes further (an immediate)
+    if constexpr (M16) {
+#pragma unroll
+        for (int b = 0; b < 2 * MB; ++b)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc16[b][j][v] = 0.f;
+        wvo16 = ((nt * NCOLS + chalf * (NCOLS / 2) + l15) * 16 + (kg & 1) * 8) * 2 + (kg >> 1) * NTAPS * slab;
+    }
+    [[maybe_unused]] auto bload16 = [&](int c, int ta, int set) {        // fragments of tap ta of chunk c (ta >= NTAPS: of the chunks behind it)
+        const int q = ta / NTAPS, tap = ta - q * NTAPS;
+        const int cc = c + q < nch ? c + q : nch - 1;
+        const int base = (cc * 2 * NTAPS + tap) * slab;
+#pragma unroll
+        for (int j = 0; j < (M16 ? NB16 : 1); ++j) bq16[set][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo16 + j * 512, base, 0));
+    };
+    [[maybe_unused]] auto compute16 = [&](int buf, int c) {
+        const unsigned char *Ab = smem + buf * A_BYTES + kg * PLANE + ((MB * ph) * HPW + l15) * 16;
+        bf16x8 a[2][4];
+        auto afrags = [&](int step, int set) {
+            const int tap = step >> 1, half = step & 1, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a[set][q] = *reinterpret_cast<const bf16x8 *>(Ab + ((half * 2 + (q >> 1) + dy) * HPW + (q & 1) * 16 + dx) * 16);
+        };
+        afrags(0, 0);
+#pragma unroll
+        for (int step = 0; step < 2 * NTAPS; ++step) {
+            const int tap = step >> 1, half = step & 1;
+            if (step + 1 < 2 * NTAPS) afrags(step + 1, (step + 1) & 1);
+            if (half == 0) bload16(c, tap + 2, (tap + 2) % 3);
+            if (step == 0 && c + 1 < nch) dma_chunk(buf ^ 1);      // (nobody reads that buffer before the barrier at the end of this chunk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < (M16 ? NB16 : 1); ++j)
+                    acc16[M16 ? half * 4 + q : 0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[step & 1][q], __builtin_bit_cast(bf16x8, bq16[tap % 3][j]),
+                                                                                               acc16[M16 ? half * 4 + q : 0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     // One chunk.  The halo of chunk c + 1 sits in registers since step 2 KS of chunk c - 1 (a whole chunk of MFMAs ago, so the
     // wait in store_chunk costs nothing); at step 2 KS it goes to the other LDS buffer - nobody reads that one before the
@@ -317,20 +435,33 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     BSTAMP(0);
     WGTRACE(0);
     RNH_SETPRIO(RNH_PRIO);
-    bload(0, 0, 0);
-    if constexpr (NTAPS == 9) {
+    if constexpr (M16) {
+        dma_chunk(0);
+        bload16(0, 0, 0);
+        bload16(0, 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB16) : "memory");        // the halo has landed, the weight fragments may still be on their way
+        __syncthreads();
+    } else {
+        bload(0, 0, 0);
+        if constexpr (NTAPS == 9) {
 #pragma unroll
-        for (int g = 1; g < AHEAD; ++g) bload(0, g, g);
+            for (int g = 1; g < AHEAD; ++g) bload(0, g, g);
+        }
     }
-    load_chunk();
-    store_chunk(0);
-    if (nch > 1) load_chunk();
-    __syncthreads();
+    if constexpr (!M16) {
+        load_chunk();
+        store_chunk(0);
+        if (nch > 1) load_chunk();
+        __syncthreads();
+    }
     for (int c = 0; c < nch; ++c) {
         BSTAMP(8 + 3 * (c & 15));
-        compute(c & 1, c);
+        if constexpr (M16) compute16(c & 1, c);
+        else compute(c & 1, c);
         BSTAMP(9 + 3 * (c & 15));
         BSTAMP(10 + 3 * (c & 15));
+        // (M16) this wave's halo requests of step 0 have landed: behind them it has issued the fragments of 8 taps (steps 2 .. 16)
+        if constexpr (M16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NB16) : "memory");
         if (!(RNH_EXP & 8)) __syncthreads();
     }
     RNH_SETPRIO(RNH_PRIO_EPI);
@@ -339,11 +470,19 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     if (RNH_EXP & 16) {                                         // keep the accumulators alive, skip the epilogue
         float s = 0.f;
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < (M16 ? 1 : MB); ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
+            for (int n = 0; n < (M16 ? 1 : NB); ++n)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) s += acc[m][n][v];
+        if constexpr (M16) {
+#pragma unroll
+            for (int b = 0; b < 2 * MB; ++b)
+#pragma unroll
+                for (int j = 0; j < NB16; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s += acc16[b][j][v];
+        }
         if (s == 1.2345e-30f) reinterpret_cast<float *>(smem)[tid] = s;
         return;
     }
@@ -415,15 +554,32 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     if constexpr (EPI == RNH_EPI_LSTM_BWD) {
         bw_fast = NCOLS == 128 && P.hd == 64 && P.dst[0].ncols == 64 && P.bw_dh_dtype == RNH_DT_BF16 && P.gates_dtype == RNH_DT_BF16 && !(RNH_EXP & 512);
     }
-    float bv[NB];
+    float bv[M16 ? NB16 : NB];
+    if constexpr (M16) {
 #pragma unroll
-    for (int n = 0; n < NB; ++n) bv[n] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31] : 0.f;
+        for (int j = 0; j < NB16; ++j) bv[j] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + j * 16 + l15] : 0.f;
+    } else {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bv[n] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31] : 0.f;
+    }
     auto park = [&](int m, float *ob) {                             // row block m of this wave -> pixels 32 ph .. 32 ph + 31 of the image
+        if constexpr (M16) {                                        // C / D of 16x16x32: column l & 15, rows 4 (l >> 4) + v
 #pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int col = chalf * (NCOLS / 2) + n * 32 + l31;
+            for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) ob[(ph * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc[m][n][v] + bv[n];
+                for (int j = 0; j < NB16; ++j) {
+                    const int col = chalf * (NCOLS / 2) + j * 16 + l15;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) ob[(ph * TW + xh * 16 + 4 * kg + v) * G::OPITCH + col] = acc16[M16 ? 2 * m + xh : 0][M16 ? j : 0][v] + bv[j];
+                }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int col = chalf * (NCOLS / 2) + n * 32 + l31;
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    ob[(ph * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc[M16 ? 0 : m][M16 ? 0 : n][v] + bv[n];
+            }
         }
     };
     park(0, ot0);
