@@ -204,6 +204,20 @@ def quoted_traffic(record, source, shape=(8, 128, 128)):
     return None, None
 
 
+def cpu_model():
+    """The host CPU's model string (/proc/cpuinfo) and its socket count."""
+    try:
+        names, sockets = [], set()
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                names.append(ln.split(':', 1)[1].strip())
+            elif ln.startswith('physical id'):
+                sockets.add(ln.split(':', 1)[1].strip())
+        return f'{max(len(sockets), 1)} x {names[0]}' if names else None
+    except OSError:
+        return None
+
+
 def cpu_baseline():
     """The oracle (bit-exact restatement of the reference) at BASELINE config 1 on the host cores: 1 warm-up + 10 timed
     steps of forward + discounted L1 loss + backward (about 10-20 s of CPU work on the GPU box's host)."""
@@ -221,20 +235,24 @@ def cpu_baseline():
     for _ in range(reps):
         orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
     dt = (time.perf_counter() - t0) / reps
-    return {'value': round(3.0 / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+    return {'value': round(3.0 / dt, 4), 'unit': 'frames/s', 'cores': threads, 'host_cores': os.cpu_count(), 'cpu_model': cpu_model(), 'kind': 'port',
             'sample': f'BASELINE config 1 (x4, N=1, T=3, F=15, 64x64->256x256, fp32), {reps} timed steps after 1 warm-up, '
                       f'{dt:.2f} s/step, PyTorch CPU oracle == reference bit for bit',
             'tflops': round(step_flops_per_lr_pixel(3) * 64 * 64 / dt / 1e12, 3)}
 
 
 # BASELINE.json configs by their 1-based number: per-GPU batch, supervised frames T, LR size, scale
-CONFIGS = {2: dict(batch=8, frames=7, size=128, scale=4), 4: dict(batch=16, frames=5, size=256, scale=2), 5: dict(batch=8, frames=11, size=96, scale=4)}
+# 'yaml' = the reference's own training shape (configs/train/refine_net/exp1_x4.yaml:20-33: 16 crops of 32 x 32, num_frames 7): the launch-bound regime
+CONFIGS = {2: dict(batch=8, frames=7, size=128, scale=4), 4: dict(batch=16, frames=5, size=256, scale=2), 5: dict(batch=8, frames=11, size=96, scale=4),
+           'yaml': dict(batch=16, frames=7, size=32, scale=4)}
 
 
 def config_label(args, bf):
     c = CONFIGS[args.config]
     if (args.batch, args.frames, args.size, args.scale) != (c['batch'], c['frames'], c['size'], c['scale']):
         return 'a shape of its own: --batch / --frames / --size given'
+    if args.config == 'yaml':
+        return "the reference YAML's training shape, exp1_x4.yaml:20-33" + (', bf16 storage' if bf else '')
     if args.config == 2:
         return f'BASELINE config {3 if bf else 2}'
     return f'BASELINE config {args.config}' + (', bf16 storage' if bf else '') + (' per GPU' if args.config == 5 else '')
@@ -268,7 +286,7 @@ def run_case(args, dtype, dev, world, rank):
     tr.net, tr.loss_fns, tr.metric_fns, tr.optimizer = net, [torch.nn.L1Loss()], [], opt
     tr.loss_weights = torch.tensor([1.0], device=dev)
     tr.graph, tr._graphed = args.graph == 'on', None
-    inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + args.config + rank, s=args.scale)
+    inputs, targets, pos = synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + (9 if args.config == 'yaml' else args.config) + rank, s=args.scale)
 
     def barrier():
         if world > 1:
@@ -280,6 +298,7 @@ def run_case(args, dtype, dev, world, rank):
     for _ in range(args.warmup):
         _, loss, _ = tr.train_step(inputs, targets, pos)
     barrier()
+    dp.allreduce_ms()                                # (forget the warm-up steps' collectives)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step times (no host sync inside the region)
     t0 = time.perf_counter()
     marks[0].record()
@@ -296,8 +315,15 @@ def run_case(args, dtype, dev, world, rank):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    # the ranks' own times (median step by HIP events, wall time of the timed region) and the gradient all-reduce's own HIP-event time, so that a
+    # scaling run explains itself: a slow rank, or a slow collective, shows in the line
+    ar_ms = dp.allreduce_ms()
+    mine = torch.tensor([median_ms, dt * 1e3 / args.steps, ar_ms if ar_ms is not None else -1.0], device=dev, dtype=torch.float64)
+    per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
+    per_rank = [[round(float(v), 3) for v in r.tolist()] for r in per_rank]
     dt = float(tt)
     n_global = args.batch * world
     bf = dtype == 'bf16'
@@ -324,6 +350,10 @@ def run_case(args, dtype, dev, world, rank):
                                    f'{" with upscale_factor=2" if args.scale == 2 else ""} ({config_label(args, bf)})',
                        'global_batch': n_global, 'frames_per_sample': args.frames, 'parallelism': f'dp{world}',
                        'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
+                       'rank_ms_per_step_median_min_max': [min(r[0] for r in per_rank), max(r[0] for r in per_rank)],
+                       'rank_ms_per_step_wall_min_max': [min(r[1] for r in per_rank), max(r[1] for r in per_rank)],
+                       'grad_allreduce_ms_min_max': ([min(r[2] for r in per_rank), max(r[2] for r in per_rank)] if per_rank[0][2] >= 0 else None),
+                       'cpu_affinity': sorted(os.sched_getaffinity(0))[:4] + ['...', len(os.sched_getaffinity(0))] if hasattr(os, 'sched_getaffinity') else None,
                        'hip_graph_step': tr._graphed is not None,
                        'input_frames_per_s': round(n_global * (args.frames + 12) * args.steps / dt, 2),
                        'step_tflop_reference_formulation': round(flop_step / 1e12, 2),
@@ -350,9 +380,10 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', type=int, choices=sorted(CONFIGS), default=2,
+    ap.add_argument('--config', type=lambda v: v if v == 'yaml' else int(v), choices=list(CONFIGS), default=2,
                     help='BASELINE.json config (1-based): 2 = x4, N=8, T=7, 128x128 (the headline; 3 is its bf16 `secondary`), 4 = x2, N=16, T=5, '
-                         '256x256, 5 = x4 with phase codes, N=8 per GPU, T=11, 96x96')
+                         "256x256, 5 = x4 with phase codes, N=8 per GPU, T=11, 96x96; yaml = the reference YAML's own training shape "
+                         '(x4, batch 16 of 32x32 crops, T=7)')
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU (default: the config\'s)')
     ap.add_argument('--frames', type=int, default=None, help='supervised frames T (default: the config\'s)')
     ap.add_argument('--size', type=int, default=None, help='LR height = width (default: the config\'s)')
@@ -367,6 +398,7 @@ def parse_args(argv=None):
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU: the launch / rendezvous / barrier / max-over-ranks protocol over gloo with a stub step (what tests/ checks on CPU)')
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run-slow-rank', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     c = CONFIGS[args.config]
     args.scale = c['scale']
@@ -389,12 +421,83 @@ def launcher_command(gpus, argv, port):
             '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(gpus, smi_text=None):
+    """NUMA node of GPUs 0 .. gpus-1 as `rocm-smi --showtoponuma` reports it (a child process: this one never touches the GPU); {} if unknown."""
+    import re
+    if smi_text is None:
+        try:
+            smi_text = subprocess.run(['rocm-smi', '--showtoponuma'], capture_output=True, text=True, timeout=60).stdout
+        except (OSError, subprocess.SubprocessError):
+            return {}
+    nodes = {}
+    for m in re.finditer(r'GPU\[(\d+)\]\s*:\s*\(Topology\) Numa Node:\s*(-?\d+)', smi_text):
+        if int(m.group(1)) < gpus and int(m.group(2)) >= 0:
+            nodes[int(m.group(1))] = int(m.group(2))
+    return nodes
+
+
+def rank_cpu_map(gpus, nodes=None, node_cpus=None, allowed=None):
+    """local rank -> the CPUs it may run on: the CPUs of its GPU's NUMA node (those this process may use), split evenly among the ranks of that
+    node, so that eight Python processes that each enqueue ~700-900 launches per step neither migrate between sockets nor share cores.
+    {} (no pinning) unless every rank's node is known and has CPUs."""
+    nodes = gpu_numa_nodes(gpus) if nodes is None else nodes
+    if len(nodes) < gpus:
+        return {}
+    allowed = set(os.sched_getaffinity(0)) if allowed is None else set(allowed)
+    out = {}
+    for node in sorted(set(nodes.values())):
+        if node_cpus is not None:
+            cpus = node_cpus.get(node, [])
+        else:
+            try:
+                cpus = parse_cpulist(open(f'/sys/devices/system/node/node{node}/cpulist').read())
+            except OSError:
+                cpus = []
+        cpus = [c for c in cpus if c in allowed]
+        ranks = [r for r in range(gpus) if nodes[r] == node]
+        share = len(cpus) // max(len(ranks), 1)
+        if share < 1:
+            return {}
+        for i, r in enumerate(ranks):
+            out[r] = cpus[i * share:(i + 1) * share]
+    return out
+
+
+def apply_rank_affinity(local):
+    """In a rank, BEFORE anything touches the GPU: take the CPUs the launcher assigned (BENCH_RANK_CPUS, JSON {local rank: [cpu, ...]})."""
+    spec = os.environ.get('BENCH_RANK_CPUS')
+    if not spec or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cpus = json.loads(spec).get(str(local))
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+            torch.set_num_threads(max(1, min(len(cpus), int(os.environ.get('OMP_NUM_THREADS', '8')))))
+        except OSError:
+            return None
+    return cpus
+
+
 def launch_ranks(args, argv):
     """--gpus N > 1 without WORLD_SIZE: start the N ranks as a child torchrun (this process never touches the GPU), relay their output -
-    rank 0's JSON line - and return the children's exit code."""
+    rank 0's JSON line - and return the children's exit code.  Each rank is pinned to a share of the CPUs of its GPU's NUMA node."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    env.setdefault('OMP_NUM_THREADS', '8')
+    cpus = {} if args.dry_run else rank_cpu_map(args.gpus)
+    if cpus:
+        env['BENCH_RANK_CPUS'] = json.dumps({str(k): v for k, v in cpus.items()})
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(8, min((len(v) for v in cpus.values()), default=8)))))
     proc = subprocess.run(launcher_command(args.gpus, argv, free_port()), env=env)
     return proc.returncode
 
@@ -411,15 +514,19 @@ def dry_run(args, world, rank):
     bar()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))
+        time.sleep(0.001 * (1 + rank) + (0.05 if rank == args.dry_run_slow_rank else 0.0))
+    own = time.perf_counter() - t0                # this rank's own steps, without the wait for the others
     bar()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [torch.tensor([own * 1e3 / max(args.steps, 1)], dtype=torch.float64) for _ in range(world)]
     if dist.is_initialized():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, per_rank[rank].clone())
     if rank == 0:
         print(json.dumps({'metric': 'dry run (no GPU work)', 'value': round(args.batch * world * args.frames * args.steps / float(tt), 3), 'unit': 'frames/s',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(float(tt) / args.steps * 1e3, 3),
                           'dry_run': True, 'config': {'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                                                      'rank_ms_per_step_wall_min_max': [round(min(float(r) for r in per_rank), 3), round(max(float(r) for r in per_rank), 3)],
                                                       'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
                                                       'local_rank_env': os.environ.get('LOCAL_RANK'), 'master_addr': os.environ.get('MASTER_ADDR')}}), flush=True)
     if dist.is_initialized():
@@ -447,6 +554,7 @@ def main(argv=None):
                              f'run `python bench.py --gpus {args.gpus}` (it starts the ranks itself) or torchrun with --nproc-per-node {args.gpus}')
     if args.dry_run:
         return dry_run(args, world, rank)
+    apply_rank_affinity(local)                    # (before the first GPU call of this process)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     dev = torch.device(f'cuda:{local}')

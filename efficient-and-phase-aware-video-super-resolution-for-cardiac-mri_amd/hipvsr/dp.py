@@ -44,6 +44,19 @@ def broadcast_parameters(module, src=0):
             off += p.numel()
 
 
+_AR_EVENTS = []           # (start, end) HIP events around the gradient all-reduce of the most recent steps (GPU tensors only; at most 64 pairs)
+
+
+def allreduce_ms():
+    """Mean HIP-event time of the recorded gradient all-reduces (ms), or None if none ran; clears the record.  Synchronises the device."""
+    if not _AR_EVENTS:
+        return None
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in _AR_EVENTS]
+    _AR_EVENTS.clear()
+    return sum(ms) / len(ms)
+
+
 def allreduce_gradients(module, average=True, force=False):
     """Sum (and average) the gradients of ``module`` over all ranks with ONE collective.  Returns the number
     of bytes reduced (0 when world size is 1, unless ``force`` runs the collective anyway - used to test the
@@ -64,9 +77,16 @@ def allreduce_gradients(module, average=True, force=False):
         in_place = in_place and off == flat.numel()
     if not in_place:
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    timed = flat.is_cuda and len(_AR_EVENTS) < 64
+    if timed:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.mul_(1.0 / ws)
+    if timed:
+        ev[1].record()
+        _AR_EVENTS.append(ev)
     if not in_place:
         off = 0
         for p in params:

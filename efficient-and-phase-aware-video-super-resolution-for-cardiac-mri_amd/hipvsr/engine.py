@@ -213,13 +213,24 @@ class RefineNetEngine:
             raise ValueError(f"gate memory plan must be 'store', 'recompute', 'auto' or a number of stages, got {mode!r}")
         if mode != 'auto':
             return S if mode == 'recompute' else 0
-        total = self.ops.total_memory() if hasattr(self.ops, 'total_memory') else None
+        # the budget is what this process can still get: the device's memory, less what other engines of this process that are not ours to free,
+        # and other processes on the card, hold (free memory + this process's reserved pool; never more than the device has)
+        total = self.ops.memory_budget() if hasattr(self.ops, 'memory_budget') else (self.ops.total_memory() if hasattr(self.ops, 'total_memory') else None)
         if not total:
             return 0
+        choice = S
         for n in range(S):
             if self.memory_plan(N, H, W, F, recompute=n)['peak'] <= self.AUTO_FRACTION * total:
-                return n
-        return S
+                choice = n
+                break
+        key = (N, H, W, F, choice)
+        if key not in self.__dict__.setdefault('_rc_logged', set()):
+            self._rc_logged.add(key)
+            if choice:
+                import logging
+                logging.getLogger(__name__).info('gate memory plan (auto): %d of %d stages recompute their gates at N=%d %dx%d F=%d (budget %.1f GiB)',
+                                                 choice, S, N, H, W, F, total / 2**30)
+        return choice
 
     def recompute_gates(self, N, H, W, F):
         """Does any stage recompute its gates at this shape?"""
@@ -249,6 +260,19 @@ class RefineNetEngine:
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, params, inputs, pos_codes, need_grad, last_only=False):
+        """forward_impl behind a guard: if it raises (an allocation that does not fit, a refused launch) while side streams and the helper stream
+        still hold work on buffers that the unwinding stack is about to hand back to the allocator, everything in flight is drained first - a
+        caller that catches the error and goes on must not compute on memory another stream still writes."""
+        if need_grad and getattr(self.plans, 'inconv_bwd_error', None):
+            raise ValueError(self.plans.inconv_bwd_error)
+        try:
+            return self.forward_impl(params, inputs, pos_codes, need_grad, last_only)
+        except BaseException:
+            if hasattr(self.ops, 'quiesce'):
+                self.ops.quiesce()
+            raise
+
+    def forward_impl(self, params, inputs, pos_codes, need_grad, last_only=False):
         """inputs: list[F] of (N, Cin, H, W) tensors; pos_codes: (N, F, 1).
         Returns (O_all, ctx): O_all is (S, 3, T*N, sH, sW, Cout) with image index i*N + n.
         last_only (inference, reference predictor acdc_vsr_refinenet_predictor.py:62 consumes outputs[-1] only): the
@@ -439,6 +463,11 @@ class RefineNetEngine:
             for u in (P.up[:-1] if tail_u is not None else P.up) if nb else []:
                 hh, ww = hh * u['r'], ww * u['r']
                 Yb.append(ops.empty(nb * TN, hh, ww, C, dtype=act if tail_bf16 else f32))
+            if not need_grad and aside_keep:
+                # inference keeps nothing for a backward: the previous stage's upsampler (long finished: a whole ConvLSTM wavefront and refine block
+                # ago) is rejoined here, so that at most ONE stage's upsampler buffers are alive
+                ops.rejoin()
+                aside_keep.clear()
             with ops.aside('up_fwd'):
                 for u, Y in zip(P.up, Yb):
                     ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, u['r']))
@@ -481,6 +510,15 @@ class RefineNetEngine:
 
     # ------------------------------------------------------------------------------------------------
     def backward(self, params, ctx, dO_all, flat=None):
+        """backward_impl behind the same guard as forward."""
+        try:
+            return self.backward_impl(params, ctx, dO_all, flat)
+        except BaseException:
+            if hasattr(self.ops, 'quiesce'):
+                self.ops.quiesce()
+            raise
+
+    def backward_impl(self, params, ctx, dO_all, flat=None):
         """dO_all: gradient of the loss w.r.t. O_all (same shape).  Returns an OrderedDict name -> gradient in
         state-dict order (None for parameters that take no part, quirk Q1).  If ``flat`` (a 1-D buffer with
         room for every parameter) is given the gradients are views into it (for a single all-reduce)."""
@@ -645,10 +683,12 @@ class RefineNetEngine:
                             ops.wgrad(P.r1_wgrad_p, [sc for sc in xs if sc.t is ctx.P4], ysrc, TN, H, W, grads[k1], None, accumulate=a)
                     else:
                         ops.wgrad(P.r1_wgrad, xs, ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
-                if P.xcol:
-                    lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
-                    ops.refine_xcol_wgrad([HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]],
-                                          dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w, Cl, a)
+                    if P.xcol:
+                        # the last channel's rows of the same two gradient tensors (rows the launches above do not map: they write disjoint
+                        # elements), on the helper stream behind them - its operands (HF, HB, P4, dR1p) are held until the next rejoin
+                        lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
+                        ops.refine_xcol_wgrad([HF.frames(U - hw, U - hw + T + w - 1), HB.frames(U - hw, U - hw + T + w - 1), ctx.P4[lo:hi]],
+                                              dR1p[hw * N:(hw + T) * N], grads[k1], grads[b1], N, w, Cl, a)
                 gsrc = dR1p
                 st['R1'] = None
             else:

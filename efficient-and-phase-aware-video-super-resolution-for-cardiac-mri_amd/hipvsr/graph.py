@@ -147,7 +147,11 @@ class GraphedTrainStep:
         for p in params:
             p.grad = None
         e.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.graph, stream=st):
+        # thread-local error mode: under torch.distributed RCCL's watchdog thread makes HIP calls of its own (event queries), which a capture in the
+        # default global mode would reject as 'operation not permitted when stream is capturing'
+        import torch.distributed as dist
+        mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+        with torch.cuda.graph(e.graph, stream=st, capture_error_mode=mode):
             e.outputs, e.loss, e.losses = self._body(e)
         e.grads = [p.grad for p in params]
         e.flat = net._flat_grad

@@ -117,6 +117,21 @@ class HipOps:
         """HBM bytes of the device (what the engine's 'auto' gate-memory plan is sized against)."""
         return torch.cuda.get_device_properties(self.device).total_memory
 
+    def memory_budget(self):
+        """What this process can still use of the device: free memory + the pool torch has reserved for this process (other processes on the card
+        and everything this process holds outside torch's allocator are not ours to plan with); never more than the device has."""
+        free, total = torch.cuda.mem_get_info(self.device)
+        return min(total, free + torch.cuda.memory_reserved(self.device))
+
+    def quiesce(self):
+        """After an exception in the middle of a forward / backward: nothing may still run on the side streams or the helper stream when the buffers
+        they use go back to the allocator.  Outside a graph capture the device is drained; the helper-stream bookkeeping starts afresh."""
+        try:
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(self.device)
+        finally:
+            self._helper_used = False
+
     def mem_allocated(self):
         return torch.cuda.memory_allocated(self.device)
 

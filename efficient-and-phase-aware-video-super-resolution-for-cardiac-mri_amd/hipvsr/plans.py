@@ -243,10 +243,13 @@ class NetPlans:
         for c in nf:
             if c % (8 if bf else 4):
                 raise ValueError(f'num_features must be multiples of {8 if bf else 4} for the HIP path')
+        # rnh_inconv_prelu_bwd (four output channels per thread, include/refinenet_hip.h) serves 4, 8, 16, 32, 64, 128 or 256 features; the forward
+        # kernel serves every multiple of 4.  A constraint of the BACKWARD only: a net of another width is planned (inference, the CPU double) and
+        # refused by the first forward that is asked to keep what a backward needs (hipvsr.engine.RefineNetEngine.forward, need_grad=True)
+        self.inconv_bwd_error = None
         if nf[0] > 256 or 256 % (nf[0] // 4):
-            # rnh_inconv_prelu_bwd (four output channels per thread, include/refinenet_hip.h): refused here, when the net is planned,
-            # rather than by the first backward
-            raise ValueError(f'num_features[0] = {nf[0]}: the input block of the HIP path takes 4, 8, 16, 32, 64, 128 or 256 features')
+            self.inconv_bwd_error = (f'num_features[0] = {nf[0]}: the backward of the HIP path\'s input block takes 4, 8, 16, 32, 64, 128 or 256 '
+                                     f'features (inference runs at every multiple of 4)')
         pw = 8 if bf else 4                       # channels of a phase plane (p, 0, ..., 0)
         self.pw = pw
         self.lstm = {}

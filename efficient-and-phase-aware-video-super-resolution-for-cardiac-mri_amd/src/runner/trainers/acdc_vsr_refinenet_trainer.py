@@ -26,8 +26,10 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
     # (trainer kwarg ``graph: true`` in the YAML, ``bench.py --graph on``): no measured shape gains from it - at the reference
     # YAML's 16 crops of 32 x 32 the step is GPU-bound either way (fp32 59.4 ms eager / 59.5 ms replayed, bf16 25.1 / 27.4:
     # tools/train_shape_bench.py, profiles/r02_e_train_shape.txt, r02_l_train_shape.txt) - and the graphed step behaves
-    # differently (static gradient tensors, no zero_grad, one capture per batch shape).  Under torch.distributed with more than
-    # one rank the request is refused: a capture next to a live RCCL communicator is not covered by any test.
+    # differently (static gradient tensors, no zero_grad, one capture per batch shape).  Under torch.distributed the graph holds
+    # forward + loss + backward only: the gradient all-reduce and the optimizer step stay outside it, as in the single-rank step
+    # (the capture runs in thread-local error mode, so RCCL's watchdog thread cannot invalidate it;
+    # tests/test_parity_r05.py::test_graphed_step_beside_a_live_rccl_communicator).
 
     def __init__(self, graph=False, **kwargs):
         super().__init__(**kwargs)
@@ -61,9 +63,6 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
     def train_step(self, inputs, targets, pos_codes):
         """forward + loss + backward (+ gradient all-reduce) + optimizer step; returns (outputs, loss, losses)."""
         use_graph = bool(getattr(self, 'graph', False))
-        if use_graph and dp.world() > 1:
-            raise RuntimeError('graph=True (HIP-graph replay of the training step) is single-rank only; drop the trainer kwarg '
-                               'or run one process')
         if use_graph:
             if getattr(self, '_graphed', None) is None:
                 from hipvsr.graph import GraphedTrainStep
@@ -76,7 +75,7 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
                         if group['params']:
                             self.optimizer._adopt(gi, group)
             outputs, loss, losses = self._graphed(inputs, targets, pos_codes)      # gradients are overwritten, not accumulated
-            dp.allreduce_gradients(self.net)
+            dp.allreduce_gradients(self.net, force=bool(getattr(self, 'force_allreduce', False)))
             self.optimizer.step()
             return outputs, loss, losses
         outputs = self.net(inputs, pos_codes)
@@ -84,7 +83,7 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
         loss = self._total_loss(losses)
         self.optimizer.zero_grad()
         self._backward(loss)
-        dp.allreduce_gradients(self.net)
+        dp.allreduce_gradients(self.net, force=bool(getattr(self, 'force_allreduce', False)))      # (force: the collective with ONE rank - tests)
         self.optimizer.step()
         return outputs, loss, losses
 

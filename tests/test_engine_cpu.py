@@ -440,3 +440,65 @@ def test_auto_gate_plan_recomputes_only_where_the_stored_step_does_not_fit():
         eng.gate_memory = 'recompute'
         assert eng.recompute_gates(n, size, size, t + 12) is True
     assert RefineNetEngine(NetConfig(**orc.exp1_x4_config()), TorchOps('cpu')).recompute_gates(64, 512, 512, 19) is False    # no device: store
+
+
+def test_input_block_width_outside_the_backward_kernels_set_plans_for_inference_only():
+    """num_features[0] = 24: the forward kernels serve it, rnh_inconv_prelu_bwd does not (4, 8, ..., 256).  The net is planned and runs
+    forward without gradients (a predict-only user must not be refused at construction); the first forward that is asked to
+    keep what a backward needs raises ValueError with the reason."""
+    from oracle import refinenet_oracle as orc
+    kw = dict(in_channels=1, out_channels=1, num_features=[24, 24], num_stages=2, refine_window_size=5, upscale_factor=2,
+              update_memory=True, num_updated_frames=2, positional_encoding=True)
+    cfg = NetConfig(**kw)
+    eng = RefineNetEngine(cfg, TorchOps('cpu'))
+    assert eng.plans.inconv_bwd_error and '24' in eng.plans.inconv_bwd_error
+    ocfg = orc.Config(**kw)
+    sd = orc.init_state_dict(ocfg, seed=3)
+    inputs, targets, pos = orc.synthetic_batch(ocfg, n=1, t=2, h=6, w=5, seed=4)
+    O, ctx = eng.forward({k: v.clone() for k, v in sd.items()}, inputs, pos, need_grad=False)
+    assert ctx is None
+    with torch.no_grad():
+        ref = orc.forward(orc.as_leaf_params(sd), ocfg, inputs, pos)
+    mine = O[cfg.num_stages - 1, 2, 0:1].permute(0, 3, 1, 2)
+    torch.testing.assert_close(mine, ref[-1][0], atol=2e-5, rtol=1e-5)
+    with pytest.raises(ValueError, match='backward'):
+        eng.forward({k: v.clone() for k, v in sd.items()}, inputs, pos, need_grad=True)
+    assert RefineNetEngine(NetConfig(**dict(kw, num_features=[32, 32])), TorchOps('cpu')).plans.inconv_bwd_error is None
+
+
+def test_an_exception_inside_the_engine_drains_the_side_streams_before_it_propagates(g1):
+    """forward / backward raise between aside() and rejoin() -> the buffers of the unwinding stack go back to the allocator while
+    the helper stream may still use them.  The engine calls ops.quiesce() (HipOps: device synchronise + helper bookkeeping reset) before the
+    exception leaves it - in the forward and in the backward."""
+    c = g1['x4_pos1_mem1']
+    cfg = NetConfig(**c['kwargs'])
+
+    class Boom(RuntimeError):
+        pass
+
+    class Ops(TorchOps):
+        quiesced, fail_at, calls = 0, -1, 0
+
+        def quiesce(self):
+            self.quiesced += 1
+
+        def conv(self, *a, **k):
+            self.calls += 1
+            if self.calls == self.fail_at:
+                raise Boom('launch refused')
+            return super().conv(*a, **k)
+
+    ops = Ops('cpu')
+    eng = RefineNetEngine(cfg, ops)
+    params = {k: v.clone() for k, v in c['state_dict'].items()}
+    ops.fail_at = 7
+    with pytest.raises(Boom):
+        eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)
+    assert ops.quiesced == 1
+    ops.fail_at, ops.calls = -1, 0
+    O, ctx = eng.forward(params, c['inputs'], c['pos_codes'], need_grad=True)        # the engine is usable afterwards
+    n_fwd = ops.calls
+    ops.fail_at = n_fwd + 3
+    with pytest.raises(Boom):
+        eng.backward(params, ctx, torch.ones_like(O) * 1e-3)
+    assert ops.quiesced == 2

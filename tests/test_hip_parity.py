@@ -337,7 +337,10 @@ def test_rccl_allreduce_of_flat_gradient_single_rank(g1):
     net, _, _, _ = _module_step(c['kwargs'], c['state_dict'], c['inputs'], c['targets'], c['pos_codes'], torch.nn.L1Loss())
     before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
+    import socket
+    with socket.socket() as sk:                                             # a free port: parallel runs on one host must not collide
+        sk.bind(('127.0.0.1', 0))
+        os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=_dev())
     try:
         nbytes = dp.allreduce_gradients(net, force=True)

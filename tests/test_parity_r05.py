@@ -127,3 +127,45 @@ def test_full_width_variant_bf16_vs_oracle(variant_refs, name):
         gw = max(gw, rel)
         assert rel <= 5e-2, (name, k, rel)
     print(f'{name} at width 64, bf16: worst relative L2 error of an output {worst:.2e}, of a gradient {gw:.2e}')
+
+
+def test_graphed_step_beside_a_live_rccl_communicator(golden_dir):
+    """`graph: true` under torch.distributed (refused until round 5): forward + loss + backward replayed from a HIP graph, the gradient
+    all-reduce (RCCL, one rank: dp.allreduce_gradients(force=True)) and the optimizer step outside it.  Three graphed steps beside a live
+    communicator must equal three eager steps with the same collective bit for bit - parameters and loss."""
+    import copy
+    import torch.distributed as dist
+    from hipvsr.step_tail import FlatAdam
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    sys_path_bench = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    import bench
+    dev = _dev()
+    c = torch.load(os.path.join(golden_dir, 'g1_tiny.pt'), weights_only=False)['x4_pos1_mem1']
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(bench.free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        res = {}
+        for graph in (False, True):
+            net = RefineNet(**c['kwargs'])
+            net.load_state_dict(copy.deepcopy(c['state_dict']))
+            net = net.to(dev).train()
+            tr = object.__new__(AcdcVSRRefineNetTrainer)
+            tr.net, tr.loss_fns, tr.metric_fns = net, [torch.nn.L1Loss()], []
+            tr.optimizer = FlatAdam(net.parameters(), lr=1e-3, weight_decay=0)
+            tr.loss_weights = torch.tensor([1.0], device=dev)
+            tr.graph, tr._graphed, tr.force_allreduce = graph, None, True
+            losses = []
+            for _ in range(3):
+                _, loss, _ = tr.train_step([x.to(dev) for x in c['inputs']], [t.to(dev) for t in c['targets']], c['pos_codes'].to(dev))
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            assert (tr._graphed is not None) == graph
+            res[graph] = (losses, {k: p.detach().cpu().clone() for k, p in net.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for k, v in res[False][1].items():
+        assert torch.equal(res[True][1][k], v), k
