@@ -135,8 +135,17 @@ struct GeoD {
     static_assert(2 * SMEM0 <= 160 * 1024, "two workgroups per CU");
 };
 
+struct rnh_conv_bf16_pair_t {
+    rnh_conv_bf16_args_t call[2];
+};
+
+// PP, nA: ONE launch may serve TWO calls of equal geometry (rnh_conv_bf16_pair: the ConvLSTM cells of the two directions at small images, where a
+// call alone leaves half the chip idle): workgroups [0, nA) belong to PP.call[0], the rest to PP.call[1].  A single call passes nA = its workgroup count (call[1] is never read).
 template <int EPI, int NCOLS, int NTAPS, int KC = 16>
-__global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_args_t P, const int TYn, const int TXn, const int NT) {
+__global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_pair_t PP, const int nA, const int TYn, const int TXn, const int NT) {
+    const int second = (int)blockIdx.x >= nA;
+    const rnh_conv_bf16_args_t &P = PP.call[second];                 // (an offset into the kernel-argument segment: no copy)
+    const int bx = second ? (int)blockIdx.x - nA : (int)blockIdx.x;
     using G = GeoD<NCOLS, KC>;
     constexpr int TH = G::TH, NB = G::NB, MB = G::MB, A_BYTES = G::A_BYTES, A_PIECES = G::A_PIECES, A_ITERS = G::A_ITERS;
     constexpr int KS = G::KS, APITCH = G::APITCH, PPP = G::PPP;
@@ -149,10 +158,10 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
     [[maybe_unused]] const int l15 = lane & 15, kg = lane >> 4;
     const int ph = wave & 1, chalf = wave >> 1;
-    const int bid = rnh_xcd_remap(blockIdx.x, P.B * TYn * TXn * NT);
+    const int bid = rnh_xcd_remap(bx, P.B * TYn * TXn * NT);
     // (RNH_EXP & 32, experiment: column-tile-major block order - the workgroups that run together stream the SAME weight fragments)
     const int nt = (RNH_EXP & 32) ? bid / (P.B * TYn * TXn) : bid % NT, mt = (RNH_EXP & 32) ? bid % (P.B * TYn * TXn) : bid / NT;
-    if ((RNH_EXP & (64 | 128)) && blockIdx.x >= 256 && blockIdx.x < 512) {      // experiment: the second workgroup of every CU starts late
+    if ((RNH_EXP & (64 | 128)) && bx >= 256 && bx < 512) {      // experiment: the second workgroup of every CU starts late
         for (int i = 0; i < ((RNH_EXP & 64) ? 2 : 0) + ((RNH_EXP & 128) ? 4 : 0); ++i) __builtin_amdgcn_s_sleep(100);
     }
     const int img = mt / (TYn * TXn), trem = mt - img * (TYn * TXn), ty = trem / TXn, tx = trem - ty * TXn;
@@ -823,46 +832,93 @@ extern "C" int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp
     return 0;
 }
 
-extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
-    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: null args");
-    const rnh_conv_bf16_args_t &a = *args;
-    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad arguments");
-    if (a.ntaps != 9 && a.ntaps != 1) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: ntaps must be 9 or 1");
-    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: Npad must be a multiple of 64");
+namespace {
+
+struct BfGeo {                  // what the launch of a validated call needs
+    int ncols, TYn, TXn, NT;
+    long blocks;
+    bool k32;
+};
+
+// every check of a call's arguments (who = the entry point's name, for the messages)
+int conv_bf16_check(const rnh_conv_bf16_args_t &a, BfGeo &g, const char *who) {
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "%s: bad arguments", who);
+    if (a.ntaps != 9 && a.ntaps != 1) RNH_FAIL(RNH_E_RANGE, "%s: ntaps must be 9 or 1", who);
+    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "%s: Npad must be a multiple of 64", who);
     int chunks = 0;
     for (int i = 0; i < a.nsrc; ++i) {
-        if (int rc = check_msrc(a.src[i], "rnh_conv_bf16")) return rc;
-        if (a.src[i].scale != a.src[0].scale) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: one scale for all sources");
+        if (int rc = check_msrc(a.src[i], who)) return rc;
+        if (a.src[i].scale != a.src[0].scale) RNH_FAIL(RNH_E_RANGE, "%s: one scale for all sources", who);
         chunks += (a.src[i].nch + 15) / 16;
     }
-    if (chunks != a.nchunks) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: nchunks = %d but the sources hold %d chunks of 16 channels", a.nchunks, chunks);
-    if ((long)a.B * a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: too many pixels");
-    const int ncols = a.Npad % 128 ? 64 : 128;
+    if (chunks != a.nchunks) RNH_FAIL(RNH_E_ARG, "%s: nchunks = %d but the sources hold %d chunks of 16 channels", who, a.nchunks, chunks);
+    if ((long)a.B * a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "%s: too many pixels", who);
+    g.ncols = a.Npad % 128 ? 64 : 128;
     constexpr int TH = 8;
-    const int TYn = (a.H + TH - 1) / TH, TXn = (a.W + TW - 1) / TW, NT = a.Npad / ncols;
-    const long blocks = (long)a.B * TYn * TXn * NT;
-    if (blocks >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: grid too large");
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks), block(256);
+    g.TYn = (a.H + TH - 1) / TH, g.TXn = (a.W + TW - 1) / TW, g.NT = a.Npad / g.ncols;
+    g.blocks = (long)a.B * g.TYn * g.TXn * g.NT;
+    if (g.blocks >= (1L << 30)) RNH_FAIL(RNH_E_RANGE, "%s: grid too large", who);
     // 32-channel chunks (deeper weight-fragment ring, half the barriers) where every source is bf16 with a multiple of 32 channels
-    bool k32 = a.ntaps == 9 && !(getenv("RNH_BF16_KC") && getenv("RNH_BF16_KC")[0] == '1');
-    for (int i = 0; i < a.nsrc; ++i) k32 = k32 && a.src[i].dtype == RNH_DT_BF16 && a.src[i].nch % 32 == 0;
-#define RNH_LAUNCH(EPI, NC, NTP) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, NTP>), grid, block, 0, st, a, TYn, TXn, NT)
-#define RNH_LAUNCH9(EPI, NC)                                                                                             \
-    do {                                                                                                                 \
-        if (k32) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 32>), grid, block, 0, st, a, TYn, TXn, NT);          \
-        else hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 16>), grid, block, 0, st, a, TYn, TXn, NT);              \
+    g.k32 = a.ntaps == 9 && !(getenv("RNH_BF16_KC") && getenv("RNH_BF16_KC")[0] == '1');
+    for (int i = 0; i < a.nsrc; ++i) g.k32 = g.k32 && a.src[i].dtype == RNH_DT_BF16 && a.src[i].nch % 32 == 0;
+    const int NT = g.NT;
+    switch (a.epilogue) {
+        case RNH_EPI_STORE:
+            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "%s: bad destination count", who);
+            for (int d = 0; d < a.ndst; ++d) {
+                const rnh_mdst_t &D = a.dst[d];
+                if (!D.ptr || D.ncols < 1 || (D.dtype != RNH_DT_F32 && D.dtype != RNH_DT_BF16)) RNH_FAIL(RNH_E_ARG, "%s: bad destination %d", who, d);
+                if ((D.C & 7) || (D.c0 & 7) || (D.ncols & 7)) RNH_FAIL(RNH_E_ALIGN, "%s: destination channels must be multiples of 8", who);
+            }
+            break;
+        case RNH_EPI_PS:
+            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "%s: the pixel-shuffle epilogue serves 3x3 convolutions", who);
+            if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 8 || (a.ps_cq & 7) || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
+                RNH_FAIL(RNH_E_ARG, "%s: bad pixel-shuffle destination", who);
+            break;
+        case RNH_EPI_LSTM_BWD: {
+            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "%s: the LSTM-backward epilogue serves 3x3 convolutions", who);
+            const rnh_mdst_t &D = a.dst[0];
+            if (a.ndst != 1 || !D.ptr || D.ncols < 8 || (D.dtype != RNH_DT_F32 && D.dtype != RNH_DT_BF16) || (D.C & 7) || (D.c0 & 7) || (D.ncols & 7))
+                RNH_FAIL(RNH_E_ARG, "%s: the LSTM-backward epilogue stores the input gradient to dst[0] (channels in multiples of 8)", who);
+            if (a.hd < 8 || (a.hd & 7) || NT != 1 || D.ncols + a.hd > a.Npad)
+                RNH_FAIL(RNH_E_RANGE, "%s: LSTM-backward epilogue: input-gradient + hd columns must fit ONE column tile (Npad %d)", who, a.Npad);
+            if (!a.bw_dh || !a.bw_gates || !a.bw_c_next || !a.bw_dgates) RNH_FAIL(RNH_E_ARG, "%s: LSTM-backward epilogue needs bw_dh, bw_gates, bw_c_next, bw_dgates", who);
+            if ((a.bw_dh_dtype != RNH_DT_F32 && a.bw_dh_dtype != RNH_DT_BF16) || (a.bw_dgates_dtype != RNH_DT_F32 && a.bw_dgates_dtype != RNH_DT_BF16) ||
+                (a.bw_rec_dtype != RNH_DT_F32 && a.bw_rec_dtype != RNH_DT_BF16) ||
+                (a.gates_dtype != RNH_DT_F32 && a.gates_dtype != RNH_DT_BF16))
+                RNH_FAIL(RNH_E_ARG, "%s: LSTM-backward epilogue: bad element type", who);
+            break;
+        }
+        case RNH_EPI_LSTM:
+            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "%s: the LSTM epilogue serves 3x3 convolutions", who);
+            if (!a.h_out || !a.c_out || a.hd < 8 || (a.hd & 7) || !a.bias) RNH_FAIL(RNH_E_ARG, "%s: LSTM epilogue needs h_out, c_out, hd %% 8 == 0, bias", who);
+            if (a.Npad != 128 * ((a.hd + 31) / 32)) RNH_FAIL(RNH_E_RANGE, "%s: LSTM column layout (plans.lstm_colmap)", who);
+            break;
+        default:
+            RNH_FAIL(RNH_E_RANGE, "%s: epilogue %d not available", who, a.epilogue);
+    }
+    return 0;
+}
+
+// launch a validated call (pair: a validated second call of the same kernel instantiation and geometry rides in the same launch)
+int conv_bf16_launch(const rnh_conv_bf16_args_t &a, const rnh_conv_bf16_args_t &b, bool pair, const BfGeo &g, hipStream_t st, const char *who) {
+    const int ncols = g.ncols, TYn = g.TYn, TXn = g.TXn, NT = g.NT, nA = (int)g.blocks;
+    const bool k32 = g.k32;
+    const dim3 grid((unsigned)(pair ? 2 * g.blocks : g.blocks)), block(256);
+    rnh_conv_bf16_pair_t pp;
+    pp.call[0] = a;
+    pp.call[1] = b;
+#define RNH_LAUNCH(EPI, NC, NTP) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, NTP>), grid, block, 0, st, pp, nA, TYn, TXn, NT)
+#define RNH_LAUNCH9(EPI, NC)                                                                                                 \
+    do {                                                                                                                     \
+        if (k32) hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 32>), grid, block, 0, st, pp, nA, TYn, TXn, NT);        \
+        else hipLaunchKernelGGL((conv_bf16d_kernel<EPI, NC, 9, 16>), grid, block, 0, st, pp, nA, TYn, TXn, NT);            \
     } while (0)
     switch (a.epilogue) {
         case RNH_EPI_STORE:
-            if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad destination count");
-            for (int d = 0; d < a.ndst; ++d) {
-                const rnh_mdst_t &D = a.dst[d];
-                if (!D.ptr || D.ncols < 1 || (D.dtype != RNH_DT_F32 && D.dtype != RNH_DT_BF16)) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad destination %d", d);
-                if ((D.C & 7) || (D.c0 & 7) || (D.ncols & 7)) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_bf16: destination channels must be multiples of 8");
-            }
             if (a.ntaps == 9) {
-                if (ncols == 128 && k32 && rnh_conv_bf16_persistent(a, TYn, TXn, NT, st)) break;
+                if (!pair && ncols == 128 && k32 && rnh_conv_bf16_persistent(a, TYn, TXn, NT, st)) break;
                 if (ncols == 128) RNH_LAUNCH9(RNH_EPI_STORE, 128);
                 else RNH_LAUNCH9(RNH_EPI_STORE, 64);
             } else {
@@ -871,40 +927,41 @@ extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
             }
             break;
         case RNH_EPI_PS:
-            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the pixel-shuffle epilogue serves 3x3 convolutions");
-            if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 8 || (a.ps_cq & 7) || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
-                RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: bad pixel-shuffle destination");
             if (ncols == 128) RNH_LAUNCH9(RNH_EPI_PS, 128);
             else RNH_LAUNCH9(RNH_EPI_PS, 64);
             break;
-        case RNH_EPI_LSTM_BWD: {
-            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the LSTM-backward epilogue serves 3x3 convolutions");
-            const rnh_mdst_t &D = a.dst[0];
-            if (a.ndst != 1 || !D.ptr || D.ncols < 8 || (D.dtype != RNH_DT_F32 && D.dtype != RNH_DT_BF16) || (D.C & 7) || (D.c0 & 7) || (D.ncols & 7))
-                RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: the LSTM-backward epilogue stores the input gradient to dst[0] (channels in multiples of 8)");
-            if (a.hd < 8 || (a.hd & 7) || NT != 1 || D.ncols + a.hd > a.Npad)
-                RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: LSTM-backward epilogue: input-gradient + hd columns must fit ONE column tile (Npad %d)", a.Npad);
-            if (!a.bw_dh || !a.bw_gates || !a.bw_c_next || !a.bw_dgates) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM-backward epilogue needs bw_dh, bw_gates, bw_c_next, bw_dgates");
-            if ((a.bw_dh_dtype != RNH_DT_F32 && a.bw_dh_dtype != RNH_DT_BF16) || (a.bw_dgates_dtype != RNH_DT_F32 && a.bw_dgates_dtype != RNH_DT_BF16) ||
-                (a.bw_rec_dtype != RNH_DT_F32 && a.bw_rec_dtype != RNH_DT_BF16) ||
-                (a.gates_dtype != RNH_DT_F32 && a.gates_dtype != RNH_DT_BF16))
-                RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM-backward epilogue: bad element type");
+        case RNH_EPI_LSTM_BWD:
             if (ncols == 128) RNH_LAUNCH9(RNH_EPI_LSTM_BWD, 128);
             else RNH_LAUNCH9(RNH_EPI_LSTM_BWD, 64);
             break;
-        }
-        case RNH_EPI_LSTM:
-            if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: the LSTM epilogue serves 3x3 convolutions");
-            if (!a.h_out || !a.c_out || a.hd < 8 || (a.hd & 7) || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: LSTM epilogue needs h_out, c_out, hd % 8 == 0, bias");
-            if (a.Npad != 128 * ((a.hd + 31) / 32)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: LSTM column layout (plans.lstm_colmap)");
-            if (k32 && rnh_conv_bf16_persistent(a, TYn, TXn, NT, st)) break;
+        default:            // RNH_EPI_LSTM (conv_bf16_check has refused everything else)
+            if (!pair && k32 && rnh_conv_bf16_persistent(a, TYn, TXn, NT, st)) break;
             RNH_LAUNCH9(RNH_EPI_LSTM, 128);
             break;
-        default:
-            RNH_FAIL(RNH_E_RANGE, "rnh_conv_bf16: epilogue %d not available", a.epilogue);
     }
 #undef RNH_LAUNCH9
 #undef RNH_LAUNCH
-    RNH_CHECK_LAUNCH("rnh_conv_bf16");
+    RNH_CHECK_LAUNCH(who);
     return 0;
+}
+
+}  // namespace
+
+extern "C" int rnh_conv_bf16(const rnh_conv_bf16_args_t *args, void *stream) {
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16: null args");
+    BfGeo g;
+    if (int rc = conv_bf16_check(*args, g, "rnh_conv_bf16")) return rc;
+    return conv_bf16_launch(*args, *args, false, g, (hipStream_t)stream, "rnh_conv_bf16");
+}
+
+extern "C" int rnh_conv_bf16_pair(const rnh_conv_bf16_args_t *args_a, const rnh_conv_bf16_args_t *args_b, void *stream) {
+    if (!args_a || !args_b) RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16_pair: null args");
+    BfGeo ga, gb;
+    if (int rc = conv_bf16_check(*args_a, ga, "rnh_conv_bf16_pair (first call)")) return rc;
+    if (int rc = conv_bf16_check(*args_b, gb, "rnh_conv_bf16_pair (second call)")) return rc;
+    const rnh_conv_bf16_args_t &a = *args_a, &b = *args_b;
+    if (a.B != b.B || a.H != b.H || a.W != b.W || a.Npad != b.Npad || a.ntaps != b.ntaps || a.epilogue != b.epilogue || ga.k32 != gb.k32 ||
+        a.src[0].scale != b.src[0].scale)
+        RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16_pair: the two calls must agree in B, H, W, Npad, ntaps, epilogue, source scale and chunk size");
+    return conv_bf16_launch(a, b, true, ga, (hipStream_t)stream, "rnh_conv_bf16_pair");
 }

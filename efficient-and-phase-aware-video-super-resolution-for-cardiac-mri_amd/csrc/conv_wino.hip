@@ -143,8 +143,19 @@ struct WinoGeo {
     static_assert(PART + 4 * GS <= 2 * BUF, "the epilogue's exchange areas live in the staging buffers");
 };
 
+// PP, nA: ONE launch may serve TWO calls of equal geometry (rnh_conv_wino_pair: the ConvLSTM cells of the two directions at small images, where a call
+// alone leaves half the chip idle): workgroups [0, nA) belong to PP.call[0], the rest to PP.call[1] (an offset into the kernel-argument segment, no
+// copy).  A single call passes nA = its workgroup count and call[1] is never read.
+struct rnh_conv_pair_t {
+    rnh_conv_args_t call[2];
+};
+
 template <int EPI, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(const rnh_conv_args_t P, const int MT, const int NT, const int TX, const int TY) {
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(const rnh_conv_pair_t PP, const int nA, const int MT, const int NT, const int TX,
+                                                                               const int TY) {
+    const int second = (int)blockIdx.x >= nA;
+    const rnh_conv_args_t &P = PP.call[second];
+    const int bx = second ? (int)blockIdx.x - nA : (int)blockIdx.x;
     using G = WinoGeo<NW>;
     constexpr int TILES = H_TILES, CPC = G::CPC, CH = G::CH, CHS = G::CHS, BUF = G::BUF, SPC = G::SPC, CG = G::CG;
     constexpr int H_PART = G::PART, H_TS = G::TS, H_GS = G::GS, CW = G::CW;
@@ -160,7 +171,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_winoh_kernel(co
 #endif
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = wave & 1, cg = wave >> 1;                   // half of the transform domain, column group
-    const int bid = rnh_xcd_remap(blockIdx.x, MT * NT);
+    const int bid = rnh_xcd_remap(bx, MT * NT);
     const int mt = bid / NT, nt = bid - mt * NT;
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX;
     const int m0 = mt * TILES;
@@ -675,20 +686,24 @@ extern "C" int rnh_wino_pack_weights(const float *w, const float *bias, float *w
 }
 
 template <int NW>
-static int launch_wino(const rnh_conv_args_t &a, int MT, int NT, int TX, int TY, hipStream_t st) {
+static int launch_wino(const rnh_conv_args_t &a, const rnh_conv_args_t &b, bool pair, int MT, int NT, int TX, int TY, hipStream_t st) {
     using G = WinoGeo<NW>;
-    const dim3 grid((unsigned)(MT * NT)), block(64 * NW);
+    const int nA = MT * NT;
+    const dim3 grid((unsigned)(pair ? 2 * nA : nA)), block(64 * NW);
+    rnh_conv_pair_t pp;
+    pp.call[0] = a;
+    pp.call[1] = b;
     switch (a.epilogue) {
         case RNH_EPI_STORE:
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_STORE, NW>), grid, block, 0, st, pp, nA, MT, NT, TX, TY);
             break;
         case RNH_EPI_PS:
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_PS, NW>), grid, block, 0, st, pp, nA, MT, NT, TX, TY);
             break;
         case RNH_EPI_LSTM:
-            if (a.Npad != 32 * G::CG * ((a.hd + G::CW - 1) / G::CW))
+            if (a.Npad != 32 * G::CG * ((a.hd + G::CW - 1) / G::CW) || b.Npad != 32 * G::CG * ((b.hd + G::CW - 1) / G::CW))
                 RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: LSTM column layout (%d-column blocks = the four gates of %d hidden channels)", 32 * G::CG, G::CW);
-            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM, NW>), grid, block, 0, st, a, MT, NT, TX, TY);
+            hipLaunchKernelGGL((conv_winoh_kernel<RNH_EPI_LSTM, NW>), grid, block, 0, st, pp, nA, MT, NT, TX, TY);
             break;
         default:
             RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: epilogue %d not available", a.epilogue);
@@ -696,41 +711,66 @@ static int launch_wino(const rnh_conv_args_t &a, int MT, int NT, int TX, int TY,
     return 0;
 }
 
+struct WinoGeom {               // what the launch of a validated call needs
+    int wide, MT, NT, TX, TY;
+};
+
+static int wino_check(const rnh_conv_args_t &a, WinoGeom &g, const char *who) {
+    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "%s: bad arguments", who);
+    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "%s: 3x3 convolutions only", who);
+    const int wide = a.tile == RNH_WINO_COLS128;                // 128-column blocks (8 waves, 32-channel chunks), else 64-column blocks
+    const int bc = wide ? 128 : 64, cm = wide ? 32 : 16;
+    if (a.Npad < bc || a.Npad % bc) RNH_FAIL(RNH_E_RANGE, "%s: Npad must be a multiple of %d", who, bc);
+    int steps = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (int rc = rnh_check_src(a.src[i], who)) return rc;
+        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "%s: one scale for all sources, no second pointer", who);
+        if (a.src[i].nch % cm) RNH_FAIL(RNH_E_ALIGN, "%s: source channel counts must be multiples of %d", who, cm);
+        steps += a.src[i].nch / 4;
+    }
+    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "%s: nk = %d but the sources hold %d steps of 4 channels", who, a.nk, steps);
+    const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
+    const long ntiles = (long)a.B * TY * TX;
+    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "%s: at most 2047 images of 1023 x 1023", who);
+    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "%s: too many pixels for 32-bit offsets", who);
+    // pixel offsets inside a block (it may straddle two images) go through 24-bit multiplies
+    if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "%s: source images of at most 2^22 pixels", who);
+    g.wide = wide, g.TX = TX, g.TY = TY;
+    g.MT = (int)((ntiles + H_TILES - 1) / H_TILES), g.NT = a.Npad / bc;
+    if (a.epilogue == RNH_EPI_STORE) {
+        if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "%s: bad destination count", who);
+        for (int d = 0; d < a.ndst; ++d)
+            if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "%s: bad destination %d", who, d);
+    } else if (a.epilogue == RNH_EPI_PS) {
+        if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
+            RNH_FAIL(RNH_E_ARG, "%s: bad pixel-shuffle destination", who);
+    } else if (a.epilogue == RNH_EPI_LSTM) {
+        if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "%s: LSTM epilogue needs h_out, c_out, hd, bias", who);
+    }
+    return 0;
+}
+
 extern "C" int rnh_conv_wino(const rnh_conv_args_t *args, void *stream) {
     if (!args) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: null args");
     const rnh_conv_args_t &a = *args;
-    if (a.nsrc < 1 || a.nsrc > RNH_MAX_SRC || a.B < 1 || a.H < 1 || a.W < 1 || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad arguments");
-    if (a.ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: 3x3 convolutions only");
-    const int wide = a.tile == RNH_WINO_COLS128;                // 128-column blocks (8 waves, 32-channel chunks), else 64-column blocks
-    const int bc = wide ? 128 : 64, cm = wide ? 32 : 16;
-    if (a.Npad < bc || a.Npad % bc) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: Npad must be a multiple of %d", bc);
-    int steps = 0;
-    for (int i = 0; i < a.nsrc; ++i) {
-        if (int rc = rnh_check_src(a.src[i], "rnh_conv_wino")) return rc;
-        if (a.src[i].scale != a.src[0].scale || a.src[i].ptr2) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: one scale for all sources, no second pointer");
-        if (a.src[i].nch % cm) RNH_FAIL(RNH_E_ALIGN, "rnh_conv_wino: source channel counts must be multiples of %d", cm);
-        steps += a.src[i].nch / 4;
-    }
-    if (steps != a.nk) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: nk = %d but the sources hold %d steps of 4 channels", a.nk, steps);
-    const int TY = (a.H + 1) / 2, TX = (a.W + 1) / 2;
-    const long ntiles = (long)a.B * TY * TX;
-    if (a.H > 1023 || a.W > 1023 || a.B > 2047) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: at most 2047 images of 1023 x 1023");
-    if (ntiles * 4 >= (1L << 29)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: too many pixels for 32-bit offsets");
-    // pixel offsets inside a block (it may straddle two images) go through 24-bit multiplies
-    if ((long)a.H * a.W * a.src[0].scale * a.src[0].scale >= (1L << 22)) RNH_FAIL(RNH_E_RANGE, "rnh_conv_wino: source images of at most 2^22 pixels");
-    const int MT = (int)((ntiles + H_TILES - 1) / H_TILES), NT = a.Npad / bc;
+    WinoGeom g;
+    if (int rc = wino_check(a, g, "rnh_conv_wino")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (a.epilogue == RNH_EPI_STORE) {
-        if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination count");
-        for (int d = 0; d < a.ndst; ++d)
-            if (!a.dst[d].ptr || a.dst[d].ncols < 1) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad destination %d", d);
-    } else if (a.epilogue == RNH_EPI_PS) {
-        if (a.ndst != 1 || !a.dst[0].ptr || a.ps_r < 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad)
-            RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: bad pixel-shuffle destination");
-    } else if (a.epilogue == RNH_EPI_LSTM) {
-        if (!a.h_out || !a.c_out || a.hd < 1 || !a.bias) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino: LSTM epilogue needs h_out, c_out, hd, bias");
-    }
-    if (int rc = wide ? launch_wino<8>(a, MT, NT, TX, TY, st) : launch_wino<4>(a, MT, NT, TX, TY, st)) return rc;
+    if (int rc = g.wide ? launch_wino<8>(a, a, false, g.MT, g.NT, g.TX, g.TY, st) : launch_wino<4>(a, a, false, g.MT, g.NT, g.TX, g.TY, st)) return rc;
     RNH_CHECK_LAUNCH("rnh_conv_wino");
+    return 0;
+}
+
+extern "C" int rnh_conv_wino_pair(const rnh_conv_args_t *args_a, const rnh_conv_args_t *args_b, void *stream) {
+    if (!args_a || !args_b) RNH_FAIL(RNH_E_ARG, "rnh_conv_wino_pair: null args");
+    const rnh_conv_args_t &a = *args_a, &b = *args_b;
+    WinoGeom ga, gb;
+    if (int rc = wino_check(a, ga, "rnh_conv_wino_pair (first call)")) return rc;
+    if (int rc = wino_check(b, gb, "rnh_conv_wino_pair (second call)")) return rc;
+    if (a.B != b.B || a.H != b.H || a.W != b.W || a.Npad != b.Npad || a.epilogue != b.epilogue || a.tile != b.tile || a.src[0].scale != b.src[0].scale)
+        RNH_FAIL(RNH_E_ARG, "rnh_conv_wino_pair: the two calls must agree in B, H, W, Npad, epilogue, tile and source scale");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = ga.wide ? launch_wino<8>(a, b, true, ga.MT, ga.NT, ga.TX, ga.TY, st) : launch_wino<4>(a, b, true, ga.MT, ga.NT, ga.TX, ga.TY, st)) return rc;
+    RNH_CHECK_LAUNCH("rnh_conv_wino_pair");
     return 0;
 }

@@ -320,6 +320,7 @@ class RefineNetEngine:
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
         aside_keep = []
+        pair = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False      # the two directions' cells of a layer in one launch
 
         def run_stage(s, feat):
             """Stage s of the forward; returns the features the next stage starts from.  A function of its own so that the stage's transients die
@@ -345,36 +346,55 @@ class RefineNetEngine:
                 st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), act) for l, hd in enumerate(nf)],
                              C=[FrameStore(ops, N, lo_d, hi_d, keep, (H, W, hd), f32, ring=2, step=1 if fwd else -1) for hd in nf],
                              G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and s >= n_rc else None)
-            ops.fork(2 * Lr)
-            for idx in range(F_s):
-                for di, d in enumerate(dirs):
-                    k = idx if d == 'forward' else F - 1 - idx
-                    prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
-                    Hb, Cb, Gb = st[d]['H'], st[d]['C'], st[d]['G']
-                    grad_frame = Gb is not None and U <= k < U + T
+            def cell_call(d, l, idx):
+                """The conv() arguments of cell (direction d, layer l) at wavefront slot idx: (plan, sources, N, H, W, keyword arguments)."""
+                k = idx if d == 'forward' else F - 1 - idx
+                prev = None if idx == 0 else (k - 1 if d == 'forward' else k + 1)
+                Hb, Cb, Gb = st[d]['H'], st[d]['C'], st[d]['G']
+                grad_frame = Gb is not None and U <= k < U + T
+                pl = P.lstm[(d, l)]
+                xin = feat if l == 0 else Hb[l - 1]
+                srcs = [xin.src(k)]
+                if cfg.memory:
+                    if prev is not None:
+                        srcs.append(Hb[l].src(prev))
+                        plan = pl['full']
+                    else:
+                        plan = pl['first']
+                else:
+                    srcs.append(xin.src(k))
+                    plan = pl['full']
+                return plan, srcs, N, H, W, dict(lstm=dict(
+                    hd=pl['hd'], c_prev=Cb[l].view(prev) if prev is not None else None,
+                    h_out=Hb[l].view(k), c_out=Cb[l].view(k),
+                    gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
+
+            if pair:
+                # small images (the reference YAML's 32 x 32 crops): a cell launch is a fraction of the chip, and the two directions' cells of a
+                # layer at the same slot are independent and of equal geometry - ONE launch for both (ops.conv_pair), one stream per layer
+                ops.fork(2 * Lr)                                # (2 L logical streams as below: logical stream l is layer l's HIP stream)
+                for idx in range(F_s):
                     below = None
                     for l in range(Lr):
-                        with ops.side(di * Lr + l):
+                        with ops.side(l):
                             if below is not None:
                                 ops.wait(below)
-                            pl = P.lstm[(d, l)]
-                            xin = feat if l == 0 else Hb[l - 1]
-                            srcs = [xin.src(k)]
-                            if cfg.memory:
-                                if prev is not None:
-                                    srcs.append(Hb[l].src(prev))
-                                    plan = pl['full']
-                                else:
-                                    plan = pl['first']
-                            else:
-                                srcs.append(xin.src(k))
-                                plan = pl['full']
-                            ops.conv(plan, srcs, N, H, W, lstm=dict(
-                                hd=pl['hd'], c_prev=Cb[l].view(prev) if prev is not None else None,
-                                h_out=Hb[l].view(k), c_out=Cb[l].view(k),
-                                gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
+                            ops.conv_pair([cell_call(d, l, idx) for d in dirs])
                             below = ops.record() if l + 1 < Lr else None
-            ops.join(2 * Lr)
+                ops.join(2 * Lr)
+            else:
+                ops.fork(2 * Lr)
+                for idx in range(F_s):
+                    for di, d in enumerate(dirs):
+                        below = None
+                        for l in range(Lr):
+                            with ops.side(di * Lr + l):
+                                if below is not None:
+                                    ops.wait(below)
+                                plan, srcs, _, _, _, kw = cell_call(d, l, idx)
+                                ops.conv(plan, srcs, N, H, W, **kw)
+                                below = ops.record() if l + 1 < Lr else None
+                ops.join(2 * Lr)
             self._mem(f'fwd stage {s}: wavefront done')
             for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
                 for l in range(Lr):
@@ -754,6 +774,7 @@ class RefineNetEngine:
                 ops.conv(pl['full'], [xin.src(k), sd['H'][l].src(kp) if cfg.memory else xin.src(k)], N, H, W,
                          lstm=dict(hd=pl['hd'], c_prev=sd['C'][l].view(kp), h_out=hs, c_out=cs, gates_out=g))
                 return g
+            pair = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False      # (as the forward: small images)
             ops.fork(2 * Lr, bank=1)
             if fused:
                 # The gate backward of a frame rides in the epilogue of the data-gradient launch of the frame its chain processed just before
@@ -764,74 +785,110 @@ class RefineNetEngine:
                 # l + 1: a skewed wavefront over tau = frame index + (Lr - 1 - l).  Only the first frame of a chain still has a launch of
                 # its own for the gate backward.
                 evs = {}
+
+                def bwd_cell(d, l, idx):
+                    """Cell (d, l) at chain position idx: launches the chain head's own gate backward (idx == 0) on the current stream and returns
+                    the conv() arguments of the data-gradient launch (with the next frame's gate backward in its epilogue)."""
+                    step = 1 if d == 'forward' else -1
+                    sd, top = st[d], tops[d]
+                    Cb = sd['C']
+                    k = U + T - 1 - idx if d == 'forward' else U + idx
+                    fi, k2 = k - U, k - step
+                    fi2, has_next = k2 - U, idx + 1 < T
+                    pl = P.lstm[(d, l)]
+                    hd, cx = pl['hd'], pl['cx']
+                    dh_of = (lambda f: top[f * N:(f + 1) * N]) if l == Lr - 1 else (lambda f: DX[d][l + 1][f * N:(f + 1) * N])
+                    c_at = lambda kk: Cb[l].view(kk) if 0 <= kk < F else None               # noqa: E731
+                    if idx == 0:                                # head of the chain
+                        ops.lstm_gates_bwd(dh_of(fi), None, gates_of(d, l, k), c_at(k2), c_at(k),
+                                           Gd[d][l][fi * N:(fi + 1) * N], DCP[d][l][0] if has_next else None)
+                    dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
+                    bw = None
+                    if has_next:
+                        bw = dict(dh=dh_of(fi2), dc_next=DCP[d][l][idx & 1], gates=gates_of(d, l, k2), c_prev=c_at(k2 - step),
+                                  c_next=c_at(k2), dgates=Gd[d][l][fi2 * N:(fi2 + 1) * N],
+                                  dc_prev=DCP[d][l][(idx + 1) & 1] if idx + 2 < T else None, hd=hd, rec_dtype=act)
+                    return pl['dgrad'], [Src(Gd[d][l][fi * N:(fi + 1) * N])], N, H, W, dict(dsts=[Dst(dxbuf, cx)], lstm_bwd=bw)
+
                 for tau in range(T + Lr - 1):
-                    for di, d in enumerate(dirs):
-                        step = 1 if d == 'forward' else -1
-                        sd, top = st[d], tops[d]
-                        Cb, Gb = sd['C'], sd['G']
-                        for l in range(Lr - 1, -1, -1):
-                            idx = tau - (Lr - 1 - l)
-                            if not 0 <= idx < T:
-                                continue
-                            k = U + T - 1 - idx if d == 'forward' else U + idx
-                            fi, k2 = k - U, k - step
-                            fi2, has_next = k2 - U, idx + 1 < T
-                            pl = P.lstm[(d, l)]
-                            hd, cx = pl['hd'], pl['cx']
-                            dh_of = (lambda f: top[f * N:(f + 1) * N]) if l == Lr - 1 else (lambda f, l=l: DX[d][l + 1][f * N:(f + 1) * N])
-                            c_at = lambda kk, l=l: Cb[l].view(kk) if 0 <= kk < F else None
+                    for l in range(Lr - 1, -1, -1):
+                        idx = tau - (Lr - 1 - l)
+                        if not 0 <= idx < T:
+                            continue
+                        if pair:
+                            # the two directions' launches of (layer, chain position) in one (ops.conv_pair), one stream per layer: what this
+                            # launch reads from the layer above (its input gradients of frames idx and idx + 1, both directions) is waited for first
+                            with ops.side(l):
+                                if l < Lr - 1:
+                                    ops.wait(evs[(l + 1, min(idx + 1, T - 1))])
+                                ops.conv_pair([bwd_cell(d, l, idx) for d in dirs])
+                                if l > 0:
+                                    evs[(l, idx)] = ops.record()
+                            continue
+                        for di, d in enumerate(dirs):
                             with ops.side(di * Lr + l):
-                                if idx == 0:                        # head of the chain
-                                    if l < Lr - 1:
-                                        ops.wait(evs[(d, l + 1, 0)])
-                                    ops.lstm_gates_bwd(dh_of(fi), None, gates_of(d, l, k), c_at(k2), c_at(k),
-                                                       Gd[d][l][fi * N:(fi + 1) * N], DCP[d][l][0] if has_next else None)
-                                dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
-                                bw = None
-                                if has_next:
-                                    if l < Lr - 1:
-                                        ops.wait(evs[(d, l + 1, idx + 1)])
-                                    bw = dict(dh=dh_of(fi2), dc_next=DCP[d][l][idx & 1], gates=gates_of(d, l, k2), c_prev=c_at(k2 - step),
-                                              c_next=c_at(k2), dgates=Gd[d][l][fi2 * N:(fi2 + 1) * N],
-                                              dc_prev=DCP[d][l][(idx + 1) & 1] if idx + 2 < T else None, hd=hd, rec_dtype=act)
-                                ops.conv(pl['dgrad'], [Src(Gd[d][l][fi * N:(fi + 1) * N])], N, H, W, dsts=[Dst(dxbuf, cx)], lstm_bwd=bw)
+                                if l < Lr - 1:
+                                    ops.wait(evs[(d, l + 1, min(idx + 1, T - 1))])
+                                plan, srcs, _, _, _, kw = bwd_cell(d, l, idx)
+                                ops.conv(plan, srcs, N, H, W, **kw)
                                 if l > 0:
                                     evs[(d, l, idx)] = ops.record()
+            def bwd_cell_unfused(d, l, idx, dx_above):
+                """Separate launches (the fp32 path): the gate backward of cell (d, l) at chain position idx on the current stream; returns the
+                conv() arguments of its data gradient and the buffer the layer below reads (None at the bottom)."""
+                step = 1 if d == 'forward' else -1
+                k = U + T - 1 - idx if d == 'forward' else U + idx
+                sd, top = st[d], tops[d]
+                Cb = sd['C']
+                fi = k - U
+                prevk = k - step
+                prev_grad = U <= prevk < U + T
+                pl = P.lstm[(d, l)]
+                hd, cx = pl['hd'], pl['cx']
+                dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
+                c_prev = Cb[l].view(prevk) if 0 <= prevk < F else None
+                dg = Gd[d][l][fi * N:(fi + 1) * N]
+                dcp = DCP[d][l][idx & 1] if prev_grad else None
+                ops.lstm_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg, dcp, dh2=dh_next[d][l])
+                dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
+                dhp, tmp = None, None
+                if cfg.memory:
+                    dsts = [Dst(dxbuf, cx)]
+                    if prev_grad:
+                        dhp = DHP[d][l][idx & 1]
+                        dsts.append(Dst(dhp, hd))
+                else:
+                    tmp = TMP[d][l]
+                    dsts = [Dst(dxbuf, cx), Dst(tmp, cx)]
+                dh_next[d][l], dc_next[d][l] = dhp, dcp
+                return (pl['dgrad'], [Src(dg)], N, H, W, dict(dsts=dsts)), dxbuf, tmp
+
             for idx in range(T if not fused else 0):
+                if pair:
+                    # one stream per layer; the two directions' data gradients of (layer, chain position) in one launch
+                    dx_above, above = {d: None for d in dirs}, None
+                    for l in range(Lr - 1, -1, -1):
+                        with ops.side(l):
+                            if above is not None:
+                                ops.wait(above)
+                            cells = [bwd_cell_unfused(d, l, idx, dx_above[d]) for d in dirs]
+                            ops.conv_pair([c[0] for c in cells])
+                            for d, (_, dxbuf, tmp) in zip(dirs, cells):
+                                if tmp is not None:
+                                    ops.add(dxbuf, tmp, accumulate=True)
+                                dx_above[d] = dxbuf if l > 0 else None
+                            above = ops.record() if l > 0 else None
+                    continue
                 for di, d in enumerate(dirs):
-                    step = 1 if d == 'forward' else -1
-                    k = U + T - 1 - idx if d == 'forward' else U + idx
-                    sd, top = st[d], tops[d]
-                    Hb, Cb, Gb = sd['H'], sd['C'], sd['G']
-                    fi = k - U
-                    prevk = k - step
-                    prev_grad = U <= prevk < U + T
                     dx_above, above = None, None
                     for l in range(Lr - 1, -1, -1):
                         with ops.side(di * Lr + l):
                             if above is not None:
                                 ops.wait(above)
-                            pl = P.lstm[(d, l)]
-                            hd, cx = pl['hd'], pl['cx']
-                            dh = top[fi * N:(fi + 1) * N] if l == Lr - 1 else dx_above
-                            c_prev = Cb[l].view(prevk) if 0 <= prevk < F else None
-                            dg = Gd[d][l][fi * N:(fi + 1) * N]
-                            dcp = DCP[d][l][idx & 1] if prev_grad else None
-                            ops.lstm_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg,
-                                               dcp, dh2=dh_next[d][l])
-                            dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
-                            dhp = None
-                            if cfg.memory:
-                                dsts = [Dst(dxbuf, cx)]
-                                if prev_grad:
-                                    dhp = DHP[d][l][idx & 1]
-                                    dsts.append(Dst(dhp, hd))
-                                ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=dsts)
-                            else:
-                                tmp = TMP[d][l]
-                                ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dxbuf, cx), Dst(tmp, cx)])
+                            (plan, srcs, _, _, _, kw), dxbuf, tmp = bwd_cell_unfused(d, l, idx, dx_above)
+                            ops.conv(plan, srcs, N, H, W, **kw)
+                            if tmp is not None:
                                 ops.add(dxbuf, tmp, accumulate=True)
-                            dh_next[d][l], dc_next[d][l] = dhp, dcp
                             dx_above = dxbuf if l > 0 else None
                             above = ops.record() if l > 0 else None
             # weight gradients of the cells, batched over the T frames (each on its cell's stream).  Nothing of this stage's backward waits
@@ -849,7 +906,7 @@ class RefineNetEngine:
                 step = 1 if d == 'forward' else -1
                 Hb = st[d]['H']
                 for l in range(Lr):
-                    with ops.side(di * Lr + l):
+                    with ops.side(l if pair else di * Lr + l):      # (the stream the cell's chain ran on)
                         pl = P.lstm[(d, l)]
                         xin = feat if l == 0 else Hb[l - 1]
                         second = _span_src(Hb[l], U - step, T) if cfg.memory else _span_src(xin, U, T)

@@ -354,8 +354,42 @@ class HipOps:
         dst.img_off, dst.scale, dst.sub_y, dst.sub_x = s.img_off, s.scale, s.sub[0], s.sub[1]
 
     # ---- convolution --------------------------------------------------------------------------------
+    # ---- two independent calls of equal geometry in one launch ---------------------------------------------------------------------------
+    PAIR_BELOW = 512       # workgroups: a cell launch smaller than one full round of the chip (256 CUs x 2 workgroups) is paired with its twin
+
+    def pair_cells(self, N, H, W):
+        """Should the engine hand the ConvLSTM cells of the two directions (same layer, same wavefront slot) to conv_pair?  Yes where one cell
+        launch leaves the chip under-filled - the reference YAML's training shape (16 crops of 32 x 32: 128 workgroups per cell) - no at the
+        benchmark shapes (1024 workgroups).  RNH_PAIR=1 / 0 forces it on / off."""
+        env = os.environ.get('RNH_PAIR')
+        if env in ('0', '1'):
+            return env == '1'
+        tiles = N * (-(-H // 8)) * (-(-W // 32)) * 2               # 8 x 32 pixel tiles x two 128-column tiles (the bf16 cell; the fp32 one is similar)
+        return tiles < self.PAIR_BELOW
+
+    def conv_pair(self, calls):
+        """``calls``: two argument tuples (plan, srcs, B, H, W, kwargs) of conv().  Same results as the two conv() calls, bit for bit; ONE launch
+        (rnh_conv_bf16_pair / rnh_conv_wino_pair) where both are bf16 or both Winograd calls of equal geometry, else the two launches."""
+        built = [self._conv_args(pl, srcs, B, H, W, **kw) for pl, srcs, B, H, W, kw in calls]
+        (k0, a0, n0), (k1, a1, n1) = built
+        if k0 == k1 == 'bf16':
+            L.check(self.lib.rnh_conv_bf16_pair(C.byref(a0), C.byref(a1), self._stream()), f'rnh_conv_bf16_pair({n0}, {n1})')
+        elif k0 == k1 == 'wino':
+            L.check(self.lib.rnh_conv_wino_pair(C.byref(a0), C.byref(a1), self._stream()), f'rnh_conv_wino_pair({n0}, {n1})')
+        else:
+            for kind, a, name in built:
+                self._launch_conv(kind, a, name)
+
+    def _launch_conv(self, kind, a, name):
+        fn = {'bf16': self.lib.rnh_conv_bf16, 'wino': self.lib.rnh_conv_wino, 'igemm': self.lib.rnh_conv_igemm}[kind]
+        L.check(fn(C.byref(a), self._stream()), f'{fn.__name__}({name})')
+
     def conv(self, plan: ConvPlan, srcs, B, H, W, dsts=None, ps=None, lstm=None, lstm_bwd=None):
-        """One rnh_conv_igemm launch.  ``dsts``: list[Dst] (STORE), ``ps``: (tensor, r) with the tensor
+        """One convolution launch (rnh_conv_igemm / rnh_conv_wino / rnh_conv_bf16 by the plan): see _conv_args for the arguments."""
+        self._launch_conv(*self._conv_args(plan, srcs, B, H, W, dsts, ps, lstm, lstm_bwd))
+
+    def _conv_args(self, plan: ConvPlan, srcs, B, H, W, dsts=None, ps=None, lstm=None, lstm_bwd=None):
+        """The argument structure of one convolution launch -> (kind, args, plan name).  ``dsts``: list[Dst] (STORE), ``ps``: (tensor, r) with the tensor
         (B, rH, rW, cq) (PS), ``lstm``: dict(c_prev, h_out, c_out, gates_out, hd) (LSTM).  ``lstm_bwd`` (only where
         lstm_bwd_fusable(plan, ...)): the data gradient of a ConvLSTM cell with the gate backward of the chain's next frame in its
         epilogue - dict(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, hd, rec_dtype); dsts = [the input gradient] alone, the hd columns
@@ -365,7 +399,7 @@ class HipOps:
         if len(srcs) != len(plan.ksegs):
             raise L.HipKernelError(f'{plan.name}: {len(srcs)} sources for {len(plan.ksegs)} K segments')
         if plan.bf16:
-            return self._conv_bf16(plan, srcs, B, H, W, dsts, ps, lstm, lstm_bwd)
+            return 'bf16', self._conv_bf16(plan, srcs, B, H, W, dsts, ps, lstm, lstm_bwd), plan.name
         if lstm_bwd is not None:
             raise L.HipKernelError(f'{plan.name}: the fused gate backward is an epilogue of rnh_conv_bf16')
         a = L.ConvArgs()
@@ -415,9 +449,8 @@ class HipOps:
                 raise L.HipKernelError(f'{plan.name}: the Winograd kernel takes sources of one scale, without a second operand')
             a.nk = plan.wns
             a.tile = plan.wino_cols                             # RNH_WINO_COLS64 / RNH_WINO_COLS128
-            L.check(self.lib.rnh_conv_wino(C.byref(a), self._stream()), f'rnh_conv_wino({plan.name})')
-            return
-        L.check(self.lib.rnh_conv_igemm(C.byref(a), self._stream()), f'rnh_conv_igemm({plan.name})')
+            return 'wino', a, plan.name
+        return 'igemm', a, plan.name
 
     @staticmethod
     def _check_src_range(d, t, B, H, W, who):
@@ -510,7 +543,7 @@ class HipOps:
             a.c_out, a.gates_out = _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
             a.h_dtype = L.dt_of(lstm['h_out'])
             a.gates_dtype = L.dt_of(lstm['gates_out']) if lstm.get('gates_out') is not None else L.DT_F32
-        L.check(self.lib.rnh_conv_bf16(C.byref(a), self._stream()), f'rnh_conv_bf16({plan.name})')
+        return a
 
     def _wgrad_bf16(self, plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
         m = self._plan_maps(plan)

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
-ABI_VERSION = 3          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
+ABI_VERSION = 4          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -36,7 +36,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_wino_wgrad_supported', 'rnh_wino_wgrad_ws_floats', 'rnh_wino_wgrad', 'rnh_cine_gather', 'rnh_adam_step',
            'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
            # bf16-storage path
-           'rnh_conv_bf16', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
+           'rnh_conv_bf16', 'rnh_conv_bf16_pair', 'rnh_conv_wino_pair', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
            'rnh_phase_plane_m', 'rnh_struct_sizes_bf16']
 DT_F32, DT_BF16 = 0, 1
 
@@ -194,6 +194,8 @@ def load():
     lib.rnh_metrics_ws_floats.restype = i64
     lib.rnh_metrics_psnr_ssim.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, f32, f32, C.POINTER(C.c_float), vp, vp, vp]
     lib.rnh_conv_bf16.argtypes = [C.POINTER(ConvBf16Args), vp]
+    lib.rnh_conv_bf16_pair.argtypes = [C.POINTER(ConvBf16Args), C.POINTER(ConvBf16Args), vp]
+    lib.rnh_conv_wino_pair.argtypes = [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
     lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]

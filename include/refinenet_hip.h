@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 3       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld */
+#define RNH_ABI_VERSION 4       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -139,6 +139,10 @@ int rnh_pack_weights(const float *w, const float *bias, float *wp, float *biasp,
  * Results differ from rnh_conv_igemm by fp32 rounding of the transforms only.  (Replaces the same reference code as
  * rnh_conv_igemm: src/model/nets/refine_net.py:245-265 ConvLSTMCell.forward and the 3x3 convolutions of :102-133.) */
 int rnh_conv_wino(const rnh_conv_args_t *args /* host */, void *stream);
+/* TWO calls of rnh_conv_wino in ONE launch (ABI 4; the fp32 twin of rnh_conv_bf16_pair, same results as the two calls bit for bit): the cells of
+ * the forward- and the backward-direction ConvLSTM of a layer at the same wavefront slot (refine_net.py:82-93), and the data gradients of the two
+ * directions, where one call alone leaves much of the chip idle.  The two calls must agree in B, H, W, Npad, epilogue, tile and source scale. */
+int rnh_conv_wino_pair(const rnh_conv_args_t *args_a /* host */, const rnh_conv_args_t *args_b /* host */, void *stream);
 /* wp[s][xi][n][q] = (G g G^T)[xi], g = the 3x3 filter of (column n, input channel kbase[s] + q*kstride) - the mapping
  * conventions of rnh_pack_weights with 4-channel steps (q >= knv[s]: zero); biasp[n] as there. */
 int rnh_wino_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kbase,
@@ -475,6 +479,12 @@ typedef struct rnh_conv_bf16_args {
  * and serves all 9 taps, the packed weights stream from L2 into registers; the epilogue parks the accumulators in LDS so that
  * every global access is a contiguous run of a pixel's channels.  Same call sites as rnh_conv_igemm. */
 int rnh_conv_bf16(const rnh_conv_bf16_args_t *args /* host */, void *stream);
+/* TWO calls of rnh_conv_bf16 in ONE launch (ABI 4): workgroups [0, n) compute args_a, [n, 2n) args_b - the same results as the two calls,
+ * bit for bit.  For call pairs that are independent and small: the cells of the forward- and the backward-direction ConvLSTM of one layer at the
+ * same wavefront slot (reference refine_net.py:82-93 runs the two directions one after the other, 2 x F x L cell calls per stage) at the reference's
+ * own training shape (16 crops of 32 x 32, configs/train/refine_net/exp1_x4.yaml:20-33) are 128 workgroups each on a 256-CU chip.  The two calls must
+ * agree in B, H, W, Npad, ntaps, epilogue, source scale and chunk size (16 / 32 channels); everything else - sources, weights, destinations - is per call. */
+int rnh_conv_bf16_pair(const rnh_conv_bf16_args_t *args_a /* host */, const rnh_conv_bf16_args_t *args_b /* host */, void *stream);
 /* wp[ks][n][kk] (bf16, kk = 0..15 in natural order) with the index conventions of rnh_pack_weights; biasp fp32. */
 int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,
                           const int32_t *knv, const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk,

@@ -169,3 +169,57 @@ def test_graphed_step_beside_a_live_rccl_communicator(golden_dir):
     assert res[True][0] == res[False][0], (res[True][0], res[False][0])
     for k, v in res[False][1].items():
         assert torch.equal(res[True][1][k], v), k
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_paired_direction_launches_change_no_bit(dtype, monkeypatch):
+    """rnh_conv_bf16_pair / rnh_conv_wino_pair (ABI 4): at small images the engine hands the ConvLSTM cells of the two directions (same layer, same
+    wavefront slot) and their data gradients to ONE launch each.  The training step with pairing forced on must equal the step with pairing off
+    bit for bit - all 3 S T outputs, the loss, every gradient - at the reference YAML's crop size (width 64: the Winograd / bf16 MFMA kernels) and at
+    a ragged one; and the pairing decision itself: on at 16 crops of 32 x 32, off at BASELINE config 2's shape."""
+    from hipvsr.hip_ops import HipOps
+    ops = HipOps(_dev())
+    monkeypatch.delenv('RNH_PAIR', raising=False)
+    assert ops.pair_cells(16, 32, 32) and not ops.pair_cells(8, 128, 128)
+    cfg = orc.exp1_x4_config()
+    sd = orc.init_state_dict(cfg, seed=910)
+    for n, t, h, w in ((2, 2, 32, 32), (1, 2, 21, 40)):
+        inputs, targets, pos = orc.synthetic_batch(cfg, n, t, h, w, seed=911)
+        res = {}
+        for flag in ('0', '1'):
+            monkeypatch.setenv('RNH_PAIR', flag)
+            net, tr, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, dtype)
+            res[flag] = ([[o.detach().clone() for o in grp] for grp in outs], float(loss.detach()),
+                         {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        for ga, gb in zip(res['0'][0], res['1'][0]):
+            for a, b in zip(ga, gb):
+                assert torch.equal(a, b)
+        assert res['0'][1] == res['1'][1]
+        assert res['0'][2].keys() == res['1'][2].keys()
+        for k, v in res['0'][2].items():
+            assert torch.equal(v, res['1'][2][k]), (dtype, (n, t, h, w), k)
+
+
+def test_pair_entry_points_refuse_calls_of_different_geometry():
+    """The two calls of a paired launch must agree in geometry and kernel instantiation; anything else is refused with a message, not launched."""
+    from hipvsr import lib as L
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import NetConfig, state_dict_spec
+    dev = _dev()
+    cfg = NetConfig(1, 1, [64, 64, 64], num_stages=3, refine_window_size=5, upscale_factor=4, update_memory=True, num_updated_frames=6, positional_encoding=True)
+    for bf in (True, False):
+        P, ops = NetPlans(cfg, bf16=bf), HipOps(dev)
+        act = torch.bfloat16 if bf else torch.float32
+        params = {k: torch.randn(*s, device=dev) * 0.05 for k, s in state_dict_spec(cfg).items()}
+        pl = P.lstm[('forward', 1)]['full']
+        ops.pack(pl, params[pl.wkey], params[pl.bkey])
+
+        def call(n, h, w):
+            x, hp, cp = torch.randn(n, h, w, 64, device=dev).to(act), torch.randn(n, h, w, 64, device=dev).to(act), torch.randn(n, h, w, 64, device=dev)
+            return pl, [Src(x), Src(hp)], n, h, w, dict(lstm=dict(hd=64, c_prev=cp, h_out=ops.empty(n, h, w, 64, dtype=act), c_out=ops.empty(n, h, w, 64),
+                                                                   gates_out=None))
+        with pytest.raises(L.HipKernelError, match='must agree'):
+            ops.conv_pair([call(2, 16, 32), call(2, 16, 16)])
+        ops.conv_pair([call(2, 16, 32), call(2, 16, 32)])
+        torch.cuda.synchronize()

@@ -5,6 +5,8 @@ hipvsr.plans can be checked against the oracle on machines without a GPU, and (b
 compared, through the C ABI, against the semantics written here on random descriptors.  It lives under
 tests/ and is never importable from the product package.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -124,6 +126,13 @@ class TorchOps:
         tile = 64 if plan.Npad % 128 else 128
         return bool(getattr(plan, 'bf16', False) and plan.ntaps == 9 and plan.epilogue == L.EPI_STORE and plan.Npad == tile and
                     cx + hd <= tile and cx % 8 == 0 and hd % 8 == 0)
+
+    def pair_cells(self, N, H, W):
+        return os.environ.get('RNH_PAIR') == '1'                 # (the double has no launches to save: pairing only when a test asks for it)
+
+    def conv_pair(self, calls):
+        for pl, srcs, B, H, W, kw in calls:
+            self.conv(pl, srcs, B, H, W, **kw)
 
     def conv(self, plan, srcs, B, H, W, dsts=None, ps=None, lstm=None, lstm_bwd=None):
         if lstm_bwd is not None:
