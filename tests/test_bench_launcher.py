@@ -67,7 +67,8 @@ def test_rank_cpu_map_splits_each_numa_node_among_its_ranks():
 def test_apply_rank_affinity_takes_the_launchers_cpus(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
-    mine = sorted(os.sched_getaffinity(0))
+    import torch
+    mine, threads = sorted(os.sched_getaffinity(0)), torch.get_num_threads()
     try:
         monkeypatch.setenv('BENCH_RANK_CPUS', json.dumps({'0': mine[:1], '1': mine[-1:]}))
         assert bench.apply_rank_affinity(1) == mine[-1:] and sorted(os.sched_getaffinity(0)) == mine[-1:]
@@ -75,6 +76,7 @@ def test_apply_rank_affinity_takes_the_launchers_cpus(monkeypatch):
         assert bench.apply_rank_affinity(0) is None
     finally:
         os.sched_setaffinity(0, mine)
+        torch.set_num_threads(threads)          # (the CPU oracle is bit-exact against the goldens at the thread count they were made with)
 
 
 def test_gpus_2_without_world_size_starts_two_ranks():
