@@ -322,12 +322,12 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
             voa[i][0] = (v && cc < anch) ? o : -1;
             voa[i][1] = (v && cc + 8 < anch) ? o + 32 : -1;
         }
-        // Loads with masked lanes: round 1 saw a load whose 64 lanes are ALL out of range return ahead of older loads (wrong workgroups on border
-        // rows, wholesale with 4-channel sources) and drained while one was among the younger loads; round 4 widened that to ANY masked lane while
-        // hunting the wrong steps that turned out to be the copied tail registers described at the K loop below.  tools/probes/oob_order.hip finds
-        // out-of-range loads in order on this hardware, and a build without this drain (-DRNH_IGEMM_NO_MASK_DRAIN) is exact in 3000 cold steps and
-        // passes the 174 parity tests (profiles/r04_at_*): round 1's wrong workgroups were most likely the tail copies too.  The drain only costs the
-        // waves of the image border; it stays until more boxes have seen the build without it.
+        // Loads with masked lanes.  Round 1 saw wrong workgroups on border rows and drained the queue whenever a load with ALL lanes out of range was
+        // among the younger ones; round 4 widened that to any masked lane while hunting wrong steps - whose cause turned out to be the copied tail
+        // registers described at the K loop below, most likely round 1's too.  Vector-memory operations of a wave complete in issue order, masked or
+        // not (MI355X_MICROARCH.md; tools/probes/oob_order.hip, tools/probes/lds_dma_oob.hip), and the build without the drain is exact in 3000 cold
+        // steps on one box (round 4, profiles/r04_at_*), 3700 on a second (round 5, profiles/r05_u_*) and passes the GPU suite: since round 5 the
+        // counted waits stand alone.  -DRNH_IGEMM_MASK_DRAIN brings the drain back (diagnostic build).
         fm_prev = fm_cur;
         fm_cur = false;
 #pragma unroll
@@ -337,8 +337,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
     auto drain_if_unordered = [&]() {
 #ifdef RNH_IGEMM_DRAIN_ALL                            // diagnostic build: a full drain in front of every half step
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif defined(RNH_IGEMM_NO_MASK_DRAIN)                 // diagnostic build: counted waits everywhere, also with masked lanes among the younger loads
-#else
+#elif defined(RNH_IGEMM_MASK_DRAIN)                    // diagnostic build: the drain of rounds 1-4 whenever a masked lane is among the younger loads
         if (fm_cur || fm_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     };
