@@ -355,17 +355,12 @@ class HipOps:
 
     # ---- convolution --------------------------------------------------------------------------------
     # ---- two independent calls of equal geometry in one launch ---------------------------------------------------------------------------
-    PAIR_BELOW = 512       # workgroups: a cell launch smaller than one full round of the chip (256 CUs x 2 workgroups) is paired with its twin
-
     def pair_cells(self, N, H, W):
-        """Should the engine hand the ConvLSTM cells of the two directions (same layer, same wavefront slot) to conv_pair?  Yes where one cell
-        launch leaves the chip under-filled - the reference YAML's training shape (16 crops of 32 x 32: 128 workgroups per cell) - no at the
-        benchmark shapes (1024 workgroups).  RNH_PAIR=1 / 0 forces it on / off."""
-        env = os.environ.get('RNH_PAIR')
-        if env in ('0', '1'):
-            return env == '1'
-        tiles = N * (-(-H // 8)) * (-(-W // 32)) * 2               # 8 x 32 pixel tiles x two 128-column tiles (the bf16 cell; the fp32 one is similar)
-        return tiles < self.PAIR_BELOW
+        """Should the engine hand the ConvLSTM cells of the two directions (same layer, same wavefront slot) - and their data gradients - to conv_pair?
+        Yes: at the reference YAML's training shape (16 crops of 32 x 32: 128 workgroups per cell launch on 256 CUs) it is the difference between
+        19.6 and 14.8 ms per bf16 step, at BASELINE config 2 (1024 workgroups per cell) still 0.5-0.8 % (half as many launches and event waits;
+        profiles/r05_q_*, r05_w_*).  RNH_PAIR=0 switches it off (A/B runs)."""
+        return os.environ.get('RNH_PAIR', '1') != '0'
 
     def conv_pair(self, calls):
         """``calls``: two argument tuples (plan, srcs, B, H, W, kwargs) of conv().  Same results as the two conv() calls, bit for bit; ONE launch

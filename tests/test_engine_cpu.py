@@ -502,3 +502,23 @@ def test_an_exception_inside_the_engine_drains_the_side_streams_before_it_propag
     with pytest.raises(Boom):
         eng.backward(params, ctx, torch.ones_like(O) * 1e-3)
     assert ops.quiesced == 2
+
+
+@pytest.mark.parametrize('case,dtype', [('x4_pos1_mem1', 'f32'), ('x2_pos1_mem0', 'f32'), ('x4_pos1_mem1', 'bf16'), ('x3_pos0_mem1', 'bf16')])
+def test_engine_with_paired_direction_launches_matches_reference_golden(g1, case, dtype, monkeypatch):
+    """The product pairs the two directions' ConvLSTM cells (and data gradients) of a layer into one launch on one stream per layer
+    (ops.conv_pair, rnh_conv_*_pair).  The double executes a pair as its two calls in turn: what is checked here is the engine's paired wavefront -
+    forward, the fused and the unfused back-propagation through time - against the reference's outputs and gradients, and against the unpaired run."""
+    c = g1[case]
+    monkeypatch.setenv('RNH_PAIR', '0')
+    _, O0, t0, g0 = run_engine(c, dtype=dtype)
+    monkeypatch.setenv('RNH_PAIR', '1')
+    cfg, O1, t1, grads = run_engine(c, dtype=dtype)
+    assert torch.equal(O0, O1) and torch.equal(t0, t1)
+    for k, v in g0.items():
+        assert (v is None and grads[k] is None) or torch.equal(v, grads[k]), k
+    if dtype == 'f32':
+        torch.testing.assert_close(t1, c['train_loss'], atol=1e-5, rtol=1e-5)
+        for k, gref in c['grads'].items():
+            if gref is not None:
+                assert float((grads[k] - gref).abs().max()) <= 2e-4 * float(gref.abs().max()) + 1e-7, k
