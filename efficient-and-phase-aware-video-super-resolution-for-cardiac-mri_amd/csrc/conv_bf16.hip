@@ -65,6 +65,14 @@ __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned sho
 #ifndef RNH_M16
 #define RNH_M16 0
 #endif
+// RNH_W8 = 1 (A/B build, NOT the product): the waves of a 128-column 3x3 workgroup are its four 32-column groups, each over ALL eight tile rows (8 x 1
+// accumulator blocks) instead of (pixel half) x (column half) with 4 x 2 blocks: a weight fragment then feeds eight MFMAs instead of four and no two waves
+// of a workgroup stream the same fragment (L2 -> register traffic per MFMA halves), at twice the halo-fragment LDS reads per MFMA.  Measured in round 5:
+// bit-identical, 1-2 % SLOWER (cell 79.4 against 78.0 us, refine conv1 2.91 against 2.85 ms, bf16 step 79.0 against 78.5 ms; profiles/r05_x_*): operand
+// bytes per MFMA go from 0.75 to 1.125 KB - the 4 x 2 block shape is the one that moves the fewest, and the launch's time follows the bytes, not where they come from.
+#ifndef RNH_W8
+#define RNH_W8 0
+#endif
 
 // (experiment, tools/experiments/r05_prio.sh: s_setprio RNH_PRIO for the main loop, RNH_PRIO_EPI for the epilogue - every combination of
 // 0..3 measured within noise of no s_setprio at all, profiles/r05_d_setprio.txt; the product build issues none)
@@ -151,6 +159,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     constexpr int KS = G::KS, APITCH = G::APITCH, PPP = G::PPP;
     constexpr bool M16 = G::M16;
     constexpr int PLANE = G::PLANE, NB16 = NCOLS / 32;               // 16-column blocks of a wave (its NCOLS / 2 columns)
+    constexpr bool W8 = RNH_W8 && NCOLS == 128 && NTAPS == 9 && !M16;   // wave = (all 8 tile rows) x (32-column group `wave`)
     static_assert(NTAPS % 3 == 0 || NTAPS == 1, "the fragment ring has three sets");
     static_assert(KC == 16 || (KC == 32 && NTAPS == 9), "32-channel chunks serve the 3x3 kernels");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
@@ -262,30 +271,67 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
 
     // weight fragments: descriptor over the packed weights, per-lane offset inside a (chunk, tap) slab, slab stride
     const __amdgpu_buffer_rsrc_t wrs = bdesc(P.wp);
-    const int wlane = ((nt * NCOLS + chalf * (NCOLS / 2) + l31) * 16 + kh * 8) * 2;
+    const int wlane = ((nt * NCOLS + (W8 ? wave * 32 : chalf * (NCOLS / 2)) + l31) * 16 + kh * 8) * 2;
     const int slab = P.Npad * 32;                               // bytes of one (chunk, tap) slab
     constexpr int RING = NTAPS == 1 ? 1 : (M16 ? 1 : (KC == 32 ? 6 : 3)), AHEAD = RING - 1;
     constexpr int NSTEP = NTAPS * KS;                            // (tap, k step) pairs per chunk; NSTEP % RING == 0: the set of a step is static
     static_assert(NTAPS == 1 || NSTEP % RING == 0, "the fragment ring must divide the steps of a chunk");
-    uint4 bq[RING][NB];
+    constexpr int NBW = W8 ? 1 : NB;                                // 32-column blocks of a wave
+    uint4 bq[RING][NBW];
     const int nch = P.nchunks / KS;
     // fragments of step sa of chunk c (sa >= NSTEP: of the chunks behind it): slab (16-channel chunk KS * chunk + ks, tap).  sa is a compile-time
     // constant at every call site, so tap, k step and chunk increment are too: the slab's byte offset is ONE scalar multiply-add and goes into the
     // load's scalar offset, the per-lane offsets never change (round 4; until then a division by NSTEP per step - 14 SALU + 4 VALU instructions
     // in front of every 8 MFMAs).  Behind the last chunk the fragments are never used: the last chunk's are read again.
-    int wvo[NB];
+    int wvo[NBW];
 #pragma unroll
-    for (int n = 0; n < NB; ++n) wvo[n] = wlane + n * 32 * 32;
+    for (int n = 0; n < NBW; ++n) wvo[n] = wlane + n * 32 * 32;
     auto bload = [&](int c, int sa, int set) {
         const int q = sa / NSTEP, r = sa - q * NSTEP, tap = r / KS, ks = r - tap * KS;
         const int cc = c + q < nch ? c + q : nch - 1;
         const int base = (cc * KS + ks) * NTAPS * slab + tap * slab;
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bq[set][n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[n], base, 0));
+        for (int n = 0; n < NBW; ++n) bq[set][n] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[n], base, 0));
     };
 
-    f32x16 acc[M16 ? 1 : MB][M16 ? 1 : NB];
-    if constexpr (!M16) {
+    // (W8) accumulator block m = tile row m, the wave's 32 columns; a HALF step = (tap, k step, tile rows 0-3 / 4-7): 4 A fragments (ring of three
+    // sets, requested two half steps = 8 MFMAs ahead), 4 MFMAs; the step's one B fragment serves both half steps
+    [[maybe_unused]] f32x16 acc8[W8 ? 2 * MB : 1];
+    if constexpr (W8) {
+#pragma unroll
+        for (int m = 0; m < 2 * MB; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc8[m][v] = 0.f;
+    }
+    [[maybe_unused]] auto compute8 = [&](int buf, int c) {
+        const unsigned char *Ab = smem + buf * A_BYTES + l31 * APITCH + kh * 16;
+        bf16x8 a[3][MB];
+        auto afrags = [&](int hs, int set) {
+            const int step = hs >> 1, half = hs & 1, tap = step / KS, ks = step - tap * KS, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[set][m] = *reinterpret_cast<const bf16x8 *>(Ab + ((half * MB + m + dy) * HPW + dx) * APITCH + ks * 32);
+        };
+        afrags(0, 0);
+        afrags(1, 1);
+#pragma unroll
+        for (int hs = 0; hs < 2 * NSTEP; ++hs) {
+            const int step = hs >> 1, half = hs & 1;
+            if (hs + 2 < 2 * NSTEP) afrags(hs + 2, (hs + 2) % 3);
+            if (half == 0) bload(c, step + AHEAD, (step + AHEAD) % RING);
+            if (hs == 4 * KS) {
+                if (c + 1 < nch) store_chunk(buf ^ 1);
+                if (c + 2 < nch) load_chunk();
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                acc8[W8 ? half * MB + m : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[hs % 3][m], __builtin_bit_cast(bf16x8, bq[step % RING][0]),
+                                                                                      acc8[W8 ? half * MB + m : 0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x16 acc[(M16 || W8) ? 1 : MB][(M16 || W8) ? 1 : NB];
+    if constexpr (!M16 && !W8) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -347,7 +393,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     // One chunk.  The halo of chunk c + 1 sits in registers since step 2 KS of chunk c - 1 (a whole chunk of MFMAs ago, so the
     // wait in store_chunk costs nothing); at step 2 KS it goes to the other LDS buffer - nobody reads that one before the
     // barrier at the end of this chunk - and the loads of chunk c + 2 are issued into the same registers.
-    auto compute = [&](int buf, int c) {
+    [[maybe_unused]] auto compute = [&](int buf, int c) {
+        if constexpr (!M16 && !W8) {
         const unsigned char *Ab = smem + buf * A_BYTES + (MB * ph * HPW + l31) * APITCH + kh * 16;
         bf16x8 a[2][MB];
         auto afrags = [&](int step, int set) {
@@ -373,6 +420,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                                                                         __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
             if constexpr (NTAPS == 1) bload(c + 1, 0, 0);
             if constexpr (NTAPS == 9) __builtin_amdgcn_sched_barrier(0);     // pin the issue order: hipcc otherwise sinks the weight loads to their first use
+        }
         }
     };
 
@@ -402,6 +450,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     for (int c = 0; c < nch; ++c) {
         BSTAMP(8 + 3 * (c & 15));
         if constexpr (M16) compute16(c & 1, c);
+        else if constexpr (W8) compute8(c & 1, c);
         else compute(c & 1, c);
         BSTAMP(9 + 3 * (c & 15));
         BSTAMP(10 + 3 * (c & 15));
@@ -415,11 +464,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     if (RNH_EXP & 16) {                                         // keep the accumulators alive, skip the epilogue
         float s = 0.f;
 #pragma unroll
-        for (int m = 0; m < (M16 ? 1 : MB); ++m)
+        for (int m = 0; m < ((M16 || W8) ? 1 : MB); ++m)
 #pragma unroll
-            for (int n = 0; n < (M16 ? 1 : NB); ++n)
+            for (int n = 0; n < ((M16 || W8) ? 1 : NB); ++n)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) s += acc[m][n][v];
+        if constexpr (W8) {
+#pragma unroll
+            for (int m = 0; m < 2 * MB; ++m)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s += acc8[m][v];
+        }
         if constexpr (M16) {
 #pragma unroll
             for (int b = 0; b < 2 * MB; ++b)
@@ -500,7 +555,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         bw_fast = NCOLS == 128 && P.hd == 64 && P.dst[0].ncols == 64 && P.bw_dh_dtype == RNH_DT_BF16 && P.gates_dtype == RNH_DT_BF16 && !(RNH_EXP & 512);
     }
     float bv[M16 ? NB16 : NB];
-    if constexpr (M16) {
+    if constexpr (W8) {
+        bv[0] = P.bias ? P.bias[nt * NCOLS + wave * 32 + l31] : 0.f;
+    } else if constexpr (M16) {
 #pragma unroll
         for (int j = 0; j < NB16; ++j) bv[j] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + j * 16 + l15] : 0.f;
     } else {
@@ -508,7 +565,13 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int n = 0; n < NB; ++n) bv[n] = P.bias ? P.bias[nt * NCOLS + chalf * (NCOLS / 2) + n * 32 + l31] : 0.f;
     }
     auto park = [&](int m, float *ob) {                             // row block m of this wave -> pixels 32 ph .. 32 ph + 31 of the image
-        if constexpr (M16) {                                        // C / D of 16x16x32: column l & 15, rows 4 (l >> 4) + v
+        if constexpr (W8) {                                         // tile rows m and MB + m of the wave's 32 columns -> pixels 0 .. 31 and 32 .. 63
+            const int col = wave * 32 + l31;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) ob[(hh * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc8[W8 ? hh * MB + m : 0][v] + bv[0];
+        } else if constexpr (M16) {                                        // C / D of 16x16x32: column l & 15, rows 4 (l >> 4) + v
 #pragma unroll
             for (int xh = 0; xh < 2; ++xh)
 #pragma unroll
@@ -523,7 +586,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
                 const int col = chalf * (NCOLS / 2) + n * 32 + l31;
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    ob[(ph * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc[M16 ? 0 : m][M16 ? 0 : n][v] + bv[n];
+                    ob[(ph * TW + (v & 3) + 8 * (v >> 2) + 4 * kh) * G::OPITCH + col] = acc[(M16 || W8) ? 0 : m][(M16 || W8) ? 0 : n][v] + bv[n];
             }
         }
     };
