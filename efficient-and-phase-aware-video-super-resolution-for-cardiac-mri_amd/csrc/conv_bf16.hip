@@ -24,6 +24,7 @@
 // image-row segment, k = channel inside the chunk.
 #include "conv_bf16_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -591,9 +592,6 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         }
     };
     park(0, ot0);
-    if constexpr (EPI == RNH_EPI_LSTM_BWD) {                        // (behind the first park: 32 accumulator registers fewer are live beside the 88 of the operands)
-        if (bw_fast) bw_issue(0);
-    }
     __syncthreads();
     BSTAMP(2);
     if constexpr (EPI == RNH_EPI_LSTM) {
@@ -625,10 +623,19 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         dptr = D.ptr, ddt = D.dtype, dacc = D.accumulate, dC = D.C, dch = D.c0 + (n0 - cbase), dimg = img + D.img_off;
     }
 
+    // The four rounds.  `fast` (LSTM_BWD only) selects the gate-item form at COMPILE time inside the loop; the run-time choice between the two forms
+    // is made once, around the whole loop - so that on the prefetching path no other path's code sits between an asm load and its wait (the compiler
+    // reuses the registers of in-flight prefetches on a path where they are dead: tests/test_isa_guards.py follows the control flow to check that the
+    // path that waits for them never does)
+    auto rounds = [&](auto fast_) {
+    constexpr bool FAST = decltype(fast_)::value;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const float *ot = ot0 + (r & 1) * OBUF;
         BSTAMP(40 + 4 * r);
+        if constexpr (FAST) {
+            if (r == 0) bw_issue(0);                                // (round 0's operands: under the park of round 1; the later rounds' a whole round ahead)
+        }
         if (r + 1 < ROUNDS) park(r + 1, ot0 + ((r + 1) & 1) * OBUF);   // (its image was last read in round r - 1, in front of the last barrier)
         BSTAMP(41 + 4 * r);
         // pixel p of the image = tile row (p >> 5) * MB + r, column p & 31
@@ -675,7 +682,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             // image holds the input gradient in columns [0, ncx) and dh_rec, the recurrent part of that frame's dh, in the next hd columns.
             const rnh_mdst_t &D = P.dst[0];
             const int ncx = D.ncols, ncx8 = ncx >> 3, hd = P.hd, hd8 = hd >> 3;
-            if (bw_fast) {
+            if constexpr (FAST) {
                 // the gate items of this round from the operands requested a round ago (bw_issue), then the requests of the next round, then the
                 // input-gradient items
                 const float *dcn = P.bw_dc_next, *cprev = P.bw_c_prev;
@@ -844,6 +851,13 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         BSTAMP(42 + 4 * r);
         if (r + 1 < ROUNDS) __syncthreads();                        // image (r + 1) & 1 is written, image r & 1 is read
         BSTAMP(43 + 4 * r);
+    }
+    };
+    if constexpr (EPI == RNH_EPI_LSTM_BWD) {
+        if (bw_fast) rounds(std::true_type{});
+        else rounds(std::false_type{});
+    } else {
+        rounds(std::false_type{});
     }
     BSTAMP(3);
     WGTRACE(2);

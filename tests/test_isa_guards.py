@@ -243,3 +243,116 @@ def test_half_domain_weight_gradient_kernel_fits_two_workgroups_per_cu(tmp_path)
     lines = kernels[0][1]
     assert not any(ln.startswith('scratch_') for ln in lines)
     assert sum(ln.startswith('v_mfma_f32_32x32x2') for ln in lines) >= 2 * 4 * 16 * 2            # both halves x 4 groups x 16 MFMAs x (steady state + peeled last quad)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
+def test_bf16_convolution_epilogue_prefetches_are_not_touched_before_their_wait(tmp_path):
+    """conv_bf16d_kernel (csrc/conv_bf16.hip) requests the previous cell state (LSTM epilogue) and, since round 5, the eleven operands of a round's
+    gate items (LSTM_BWD epilogue) with inline-asm global_load_dwordx4 a whole round ahead and waits for them with an asm `s_waitcnt vmcnt(0)` that
+    names them.  hipcc does not know those registers are in flight: between an asm load and the asm wait behind it NO instruction may name one of
+    its target registers - no v_mov that splits a live range, no spill store, no reuse as a temporary (the LSTM_BWD instantiations do spill a few
+    registers at times: they must be other ones).  The check follows the control flow (a forward data-flow analysis over the basic blocks, union at joins):
+    the run-time choice between the prefetching and the generic form of the LSTM_BWD rounds is made once, around all four rounds, so that on the path
+    that waits for a prefetch no other path's code - where those registers are dead and free for reuse - lies between the load and the wait."""
+    src = os.path.join(CSRC, 'conv_bf16.hip')
+    out = os.path.join(str(tmp_path), 'conv_bf16.s')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-S', '--cuda-device-only',
+                    '-o', out, src], check=True, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    reg_re = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+
+    def named(s):
+        regs = set()
+        for a, b, c in reg_re.findall(s):
+            regs.update(range(int(a), int(b) + 1) if a else [int(c)])
+        return regs
+
+    def analyse(body):
+        """Forward data flow over the kernel's basic blocks: the set of registers with an asm load in flight at every instruction (union at joins)."""
+        blocks, cur, label_of = [], [], {}
+        in_asm = False
+        for raw in body:
+            ln = raw.strip()
+            if ln.startswith(';;#ASMSTART'):
+                in_asm = True
+                continue
+            if ln.startswith(';;#ASMEND'):
+                in_asm = False
+                continue
+            if not ln or ln.startswith(';'):
+                continue
+            if re.match(r'^\.LBB\d+_\d+:', ln):
+                if cur:
+                    blocks.append(cur)
+                cur = []
+                label_of[ln.split(':')[0]] = len(blocks)
+                continue
+            if ln.startswith('.'):
+                continue
+            cur.append((ln.split(';')[0].strip(), in_asm))
+            if ln.startswith(('s_branch', 's_cbranch', 's_endpgm')):
+                blocks.append(cur)
+                cur = []
+        if cur:
+            blocks.append(cur)
+        succ = []
+        for i, b in enumerate(blocks):
+            last = b[-1][0] if b else ''
+            out = []
+            if last.startswith(('s_branch', 's_cbranch')):
+                out.append(label_of[last.split()[-1]])
+            if not last.startswith(('s_branch', 's_endpgm')) and i + 1 < len(blocks):
+                out.append(i + 1)
+            succ.append(out)
+
+        def transfer(b, state, report):
+            state = set(state)
+            for ins, asm in b:
+                if asm:
+                    ld = re.match(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', ins)
+                    if ld:
+                        state.update(range(int(ld.group(1)), int(ld.group(2)) + 1))
+                        report['loads'] += 1
+                    elif ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
+                        state.clear()
+                        report['waits'] += 1
+                    continue
+                if ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
+                    state.clear()
+                    continue
+                hit = state & named(ins.split(None, 1)[1] if ' ' in ins else '')
+                if hit:
+                    report['bad'].append((ins, sorted(hit)[:4]))
+            return state
+
+        ins_state = [None] * len(blocks)
+        ins_state[0] = frozenset()
+        work = [0]
+        while work:
+            i = work.pop()
+            out = frozenset(transfer(blocks[i], ins_state[i], {'loads': 0, 'waits': 0, 'bad': []}))
+            for j in succ[i]:
+                new = out if ins_state[j] is None else ins_state[j] | out
+                if new != ins_state[j]:
+                    ins_state[j] = new
+                    work.append(j)
+        report = {'loads': 0, 'waits': 0, 'bad': []}
+        left = set()
+        for i, b in enumerate(blocks):
+            if ins_state[i] is not None:
+                end = transfer(b, ins_state[i], report)
+                if b and b[-1][0].startswith('s_endpgm'):
+                    left |= end
+        return report, left
+
+    checked = 0
+    for m in re.finditer(r'^(_Z\S*conv_bf16d_kernelILi[23]E\S*):\s*;', text, re.M):        # the LSTM and LSTM_BWD instantiations
+        body = text[m.end():text.index('.Lfunc_end', m.end())].split('\n')
+        report, left = analyse(body)
+        if report['loads'] == 0:                              # (the 64-column LSTM_BWD instantiations: no prefetching form)
+            continue
+        assert report['loads'] >= 8 and report['waits'] >= 1, (m.group(1), report['loads'], report['waits'])
+        assert not left, (m.group(1), 'asm loads without a wait behind them', sorted(left)[:8])
+        assert not report['bad'], (m.group(1), len(report['bad']), report['bad'][:6])
+        checked += 1
+    assert checked >= 4
