@@ -72,6 +72,7 @@ class HipOps:
         self.lib = L.load()
         self._maps = {}        # id(plan) -> dict of device int32 arrays
         self._packed = {}      # id(plan) -> (wp, biasp)
+        self._maps44, self._packed44 = {}, {}      # the same for the F(4x4, 3x3) form of the ConvLSTM cell plans
         self._ws = {}
         self._ws_retired = []   # outgrown scratch buffers a captured HIP graph may still address (see _workspace)
         self.graph_captures = 0
@@ -312,7 +313,79 @@ class HipOps:
         return m
 
     def pack(self, plan: ConvPlan, w, b=None):
-        """Re-lay the OIHW weight (and bias) of ``plan`` into the kernel's [nk][Npad][16] slabs."""
+        """Re-lay the OIHW weight (and bias) of ``plan`` into the kernel's [nk][Npad][16] slabs (and, for a ConvLSTM cell plan that may run in
+        F(4x4, 3x3) form, into that kernel's layout as well)."""
+        self._pack(plan, w, b)
+        if getattr(plan, 'wino44', False):
+            self._pack44(plan, w, b)
+
+    # ---- the ConvLSTM cell in Winograd form F(4x4, 3x3): rnh_wino44_* (csrc/conv_wino44.hip) ---------------------------------------------
+    def _pack44(self, plan, w, b):
+        from .plans import lstm_colmap64
+        hd = plan.Cout // 4
+        m = self._maps44.get(id(plan))
+        if m is None:
+            kch = [sg.kbase + c if c < sg.nvalid else -1 for sg in plan.ksegs for c in range(sg.nch)]
+            m = self._maps44[id(plan)] = dict(kch=self._i32(kch), colmap=self._i32(lstm_colmap64(hd)), K=len(kch), _plan=plan)
+        K, Npad = m['K'], 4 * hd
+        buf = self._packed44.get(id(plan))
+        if buf is None:
+            buf = self._packed44[id(plan)] = (self.empty(K // 8 * 36 * Npad * 8), self.empty(Npad))
+        L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
+                                                 plan.Cin, self._stream()), f'rnh_wino44_pack_weights({plan.name})')
+
+    def wino44_ok(self, plan, B, H, W):
+        """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it, the images whole 4x4 tiles,
+        and the launch at least RNH_WINO44_MIN (default 1024) workgroups of 512 pixels x 64 columns - four rounds of the chip: below that the
+        F(2x2) kernel's 128-pixel workgroups fill it better.  RNH_WINO44=0 switches the form off, RNH_WINO44=force drops the size condition."""
+        mode = os.environ.get('RNH_WINO44', '1')
+        if mode == '0' or id(plan) not in self._packed44 or (H & 3) or (W & 3):
+            return False
+        wgs = -(-(B * (H // 4) * (W // 4)) // 32) * (plan.Cout // 64)
+        return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1024'))
+
+    def wino44_v(self, B, H, W, nch, frames=1):
+        """Buffer(s) for the transformed form of ``frames`` tensors (B, H, W, nch): a (frames, floats) tensor."""
+        return self.empty(frames, int(self.lib.rnh_wino44_v_floats(B, H, W, nch)))
+
+    def wino44_transform(self, s: Src, B, H, W, out):
+        """out = B^T d B of the source's channels (rnh_wino44_transform); the source as conv() takes it (scale 1, no second operand)."""
+        t = s.t
+        self._chk(t, out)
+        nch = t.shape[-1] - s.c0 if s.nch is None else s.nch
+        if s.scale != 1 or s.add is not None or tuple(t.shape[1:3]) != (H, W) or s.img_off < 0 or s.img_off + B > t.shape[0]:
+            raise L.HipKernelError('wino44_transform: a plain source of the output geometry')
+        if out.numel() != int(self.lib.rnh_wino44_v_floats(B, H, W, nch)):
+            raise L.HipKernelError('wino44_transform: output size')
+        L.check(self.lib.rnh_wino44_transform(t.data_ptr() + s.img_off * H * W * t.shape[-1] * 4, t.shape[-1], s.c0, nch, B, H, W, _ptr(out), self._stream()),
+                'rnh_wino44_transform')
+
+    def wino44_cell(self, plan, vsrcs, B, H, W, lstm):
+        """One ConvLSTM cell on its transformed sources ``vsrcs`` (tensors of wino44_transform, in the order of the plan's K segments);
+        ``lstm`` as for conv()."""
+        if id(plan) not in self._packed44:
+            raise L.HipKernelError(f'{plan.name}: weights were not packed for the F(4x4, 3x3) form')
+        if len(vsrcs) != len(plan.ksegs):
+            raise L.HipKernelError(f'{plan.name}: {len(vsrcs)} sources for {len(plan.ksegs)} K segments')
+        hd = lstm['hd']
+        a = L.Wino44CellArgs()
+        for i, (v, sg) in enumerate(zip(vsrcs, plan.ksegs)):
+            self._chk(v)
+            if v.numel() != int(self.lib.rnh_wino44_v_floats(B, H, W, sg.nch)):
+                raise L.HipKernelError(f'{plan.name}: transformed source {i} size')
+            a.v[i], a.vchunks[i] = v.data_ptr(), sg.nch // 16
+        for k in ('c_prev', 'h_out', 'c_out', 'gates_out'):
+            t = lstm.get(k)
+            self._chk(t)
+            if t is not None and tuple(t.shape) != (B, H, W, hd * (4 if k == 'gates_out' else 1)):
+                raise L.HipKernelError(f'{plan.name}: {k} shape {tuple(t.shape)}')
+        wp, bp = self._packed44[id(plan)]
+        a.nsrc, a.B, a.H, a.W, a.Npad, a.hd = len(vsrcs), B, H, W, 4 * hd, hd
+        a.wp, a.bias = wp.data_ptr(), bp.data_ptr()
+        a.c_prev, a.h_out, a.c_out, a.gates_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out']), _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
+        L.check(self.lib.rnh_wino44_cell(C.byref(a), self._stream()), f'rnh_wino44_cell({plan.name})')
+
+    def _pack(self, plan: ConvPlan, w, b=None):
         self._chk(w, b)
         if tuple(w.shape) != (plan.Cout, plan.Cin) + ((3, 3) if plan.ntaps == 9 else (1, 1)):
             raise L.HipKernelError(f'{plan.name}: weight shape {tuple(w.shape)} does not match the plan')

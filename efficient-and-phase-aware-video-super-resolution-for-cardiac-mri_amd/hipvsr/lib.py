@@ -12,7 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
-ABI_VERSION = 4          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
+ABI_VERSION = 5          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -37,7 +37,9 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_metrics_ws_floats', 'rnh_metrics_psnr_ssim',
            # bf16-storage path
            'rnh_conv_bf16', 'rnh_conv_bf16_pair', 'rnh_conv_wino_pair', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
-           'rnh_phase_plane_m', 'rnh_struct_sizes_bf16']
+           'rnh_phase_plane_m', 'rnh_struct_sizes_bf16',
+           # F(4x4, 3x3) ConvLSTM cell (ABI 5)
+           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -63,6 +65,13 @@ class Src(C.Structure):
 class Dst(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('C', C.c_int32), ('c0', C.c_int32), ('ncols', C.c_int32),
                 ('accumulate', C.c_int32), ('img_off', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Wino44CellArgs(C.Structure):
+    """rnh_wino44_cell_args_t"""
+    _fields_ = [('v', C.c_void_p * 2), ('vchunks', C.c_int32 * 2), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Npad', C.c_int32), ('hd', C.c_int32), ('_pad', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p), ('c_prev', C.c_void_p),
+                ('h_out', C.c_void_p), ('c_out', C.c_void_p), ('gates_out', C.c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -196,6 +205,11 @@ def load():
     lib.rnh_conv_bf16.argtypes = [C.POINTER(ConvBf16Args), vp]
     lib.rnh_conv_bf16_pair.argtypes = [C.POINTER(ConvBf16Args), C.POINTER(ConvBf16Args), vp]
     lib.rnh_conv_wino_pair.argtypes = [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp]
+    lib.rnh_wino44_v_floats.argtypes = [i32, i32, i32, i32]
+    lib.rnh_wino44_v_floats.restype = i64
+    lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
     lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]

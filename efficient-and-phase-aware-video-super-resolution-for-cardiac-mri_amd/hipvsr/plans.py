@@ -277,6 +277,10 @@ class NetPlans:
                     full, first = mk(lcm, False)
                 for pl_ in (full, first):                           # hidden channels per column group of the gate layout
                     pl_.gate_group = 16 if len(lcm) == 64 * ((hd + 15) // 16) and lcm == lstm_colmap64(hd) else 32
+                    # eligible for the F(4x4, 3x3) form of the cell (rnh_wino44_cell: csrc/conv_wino44.hip)?  fp32, whole 16-channel chunks,
+                    # an even number of them, hidden channels in sixteens; HipOps.wino44_ok decides per call (image size, launch size)
+                    pl_.wino44 = (not bf and wino and hd % 16 == 0 and all(sg.nch % 16 == 0 and sg.nvalid == sg.nch for sg in pl_.ksegs)
+                                  and sum(sg.nch for sg in pl_.ksegs) % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0')
                 dgrad = ConvPlan_(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
                                  wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
                 wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 4       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair */
+#define RNH_ABI_VERSION 5       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_* */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -516,6 +516,38 @@ int rnh_lstm_gates_bwd_m(const void *dh, int dh_dt, const void *dh2, int dh2_dt,
 int rnh_cast(const void *src, int src_dt, void *dst, int dst_dt, int64_t n, void *stream);   /* n % 8 == 0 */
 /* out[(f*N + n)][y][x][0..8) = (pos[n*F + f], 0, ..., 0): the phase plane as an 8-channel source of either type */
 int rnh_phase_plane_m(const float *pos /* [N][F] */, void *out, int out_dt, int N, int F, int H, int W, void *stream);
+
+/* ---- The ConvLSTM cell in Winograd form F(4x4, 3x3) (csrc/conv_wino44.hip; ABI 5) -------------------------------------------------------
+ * 2.25 multiplications per output (F(2x2, 3x3): 4, direct: 9), true fp32 arithmetic.  The input transform is a kernel of its own:
+ * rnh_wino44_transform writes V = B^T d B of `nch` channels [c0, c0 + nch) of an NHWC tensor x [B][H][W][C] (H, W multiples of 4; nch a multiple
+ * of 16; zero padding of 1 as nn.Conv2d(padding=1)) into v, rnh_wino44_v_floats(B, H, W, nch) floats, laid out
+ *   [tile block of 32 tiles][16-channel chunk][position xi = 6 i + j of the 6x6 domain][tile][16 channels, 16-byte pieces swizzled by tile]
+ * = the image rnh_wino44_cell copies to LDS as it is.  A cell output h is transformed once and serves both cells that read it (reference
+ * refine_net.py:88-93: the next frame of its layer, the same frame of the next layer). */
+int64_t rnh_wino44_v_floats(int B, int H, int W, int nch);
+int rnh_wino44_transform(const float *x, int C, int c0, int nch, int B, int H, int W, float *v, void *stream);
+/* wp[s8][xi][n][kh][m] = (G g G^T)[xi], g = the 3x3 filter w[colmap[n]][kch[8 s8 + 4 kh + m]] (w OIHW [Cout][Cin][3][3]; kch [K] = the
+ * weight's input channel of every K slot in the order the transformed sources are passed to rnh_wino44_cell, colmap [Npad]; device int32
+ * arrays, negative = zero); wp: K / 8 * 36 * Npad * 8 floats; biasp[n] = bias[colmap[n]].  K a multiple of 32, Npad of 64. */
+int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *colmap, int K, int Npad,
+                            int Cout, int Cin, void *stream);
+typedef struct rnh_wino44_cell_args {
+    const float *v[2];          /* transformed sources (rnh_wino44_transform) in K order: the cell's input x_t, its previous output h_{t-1} */
+    int32_t vchunks[2];         /* their 16-channel chunks; the sum must be even                                                       */
+    int32_t nsrc;               /* 1 (zero state: no h) or 2                                                                            */
+    int32_t B, H, W;            /* output geometry; H, W multiples of 4                                                                 */
+    int32_t Npad, hd;           /* columns = 4 hd in the order of plans.lstm_colmap64 (blocks of 64 = gates i, f | o, g of 16 channels); hd % 16 == 0 */
+    int32_t _pad;
+    const float *wp;            /* rnh_wino44_pack_weights                                                                              */
+    const float *bias;          /* packed bias [Npad]                                                                                   */
+    const float *c_prev;        /* [B][H][W][hd] or 0 (zero state)                                                                      */
+    float *h_out, *c_out;       /* [B][H][W][hd]                                                                                        */
+    float *gates_out;           /* [B][H][W][4 hd] post-activation i, f, o, g (channel = gate * hd + ch) or 0                           */
+} rnh_wino44_cell_args_t;
+/* One ConvLSTM cell (reference src/model/nets/refine_net.py:245-265 ConvLSTMCell.forward: cat, 3x3 conv, split, sigmoid / tanh, c' = f c + i g,
+ * h' = o tanh c') on its transformed inputs: 36 GEMMs on v_mfma_f32_32x32x2_f32 with V through LDS-DMA, output transform and gate math in the
+ * epilogue.  Same results as rnh_conv_wino / rnh_conv_igemm with RNH_EPI_LSTM up to the rounding of the transforms. */
+int rnh_wino44_cell(const rnh_wino44_cell_args_t *args /* host */, void *stream);
 
 const char *rnh_last_error(void);
 int rnh_abi_version(void);

@@ -123,7 +123,8 @@ def suspicious_copies(lines):
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
-@pytest.mark.parametrize('src,pattern,nmin', [('conv_wino.hip', 'conv_winoh_kernel', 3), ('wgrad_wino.hip', 'wino_wgrad_kernel', 1)])
+@pytest.mark.parametrize('src,pattern,nmin', [('conv_wino.hip', 'conv_winoh_kernel', 3), ('wgrad_wino.hip', 'wino_wgrad_kernel', 1),
+                                              ('conv_wino44.hip', 'wino44_cell_kernel', 1)])
 def test_no_copies_of_async_load_targets(tmp_path, src, pattern, nmin):
     text = _asm(os.path.join(CSRC, src), str(tmp_path))
     seen = 0
@@ -245,6 +246,97 @@ def test_half_domain_weight_gradient_kernel_fits_two_workgroups_per_cu(tmp_path)
     assert sum(ln.startswith('v_mfma_f32_32x32x2') for ln in lines) >= 2 * 4 * 16 * 2            # both halves x 4 groups x 16 MFMAs x (steady state + peeled last quad)
 
 
+_REG_RE = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+
+def _named(s):
+    regs = set()
+    for a, b, c in _REG_RE.findall(s):
+        regs.update(range(int(a), int(b) + 1) if a else [int(c)])
+    return regs
+
+def _inflight_analysis(body, partial_wait=None):
+    """Forward data flow over the kernel's basic blocks: the set of registers with an asm global_load in flight at every instruction (union at
+    joins).  Every instruction outside the asm statements that names such a register is reported.  ``partial_wait``: (text of a counted asm wait,
+    regex of the loads it covers) - e.g. the wait for a bias word that leaves younger requests in flight."""
+    blocks, cur, label_of = [], [], {}
+    in_asm = False
+    for raw in body:
+        ln = raw.strip()
+        if ln.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if ln.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        if not ln or ln.startswith(';'):
+            continue
+        if re.match(r'^\.LBB\d+_\d+:', ln):
+            if cur:
+                blocks.append(cur)
+            cur = []
+            label_of[ln.split(':')[0]] = len(blocks)
+            continue
+        if ln.startswith('.'):
+            continue
+        cur.append((ln.split(';')[0].strip(), in_asm))
+        if ln.startswith(('s_branch', 's_cbranch', 's_endpgm')):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    succ = []
+    for i, b in enumerate(blocks):
+        last = b[-1][0] if b else ''
+        out = []
+        if last.startswith(('s_branch', 's_cbranch')):
+            out.append(label_of[last.split()[-1]])
+        if not last.startswith(('s_branch', 's_endpgm')) and i + 1 < len(blocks):
+            out.append(i + 1)
+        succ.append(out)
+
+    narrow = set()          # targets of the loads a partial wait covers
+
+    def transfer(b, state, report):
+        state = set(state)
+        for ins, asm in b:
+            if asm:
+                ld = re.match(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', ins)
+                if ld:
+                    state.update(range(int(ld.group(1)), int(ld.group(2)) + 1))
+                    report['loads'] += 1
+                elif ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
+                    state.clear()
+                    report['waits'] += 1
+                continue
+            if ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
+                state.clear()
+                continue
+            hit = state & _named(ins.split(None, 1)[1] if ' ' in ins else '')
+            if hit:
+                report['bad'].append((ins, sorted(hit)[:4]))
+        return state
+
+    ins_state = [None] * len(blocks)
+    ins_state[0] = frozenset()
+    work = [0]
+    while work:
+        i = work.pop()
+        out = frozenset(transfer(blocks[i], ins_state[i], {'loads': 0, 'waits': 0, 'bad': []}))
+        for j in succ[i]:
+            new = out if ins_state[j] is None else ins_state[j] | out
+            if new != ins_state[j]:
+                ins_state[j] = new
+                work.append(j)
+    report = {'loads': 0, 'waits': 0, 'bad': []}
+    left = set()
+    for i, b in enumerate(blocks):
+        if ins_state[i] is not None:
+            end = transfer(b, ins_state[i], report)
+            if b and b[-1][0].startswith('s_endpgm'):
+                left |= end
+    return report, left
+
+
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
 def test_bf16_convolution_epilogue_prefetches_are_not_touched_before_their_wait(tmp_path):
     """conv_bf16d_kernel (csrc/conv_bf16.hip) requests the previous cell state (LSTM epilogue) and, since round 5, the eleven operands of a round's
@@ -259,96 +351,10 @@ def test_bf16_convolution_epilogue_prefetches_are_not_touched_before_their_wait(
     subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-S', '--cuda-device-only',
                     '-o', out, src], check=True, stderr=subprocess.DEVNULL)
     text = open(out).read()
-    reg_re = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
-
-    def named(s):
-        regs = set()
-        for a, b, c in reg_re.findall(s):
-            regs.update(range(int(a), int(b) + 1) if a else [int(c)])
-        return regs
-
-    def analyse(body):
-        """Forward data flow over the kernel's basic blocks: the set of registers with an asm load in flight at every instruction (union at joins)."""
-        blocks, cur, label_of = [], [], {}
-        in_asm = False
-        for raw in body:
-            ln = raw.strip()
-            if ln.startswith(';;#ASMSTART'):
-                in_asm = True
-                continue
-            if ln.startswith(';;#ASMEND'):
-                in_asm = False
-                continue
-            if not ln or ln.startswith(';'):
-                continue
-            if re.match(r'^\.LBB\d+_\d+:', ln):
-                if cur:
-                    blocks.append(cur)
-                cur = []
-                label_of[ln.split(':')[0]] = len(blocks)
-                continue
-            if ln.startswith('.'):
-                continue
-            cur.append((ln.split(';')[0].strip(), in_asm))
-            if ln.startswith(('s_branch', 's_cbranch', 's_endpgm')):
-                blocks.append(cur)
-                cur = []
-        if cur:
-            blocks.append(cur)
-        succ = []
-        for i, b in enumerate(blocks):
-            last = b[-1][0] if b else ''
-            out = []
-            if last.startswith(('s_branch', 's_cbranch')):
-                out.append(label_of[last.split()[-1]])
-            if not last.startswith(('s_branch', 's_endpgm')) and i + 1 < len(blocks):
-                out.append(i + 1)
-            succ.append(out)
-
-        def transfer(b, state, report):
-            state = set(state)
-            for ins, asm in b:
-                if asm:
-                    ld = re.match(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', ins)
-                    if ld:
-                        state.update(range(int(ld.group(1)), int(ld.group(2)) + 1))
-                        report['loads'] += 1
-                    elif ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
-                        state.clear()
-                        report['waits'] += 1
-                    continue
-                if ins.startswith('s_waitcnt') and 'vmcnt(0)' in ins:
-                    state.clear()
-                    continue
-                hit = state & named(ins.split(None, 1)[1] if ' ' in ins else '')
-                if hit:
-                    report['bad'].append((ins, sorted(hit)[:4]))
-            return state
-
-        ins_state = [None] * len(blocks)
-        ins_state[0] = frozenset()
-        work = [0]
-        while work:
-            i = work.pop()
-            out = frozenset(transfer(blocks[i], ins_state[i], {'loads': 0, 'waits': 0, 'bad': []}))
-            for j in succ[i]:
-                new = out if ins_state[j] is None else ins_state[j] | out
-                if new != ins_state[j]:
-                    ins_state[j] = new
-                    work.append(j)
-        report = {'loads': 0, 'waits': 0, 'bad': []}
-        left = set()
-        for i, b in enumerate(blocks):
-            if ins_state[i] is not None:
-                end = transfer(b, ins_state[i], report)
-                if b and b[-1][0].startswith('s_endpgm'):
-                    left |= end
-        return report, left
-
     checked = 0
     for m in re.finditer(r'^(_Z\S*conv_bf16d_kernelILi[23]E\S*):\s*;', text, re.M):        # the LSTM and LSTM_BWD instantiations
         body = text[m.end():text.index('.Lfunc_end', m.end())].split('\n')
-        report, left = analyse(body)
+        report, left = _inflight_analysis(body)
         if report['loads'] == 0:                              # (the 64-column LSTM_BWD instantiations: no prefetching form)
             continue
         assert report['loads'] >= 8 and report['waits'] >= 1, (m.group(1), report['loads'], report['waits'])
@@ -356,3 +362,21 @@ def test_bf16_convolution_epilogue_prefetches_are_not_touched_before_their_wait(
         assert not report['bad'], (m.group(1), len(report['bad']), report['bad'][:6])
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
+def test_wino44_cell_kernel_has_no_register_target_in_flight_outside_its_rings(tmp_path):
+    """wino44_cell_kernel (csrc/conv_wino44.hip) at first requested the bias word and the previous cell state into registers with inline-asm global
+    loads, as conv_wino.hip does.  At 251-256 registers hipcc (a) spilled one of the targets right behind its request and reused the register for
+    the next address - a memory fault on the GPU - and, with fewer requests, (b) copied the targets to other registers in FRONT of the asm wait that
+    names them as read-write operands (a tied operand is satisfied by a copy).  Those requests now go to LDS by LDS-DMA: the only registers with a
+    load in flight are the weight ring and the LDS operand ring of the main loop (checked by test_no_copies_of_async_load_targets).  Here: no
+    global load with a register target in the kernel's asm statements, three LDS-DMA request sites for the epilogue per instantiation, no spill."""
+    text = _asm(os.path.join(CSRC, 'conv_wino44.hip'), str(tmp_path))
+    m = re.search(r'^(_Z\S*wino44_cell_kernel\S*):\s*;', text, re.M)
+    body = text[m.end():text.index('.Lfunc_end', m.end())].split('\n')
+    report, left = _inflight_analysis(body)
+    assert report['loads'] == 0 and not left, report
+    dma = [ln for ln in body if re.search(r'buffer_load_dword(x4)?\s+v\d+, s\[\d+:\d+\], \S+ offen lds', ln)]
+    assert len([ln for ln in dma if 'dwordx4' not in ln]) >= 1 and len(dma) >= 9 * 2 + 9 + 3, len(dma)
+    assert not any('scratch_' in ln for ln in body), 'the kernel spills'

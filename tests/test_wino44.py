@@ -1,0 +1,200 @@
+"""The ConvLSTM cell in Winograd form F(4x4, 3x3) (csrc/conv_wino44.hip: rnh_wino44_transform, rnh_wino44_pack_weights, rnh_wino44_cell) against
+float64 evaluations of reference src/model/nets/refine_net.py:245-265 and of the transforms themselves.  Tolerances: the transform-domain tensors
+1e-5 relative to their largest value (fp32 rounding of 12-term sums with coefficients up to 5), gates / c' / h' 1e-4 absolute as for the
+F(2x2) kernel (tests/test_parity_r03.py::test_lstm_cell_gates_config2_size_vs_float64)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd'))
+from oracle import refinenet_oracle as orc                                    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+                  dtype=torch.float64)
+G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _tile_xy(t, TX, TY):
+    img, rem = divmod(t, TY * TX)
+    if TX % 8 == 0 and TY % 4 == 0:
+        bi, wi = divmod(rem, 32)
+        by, bx = divmod(bi, TX // 8)
+        return img, by * 4 + wi // 8, bx * 8 + wi % 8
+    return (img,) + divmod(rem, TX)
+
+
+def _v_reference(x, c0, nch):
+    """[tile block][chunk][xi][tile][16 channels in natural order] in float64, zero for tiles past the end."""
+    import torch.nn.functional as F
+    B, H, W, _ = x.shape
+    TY, TX = H // 4, W // 4
+    xp = F.pad(x[..., c0:c0 + nch].double().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    d = xp.unfold(2, 6, 4).unfold(3, 6, 4)                                     # B C TY TX 6 6
+    V = torch.einsum('ij,nctujk,lk->ntuilc', BT, d, BT)                        # B TY TX 6 6 C
+    nt = B * TY * TX
+    MT = (nt + 31) // 32
+    out = torch.zeros(MT, nch // 16, 36, 32, 16, dtype=torch.float64)
+    for t in range(nt):
+        img, ty, tx = _tile_xy(t, TX, TY)
+        out[t // 32, :, :, t % 32, :] = V[img, ty, tx].reshape(36, nch // 16, 16).permute(1, 0, 2)
+    return out
+
+
+def _v_decode(v, MT, nchunks):
+    """The device image [xi][tile][piece ^ ((tile >> 2) & 3)][4] -> natural channel order (piece p holds channels 4 p .. 4 p + 3)."""
+    v = v.view(MT, nchunks, 36, 32, 4, 4).cpu()
+    out = torch.empty_like(v)
+    for t in range(32):
+        for p in range(4):
+            out[:, :, :, t, p] = v[:, :, :, t, p ^ ((t >> 2) & 3)]
+    return out.reshape(MT, nchunks, 36, 32, 16)
+
+
+@pytest.mark.parametrize('B,H,W,C,c0,nch', [(1, 8, 8, 16, 0, 16), (2, 16, 32, 64, 0, 64), (3, 12, 20, 48, 16, 32), (1, 32, 64, 64, 0, 64)])
+def test_input_transform_vs_float64(B, H, W, C, c0, nch):
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Src
+    dev = _dev()
+    ops = HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(B * 1000 + H)
+    x = torch.randn(B + 1, H, W, C, generator=g)
+    ref = _v_reference(x[1:], c0, nch)
+    v = ops.wino44_v(B, H, W, nch)[0]
+    v.fill_(float('nan'))
+    ops.wino44_transform(Src(x.to(dev), c0=c0, nch=nch, img_off=1), B, H, W, v)
+    torch.cuda.synchronize()
+    mine = _v_decode(v, ref.shape[0], nch // 16).double()
+    assert not torch.isnan(mine).any()
+    err = float((mine - ref).abs().max())
+    assert err <= 1e-5 * float(ref.abs().max()), (err, float(ref.abs().max()))
+
+
+def _cell_reference(x, h, c, w, b, hd):
+    import torch.nn.functional as F
+    n64 = lambda t: t.double().permute(0, 3, 1, 2)                             # noqa: E731
+    srcs = [n64(x)] + ([n64(h)] if h is not None else [])
+    pre = F.conv2d(torch.cat(srcs, 1), w.double()[:, :sum(s.shape[1] for s in srcs)], b.double(), padding=1)
+    gi, gf, go, gg = pre.split(hd, dim=1)
+    gi, gf, go, gg = torch.sigmoid(gi), torch.sigmoid(gf), torch.sigmoid(go), torch.tanh(gg)
+    cn = gf * (n64(c) if c is not None else 0.0) + gi * gg
+    hn = go * torch.tanh(cn)
+    p = lambda t: t.permute(0, 2, 3, 1)                                        # noqa: E731
+    return p(torch.cat([gi, gf, go, gg], 1)), p(cn), p(hn)
+
+
+def _run_cell(ops, plan, x, h, c, B, H, W, hd, with_gates=True):
+    from hipvsr.plans import Src
+    dev = ops.device
+    xd = x.to(dev)
+    vs = [ops.wino44_v(B, H, W, x.shape[-1])[0]]
+    ops.wino44_transform(Src(xd), B, H, W, vs[0])
+    if h is not None:
+        hd_ = h.to(dev)
+        vs.append(ops.wino44_v(B, H, W, h.shape[-1])[0])
+        ops.wino44_transform(Src(hd_), B, H, W, vs[1])
+    ho, co = (torch.full((B, H, W, hd), float('nan'), device=dev) for _ in range(2))
+    go = torch.full((B, H, W, 4 * hd), float('nan'), device=dev) if with_gates else None
+    ops.wino44_cell(plan, vs, B, H, W, dict(hd=hd, c_prev=c.to(dev) if c is not None else None, h_out=ho, c_out=co, gates_out=go))
+    torch.cuda.synchronize()
+    return go, co, ho
+
+
+@pytest.mark.parametrize('feat,B,H,W,state,gates', [(16, 1, 8, 8, True, True), (32, 3, 12, 20, False, True), (32, 2, 16, 32, True, False),
+                                                     (64, 2, 32, 64, True, True), (64, 1, 64, 64, False, True)])
+def test_cell_vs_float64_small(feat, B, H, W, state, gates):
+    """Partial tile blocks (4, 45 tiles), linear and blocked tile order, with and without previous state (the one-source plan of the first frame),
+    with and without the gate tensor."""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    cfg.num_features = [feat, feat]
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    pl = P.lstm[('forward', 1)]
+    plan = pl['full'] if state else pl['first']
+    assert plan.wino44
+    g = torch.Generator('cpu').manual_seed(feat + H)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    w, b = R(*spec[plan.wkey]) * 0.05, R(*spec[plan.bkey]) * 0.1
+    ops.pack(plan, w.to(dev), b.to(dev))
+    x = R(B, H, W, feat)
+    h, c = (R(B, H, W, feat), R(B, H, W, feat)) if state else (None, None)
+    ref_g, ref_c, ref_h = _cell_reference(x, h, c, w, b, feat)
+    go, co, ho = _run_cell(ops, plan, x, h, c, B, H, W, feat, with_gates=gates)
+    for nm, mine, ref in (('gates', go, ref_g), ('c', co, ref_c), ('h', ho, ref_h)):
+        if mine is None:
+            continue
+        m = mine.cpu().double()
+        assert not torch.isnan(m).any(), (nm, int(torch.isnan(m).sum()))
+        err = float((m - ref).abs().max())
+        assert err <= 1e-4, (nm, err)
+
+
+def test_cell_config2_size_vs_float64():
+    """One cell launch at N = 8, 128 x 128, 64 + 64 -> 256 columns (1024 workgroups): gates, c', h' of every pixel against float64; three times."""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    B, H, W = 8, 128, 128
+    g = torch.Generator('cpu').manual_seed(7)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    plan = P.lstm[('backward', 2)]['full']
+    assert plan.wino44 and ops.wino44_ok(plan, B, H, W) is False               # (not packed yet)
+    w, b = R(*spec[plan.wkey]) * 0.03, R(*spec[plan.bkey]) * 0.1
+    ops.pack(plan, w.to(dev), b.to(dev))
+    assert ops.wino44_ok(plan, B, H, W) and not ops.wino44_ok(plan, B, H, W + 2) and not ops.wino44_ok(plan, 1, 32, 32)
+    x, h, c = R(B, H, W, 64), R(B, H, W, 64), R(B, H, W, 64)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref_g, ref_c, ref_h = _cell_reference(x, h, c, w, b, 64)
+    for rep in range(3):
+        go, co, ho = _run_cell(ops, plan, x, h, c, B, H, W, 64)
+        for nm, mine, ref in (('gates', go, ref_g), ('c', co, ref_c), ('h', ho, ref_h)):
+            m = mine.cpu().double()
+            assert not torch.isnan(m).any(), (rep, nm, int(torch.isnan(m).sum()))
+            err = float((m - ref).abs().max())
+            assert err <= 1e-4, (rep, nm, err)
+
+
+def test_refusals():
+    """Images that are not whole 4x4 tiles, an odd number of chunks, a source of the wrong size: refused with a message, nothing launched."""
+    from hipvsr import lib as L
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    cfg.num_features = [16, 16]
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.lstm[('forward', 0)]['full']
+    ops.pack(plan, torch.zeros(*spec[plan.wkey], device=dev), torch.zeros(*spec[plan.bkey], device=dev))
+    x = torch.zeros(1, 10, 8, 16, device=dev)
+    with pytest.raises(L.HipKernelError):
+        ops.wino44_transform(Src(x), 1, 10, 8, torch.empty(int(ops.lib.rnh_wino44_v_floats(1, 10, 8, 16)), device=dev))
+    assert 'multiples of 4' in ops.lib.rnh_last_error().decode()
+    first = P.lstm[('forward', 0)]['first']
+    assert not first.wino44                                                    # one 16-channel chunk: odd
+    v = ops.wino44_v(1, 8, 8, 16)[0]
+    o = torch.empty(1, 8, 8, 16, device=dev)
+    with pytest.raises(L.HipKernelError):
+        ops.wino44_cell(plan, [v], 1, 8, 8, dict(hd=16, h_out=o, c_out=o.clone()))
+    with pytest.raises(L.HipKernelError):
+        ops.wino44_cell(plan, [v, v[:100]], 1, 8, 8, dict(hd=16, h_out=o, c_out=o.clone()))
