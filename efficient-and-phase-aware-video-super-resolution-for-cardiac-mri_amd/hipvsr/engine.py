@@ -369,6 +369,42 @@ class RefineNetEngine:
                     h_out=Hb[l].view(k), c_out=Cb[l].view(k),
                     gates_out=Gb[l][(k - U) * N:(k - U + 1) * N] if grad_frame else None))
 
+            # The cells in Winograd form F(4x4, 3x3) (rnh_wino44_cell, csrc/conv_wino44.hip) where every cell plan of the net is packed for it
+            # and the launch is large enough (HipOps.wino44_ok): the kernel reads its inputs in transform-domain form, written by a kernel of
+            # its own - the features of every frame once, in front of the wavefront, and every cell's h' right behind the cell on the cell's
+            # stream (the event the layer above waits for is recorded behind it): one transform serves both readers of an h'.
+            use44 = hasattr(ops, 'wino44_ok') and all(ops.wino44_ok(P.lstm[(d, l)][kind], N, H, W) for d in dirs for l in range(Lr) for kind in ('full', 'first'))
+            v44_bytes = 2 * F_s * sum(nf) * N * H * W * 9 if use44 else 0        # a slot per frame: 2.25 x 4 bytes per element of every h'
+            if use44 and v44_bytes > 0.08 * ops.total_memory() and ops.capturing():
+                use44 = False
+            st['use44'] = use44
+            if use44:
+                VF = ops.wino44_v(N, H, W, C, frames=F)
+                for k in (range(F) if F_s == F else sorted(set(range(F_s)) | set(range(F - F_s, F)))):
+                    ops.wino44_transform(feat.src(k), N, H, W, VF[k])
+                # the transformed h' of a (direction, layer) live in a ring of R44 slots (2.25 x the bytes of h each): slot idx % R44 is written
+                # behind cell idx and read by cell idx + 1 of the layer (same stream) and by cell idx of the layer above - whose event the
+                # layer waits for before it overwrites the slot R44 cells later (it rarely has to: the layers run in step)
+                # - only where a slot per frame would take more than 8 % of the card (BASELINE config 4 at N = 16: 62 GB), and not under HIP-graph
+                # capture: the layer's stream then waits on the stream above while that waits on it, and hipStreamEndCapture (ROCm 7.2) never
+                # returns from two streams that reference each other (hazard 3)
+                R44 = F_s if v44_bytes <= 0.08 * ops.total_memory() else min(F_s, 4)
+                VH = {d: [ops.wino44_v(N, H, W, hd, frames=R44) for hd in nf] for d in dirs}
+                read44 = {}
+
+            def cell44(d, l, idx):
+                plan, srcs, _, _, _, kw = cell_call(d, l, idx)
+                k = idx if d == 'forward' else F - 1 - idx
+                vx = VF[k] if l == 0 else VH[d][l - 1][idx % R44]
+                vs = [vx] + ([VH[d][l][(idx - 1) % R44]] if cfg.memory else [vx])[:len(srcs) - 1]
+                ops.wino44_cell(plan, vs, N, H, W, kw['lstm'])
+                if l > 0 and idx + R44 < F_s:                                # (only with a ring: R44 < F_s)
+                    read44[(d, l, idx)] = ops.record()                       # slot idx % R44 of the layer below has been read
+                if l + 1 < Lr or (cfg.memory and idx + 1 < F_s):            # somebody reads this h' as a cell input
+                    if l + 1 < Lr and idx >= R44:
+                        ops.wait(read44.pop((d, l + 1, idx - R44)))
+                    ops.wino44_transform(st[d]['H'][l].src(k), N, H, W, VH[d][l][idx % R44])
+
             if pair:
                 # small images (the reference YAML's 32 x 32 crops): a cell launch is a fraction of the chip, and the two directions' cells of a
                 # layer at the same slot are independent and of equal geometry - ONE launch for both (ops.conv_pair), one stream per layer
@@ -379,7 +415,11 @@ class RefineNetEngine:
                         with ops.side(l):
                             if below is not None:
                                 ops.wait(below)
-                            ops.conv_pair([cell_call(d, l, idx) for d in dirs])
+                            if use44:
+                                for d in dirs:
+                                    cell44(d, l, idx)
+                            else:
+                                ops.conv_pair([cell_call(d, l, idx) for d in dirs])
                             below = ops.record() if l + 1 < Lr else None
                 ops.join(2 * Lr)
             else:
@@ -391,10 +431,15 @@ class RefineNetEngine:
                             with ops.side(di * Lr + l):
                                 if below is not None:
                                     ops.wait(below)
-                                plan, srcs, _, _, _, kw = cell_call(d, l, idx)
-                                ops.conv(plan, srcs, N, H, W, **kw)
+                                if use44:
+                                    cell44(d, l, idx)
+                                else:
+                                    plan, srcs, _, _, _, kw = cell_call(d, l, idx)
+                                    ops.conv(plan, srcs, N, H, W, **kw)
                                 below = ops.record() if l + 1 < Lr else None
                 ops.join(2 * Lr)
+            if use44:
+                del VF, VH
             self._mem(f'fwd stage {s}: wavefront done')
             for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
                 for l in range(Lr):
@@ -771,9 +816,18 @@ class RefineNetEngine:
                 pl = P.lstm[(d, l)]
                 xin = feat if l == 0 else sd['H'][l - 1]
                 g, hs, cs = RG[d][l]
-                ops.conv(pl['full'], [xin.src(k), sd['H'][l].src(kp) if cfg.memory else xin.src(k)], N, H, W,
-                         lstm=dict(hd=pl['hd'], c_prev=sd['C'][l].view(kp), h_out=hs, c_out=cs, gates_out=g))
+                lstm = dict(hd=pl['hd'], c_prev=sd['C'][l].view(kp), h_out=hs, c_out=cs, gates_out=g)
+                if st.get('use44'):                               # (the form the forward ran: the same kernels on the same operands)
+                    vx, vh = RV[d][l]
+                    ops.wino44_transform(xin.src(k), N, H, W, vx)
+                    if cfg.memory:
+                        ops.wino44_transform(sd['H'][l].src(kp), N, H, W, vh)
+                    ops.wino44_cell(pl['full'], [vx, vh if cfg.memory else vx], N, H, W, lstm)
+                else:
+                    ops.conv(pl['full'], [xin.src(k), sd['H'][l].src(kp) if cfg.memory else xin.src(k)], N, H, W, lstm=lstm)
                 return g
+            RV = {d: [(ops.wino44_v(N, H, W, P.lstm[(d, l)]['cx'])[0], ops.wino44_v(N, H, W, hd)[0]) for l, hd in enumerate(nf)]
+                  for d in dirs} if RG is not None and st.get('use44') else None
             pair = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False      # (as the forward: small images)
             ops.fork(2 * Lr, bank=1)
             if fused:

@@ -118,6 +118,10 @@ class HipOps:
         """HBM bytes of the device (what the engine's 'auto' gate-memory plan is sized against)."""
         return torch.cuda.get_device_properties(self.device).total_memory
 
+    def capturing(self):
+        """Is the current stream being captured into a HIP graph?"""
+        return torch.cuda.is_current_stream_capturing()
+
     def memory_budget(self):
         """What this process can still use of the device: free memory + the pool torch has reserved for this process (other processes on the card
         and everything this process holds outside torch's allocator are not ours to plan with); never more than the device has."""

@@ -651,7 +651,15 @@ def _cfg2_step(n, seed=202):
     return cfg, sd, inputs, targets, pos
 
 
-def test_cfg2_geometry_vs_oracle():
+@pytest.fixture(params=['0', 'force'], ids=['cell_f2x2', 'cell_f4x4'])
+def cell_form(request, monkeypatch):
+    """The two forms of the fp32 ConvLSTM cell forward: Winograd F(2x2, 3x3) (rnh_conv_wino) and F(4x4, 3x3) (rnh_wino44_cell; the engine's
+    choice where a cell launch is at least 1024 workgroups, i.e. at the benchmark's N = 8 - forced here so that N = 2 runs it too)."""
+    monkeypatch.setenv('RNH_WINO44', request.param)
+    return request.param
+
+
+def test_cfg2_geometry_vs_oracle(cell_form):
     """BASELINE config 2's geometry - exp1_x4 net, T = 7 (F = 19), 128x128 -> 512x512 - at N = 2 against the CPU oracle
     (== the reference, reference acdc_vsr_refinenet_trainer.py:42-46, :83-94): all 63 outputs, the training loss, every
     parameter gradient under the contract's elementwise + L2 criterion, and PSNR |delta| < 0.01 dB.  (Refine conv1 was
@@ -685,7 +693,7 @@ def test_cfg2_geometry_vs_oracle():
     print(f'cfg2 geometry N=2: max |output - oracle| = {worst:.3e}, loss {float(loss):.7f} vs {float(ref_loss):.7f}, PSNR {psnr:.4f} vs {want:.4f}')
 
 
-def test_bench_launch_geometry_n8_equals_replicated_n2():
+def test_bench_launch_geometry_n8_equals_replicated_n2(cell_form):
     """The exact launch geometry of the benchmark (N = 8, T = 7, 128x128): a batch made of four copies of the N = 2
     batch of the test above.  Samples are independent bit for bit (quirk Q8), so every one of the 8 samples of every
     output of the forward must equal its N = 2 twin exactly - which pins all 2048-workgroup cell launches, the 45-window
