@@ -53,7 +53,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (the 5 PF headline figure in
 PEAK_HBM_TBS = 8.0
 
 
-def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
+def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False):
     """Conv FLOPs (2*MAC) per LR pixel per sample.  executed=False: the reference's layer-by-layer formulation
      - what its PyTorch step computes and what `step_tflop` reports.  executed=True (x4 only):
     what this implementation issues - the last PixelShuffle conv + final conv (1 198 080 FLOP/LR pixel forward, twice
@@ -66,7 +66,9 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False):
         out_f, out_b = w * 294912 + 51200, 2 * w * 294912 + 65536             # first PixelShuffle conv: fwd, dgrad, wgrad Winograd; tail collapsed
     elif executed and scale == 2:
         out_f, out_b = 12800, 16384                                           # the whole upsampler IS the collapsed tail (one PixelShuffle stage)
-    lstm_f, lstm_b = w * 589824, 2 * w * 589824                               # fwd, dgrad, wgrad Winograd
+    # fwd, dgrad, wgrad in Winograd F(2x2, 3x3) form; cell44: the forward cell in F(4x4, 3x3) form (rnh_wino44_cell: 36 products per 16 outputs,
+    # 1/4 of the direct FLOPs) where the engine selects it (HipOps.wino44_ok)
+    lstm_f, lstm_b = (0.25 if executed and cell44 else w) * 589824, 2 * w * 589824
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
     r2h, r2x = 128 * 64 * 18, 1 * 64 * 18                                     # conv2: the 128 hidden-state channels / channel 128
     # conv1 in Winograd form (fwd, dgrad, wgrad); conv2 forward and data gradient in Winograd form over its 128 hidden-state
@@ -130,8 +132,19 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=200, warm=50):
     ho, co = ops.empty(n, h, w, hd, dtype=act), ops.empty(n, h, w, hd)
     go = ops.empty(n, h, w, 4 * hd, dtype=act)
 
+    lstm = dict(hd=hd, c_prev=cp, h_out=ho, c_out=co, gates_out=go)
+    # the form the engine runs this launch in: Winograd F(4x4, 3x3) on transformed inputs (rnh_wino44_cell) or F(2x2, 3x3) (rnh_conv_wino)
+    cell44 = (not eng.bf16) and ops.wino44_ok(pl['full'], n, h, w)
+    if cell44:
+        vx, vh = ops.wino44_v(n, h, w, cx)[0], ops.wino44_v(n, h, w, hd)[0]
+        ops.wino44_transform(Src(x), n, h, w, vx)
+        ops.wino44_transform(Src(hp), n, h, w, vh)
+
     def launch():
-        ops.conv(pl['full'], [Src(x), Src(hp)], n, h, w, lstm=dict(hd=hd, c_prev=cp, h_out=ho, c_out=co, gates_out=go))
+        if cell44:
+            ops.wino44_cell(pl['full'], [vx, vh], n, h, w, lstm)
+        else:
+            ops.conv(pl['full'], [Src(x), Src(hp)], n, h, w, lstm=lstm)
     for _ in range(warm):                                  # (50 launches = 16 ms: the clocks have settled; with 3 the 20 timed launches that followed came
         launch()                                           #  out anywhere between 0.325 and 0.346 ms on the same tree - the profiler's 403-launch average is 0.325)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -157,6 +170,34 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=200, warm=50):
                 'algorithmic_bytes_per_launch': byts, 'hbm_algorithmic_tbs': round(tbs, 3), 'hbm_frac_of_8tbs': round(tbs / PEAK_HBM_TBS, 4)}
     # ALGORITHMIC work of the launch: 589 824 FLOP per pixel at cx = hd = 64, the direct 3x3 form
     flops = 2.0 * n * h * w * (4 * hd) * (9 * (cx + hd))
+    if cell44:
+        # the F(4x4, 3x3) cell: 36 GEMMs over n*h*w/16 tiles = 1/4 of the direct FLOPs on the matrix cores.  Its inputs arrive in transform-domain
+        # form, written by rnh_wino44_transform - one launch per cell (the cell's own h', read by both cells that consume it), timed here too
+        for _ in range(warm):
+            ops.wino44_transform(Src(ho), n, h, w, vh)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.wino44_transform(Src(ho), n, h, w, vh)
+        e1.record()
+        torch.cuda.synchronize()
+        t_ms = e0.elapsed_time(e1) / reps
+        flops_exec = flops * 0.25
+        executed, algorithmic = flops_exec / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12
+        traffic, traffic_src = quoted_traffic('lstm44_kernel_hbm_bytes.json', 'conv_wino44.hip', (n, h, w))
+        return {'bound': 'mfma', 'kernel': 'wino44_cell_kernel (ConvLSTM cell 128->256 in Winograd F(4x4,3x3) form on transformed inputs, fused gates)',
+                'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops_exec,
+                'algorithmic_flop_per_launch': flops, 'algorithmic_equiv_tflops': round(algorithmic, 2),
+                'algorithmic_equiv_frac': round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
+                # x, h, c in; h', c', gates out - in the reference's formulation; this kernel reads x and h in transform-domain form, 2.25 x their bytes
+                'algorithmic_bytes_per_launch': 4 * n * h * w * (cx + 2 * hd + 2 * hd + 4 * hd),
+                'formulation_bytes_per_launch': 4 * n * h * w * (2.25 * (cx + hd) + hd + 2 * hd + 4 * hd),
+                'input_transform': {'kernel': 'wino44_transform_kernel (B^T d B of the cell output, 64 channels: one launch per cell)', 'avg_launch_ms': round(t_ms, 4),
+                                    'bound': 'hbm', 'bytes_per_launch': int(4 * n * h * w * hd * 3.25), 'achieved_tbs': round(4 * n * h * w * hd * 3.25 / (t_ms * 1e-3) / 1e12, 3),
+                                    'frac_of_8tbs': round(4 * n * h * w * hd * 3.25 / (t_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)},
+                'cell_plus_transform_ms': round(ms + t_ms, 4),
+                'algorithmic_equiv_tflops_with_transform': round(flops / ((ms + t_ms) * 1e-3) / 1e12, 2)}
     # what the matrix cores execute: the Winograd F(2x2,3x3) kernel runs 16 GEMMs over n*h*w/4 tiles = 4/9 of it
     flops_exec = flops * 4.0 / 9.0 if wino else flops
     algorithmic = flops / (ms * 1e-3) / 1e12
@@ -328,12 +369,14 @@ def run_case(args, dtype, dev, world, rank):
     n_global = args.batch * world
     bf = dtype == 'bf16'
     flop_step = step_flops_per_lr_pixel(args.frames, scale=args.scale) * args.size * args.size * n_global
-    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True) * args.size * args.size * n_global
+    eng_ = net._engine()
+    cell44 = eng_.cells_f4x4(args.batch, args.size, args.size)
+    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages
     n_rc = net._engine().recompute_stages(args.batch, args.size, args.size, args.frames + 12)
-    flop_exec += n_rc * 2 * args.frames * 3 * 589824 * (1.0 if bf else 4.0 / 9.0) * args.size * args.size * n_global
+    flop_exec += n_rc * 2 * args.frames * 3 * 589824 * (1.0 if bf else (0.25 if cell44 else 4.0 / 9.0)) * args.size * args.size * n_global
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
     out = None

@@ -176,6 +176,11 @@ class RefineNetEngine:
         o_all = 2 * S * 3 * T * px * cfg.upscale_factor ** 2 * cfg.out_channels * 4               # outputs and their gradient
         fwd_t = (2 * sum(nf[:-1]) * (F - T - 1) * px * ea + 4 * sum(nf) * 2 * px * 4 + (F - 2 * hw) * px * Cl * ea +
                  max(U - hw, 1) * px * c1p * ea + 2 * F * px * C * ea)
+        if self.cells_f4x4(N, H, W):
+            # the cells in F(4x4, 3x3) form read transformed inputs, 2.25 x 4 bytes per element: the features of every frame and the h' of every cell -
+            # a slot per frame, or a ring of four where that would take more than 8 % of the card (forward_impl)
+            slots = 2 * F * sum(nf) * px * 9
+            fwd_t += F * px * C * 9 + (slots if slots <= 0.08 * self.ops.total_memory() else 2 * min(F, 4) * sum(nf) * px * 9)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
         # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
@@ -186,6 +191,11 @@ class RefineNetEngine:
         peak = kept + o_all + max(fwd_t, bwd_t, bwd_t + held - last if S > 1 else 0)
         return dict(per_stage=per, recomputing_stages=n_rc, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
                     held_for_weight_gradients=held, peak=peak)
+
+    def cells_f4x4(self, N, H, W):
+        """Do the ConvLSTM cells of a forward at this shape run in Winograd form F(4x4, 3x3) (rnh_wino44_cell)?  All of them or none."""
+        ops, P = self.ops, self.plans
+        return (not self.bf16) and hasattr(ops, 'wino44_ok') and all(ops.wino44_ok(P.lstm[k][kind], N, H, W, packed=False) for k in P.lstm for kind in ('full', 'first'))
 
     def _mem(self, label):
         """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
@@ -373,7 +383,7 @@ class RefineNetEngine:
             # and the launch is large enough (HipOps.wino44_ok): the kernel reads its inputs in transform-domain form, written by a kernel of
             # its own - the features of every frame once, in front of the wavefront, and every cell's h' right behind the cell on the cell's
             # stream (the event the layer above waits for is recorded behind it): one transform serves both readers of an h'.
-            use44 = hasattr(ops, 'wino44_ok') and all(ops.wino44_ok(P.lstm[(d, l)][kind], N, H, W) for d in dirs for l in range(Lr) for kind in ('full', 'first'))
+            use44 = self.cells_f4x4(N, H, W) and all(ops.wino44_ok(P.lstm[(d, l)][kind], N, H, W) for d in dirs for l in range(Lr) for kind in ('full', 'first'))
             v44_bytes = 2 * F_s * sum(nf) * N * H * W * 9 if use44 else 0        # a slot per frame: 2.25 x 4 bytes per element of every h'
             if use44 and v44_bytes > 0.08 * ops.total_memory() and ops.capturing():
                 use44 = False

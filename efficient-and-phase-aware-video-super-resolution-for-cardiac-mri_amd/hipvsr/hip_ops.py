@@ -338,12 +338,13 @@ class HipOps:
         L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
                                                  plan.Cin, self._stream()), f'rnh_wino44_pack_weights({plan.name})')
 
-    def wino44_ok(self, plan, B, H, W):
+    def wino44_ok(self, plan, B, H, W, packed=True):
         """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it, the images whole 4x4 tiles,
         and the launch at least RNH_WINO44_MIN (default 1024) workgroups of 512 pixels x 64 columns - four rounds of the chip: below that the
-        F(2x2) kernel's 128-pixel workgroups fill it better.  RNH_WINO44=0 switches the form off, RNH_WINO44=force drops the size condition."""
+        F(2x2) kernel's 128-pixel workgroups fill it better.  RNH_WINO44=0 switches the form off, RNH_WINO44=force drops the size condition.
+        ``packed=False``: the question before the weights are packed (the engine's memory plan)."""
         mode = os.environ.get('RNH_WINO44', '1')
-        if mode == '0' or id(plan) not in self._packed44 or (H & 3) or (W & 3):
+        if mode == '0' or not getattr(plan, 'wino44', False) or (packed and id(plan) not in self._packed44) or (H & 3) or (W & 3):
             return False
         wgs = -(-(B * (H // 4) * (W // 4)) // 32) * (plan.Cout // 64)
         return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1024'))

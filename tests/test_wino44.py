@@ -198,3 +198,103 @@ def test_refusals():
         ops.wino44_cell(plan, [v], 1, 8, 8, dict(hd=16, h_out=o, c_out=o.clone()))
     with pytest.raises(L.HipKernelError):
         ops.wino44_cell(plan, [v, v[:100]], 1, 8, 8, dict(hd=16, h_out=o, c_out=o.clone()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole training step with the cells forced into F(4x4, 3x3) form, against the CPU oracle (== the reference)
+# ---------------------------------------------------------------------------------------------------------------------
+def _grad_close(mine, ref, name, atol=1e-5, rtol=1e-3, l2=1e-3):
+    a, b = mine.detach().cpu().double(), ref.detach().cpu().double()
+    d = (a - b).abs()
+    over = d - (atol + rtol * b.abs())
+    i = int(over.argmax())
+    assert float(over.flatten()[i]) <= 0, (name, 'element', i, float(a.flatten()[i]), float(b.flatten()[i]), 'max|g|', float(b.abs().max()))
+    assert float(d.norm()) <= l2 * float(b.norm()) + 1e-12, (name, 'L2', float(d.norm()), float(b.norm()))
+
+
+def _module_step(kwargs, sd, inputs, targets, pos, gate_memory=None):
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    dev = _dev()
+    net = RefineNet(**kwargs)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    if gate_memory:
+        net.set_gate_memory(gate_memory)
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.net, tr.loss_fns, tr.metric_fns = net, [torch.nn.L1Loss()], []
+    outs = net([x.to(dev) for x in inputs], pos.to(dev))
+    loss = tr._compute_losses(outs, [t.to(dev) for t in targets])[0]
+    net.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    return net, outs, loss
+
+
+@pytest.mark.parametrize('name,over,n,t,h,w', [('x4', dict(), 2, 2, 24, 20), ('x8', dict(upscale_factor=8), 1, 2, 24, 20),
+                                               ('no_memory', dict(memory=False), 1, 2, 32, 20), ('no_phase_code', dict(positional_encoding=False), 1, 2, 20, 32)])
+def test_training_step_with_f4x4_cells_vs_oracle(name, over, n, t, h, w, monkeypatch):
+    """Full-width nets (num_features [64, 64, 64]) and the constructor variants that change the cell's inputs (memory=False: cat[x, x]), every cell of
+    the forward in F(4x4, 3x3) form (forced: these launches are far below the size the engine switches at): outputs 1e-4, loss 1e-5, every
+    gradient elementwise 1e-5 + 1e-3 |g| and 1e-3 in L2 - the contract's criterion, unchanged; and the backward's gate recomputation runs the
+    same form: stored and recomputed gates give the same gradients bit for bit."""
+    monkeypatch.setenv('RNH_WINO44', 'force')
+    cfg = orc.exp1_x4_config(**over)
+    sd = orc.init_state_dict(cfg, seed=700)
+    inputs, targets, pos = orc.synthetic_batch(cfg, n, t, h, w, seed=701)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref_out, ref_loss, ref_grads = orc.step(sd, cfg, [x.clone() for x in inputs], targets, pos)
+    grads = {}
+    for mode in ('store', 'recompute'):
+        net, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, gate_memory=mode)
+        eng = net._engine()
+        assert all(eng.ops.wino44_ok(eng.plans.lstm[k][kind], n, h, w) for k in eng.plans.lstm for kind in ('full', 'first'))
+        for go, gr in zip(outs, ref_out):
+            for a, b in zip(go, gr):
+                torch.testing.assert_close(a.detach().cpu(), b, atol=1e-4, rtol=1e-4)
+        assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+        grads[mode] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        for k, p in net.named_parameters():
+            if ref_grads[k] is None:
+                assert p.grad is None
+            else:
+                _grad_close(p.grad, ref_grads[k], f'{name} {mode} {k}')
+    for k, g in grads['store'].items():
+        assert torch.equal(g, grads['recompute'][k]), ('stored vs recomputed gates', k)
+
+
+def test_graphed_training_steps_with_f4x4_cells_equal_eager_bit_for_bit(monkeypatch):
+    """The captured training step (hipvsr.graph.GraphedTrainStep) with the cells in F(4x4, 3x3) form - the transforms and their buffers inside the
+    graph - against the eager step: same losses, outputs and weights after every one of 4 steps."""
+    from hipvsr.step_tail import FlatAdam
+    from src.model.nets import RefineNet
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    monkeypatch.setenv('RNH_WINO44', 'force')
+    dev = _dev()
+    cfg = orc.Config(in_channels=1, out_channels=1, num_features=[32, 32], num_stages=2, refine_window_size=5, upscale_factor=4,
+                     update_memory=True, num_updated_frames=2, positional_encoding=True)
+    sd = orc.init_state_dict(cfg, seed=8)
+    g = torch.Generator('cpu').manual_seed(5)
+    batches = [([torch.randn(4, 1, 16, 16, generator=g).to(dev) for _ in range(7)], [torch.randn(4, 1, 64, 64, generator=g).to(dev) for _ in range(3)],
+                (torch.rand(4, 7, 1, generator=g) * 2 - 1).to(dev)) for _ in range(4)]
+    runs = {}
+    for graph in (False, True):
+        net = RefineNet(**cfg)
+        net.load_state_dict(sd)
+        net = net.to(dev).train()
+        eng = net._engine()
+        tr = object.__new__(AcdcVSRRefineNetTrainer)
+        tr.net, tr.loss_fns, tr.metric_fns, tr.graph, tr._graphed = net, [torch.nn.L1Loss()], [], graph, None
+        tr.loss_weights = torch.tensor([1.0], device=dev)
+        tr.optimizer = FlatAdam(net.parameters(), lr=1e-3)
+        hist = []
+        for xs, ys, pc in batches:
+            outs, loss, _ = tr.train_step(xs, ys, pc)
+            torch.cuda.synchronize()
+            hist.append((float(loss), [p.detach().clone() for p in net.parameters()], outs[-1][0].detach().clone()))
+        assert all(eng.ops.wino44_ok(eng.plans.lstm[k][kind], 4, 16, 16) for k in eng.plans.lstm for kind in ('full', 'first'))
+        runs[graph] = hist
+    for (la, pa, oa), (lb, pb, ob) in zip(runs[False], runs[True]):
+        assert la == lb and torch.equal(oa, ob)
+        assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    assert runs[True][0][0] != runs[True][-1][0]

@@ -53,6 +53,14 @@ x, hp, cp = R(N, H, W, 64), R(N, H, W, 64), R(N, H, W, 64)
 ho, co, go = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64), ops.empty(N, H, W, 256)
 timeit('lstm.fwd', lambda: ops.conv(pl['full'], [Src(x), Src(hp)], N, H, W, lstm=dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go)),
        2.0 * N * H * W * 256 * 1152, 20)
+if hasattr(ops, 'wino44_cell') and getattr(pl['full'], 'wino44', False):
+    # the same cell in Winograd form F(4x4, 3x3) on transformed inputs (rnh_wino44_cell), and the input transform of one 64-channel tensor
+    vx, vh = ops.wino44_v(N, H, W, 64)[0], ops.wino44_v(N, H, W, 64)[0]
+    ops.wino44_transform(Src(x), N, H, W, vx)
+    ops.wino44_transform(Src(hp), N, H, W, vh)
+    timeit('lstm44.fwd', lambda: ops.wino44_cell(pl['full'], [vx, vh], N, H, W, dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go)),
+           2.0 * N * H * W * 256 * 1152, 20)
+    timeit('lstm44.transform', lambda: ops.wino44_transform(Src(hp), N, H, W, vh), 0.0, 20)
 dg = R(N, H, W, 256)
 dx, dh = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64)
 timeit('lstm.dgrad', lambda: ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dx, 64), Dst(dh, 64)]), 2.0 * N * H * W * 128 * 2304, 20)
