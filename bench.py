@@ -14,17 +14,19 @@ N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 ->
 
 Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
 ranks); `ms_per_step_median` is the median of the per-step HIP-event times of the same steps.  `roofline` prices the
-dominant kernel (the ConvLSTM cell forward, a Winograd F(2x2,3x3) convolution with fused gates, 342 - 24 launches per
-step) from HIP-event timing of that launch on this run: `achieved` / `frac` = the FLOPs the matrix cores EXECUTE
-(16 GEMMs over the 2x2 tiles = 4/9 of the direct form) over the launch time and the fp32 MFMA peak - a fraction of a
-ceiling, <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per
-pixel) is reported beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not
-do that work).  `secondary` carries the SAME step in the bf16-storage path (BASELINE config 3 per GPU: same N, T,
+ConvLSTM cell forward (318 launches per step) from HIP-event timing of that launch on this run, in the form the engine runs it at
+the benchmark's shape: Winograd F(4x4,3x3) on transformed inputs (rnh_wino44_cell: configs 2 and 4, where a launch is at least 1024
+workgroups) or F(2x2,3x3) (rnh_conv_wino).  `achieved` / `frac` = the FLOPs the matrix cores EXECUTE (36 GEMMs over the 4x4 tiles =
+1/4 of the direct form; 16 GEMMs over the 2x2 tiles = 4/9) over the launch time and the fp32 MFMA peak - a fraction of a ceiling,
+<= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per pixel) is reported
+beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not do that work).  The F(4x4) form
+needs one launch of the input transform per cell (rnh_wino44_transform, HBM-bound): `input_transform` times it against 8 TB/s and
+`cell_plus_transform_ms` / `algorithmic_equiv_tflops_with_transform` price the pair.  `secondary` carries the SAME step in the bf16-storage path (BASELINE config 3 per GPU: same N, T,
 size, steps and warm-up, timed the same way in the same process right after the headline) with its own `ms_per_step`, `value`,
 `roofline` (conv_bf16d_kernel<LSTM> against the dense bf16 MFMA peak; executed = algorithmic there) and `dtype: "bf16"`;
 `--no-secondary` skips it, `--dtype bf16` makes it the only line as before.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
-(profiles/lstm_kernel_hbm_bytes.json; profiles/lstm_bf16_kernel_hbm_bytes.json for the secondary), reported only if that record was measured on THIS
-kernel source (sha256 of csrc/conv_wino.hip / csrc/conv_bf16.hip), else null.  `cpu_baseline` times
+(profiles/lstm44_kernel_hbm_bytes.json or lstm_kernel_hbm_bytes.json; profiles/lstm_bf16_kernel_hbm_bytes.json for the secondary), reported only if that
+record was measured on THIS kernel source (sha256 of csrc/conv_wino44.hip / conv_wino.hip / conv_bf16.hip), else null.  `cpu_baseline` times
 the CPU oracle (= the reference's computation, bit-exact) on this host's cores at BASELINE config 1 (rank 0, 1 GPU runs
 only).  `config` carries the step's FLOPs in the reference's formulation and as executed here.
 Diagnosis (environment, no effect on the numbers' definition): BENCH_EACH_STEP=1 prints every timed step's HIP-event time and host enqueue time to stderr;

@@ -447,7 +447,11 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
                 const f32x4w gi = *reinterpret_cast<const f32x4w *>(xi), gf = *reinterpret_cast<const f32x4w *>(xi + W4_GS);
                 const f32x4w go = *reinterpret_cast<const f32x4w *>(xi + 2 * W4_GS), gg = *reinterpret_cast<const f32x4w *>(xi + 3 * W4_GS);
                 const long po = item_o[2 * S + q];
+#ifdef W4_DIAG_NOSTORE                                                         // (diagnostic build: how long is the epilogue without its HBM stores?)
+                if (P.gates_out == P.c_out) {
+#else
                 if (P.gates_out) {
+#endif
                     f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + po * 4 * hd + nt * 16 + c4 * 4);
                     gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
                 }
@@ -458,8 +462,13 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
                     hn[j] = go[j] * w4_tanh(cn[j]);
                 }
                 const long o = po * hd + nt * 16 + c4 * 4;
-                *reinterpret_cast<f32x4w *>(P.c_out + o) = cn;
-                *reinterpret_cast<f32x4w *>(P.h_out + o) = hn;
+#ifdef W4_DIAG_NOSTORE
+                if (cn[0] + hn[1] == 1.2345f)
+#endif
+                {
+                    *reinterpret_cast<f32x4w *>(P.c_out + o) = cn;
+                    *reinterpret_cast<f32x4w *>(P.h_out + o) = hn;
+                }
             }
             if constexpr (S == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (the gates are read: the next exchange goes over them)
         };
