@@ -15,8 +15,8 @@ N = 8 samples per GPU, T = 7 supervised frames (F = 19 input frames), 128x128 ->
 Rank 0 prints ONE JSON line.  `value` = supervised frames (N_global * T) per second over the timed steps (max over
 ranks); `ms_per_step_median` is the median of the per-step HIP-event times of the same steps.  `roofline` prices the
 ConvLSTM cell forward (318 launches per step) from HIP-event timing of that launch on this run, in the form the engine runs it at
-the benchmark's shape: Winograd F(4x4,3x3) on transformed inputs (rnh_wino44_cell: configs 2 and 4, where a launch is at least 1024
-workgroups) or F(2x2,3x3) (rnh_conv_wino).  `achieved` / `frac` = the FLOPs the matrix cores EXECUTE (36 GEMMs over the 4x4 tiles =
+the benchmark's shape: Winograd F(4x4,3x3) on transformed inputs (rnh_wino44_cell: wherever the images are whole
+4x4 tiles - every BASELINE config) or F(2x2,3x3) (rnh_conv_wino).  `achieved` / `frac` = the FLOPs the matrix cores EXECUTE (36 GEMMs over the 4x4 tiles =
 1/4 of the direct form; 16 GEMMs over the 2x2 tiles = 4/9) over the launch time and the fp32 MFMA peak - a fraction of a ceiling,
 <= 1; the same launch priced in the reference's direct 3x3 formulation (589 824 FLOP per pixel) is reported
 beside it as `algorithmic_equiv_tflops` / `algorithmic_equiv_frac` (may exceed 1: Winograd does not do that work).  The F(4x4) form

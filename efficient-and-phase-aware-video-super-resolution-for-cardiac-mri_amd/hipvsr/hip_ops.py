@@ -339,15 +339,17 @@ class HipOps:
                                                  plan.Cin, self._stream()), f'rnh_wino44_pack_weights({plan.name})')
 
     def wino44_ok(self, plan, B, H, W, packed=True):
-        """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it, the images whole 4x4 tiles,
-        and the launch at least RNH_WINO44_MIN (default 1024) workgroups of 512 pixels x 64 columns - four rounds of the chip: below that the
-        F(2x2) kernel's 128-pixel workgroups fill it better.  RNH_WINO44=0 switches the form off, RNH_WINO44=force drops the size condition.
+        """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it and the images whole 4x4
+        tiles.  No size condition: measured against the F(2x2) kernel on one box each, the step is faster at every launch size tried - BASELINE
+        config 4 (8192 workgroups per cell launch) 1742 -> 1495 ms, config 2 (1024) 304 -> 277, config 5 (576) 247.9 -> 230.7, the same at N = 4 /
+        N = 2 (288 / 144) 127.8 -> 119.8 / 66.1 -> 62.4, the reference YAML's 16 crops of 32 x 32 (128, graph replay) 42.4 -> 40.8
+        (profiles/r05_zb_*).  RNH_WINO44=0 switches the form off; RNH_WINO44_MIN=n asks for launches of at least n workgroups (A/B runs).
         ``packed=False``: the question before the weights are packed (the engine's memory plan)."""
         mode = os.environ.get('RNH_WINO44', '1')
         if mode == '0' or not getattr(plan, 'wino44', False) or (packed and id(plan) not in self._packed44) or (H & 3) or (W & 3):
             return False
         wgs = -(-(B * (H // 4) * (W // 4)) // 32) * (plan.Cout // 64)
-        return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1024'))
+        return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1'))
 
     def wino44_v(self, B, H, W, nch, frames=1):
         """Buffer(s) for the transformed form of ``frames`` tensors (B, H, W, nch): a (frames, floats) tensor."""

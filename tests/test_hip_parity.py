@@ -653,8 +653,8 @@ def _cfg2_step(n, seed=202):
 
 @pytest.fixture(params=['0', 'force'], ids=['cell_f2x2', 'cell_f4x4'])
 def cell_form(request, monkeypatch):
-    """The two forms of the fp32 ConvLSTM cell forward: Winograd F(2x2, 3x3) (rnh_conv_wino) and F(4x4, 3x3) (rnh_wino44_cell; the engine's
-    choice where a cell launch is at least 1024 workgroups, i.e. at the benchmark's N = 8 - forced here so that N = 2 runs it too)."""
+    """The two forms of the fp32 ConvLSTM cell forward: Winograd F(2x2, 3x3) (rnh_conv_wino; RNH_WINO44=0) and F(4x4, 3x3) (rnh_wino44_cell; the engine's
+    choice wherever the images are whole 4x4 tiles)."""
     monkeypatch.setenv('RNH_WINO44', request.param)
     return request.param
 

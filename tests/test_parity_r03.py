@@ -143,9 +143,9 @@ _FULL = [('cfg4 x2 T=5 256x256', dict(upscale_factor=2), 5, 256, 4, 8, 4),
 
 @pytest.mark.parametrize('name,over,t,size,n_bwd,n_fwd,n_bf16', _FULL)
 def test_full_size_baseline_configs(name, over, t, size, n_bwd, n_fwd, n_bf16, monkeypatch):
-    # the fp32 cell's form follows the launch size (HipOps.wino44_ok): config 4's batches of 4 and 8 run F(4x4, 3x3), the N = 1 run that is checked
-    # against the oracle would not - forced, so that the per-sample bit-identity below compares like with like; config 5 runs F(2x2) at every N
-    monkeypatch.setenv('RNH_WINO44', 'force' if size == 256 else '0')
+    # the per-sample bit-identity below compares runs at N = 1, 4 and 8: one form of the fp32 cell for all of them (F(4x4, 3x3), the default where
+    # the images are whole 4x4 tiles - 256 and 96 are -, whatever RNH_WINO44_MIN says)
+    monkeypatch.setenv('RNH_WINO44', 'force')
     cfg = orc.exp1_x4_config(**over)
     sd = orc.init_state_dict(cfg, seed=51)
     inputs, targets, pos = orc.synthetic_batch(cfg, 1, t, size, size, seed=52)

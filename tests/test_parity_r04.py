@@ -74,8 +74,7 @@ def _grads(net):
 # BASELINE config 4 at N = 16
 # ---------------------------------------------------------------------------------------------------------------------
 def test_config4_full_batch_training_step_fp32_and_bf16(monkeypatch):
-    # (the fp32 cell runs in F(4x4, 3x3) form at N = 4 and 16 - launches of >= 1024 workgroups - and would not at N = 1: forced, so that the
-    # per-sample bit-identity below compares like with like)
+    # (the fp32 cell in F(4x4, 3x3) form whatever RNH_WINO44_MIN says: the per-sample bit-identity below compares N = 1, 4 and 16)
     monkeypatch.setenv('RNH_WINO44', 'force')
     cfg = orc.exp1_x4_config(upscale_factor=2)
     t, size, nfull = 5, 256, 16

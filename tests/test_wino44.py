@@ -160,7 +160,7 @@ def test_cell_config2_size_vs_float64():
     assert plan.wino44 and ops.wino44_ok(plan, B, H, W) is False               # (not packed yet)
     w, b = R(*spec[plan.wkey]) * 0.03, R(*spec[plan.bkey]) * 0.1
     ops.pack(plan, w.to(dev), b.to(dev))
-    assert ops.wino44_ok(plan, B, H, W) and not ops.wino44_ok(plan, B, H, W + 2) and not ops.wino44_ok(plan, 1, 32, 32)
+    assert ops.wino44_ok(plan, B, H, W) and not ops.wino44_ok(plan, B, H, W + 2) and ops.wino44_ok(plan, 1, 32, 32)
     x, h, c = R(B, H, W, 64), R(B, H, W, 64), R(B, H, W, 64)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     ref_g, ref_c, ref_h = _cell_reference(x, h, c, w, b, 64)
