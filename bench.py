@@ -187,7 +187,7 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=200, warm=50):
         flops_exec = flops * 0.25
         executed, algorithmic = flops_exec / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12
         traffic, traffic_src = quoted_traffic('lstm44_kernel_hbm_bytes.json', 'conv_wino44.hip', (n, h, w))
-        return {'bound': 'mfma', 'kernel': 'wino44_cell_kernel (ConvLSTM cell 128->256 in Winograd F(4x4,3x3) form on transformed inputs, fused gates)',
+        return {'bound': 'mfma', 'kernel': 'wino44_kernel<LSTM> (ConvLSTM cell 128->256 in Winograd F(4x4,3x3) form on transformed inputs, fused gates)',
                 'achieved': round(executed, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4),
                 'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': round(ms, 4), 'executed_mfma_flop_per_launch': flops_exec,
                 'algorithmic_flop_per_launch': flops, 'algorithmic_equiv_tflops': round(algorithmic, 2),

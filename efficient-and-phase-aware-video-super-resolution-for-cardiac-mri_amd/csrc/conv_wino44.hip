@@ -161,17 +161,23 @@ __global__ void __launch_bounds__(256) wino44_transform_kernel(const float *x, c
     }
 }
 
-struct w4_cell_args {                     // the device view of rnh_wino44_cell_args_t
-    const float *v[2];
-    int vchunks[2];
-    int nchunks, B, H, W;
+constexpr int W4_MAX_SRC = 16;
+constexpr int W4_EPI_LSTM = 0, W4_EPI_STORE = 1;
+
+struct w4_args {                          // the device view of rnh_wino44_cell_args_t / rnh_wino44_conv_args_t
+    const float *v[W4_MAX_SRC];           // transformed sources in K order, each already advanced by its tile-block offset
+    int vchunks[W4_MAX_SRC];
+    int nsrc, nchunks, B, H, W;
     const float *wp, *bias;
     int Npad, hd;
-    const float *c_prev;
+    const float *c_prev;                  // LSTM epilogue
     float *h_out, *c_out, *gates_out;
+    float *dst;                           // STORE epilogue: columns [0, dncols) -> channels [dc0, dc0 + dncols) of an NHWC tensor of dC channels
+    int dC, dc0, dncols, daccumulate;
 };
 
-__global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args P, const int MT, const int NT, const int TX, const int TY) {
+template <int EPI>
+__global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const int MT, const int NT, const int TX, const int TY) {
     __shared__ __attribute__((aligned(16))) float stage[2 * W4_BUF];          // 147 456 bytes: two staged chunks; the epilogue's exchange areas afterwards
     __shared__ int tpix[W4_TILES];                                            // top-left output pixel of the block's tiles, -1: no such tile
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
@@ -189,8 +195,6 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
 
     const unsigned lds0 = (unsigned)(size_t)stage;
     // ---- V: LDS-DMA, nine 16-byte pieces per thread and chunk (lane slot = M0 + 16 lane) ------------------------------------------------------
-    const i32x4 vdesc0 = w4_desc(P.v[0]), vdesc1 = w4_desc(P.v[1] ? P.v[1] : P.v[0]);
-    const int n0 = P.vchunks[0];
     const int vvoff = tid * 16;
     auto dma = [&, &vvoff = vvoff, &lds0 = lds0, &wave = wave](int buf, const i32x4 &vd, int blockoff, auto d_tag) W4_INL {
         constexpr int d = decltype(d_tag)::value;
@@ -198,13 +202,16 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
         const int soff = __builtin_amdgcn_readfirstlane(blockoff + d * 8192);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ld), "v"(vvoff), "s"(vd), "s"(soff) : "memory");
     };
-    // chunk c of the K dimension -> descriptor and byte offset of its image ((tile block, local chunk) of its source)
-    auto chunk_src = [&](int c, i32x4 &vd, int &blockoff) W4_INL {
-        const bool second = c >= n0;
-        const int lc = second ? c - n0 : c, nl = second ? nchunks - n0 : n0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vd[k] = second ? vdesc1[k] : vdesc0[k];
-        blockoff = (mt * nl + lc) * (W4_BUF * 4);
+    // the chunks of the K dimension run through the sources in order: (source, chunk of the source) of the chunk whose image is requested next
+    int src_i = 0, src_c = 0;
+    auto chunk_src = [&](i32x4 &vd, int &blockoff) W4_INL {                    // descriptor and byte offset of that chunk's image; advances
+        const int nl = P.vchunks[src_i];
+        vd = w4_desc(P.v[src_i]);
+        blockoff = (mt * nl + src_c) * (W4_BUF * 4);
+        if (++src_c == nl) {
+            src_c = 0;
+            src_i = src_i + 1 < P.nsrc ? src_i + 1 : src_i;                    // (past the end: never requested)
+        }
     };
     // ---- A operand: lane (tile l31, k half kh), position p of this wave's nine, 8-channel block kb: 16 bytes = channels 8 kb + 4 kh + m -------
     const int I0 = 3 * (pg >> 1), J0 = 3 * (pg & 1);
@@ -244,7 +251,7 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
     {
         i32x4 vd;
         int bo;
-        chunk_src(0, vd, bo);
+        chunk_src(vd, bo);
         w4_sfor<9>([&](auto d) W4_INL { dma(1, vd, bo, d); });
     }
     w4_sfor<8>([&](auto g) W4_INL { loadb(0, g); });
@@ -273,7 +280,7 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
         tslot = it >> 6, px = (it >> 2) & 15, c4 = it & 3;
         tile = 8 * (tslot >> 2) + 4 * (tslot & 1) + 2 * s + ((tslot >> 1) & 1);   // tile slot = 4 pg + 2 (entry & 1) + kh
     };
-    const i32x4 cdesc = w4_desc(P.c_prev ? P.c_prev : P.c_out);                // (no previous state: a valid address, zeros behind the wait)
+    const i32x4 cdesc = w4_desc(EPI == W4_EPI_LSTM ? (P.c_prev ? P.c_prev : P.c_out) : P.wp);   // (no previous state: a valid address, zeros behind the wait)
     auto state_request = [&](int s) W4_INL {                                   // two requests; the thread's own slots (no barrier between request and use)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -287,12 +294,13 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ld), "v"(voff), "s"(cdesc) : "memory");
         }
     };
-    const i32x4 biasdesc = w4_desc(P.bias);
-    auto epi_request = [&]() W4_INL {                                          // three requests
+    const i32x4 biasdesc = w4_desc(P.bias ? P.bias : P.wp);                    // (no bias: a valid address, zero behind the wait)
+    constexpr int NEPI = EPI == W4_EPI_LSTM ? 3 : 1;                           // requests of the epilogue in the last chunk
+    auto epi_request = [&]() W4_INL {
         const unsigned ld = __builtin_amdgcn_readfirstlane(lds0 + W4_LBIAS + wave * 256);
         const int voff = (nt * 64 + lane) * 4;                                 // the 64 columns of the workgroup, once per wave (lane slot = M0 + 4 lane)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(ld), "v"(voff), "s"(biasdesc) : "memory");
-        state_request(0);
+        if constexpr (EPI == W4_EPI_LSTM) state_request(0);
     };
 
     auto chunk_body = [&](const int c, auto buf_tag, auto more_tag) W4_INL {
@@ -300,18 +308,18 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
         constexpr int buf = decltype(buf_tag)::value;
         i32x4 vd;
         int bo = 0;
-        if constexpr (more) chunk_src(c + 1, vd, bo);
+        if constexpr (more) chunk_src(vd, bo);
         w4_sfor<W4_NQ>([&](auto q_tag) W4_INL {
             constexpr int q = decltype(q_tag)::value;
             constexpr int p = q % 9;
             if constexpr (more || q + 8 < W4_NQ) loadb(c, std::integral_constant<int, q + 8>());
             // outstanding requests younger than this step's weights (requested 8 steps ago): the weight requests since (8; in the last chunk
             // they stop at its end), the DMA requests of steps 0 .. 8 of a chunk that has a successor, and in the last chunk the epilogue's
-            // three (issued at its step 9, behind the last weight request)
+            // NEPI (issued at its step 9, behind the last weight request)
             constexpr int lo = q - 8 > 0 ? q - 8 : 0, hi = q - 1 < 8 ? q - 1 : 8;
             constexpr int nd = more && hi >= lo ? hi - lo + 1 : 0;
             constexpr int nw = more ? 8 : (W4_NQ - 1 - q < 8 ? W4_NQ - 1 - q : 8);
-            constexpr int ne = !more && q >= 9 ? 3 : 0;
+            constexpr int ne = !more && q >= 9 ? NEPI : 0;
             if constexpr (!more && q == 9) epi_request();
             if constexpr (q == 16) {
                 // every DMA of the next chunk has landed (its youngest is older than the weight request of step 9), all LDS reads of this buffer
@@ -414,8 +422,28 @@ __global__ void __launch_bounds__(512, 1) wino44_cell_kernel(const w4_cell_args 
             }
             float bv;
             {
-                if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // the bias has landed, the state may still be on its way
-                bv = stage[W4_LBIAS / 4 + wave * 64 + cg * 32 + l31];
+                if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(NEPI - 1) : "memory");     // the bias has landed, the state may still be on its way
+                bv = P.bias ? stage[W4_LBIAS / 4 + wave * 64 + cg * 32 + l31] : 0.f;
+            }
+            if constexpr (EPI == W4_EPI_STORE) {
+                // plain store of the lane's column: 32 pixels of 2 tiles per pass (a wave's store covers 32 consecutive channels of 2 pixels)
+                const int dcol = ncol;
+                if (dcol < P.dncols) {
+                    float *dp = P.dst + P.dc0 + dcol;
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int tp = tpix[8 * PG + 4 * kh + 2 * S + e2];
+                        if (tp < 0) continue;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            float *o = dp + (long)(tp + (k >> 2) * W + (k & 3)) * P.dC;
+                            *o = P.daccumulate ? *o + Y[e2][k] + bv : Y[e2][k] + bv;
+                        }
+                    }
+                }
+                // (all reads of the exchange area are back: the next pass writes over it)
+                if constexpr (S == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                return;
             }
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2)
@@ -528,6 +556,14 @@ extern "C" int rnh_wino44_transform(const float *x, int C, int c0, int nch, int 
     return 0;
 }
 
+static int w4_launch(const w4_args &p, int epi, int MT, int TX, int TY, hipStream_t st, const char *who) {
+    const int NT = p.Npad / 64;
+    if (epi == W4_EPI_LSTM) hipLaunchKernelGGL((wino44_kernel<W4_EPI_LSTM>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, p, MT, NT, TX, TY);
+    else hipLaunchKernelGGL((wino44_kernel<W4_EPI_STORE>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, p, MT, NT, TX, TY);
+    RNH_CHECK_LAUNCH(who);
+    return 0;
+}
+
 extern "C" int rnh_wino44_cell(const rnh_wino44_cell_args_t *args, void *stream) {
     if (!args) RNH_FAIL(RNH_E_ARG, "rnh_wino44_cell: null args");
     const rnh_wino44_cell_args_t &a = *args;
@@ -540,14 +576,38 @@ extern "C" int rnh_wino44_cell(const rnh_wino44_cell_args_t *args, void *stream)
     if (a.hd < 16 || (a.hd & 15) || a.Npad != 4 * a.hd) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: hidden channels in multiples of 16, Npad = 4 hd (plans.lstm_colmap64)");
     if ((long)MT * nchunks * W4_BUF * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: a transformed source of at most 2 GiB");
     if ((long)a.B * a.H * a.W * a.hd * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: a cell state of at most 2 GiB");
-    w4_cell_args p;
-    p.v[0] = a.v[0], p.v[1] = a.nsrc == 2 ? a.v[1] : nullptr;
-    p.vchunks[0] = a.vchunks[0], p.vchunks[1] = a.nsrc == 2 ? a.vchunks[1] : 0;
-    p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
+    w4_args p = {};
+    for (int i = 0; i < a.nsrc; ++i) p.v[i] = a.v[i], p.vchunks[i] = a.vchunks[i];
+    p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
     p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad, p.hd = a.hd;
     p.c_prev = a.c_prev, p.h_out = a.h_out, p.c_out = a.c_out, p.gates_out = a.gates_out;
-    const int NT = a.Npad / 64;
-    hipLaunchKernelGGL(wino44_cell_kernel, dim3((unsigned)(MT * NT)), dim3(512), 0, (hipStream_t)stream, p, MT, NT, TX, TY);
-    RNH_CHECK_LAUNCH("rnh_wino44_cell");
-    return 0;
+    return w4_launch(p, W4_EPI_LSTM, MT, TX, TY, (hipStream_t)stream, "rnh_wino44_cell");
+}
+
+extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream) {
+    if (!args) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: null args");
+    const rnh_wino44_conv_args_t &a = *args;
+    if (a.nsrc < 1 || a.nsrc > W4_MAX_SRC || !a.wp || !a.dst.ptr) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad arguments");
+    int TX, TY, MT;
+    long ntiles;
+    if (int rc = w4_geometry(a.B, a.H, a.W, "rnh_wino44_conv", TX, TY, ntiles, MT)) return rc;
+    if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: Npad must be a multiple of 64");
+    if (a.dst.ncols < 1 || a.dst.ncols > a.Npad || a.dst.c0 < 0 || a.dst.c0 + a.dst.ncols > a.dst.C || a.dst.img_off < 0)
+        RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination");
+    if ((long)(a.B + a.dst.img_off) * a.H * a.W * a.dst.C >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: a destination of at most 2^31 elements");
+    w4_args p = {};
+    int nchunks = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (!a.v[i] || a.vchunks[i] < 1 || a.vblock_off[i] < 0) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad source %d", i);
+        if ((long)MT * a.vchunks[i] * W4_BUF * 4 >= (1L << 31))
+            RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: at most 2 GiB of a transformed source per launch");
+        p.v[i] = a.v[i] + (long)a.vblock_off[i] * a.vchunks[i] * W4_BUF;        // (a transformed tensor may hold several frames: the launch starts at this tile block)
+        p.vchunks[i] = a.vchunks[i];
+        nchunks += a.vchunks[i];
+    }
+    if (nchunks & 1) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: an even number of 16-channel chunks");
+    p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
+    p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad;
+    p.dst = a.dst.ptr + (long)a.dst.img_off * a.H * a.W * a.dst.C, p.dC = a.dst.C, p.dc0 = a.dst.c0, p.dncols = a.dst.ncols, p.daccumulate = a.dst.accumulate;
+    return w4_launch(p, W4_EPI_STORE, MT, TX, TY, (hipStream_t)stream, "rnh_wino44_conv");
 }

@@ -388,6 +388,7 @@ class RefineNetEngine:
             if use44 and v44_bytes > 0.08 * ops.total_memory() and ops.capturing():
                 use44 = False
             st['use44'] = use44
+            ref44, R44 = False, 1
             if use44:
                 VF = ops.wino44_v(N, H, W, C, frames=F)
                 for k in (range(F) if F_s == F else sorted(set(range(F_s)) | set(range(F - F_s, F)))):
@@ -401,19 +402,25 @@ class RefineNetEngine:
                 R44 = F_s if v44_bytes <= 0.08 * ops.total_memory() else min(F_s, 4)
                 VH = {d: [ops.wino44_v(N, H, W, hd, frames=R44) for hd in nf] for d in dirs}
                 read44 = {}
+                # refine conv1's forward reads the top layer's h' of both directions (refine_net.py:170-181): in the same form
+                # (rnh_wino44_conv) it takes the transformed h' the cells wrote - every frame's then, the slots in frame order, and a window's
+                # frames whole tile blocks apart
+                ref44 = (P.pos and P.r1_wino and R44 == F_s and (N * (H // 4) * (W // 4)) % 32 == 0 and
+                         ops.wino44_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W))
+            slot44 = lambda d, l, idx: (idx if d == 'forward' else F_s - 1 - idx) if ref44 and l == Lr - 1 else idx % R44   # noqa: E731
 
             def cell44(d, l, idx):
                 plan, srcs, _, _, _, kw = cell_call(d, l, idx)
                 k = idx if d == 'forward' else F - 1 - idx
-                vx = VF[k] if l == 0 else VH[d][l - 1][idx % R44]
-                vs = [vx] + ([VH[d][l][(idx - 1) % R44]] if cfg.memory else [vx])[:len(srcs) - 1]
+                vx = VF[k] if l == 0 else VH[d][l - 1][slot44(d, l - 1, idx)]
+                vs = [vx] + ([VH[d][l][slot44(d, l, idx - 1)]] if cfg.memory and idx > 0 else [vx])[:len(srcs) - 1]
                 ops.wino44_cell(plan, vs, N, H, W, kw['lstm'])
                 if l > 0 and idx + R44 < F_s:                                # (only with a ring: R44 < F_s)
                     read44[(d, l, idx)] = ops.record()                       # slot idx % R44 of the layer below has been read
-                if l + 1 < Lr or (cfg.memory and idx + 1 < F_s):            # somebody reads this h' as a cell input
+                if l + 1 < Lr or (cfg.memory and idx + 1 < F_s) or ref44:   # somebody reads this h' in transformed form (ref44: only the top layer gets here)
                     if l + 1 < Lr and idx >= R44:
                         ops.wait(read44.pop((d, l + 1, idx - R44)))
-                    ops.wino44_transform(st[d]['H'][l].src(k), N, H, W, VH[d][l][idx % R44])
+                    ops.wino44_transform(st[d]['H'][l].src(k), N, H, W, VH[d][l][slot44(d, l, idx)])
 
             if pair:
                 # small images (the reference YAML's 32 x 32 crops): a cell launch is a fraction of the chip, and the two directions' cells of a
@@ -448,7 +455,9 @@ class RefineNetEngine:
                                     ops.conv(plan, srcs, N, H, W, **kw)
                                 below = ops.record() if l + 1 < Lr else None
                 ops.join(2 * Lr)
+            VT = None
             if use44:
+                VT = {d: VH[d][-1] for d in dirs} if ref44 else None      # the top layer's transformed h', slot = frame - first frame of the direction
                 del VF, VH
             self._mem(f'fwd stage {s}: wavefront done')
             for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
@@ -480,7 +489,13 @@ class RefineNetEngine:
                     srcs = win_srcs(a)
                     R1 = ops.empty(nw * N, H, W, P.C1p, dtype=act)
                     hfs, hbs, p4s = HF.frames(a, b + w - 1), HB.frames(a, b + w - 1), P4[a * N:(b + w - 1) * N]   # the source frames of these windows
-                    if P.r1_wino:
+                    if P.r1_wino and VT is not None:
+                        mtf = N * (H // 4) * (W // 4) // 32                 # tile blocks per frame
+                        lo_b = F - F_s                                      # first frame the backward direction holds
+                        ops.wino44_conv(P.r1_fwd_h, [(VT[d], (a + j - (0 if d == 'forward' else lo_b)) * mtf) for j in range(w) for d in dirs], nw * N, H, W,
+                                        Dst(R1, P.r1_cols))
+                        ops.refine_phase_bias(R1, p4s, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
+                    elif P.r1_wino:
                         ops.conv(P.r1_fwd_h, [sc for sc in srcs if sc.t is not P4], nw * N, H, W, dsts=[Dst(R1, P.r1_cols)])
                         ops.refine_phase_bias(R1, p4s, params[P.r1_fwd_h.wkey], N, w, Cl, P.r1_cols)
                     elif P.xcol_m:

@@ -326,17 +326,43 @@ class HipOps:
     # ---- the ConvLSTM cell in Winograd form F(4x4, 3x3): rnh_wino44_* (csrc/conv_wino44.hip) ---------------------------------------------
     def _pack44(self, plan, w, b):
         from .plans import lstm_colmap64
-        hd = plan.Cout // 4
         m = self._maps44.get(id(plan))
         if m is None:
             kch = [sg.kbase + c if c < sg.nvalid else -1 for sg in plan.ksegs for c in range(sg.nch)]
-            m = self._maps44[id(plan)] = dict(kch=self._i32(kch), colmap=self._i32(lstm_colmap64(hd)), K=len(kch), _plan=plan)
-        K, Npad = m['K'], 4 * hd
+            # the cell's columns in blocks of 64 = the gates i, f | o, g of 16 hidden channels; any other plan's columns as they are, padded to 64
+            cm = lstm_colmap64(plan.Cout // 4) if plan.epilogue == L.EPI_LSTM else list(plan.colmap) + [-1] * (-len(plan.colmap) % 64)
+            m = self._maps44[id(plan)] = dict(kch=self._i32(kch), colmap=self._i32(cm), K=len(kch), Npad=len(cm), _plan=plan)
+        K, Npad = m['K'], m['Npad']
         buf = self._packed44.get(id(plan))
         if buf is None:
             buf = self._packed44[id(plan)] = (self.empty(K // 8 * 36 * Npad * 8), self.empty(Npad))
         L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
                                                  plan.Cin, self._stream()), f'rnh_wino44_pack_weights({plan.name})')
+
+    def wino44_conv(self, plan, vsrcs, B, H, W, dst: Dst):
+        """A plain-store convolution in F(4x4, 3x3) form on transformed sources (rnh_wino44_conv): ``vsrcs`` = (tensor of wino44_transform images,
+        first tile block) per K segment of the plan; ``dst`` as for conv()."""
+        if id(plan) not in self._packed44:
+            raise L.HipKernelError(f'{plan.name}: weights were not packed for the F(4x4, 3x3) form')
+        if len(vsrcs) != len(plan.ksegs) or len(vsrcs) > 16:
+            raise L.HipKernelError(f'{plan.name}: {len(vsrcs)} sources for {len(plan.ksegs)} K segments')
+        a = L.Wino44ConvArgs()
+        need = int(self.lib.rnh_wino44_v_floats(B, H, W, 16)) // 16             # floats per channel of one launch's worth of tile blocks
+        for i, ((v, boff), sg) in enumerate(zip(vsrcs, plan.ksegs)):
+            self._chk(v)
+            per_block = 36 * 32 * sg.nch
+            if boff < 0 or boff * per_block + need * sg.nch > v.numel():
+                raise L.HipKernelError(f'{plan.name}: transformed source {i} does not hold the launch\'s tile blocks')
+            a.v[i], a.vchunks[i], a.vblock_off[i] = v.data_ptr(), sg.nch // 16, boff
+        self._chk(dst.t)
+        if tuple(dst.t.shape[1:3]) != (H, W) or dst.img_off < 0 or dst.img_off + B > dst.t.shape[0] or dst.c0 + dst.ncols > dst.t.shape[-1]:
+            raise L.HipKernelError(f'{plan.name}: destination geometry')
+        wp, bp = self._packed44[id(plan)]
+        a.nsrc, a.B, a.H, a.W, a.Npad = len(vsrcs), B, H, W, self._maps44[id(plan)]['Npad']
+        a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
+        a.dst.ptr, a.dst.C, a.dst.c0 = dst.t.data_ptr(), dst.t.shape[-1], dst.c0
+        a.dst.ncols, a.dst.accumulate, a.dst.img_off = dst.ncols, int(dst.accumulate), dst.img_off
+        L.check(self.lib.rnh_wino44_conv(C.byref(a), self._stream()), f'rnh_wino44_conv({plan.name})')
 
     def wino44_ok(self, plan, B, H, W, packed=True):
         """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it and the images whole 4x4
@@ -348,7 +374,7 @@ class HipOps:
         mode = os.environ.get('RNH_WINO44', '1')
         if mode == '0' or not getattr(plan, 'wino44', False) or (packed and id(plan) not in self._packed44) or (H & 3) or (W & 3):
             return False
-        wgs = -(-(B * (H // 4) * (W // 4)) // 32) * (plan.Cout // 64)
+        wgs = -(-(B * (H // 4) * (W // 4)) // 32) * max(len(plan.colmap) // 64, 1)
         return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1'))
 
     def wino44_v(self, B, H, W, nch, frames=1):

@@ -39,7 +39,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_conv_bf16', 'rnh_conv_bf16_pair', 'rnh_conv_wino_pair', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
            'rnh_phase_plane_m', 'rnh_struct_sizes_bf16',
            # F(4x4, 3x3) ConvLSTM cell (ABI 5)
-           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell']
+           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_conv']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -72,6 +72,12 @@ class Wino44CellArgs(C.Structure):
     _fields_ = [('v', C.c_void_p * 2), ('vchunks', C.c_int32 * 2), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('Npad', C.c_int32), ('hd', C.c_int32), ('_pad', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p), ('c_prev', C.c_void_p),
                 ('h_out', C.c_void_p), ('c_out', C.c_void_p), ('gates_out', C.c_void_p)]
+
+
+class Wino44ConvArgs(C.Structure):
+    """rnh_wino44_conv_args_t"""
+    _fields_ = [('v', C.c_void_p * 16), ('vchunks', C.c_int32 * 16), ('vblock_off', C.c_int32 * 16), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32),
+                ('W', C.c_int32), ('Npad', C.c_int32), ('_pad', C.c_int32 * 3), ('wp', C.c_void_p), ('bias', C.c_void_p), ('dst', Dst)]
 
 
 class ConvArgs(C.Structure):
@@ -210,6 +216,7 @@ def load():
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
+    lib.rnh_wino44_conv.argtypes = [C.POINTER(Wino44ConvArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
     lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]

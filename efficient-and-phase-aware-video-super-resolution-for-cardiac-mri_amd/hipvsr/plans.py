@@ -317,6 +317,9 @@ class NetPlans:
                 psegs = [sg for sg in segs if sg.nch == 4]
                 self.r1_fwd_h = ConvPlan_('refine1.fwd.h', k1, b1, ws1, hsegs, list(range(C1 - 1)), wino=True)
                 self.r1_fwd_p = ConvPlan_('refine1.fwd.p', k1, None, ws1, psegs, list(range(C1 - 1)))
+                # refine conv1's forward over the hidden states in F(4x4, 3x3) form (rnh_wino44_conv) on the transformed h' of the top ConvLSTM layer
+                self.r1_fwd_h.wino44 = Cl % 16 == 0 and (len(hsegs) * Cl) % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0' and \
+                    os.environ.get('RNH_WINO44_REFINE', '1') != '0'
                 self.r1_wgrad_h = WgradPlan_('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_wgrad_p = WgradPlan_('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_dgrad_h = ConvPlan_('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],

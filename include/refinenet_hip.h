@@ -549,6 +549,26 @@ typedef struct rnh_wino44_cell_args {
  * epilogue.  Same results as rnh_conv_wino / rnh_conv_igemm with RNH_EPI_LSTM up to the rounding of the transforms. */
 int rnh_wino44_cell(const rnh_wino44_cell_args_t *args /* host */, void *stream);
 
+/* A 3x3 convolution (padding 1) with a plain-store epilogue in the same F(4x4, 3x3) form, on transformed sources that already exist: refine
+ * conv1's forward over the hidden states of the top ConvLSTM layer (reference refine_net.py:149, :170-181: torch.cat of the window's frames,
+ * conv) reads the transformed h' the cells of that layer wrote for their own successors.  The K dimension is the list of sources
+ * (wp from rnh_wino44_pack_weights with the matching kch); a transformed tensor may hold several frames of B images each - `vblock_off[i]` is the
+ * tile block (32 tiles; B * H/4 * W/4 must then be a multiple of 32) the launch starts at in source i.  Columns [0, dst.ncols) go to channels
+ * [dst.c0, ...) of dst.ptr (image offset dst.img_off; accumulate: added to what is there); bias packed [Npad] or 0. */
+typedef struct rnh_wino44_conv_args {
+    const float *v[16];
+    int32_t vchunks[16];        /* 16-channel chunks of each source; the sum must be even                                             */
+    int32_t vblock_off[16];
+    int32_t nsrc;
+    int32_t B, H, W;
+    int32_t Npad;               /* padded column count, a multiple of 64                                                              */
+    int32_t _pad[3];
+    const float *wp;
+    const float *bias;
+    rnh_dst_t dst;
+} rnh_wino44_conv_args_t;
+int rnh_wino44_conv(const rnh_wino44_conv_args_t *args /* host */, void *stream);
+
 const char *rnh_last_error(void);
 int rnh_abi_version(void);
 /* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding

@@ -298,3 +298,50 @@ def test_graphed_training_steps_with_f4x4_cells_equal_eager_bit_for_bit(monkeypa
         assert la == lb and torch.equal(oa, ob)
         assert all(torch.equal(a, b) for a, b in zip(pa, pb))
     assert runs[True][0][0] != runs[True][-1][0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the plain-store form (rnh_wino44_conv): refine conv1's forward over transformed hidden states
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,H,W,nwin', [(2, 16, 32, 3), (1, 32, 32, 2)])
+def test_refine_conv1_in_f4x4_form_vs_float64(N, H, W, nwin):
+    """refine conv1's hidden-state part (10 sources of 64 channels = the 5 frames of a window in both directions, 128 columns, reference
+    refine_net.py:149, :170-181) as ONE launch over nwin windows on transformed frame tensors that hold all frames of a direction - the
+    sources of window a, slot j start (a + j) frames = whole tile blocks into them - against a float64 convolution of the concatenated frames."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.r1_fwd_h
+    assert P.r1_wino and plan.wino44 and len(plan.ksegs) == 10
+    g = torch.Generator('cpu').manual_seed(N * 100 + H)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    w, b = R(*spec[plan.wkey]) * 0.02, R(*spec[plan.bkey]) * 0.1
+    ops.pack(plan, w.to(dev), b.to(dev))
+    nfr, a0 = nwin + 4 + 1, 1                                                  # frames held; the first window starts at frame 1
+    hf, hb = R(nfr * N, H, W, 64), R(nfr * N, H, W, 64)
+    mtf = N * (H // 4) * (W // 4) // 32
+    assert N * (H // 4) * (W // 4) % 32 == 0
+    vf, vb = ops.wino44_v(N, H, W, 64, frames=nfr), ops.wino44_v(N, H, W, 64, frames=nfr)
+    hfd, hbd = hf.to(dev), hb.to(dev)
+    for k in range(nfr):
+        ops.wino44_transform(Src(hfd, img_off=k * N), N, H, W, vf[k])
+        ops.wino44_transform(Src(hbd, img_off=k * N), N, H, W, vb[k])
+    C1p = P.C1p
+    out = torch.full((nwin * N + 1, H, W, C1p), float('nan'), device=dev)
+    ops.wino44_conv(plan, [(v, (a0 + j) * mtf) for j in range(5) for v in (vf, vb)], nwin * N, H, W, Dst(out, P.r1_cols, img_off=1))
+    torch.cuda.synchronize()
+    C1 = 129
+    for wi in range(nwin):
+        x = torch.cat([t[(a0 + wi + j) * N:(a0 + wi + j + 1) * N].double().permute(0, 3, 1, 2) for j in range(5) for t in (hf, hb)], 1)   # N, 640, H, W
+        wsel = torch.cat([w.double()[:128, j * C1 + o:j * C1 + o + 64] for j in range(5) for o in (0, 64)], 1)
+        ref = F.conv2d(x, wsel, b.double()[:128], padding=1).permute(0, 2, 3, 1)
+        mine = out[1 + wi * N:1 + (wi + 1) * N, ..., :128].cpu().double()
+        assert not torch.isnan(mine).any()
+        err = float((mine - ref).abs().max())
+        assert err <= 2e-4 * max(1.0, float(ref.abs().max())), (wi, err, float(ref.abs().max()))
+    assert torch.isnan(out[0]).all() and torch.isnan(out[1:, ..., 128:]).all()         # nothing else was written

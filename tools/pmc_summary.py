@@ -92,12 +92,12 @@ if hbf:
                   open(hbf, 'w'), indent=1)
 
 if h44:
-    # the F(4x4, 3x3) ConvLSTM cell kernel of the run: wino44_cell_kernel (csrc/conv_wino44.hip); run over `tools/kbench.py lstm44`
+    # the F(4x4, 3x3) ConvLSTM cell kernel of the run: wino44_kernel<0> = <LSTM> (csrc/conv_wino44.hip); run over `tools/kbench.py lstm44`
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    key = next((k for k in summary if k.startswith('wino44_cell_kernel')), None)
+    key = next((k for k in summary if k.startswith('wino44_kernel<0')), None)
     src = os.path.join(here, 'efficient-and-phase-aware-video-super-resolution-for-cardiac-mri_amd', 'csrc', 'conv_wino44.hip')
     if key and 'hbm_bytes_per_launch' in summary[key]:
-        json.dump({'kernel': 'wino44_cell_kernel at N=8,128x128 (one ConvLSTM cell launch, Winograd F(4x4,3x3) on transformed inputs)',
+        json.dump({'kernel': 'wino44_kernel<LSTM> at N=8,128x128 (one ConvLSTM cell launch, Winograd F(4x4,3x3) on transformed inputs)',
                    'FETCH_SIZE_KB_raw': summary[key]['FETCH_SIZE'], 'WRITE_SIZE_KB': summary[key]['WRITE_SIZE'],
                    'correction': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact',
                    'hbm_bytes_per_launch': summary[key]['hbm_bytes_per_launch'], 'algorithmic_bytes_per_launch': 301989888,
