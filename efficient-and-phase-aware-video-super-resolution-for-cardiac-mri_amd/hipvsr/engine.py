@@ -197,6 +197,16 @@ class RefineNetEngine:
         ops, P = self.ops, self.plans
         return (not self.bf16) and hasattr(ops, 'wino44_ok') and all(ops.wino44_ok(P.lstm[k][kind], N, H, W, packed=False) for k in P.lstm for kind in ('full', 'first'))
 
+    def refine_f4x4(self, N, H, W, F):
+        """Does refine conv1's forward over the hidden states run in F(4x4, 3x3) form (rnh_wino44_conv) at this shape?  It reads the transformed h'
+        the top layer's cells wrote: the cells must run in that form with a slot per frame (no ring), a frame must be whole tile blocks."""
+        P, cfg = self.plans, self.cfg
+        if not (self.cells_f4x4(N, H, W) and P.pos and P.r1_wino and getattr(P.r1_fwd_h, 'wino44', False)):
+            return False
+        slots = 2 * F * sum(P.nf) * N * H * W * 9
+        return (slots <= 0.08 * self.ops.total_memory() and (N * (H // 4) * (W // 4)) % 32 == 0 and
+                self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False))
+
     def _mem(self, label):
         """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
         if os.environ.get('RNH_MEMLOG') == '1' and hasattr(self.ops, 'mem_allocated'):
@@ -405,8 +415,7 @@ class RefineNetEngine:
                 # refine conv1's forward reads the top layer's h' of both directions (refine_net.py:170-181): in the same form
                 # (rnh_wino44_conv) it takes the transformed h' the cells wrote - every frame's then, the slots in frame order, and a window's
                 # frames whole tile blocks apart
-                ref44 = (P.pos and P.r1_wino and R44 == F_s and (N * (H // 4) * (W // 4)) % 32 == 0 and
-                         ops.wino44_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W))
+                ref44 = R44 == F_s and self.refine_f4x4(N, H, W, F) and ops.wino44_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W)
             slot44 = lambda d, l, idx: (idx if d == 'forward' else F_s - 1 - idx) if ref44 and l == Lr - 1 else idx % R44   # noqa: E731
 
             def cell44(d, l, idx):
