@@ -78,27 +78,29 @@ __device__ __forceinline__ void w4_tile_xy(int t, int TX, int TY, int &img, int 
     }
 }
 
-// U[s8][xi][n][kh][m] = (G g G^T)[xi] of (output column colmap[n], input channel kch[8 s8 + 4 kh + m])
-__global__ void wino44_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kch, const int *colmap, int K, int Npad, int Cin) {
+// U[s8][xi][n][kh][m] = (G g G^T)[xi] of (output column colmap[n], input channel kch[8 s8 + 4 kh + m]); transposed: of the data gradient's filter
+__global__ void wino44_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kch, const int *colmap, int K, int Npad, int Cin,
+                                   int transposed) {
     const long total = (long)(K / 8) * 36 * Npad * 8;
     const float G[6][3] = {{0.25f, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Npad; e += (long)gridDim.x * blockDim.x) {
         if (e >= total) {
             const int n = (int)(e - total);
-            if (biasp) biasp[n] = (bias && colmap[n] >= 0) ? bias[colmap[n]] : 0.f;
+            if (biasp) biasp[n] = (bias && !transposed && colmap[n] >= 0) ? bias[colmap[n]] : 0.f;
             continue;
         }
         const int km = (int)(e & 7), n = (int)((e >> 3) % Npad), xi = (int)((e / (8L * Npad)) % 36), s8 = (int)(e / (8L * Npad * 36));
         const int col = colmap[n], c = kch[8 * s8 + km];
         float v = 0.f;
         if (col >= 0 && c >= 0) {
-            const float *g = w + ((long)col * Cin + c) * 9;
+            // (transposed: the data gradient - the K slot is the forward weight's OUTPUT channel, the column its input channel, the taps flipped)
+            const float *g = transposed ? w + ((long)c * Cin + col) * 9 : w + ((long)col * Cin + c) * 9;
             const int i = xi / 6, j = xi % 6;
             // (double: the products of sixths and twenty-fourths are rounded once)
             double a = 0.0;
             for (int p = 0; p < 3; ++p)
-                for (int q = 0; q < 3; ++q) a += (double)G[i][p] * (double)G[j][q] * (double)g[p * 3 + q];
+                for (int q = 0; q < 3; ++q) a += (double)G[i][p] * (double)G[j][q] * (double)g[transposed ? 8 - (p * 3 + q) : p * 3 + q];
             v = (float)a;
         }
         wp[e] = v;
@@ -172,8 +174,11 @@ struct w4_args {                          // the device view of rnh_wino44_cell_
     int Npad, hd;
     const float *c_prev;                  // LSTM epilogue
     float *h_out, *c_out, *gates_out;
-    float *dst;                           // STORE epilogue: columns [0, dncols) -> channels [dc0, dc0 + dncols) of an NHWC tensor of dC channels
-    int dC, dc0, dncols, daccumulate;
+    struct {                              // STORE epilogue: consecutive column ranges -> channels [c0, c0 + ncols) of NHWC tensors of C channels
+        float *ptr;
+        int C, c0, ncols, accumulate;
+    } dst[RNH_MAX_DST];
+    int ndst;
 };
 
 template <int EPI>
@@ -427,17 +432,23 @@ __global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const i
             }
             if constexpr (EPI == W4_EPI_STORE) {
                 // plain store of the lane's column: 32 pixels of 2 tiles per pass (a wave's store covers 32 consecutive channels of 2 pixels)
-                const int dcol = ncol;
-                if (dcol < P.dncols) {
-                    float *dp = P.dst + P.dc0 + dcol;
+                int seg = -1, cbase = 0;                                    // destination segment of this lane's column
+                for (int dd = 0; dd < P.ndst; ++dd) {
+                    if (seg < 0 && ncol < cbase + P.dst[dd].ncols) seg = dd;
+                    if (seg < 0) cbase += P.dst[dd].ncols;
+                }
+                if (seg >= 0) {
+                    const int dC = P.dst[seg].C;
+                    const bool accum = P.dst[seg].accumulate != 0;
+                    float *dp = P.dst[seg].ptr + P.dst[seg].c0 + (ncol - cbase);
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {
                         const int tp = tpix[8 * PG + 4 * kh + 2 * S + e2];
                         if (tp < 0) continue;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
-                            float *o = dp + (long)(tp + (k >> 2) * W + (k & 3)) * P.dC;
-                            *o = P.daccumulate ? *o + Y[e2][k] + bv : Y[e2][k] + bv;
+                            float *o = dp + (long)(tp + (k >> 2) * W + (k & 3)) * dC;
+                            *o = accum ? *o + Y[e2][k] + bv : Y[e2][k] + bv;
                         }
                     }
                 }
@@ -533,12 +544,12 @@ extern "C" int64_t rnh_wino44_v_floats(int B, int H, int W, int nch) {
 }
 
 extern "C" int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *colmap, int K, int Npad,
-                                       int Cout, int Cin, void *stream) {
+                                       int Cout, int Cin, int transposed, void *stream) {
     if (!w || !wp || !kch || !colmap || K < 16 || Npad < 64 || Cout < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "rnh_wino44_pack_weights: bad arguments");
     if (K % 32) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_pack_weights: K must be a multiple of 32 (an even number of 16-channel chunks)");
     if (Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_pack_weights: Npad must be a multiple of 64");
     hipLaunchKernelGGL(wino44_pack_kernel, dim3(w4_grid((long)(K / 8) * 36 * Npad * 8 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, biasp, kch, colmap, K,
-                       Npad, Cin);
+                       Npad, Cin, transposed);
     RNH_CHECK_LAUNCH("rnh_wino44_pack_weights");
     return 0;
 }
@@ -587,14 +598,20 @@ extern "C" int rnh_wino44_cell(const rnh_wino44_cell_args_t *args, void *stream)
 extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream) {
     if (!args) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: null args");
     const rnh_wino44_conv_args_t &a = *args;
-    if (a.nsrc < 1 || a.nsrc > W4_MAX_SRC || !a.wp || !a.dst.ptr) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad arguments");
+    if (a.nsrc < 1 || a.nsrc > W4_MAX_SRC || !a.wp) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad arguments");
     int TX, TY, MT;
     long ntiles;
     if (int rc = w4_geometry(a.B, a.H, a.W, "rnh_wino44_conv", TX, TY, ntiles, MT)) return rc;
     if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: Npad must be a multiple of 64");
-    if (a.dst.ncols < 1 || a.dst.ncols > a.Npad || a.dst.c0 < 0 || a.dst.c0 + a.dst.ncols > a.dst.C || a.dst.img_off < 0)
-        RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination");
-    if ((long)(a.B + a.dst.img_off) * a.H * a.W * a.dst.C >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: a destination of at most 2^31 elements");
+    if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination count");
+    int cols = 0;
+    for (int d = 0; d < a.ndst; ++d) {
+        const rnh_dst_t &D = a.dst[d];
+        if (!D.ptr || D.ncols < 1 || D.c0 < 0 || D.c0 + D.ncols > D.C || D.img_off < 0) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination %d", d);
+        if ((long)(a.B + D.img_off) * a.H * a.W * D.C >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: a destination of at most 2^31 elements");
+        cols += D.ncols;
+    }
+    if (cols > a.Npad) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: destination columns exceed Npad");
     w4_args p = {};
     int nchunks = 0;
     for (int i = 0; i < a.nsrc; ++i) {
@@ -608,6 +625,10 @@ extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream)
     if (nchunks & 1) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: an even number of 16-channel chunks");
     p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
     p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad;
-    p.dst = a.dst.ptr + (long)a.dst.img_off * a.H * a.W * a.dst.C, p.dC = a.dst.C, p.dc0 = a.dst.c0, p.dncols = a.dst.ncols, p.daccumulate = a.dst.accumulate;
+    p.ndst = a.ndst;
+    for (int d = 0; d < a.ndst; ++d) {
+        const rnh_dst_t &D = a.dst[d];
+        p.dst[d].ptr = D.ptr + (long)D.img_off * a.H * a.W * D.C, p.dst[d].C = D.C, p.dst[d].c0 = D.c0, p.dst[d].ncols = D.ncols, p.dst[d].accumulate = D.accumulate;
+    }
     return w4_launch(p, W4_EPI_STORE, MT, TX, TY, (hipStream_t)stream, "rnh_wino44_conv");
 }

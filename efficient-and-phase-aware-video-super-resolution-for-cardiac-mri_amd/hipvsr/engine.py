@@ -951,6 +951,20 @@ class RefineNetEngine:
                 dh_next[d][l], dc_next[d][l] = dhp, dcp
                 return (pl['dgrad'], [Src(dg)], N, H, W, dict(dsts=dsts)), dxbuf, tmp
 
+            # the fp32 path's data gradients in F(4x4, 3x3) form where the forward's cells ran in it: one transform of the frame's gate gradients
+            # (4 hd channels) into a scratch image per (direction, layer), then rnh_wino44_conv with the transposed weights
+            dg44 = (not fused and bool(st.get('use44')) and
+                    all(ops.wino44_ok(P.lstm[(d, l)]['dgrad'], N, H, W) for d in dirs for l in range(Lr)))
+            VG = {d: [ops.wino44_v(N, H, W, 4 * hd)[0] for hd in nf] for d in dirs} if dg44 else None
+
+            def dgrad_launch(d, l, call):
+                plan, srcs, _, _, _, kw = call
+                if dg44:
+                    ops.wino44_transform(srcs[0], N, H, W, VG[d][l])
+                    ops.wino44_conv(plan, [(VG[d][l], 0)], N, H, W, kw['dsts'])
+                else:
+                    ops.conv(plan, srcs, N, H, W, **kw)
+
             for idx in range(T if not fused else 0):
                 if pair:
                     # one stream per layer; the two directions' data gradients of (layer, chain position) in one launch
@@ -960,7 +974,11 @@ class RefineNetEngine:
                             if above is not None:
                                 ops.wait(above)
                             cells = [bwd_cell_unfused(d, l, idx, dx_above[d]) for d in dirs]
-                            ops.conv_pair([c[0] for c in cells])
+                            if dg44:
+                                for d, c in zip(dirs, cells):
+                                    dgrad_launch(d, l, c[0])
+                            else:
+                                ops.conv_pair([c[0] for c in cells])
                             for d, (_, dxbuf, tmp) in zip(dirs, cells):
                                 if tmp is not None:
                                     ops.add(dxbuf, tmp, accumulate=True)
@@ -973,8 +991,8 @@ class RefineNetEngine:
                         with ops.side(di * Lr + l):
                             if above is not None:
                                 ops.wait(above)
-                            (plan, srcs, _, _, _, kw), dxbuf, tmp = bwd_cell_unfused(d, l, idx, dx_above)
-                            ops.conv(plan, srcs, N, H, W, **kw)
+                            call, dxbuf, tmp = bwd_cell_unfused(d, l, idx, dx_above)
+                            dgrad_launch(d, l, call)
                             if tmp is not None:
                                 ops.add(dxbuf, tmp, accumulate=True)
                             dx_above = dxbuf if l > 0 else None

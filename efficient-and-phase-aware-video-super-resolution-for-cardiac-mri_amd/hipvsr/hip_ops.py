@@ -337,11 +337,11 @@ class HipOps:
         if buf is None:
             buf = self._packed44[id(plan)] = (self.empty(K // 8 * 36 * Npad * 8), self.empty(Npad))
         L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
-                                                 plan.Cin, self._stream()), f'rnh_wino44_pack_weights({plan.name})')
+                                                 plan.Cin, int(plan.transposed), self._stream()), f'rnh_wino44_pack_weights({plan.name})')
 
     def wino44_conv(self, plan, vsrcs, B, H, W, dst: Dst):
         """A plain-store convolution in F(4x4, 3x3) form on transformed sources (rnh_wino44_conv): ``vsrcs`` = (tensor of wino44_transform images,
-        first tile block) per K segment of the plan; ``dst`` as for conv()."""
+        first tile block) per K segment of the plan; ``dst``: a Dst or a list of them, as conv()'s dsts."""
         if id(plan) not in self._packed44:
             raise L.HipKernelError(f'{plan.name}: weights were not packed for the F(4x4, 3x3) form')
         if len(vsrcs) != len(plan.ksegs) or len(vsrcs) > 16:
@@ -354,14 +354,16 @@ class HipOps:
             if boff < 0 or boff * per_block + need * sg.nch > v.numel():
                 raise L.HipKernelError(f'{plan.name}: transformed source {i} does not hold the launch\'s tile blocks')
             a.v[i], a.vchunks[i], a.vblock_off[i] = v.data_ptr(), sg.nch // 16, boff
-        self._chk(dst.t)
-        if tuple(dst.t.shape[1:3]) != (H, W) or dst.img_off < 0 or dst.img_off + B > dst.t.shape[0] or dst.c0 + dst.ncols > dst.t.shape[-1]:
-            raise L.HipKernelError(f'{plan.name}: destination geometry')
+        dsts = [dst] if isinstance(dst, Dst) else list(dst)
         wp, bp = self._packed44[id(plan)]
-        a.nsrc, a.B, a.H, a.W, a.Npad = len(vsrcs), B, H, W, self._maps44[id(plan)]['Npad']
+        a.nsrc, a.B, a.H, a.W, a.Npad, a.ndst = len(vsrcs), B, H, W, self._maps44[id(plan)]['Npad'], len(dsts)
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
-        a.dst.ptr, a.dst.C, a.dst.c0 = dst.t.data_ptr(), dst.t.shape[-1], dst.c0
-        a.dst.ncols, a.dst.accumulate, a.dst.img_off = dst.ncols, int(dst.accumulate), dst.img_off
+        for i, d in enumerate(dsts):
+            self._chk(d.t)
+            if tuple(d.t.shape[1:3]) != (H, W) or d.img_off < 0 or d.img_off + B > d.t.shape[0] or d.c0 + d.ncols > d.t.shape[-1]:
+                raise L.HipKernelError(f'{plan.name}: destination {i} geometry')
+            a.dst[i].ptr, a.dst[i].C, a.dst[i].c0 = d.t.data_ptr(), d.t.shape[-1], d.c0
+            a.dst[i].ncols, a.dst[i].accumulate, a.dst[i].img_off = d.ncols, int(d.accumulate), d.img_off
         L.check(self.lib.rnh_wino44_conv(C.byref(a), self._stream()), f'rnh_wino44_conv({plan.name})')
 
     def wino44_ok(self, plan, B, H, W, packed=True):

@@ -77,7 +77,7 @@ class Wino44CellArgs(C.Structure):
 class Wino44ConvArgs(C.Structure):
     """rnh_wino44_conv_args_t"""
     _fields_ = [('v', C.c_void_p * 16), ('vchunks', C.c_int32 * 16), ('vblock_off', C.c_int32 * 16), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32),
-                ('W', C.c_int32), ('Npad', C.c_int32), ('_pad', C.c_int32 * 3), ('wp', C.c_void_p), ('bias', C.c_void_p), ('dst', Dst)]
+                ('W', C.c_int32), ('Npad', C.c_int32), ('_pad', C.c_int32 * 3), ('wp', C.c_void_p), ('bias', C.c_void_p), ('ndst', C.c_int32), ('_pad2', C.c_int32), ('dst', Dst * MAX_DST)]
 
 
 class ConvArgs(C.Structure):
@@ -214,7 +214,7 @@ def load():
     lib.rnh_wino44_v_floats.argtypes = [i32, i32, i32, i32]
     lib.rnh_wino44_v_floats.restype = i64
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
-    lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_conv.argtypes = [C.POINTER(Wino44ConvArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

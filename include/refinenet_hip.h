@@ -528,9 +528,10 @@ int64_t rnh_wino44_v_floats(int B, int H, int W, int nch);
 int rnh_wino44_transform(const float *x, int C, int c0, int nch, int B, int H, int W, float *v, void *stream);
 /* wp[s8][xi][n][kh][m] = (G g G^T)[xi], g = the 3x3 filter w[colmap[n]][kch[8 s8 + 4 kh + m]] (w OIHW [Cout][Cin][3][3]; kch [K] = the
  * weight's input channel of every K slot in the order the transformed sources are passed to rnh_wino44_cell, colmap [Npad]; device int32
- * arrays, negative = zero); wp: K / 8 * 36 * Npad * 8 floats; biasp[n] = bias[colmap[n]].  K a multiple of 32, Npad of 64. */
+ * arrays, negative = zero); wp: K / 8 * 36 * Npad * 8 floats; biasp[n] = bias[colmap[n]].  K a multiple of 32, Npad of 64.
+ * transposed (the data gradient, as rnh_pack_weights): g = w[kch[..]][colmap[n]] with the taps flipped, no bias. */
 int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *colmap, int K, int Npad,
-                            int Cout, int Cin, void *stream);
+                            int Cout, int Cin, int transposed, void *stream);
 typedef struct rnh_wino44_cell_args {
     const float *v[2];          /* transformed sources (rnh_wino44_transform) in K order: the cell's input x_t, its previous output h_{t-1} */
     int32_t vchunks[2];         /* their 16-channel chunks; the sum must be even                                                       */
@@ -553,8 +554,9 @@ int rnh_wino44_cell(const rnh_wino44_cell_args_t *args /* host */, void *stream)
  * conv1's forward over the hidden states of the top ConvLSTM layer (reference refine_net.py:149, :170-181: torch.cat of the window's frames,
  * conv) reads the transformed h' the cells of that layer wrote for their own successors.  The K dimension is the list of sources
  * (wp from rnh_wino44_pack_weights with the matching kch); a transformed tensor may hold several frames of B images each - `vblock_off[i]` is the
- * tile block (32 tiles; B * H/4 * W/4 must then be a multiple of 32) the launch starts at in source i.  Columns [0, dst.ncols) go to channels
- * [dst.c0, ...) of dst.ptr (image offset dst.img_off; accumulate: added to what is there); bias packed [Npad] or 0. */
+ * tile block (32 tiles; B * H/4 * W/4 must then be a multiple of 32) the launch starts at in source i.  Destination segments as for
+ * rnh_conv_igemm (RNH_EPI_STORE); bias packed [Npad] or 0.  With transposed-packed weights: the ConvLSTM cell's data gradient (autograd of
+ * refine_net.py:253-257) on the transformed gate gradients. */
 typedef struct rnh_wino44_conv_args {
     const float *v[16];
     int32_t vchunks[16];        /* 16-channel chunks of each source; the sum must be even                                             */
@@ -565,7 +567,9 @@ typedef struct rnh_wino44_conv_args {
     int32_t _pad[3];
     const float *wp;
     const float *bias;
-    rnh_dst_t dst;
+    int32_t ndst;               /* destination segments as for rnh_conv_igemm's RNH_EPI_STORE: consecutive column ranges                 */
+    int32_t _pad2;
+    rnh_dst_t dst[RNH_MAX_DST];
 } rnh_wino44_conv_args_t;
 int rnh_wino44_conv(const rnh_wino44_conv_args_t *args /* host */, void *stream);
 

@@ -345,3 +345,41 @@ def test_refine_conv1_in_f4x4_form_vs_float64(N, H, W, nwin):
         err = float((mine - ref).abs().max())
         assert err <= 2e-4 * max(1.0, float(ref.abs().max())), (wi, err, float(ref.abs().max()))
     assert torch.isnan(out[0]).all() and torch.isnan(out[1:, ..., 128:]).all()         # nothing else was written
+
+
+@pytest.mark.parametrize('feat,B,H,W', [(32, 3, 12, 20), (64, 2, 32, 32)])
+def test_cell_data_gradient_in_f4x4_form_vs_float64(feat, B, H, W, monkeypatch):
+    """The ConvLSTM cell's data gradient (autograd of reference refine_net.py:253-257: conv over cat[x, h]) through rnh_wino44_transform of the gate
+    gradients + rnh_wino44_conv with transposed-packed weights, two destinations (dx, dh; the second one accumulating): against float64
+    conv_transpose2d."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    monkeypatch.setenv('RNH_WINO44_DGRAD', '1')                                # (opt-in: measured barely faster than the F(2x2) launch)
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    cfg.num_features = [feat, feat]
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.lstm[('backward', 1)]['dgrad']
+    assert plan.wino44 and plan.transposed
+    g = torch.Generator('cpu').manual_seed(feat + W)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    w = R(*spec[plan.wkey]) * 0.05
+    ops.pack(plan, w.to(dev))
+    dg = R(B, H, W, 4 * feat)
+    ref = F.conv_transpose2d(dg.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)       # B H W 2 feat
+    v = ops.wino44_v(B, H, W, 4 * feat)[0]
+    ops.wino44_transform(Src(dg.to(dev)), B, H, W, v)
+    dx = torch.full((B, H, W, feat), float('nan'), device=dev)
+    base = R(B, H, W, feat)
+    dh = base.to(dev)
+    ops.wino44_conv(plan, [(v, 0)], B, H, W, [Dst(dx, feat), Dst(dh, feat, accumulate=True)])
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    for nm, mine, want in (('dx', dx, ref[..., :feat]), ('dh', dh, ref[..., feat:] + base.double())):
+        m = mine.cpu().double()
+        assert not torch.isnan(m).any(), nm
+        err = float((m - want).abs().max())
+        assert err <= 2e-5 * max(1.0, scale), (nm, err, scale)
