@@ -492,7 +492,12 @@ __global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const i
                 if (P.gates_out) {
 #endif
                     f32x4w *gp = reinterpret_cast<f32x4w *>(P.gates_out + po * 4 * hd + nt * 16 + c4 * 4);
+#ifdef W4_GATES_NT          // experiment: the gates past the caches (nobody reads them before the backward)
+                    __builtin_nontemporal_store(gi, gp); __builtin_nontemporal_store(gf, gp + hd / 4);
+                    __builtin_nontemporal_store(go, gp + 2 * (hd / 4)); __builtin_nontemporal_store(gg, gp + 3 * (hd / 4));
+#else
                     gp[0] = gi; gp[hd / 4] = gf; gp[2 * (hd / 4)] = go; gp[3 * (hd / 4)] = gg;
+#endif
                 }
                 f32x4w cn, hn;
 #pragma unroll
