@@ -179,6 +179,7 @@ struct w4_args {                          // the device view of rnh_wino44_cell_
         int C, c0, ncols, accumulate;
     } dst[RNH_MAX_DST];
     int ndst;
+    int ps_r, ps_cq;                      // > 0: nn.PixelShuffle(ps_r) fused into the store - column n = (i r + j) cq + c -> pixel (r y + i, r x + j), channel c of dst[0]
 };
 
 template <int EPI>
@@ -432,6 +433,25 @@ __global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const i
             }
             if constexpr (EPI == W4_EPI_STORE) {
                 // plain store of the lane's column: 32 pixels of 2 tiles per pass (a wave's store covers 32 consecutive channels of 2 pixels)
+                if (P.ps_r) {
+                    const int r = P.ps_r, cq = P.ps_cq;
+                    if (ncol < cq * r * r) {
+                        const int sub = ncol / cq, c = ncol - sub * cq, pi = sub / r, pj = sub - pi * r;
+                        float *dp = P.dst[0].ptr + c;
+                        const long Wr = (long)W * r;
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int tp = tpix[8 * PG + 4 * kh + 2 * S + e2];
+                            if (tp < 0) continue;
+                            const int row = tp / W, x0 = tp - row * W;      // row = image * H + y: the images' rows follow each other in both tensors
+#pragma unroll
+                            for (int k = 0; k < 16; ++k)
+                                dp[((long)(row + (k >> 2)) * r + pi) * Wr * cq + ((long)(x0 + (k & 3)) * r + pj) * cq] = Y[e2][k] + bv;
+                        }
+                    }
+                    if constexpr (S == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    return;
+                }
                 int seg = -1, cbase = 0;                                    // destination segment of this lane's column
                 for (int dd = 0; dd < P.ndst; ++dd) {
                     if (seg < 0 && ncol < cbase + P.dst[dd].ncols) seg = dd;
@@ -609,11 +629,13 @@ extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream)
     if (int rc = w4_geometry(a.B, a.H, a.W, "rnh_wino44_conv", TX, TY, ntiles, MT)) return rc;
     if (a.Npad < 64 || a.Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: Npad must be a multiple of 64");
     if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination count");
+    if (a.ps_r < 0 || (a.ps_r > 0 && (a.ndst != 1 || a.ps_cq < 1 || a.ps_cq * a.ps_r * a.ps_r > a.Npad || a.dst[0].img_off != 0)))
+        RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad pixel-shuffle destination");
     int cols = 0;
     for (int d = 0; d < a.ndst; ++d) {
         const rnh_dst_t &D = a.dst[d];
         if (!D.ptr || D.ncols < 1 || D.c0 < 0 || D.c0 + D.ncols > D.C || D.img_off < 0) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad destination %d", d);
-        if ((long)(a.B + D.img_off) * a.H * a.W * D.C >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: a destination of at most 2^31 elements");
+        if (!a.ps_r && (long)(a.B + D.img_off) * a.H * a.W * D.C >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: a destination of at most 2^31 elements");
         cols += D.ncols;
     }
     if (cols > a.Npad) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: destination columns exceed Npad");
@@ -630,7 +652,7 @@ extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream)
     if (nchunks & 1) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: an even number of 16-channel chunks");
     p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
     p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad;
-    p.ndst = a.ndst;
+    p.ndst = a.ndst, p.ps_r = a.ps_r, p.ps_cq = a.ps_cq;
     for (int d = 0; d < a.ndst; ++d) {
         const rnh_dst_t &D = a.dst[d];
         p.dst[d].ptr = D.ptr + (long)D.img_off * a.H * a.W * D.C, p.dst[d].C = D.C, p.dst[d].c0 = D.c0, p.dst[d].ncols = D.ncols, p.dst[d].accumulate = D.accumulate;

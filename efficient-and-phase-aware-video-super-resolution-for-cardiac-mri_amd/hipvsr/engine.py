@@ -207,6 +207,12 @@ class RefineNetEngine:
         return (slots <= 0.08 * self.ops.total_memory() and (N * (H // 4) * (W // 4)) % 32 == 0 and
                 self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False))
 
+    def up_f4x4(self, N, H, W):
+        """Does the first PixelShuffle convolution of the upsampler (the one in front of the collapsed tail) run in F(4x4, 3x3) form at this shape?"""
+        P = self.plans
+        return (self.cells_f4x4(N, H, W) and len(P.up) > 1 and P.up[0]['r'] == 2 and getattr(P.up[0]['fwd'], 'wino44', False) and
+                self.ops.wino44_ok(P.up[0]['fwd'], N, H, W, packed=False))
+
     def _mem(self, label):
         """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
         if os.environ.get('RNH_MEMLOG') == '1' and hasattr(self.ops, 'mem_allocated'):
@@ -567,9 +573,17 @@ class RefineNetEngine:
                 # ago) is rejoined here, so that at most ONE stage's upsampler buffers are alive
                 ops.rejoin()
                 aside_keep.clear()
+            # (the PixelShuffle convolutions in F(4x4, 3x3) form where the cells run in it: one transform of the input, allocated here like Yb)
+            up44 = [bool(st.get('use44')) and getattr(u['fwd'], 'wino44', False) and ops.wino44_ok(u['fwd'], nb * TN, H * 2 ** i, W * 2 ** i) and u['r'] == 2
+                    for i, u in enumerate(P.up[:len(Yb)])] if nb else []
+            Vup = [ops.wino44_v(nb * TN, H * 2 ** i, W * 2 ** i, C)[0] if f44 else None for i, f44 in enumerate(up44)]
             with ops.aside('up_fwd'):
-                for u, Y in zip(P.up, Yb):
-                    ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, u['r']))
+                for i, (u, Y) in enumerate(zip(P.up, Yb)):
+                    if up44[i]:
+                        ops.wino44_transform(Src(cur), nb * TN, h, wd, Vup[i])
+                        ops.wino44_conv(u['fwd'], [(Vup[i], 0)], nb * TN, h, wd, ps=(Y, u['r']))
+                    else:
+                        ops.conv(u['fwd'], [Src(cur)], nb * TN, h, wd, ps=(Y, u['r']))
                     Ys.append(Y)
                     cur, h, wd = Y, h * u['r'], wd * u['r']
                 if tail_u is not None:
@@ -580,7 +594,7 @@ class RefineNetEngine:
                                    Oview.reshape(nb * TN, h * r, wd * r, cfg.out_channels))
                 elif nb:
                     ops.outconv_fwd(cur, params[P.last_w], params[P.last_b], out=Oview.reshape(nb * TN, h, wd, cfg.out_channels))
-            aside_keep.append((Sb if nb else None, Yb))        # alive until the forward has rejoined the helper stream
+            aside_keep.append((Sb if nb else None, Yb, Vup))   # alive until the forward has rejoined the helper stream
             if tail_u is None and nb:
                 Ys = Ys[:-1]                                  # the tail's output is not needed by the collapsed backward
             if need_grad:

@@ -339,9 +339,10 @@ class HipOps:
         L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
                                                  plan.Cin, int(plan.transposed), self._stream()), f'rnh_wino44_pack_weights({plan.name})')
 
-    def wino44_conv(self, plan, vsrcs, B, H, W, dst: Dst):
+    def wino44_conv(self, plan, vsrcs, B, H, W, dst=None, ps=None):
         """A plain-store convolution in F(4x4, 3x3) form on transformed sources (rnh_wino44_conv): ``vsrcs`` = (tensor of wino44_transform images,
-        first tile block) per K segment of the plan; ``dst``: a Dst or a list of them, as conv()'s dsts."""
+        first tile block) per K segment of the plan; ``dst``: a Dst or a list of them, as conv()'s dsts, or ``ps`` = (tensor (B, rH, rW, cq), r): the
+        PixelShuffle fused into the store, as conv()'s ps."""
         if id(plan) not in self._packed44:
             raise L.HipKernelError(f'{plan.name}: weights were not packed for the F(4x4, 3x3) form')
         if len(vsrcs) != len(plan.ksegs) or len(vsrcs) > 16:
@@ -354,9 +355,20 @@ class HipOps:
             if boff < 0 or boff * per_block + need * sg.nch > v.numel():
                 raise L.HipKernelError(f'{plan.name}: transformed source {i} does not hold the launch\'s tile blocks')
             a.v[i], a.vchunks[i], a.vblock_off[i] = v.data_ptr(), sg.nch // 16, boff
-        dsts = [dst] if isinstance(dst, Dst) else list(dst)
+        if ps is not None:
+            t, r = ps
+            self._chk(t)
+            cq = t.shape[-1]
+            if tuple(t.shape) != (B, H * r, W * r, cq) or plan.epilogue != L.EPI_PS:
+                raise L.HipKernelError(f'{plan.name}: pixel-shuffle destination shape {tuple(t.shape)}')
+            a.ps_r, a.ps_cq = r, cq
+            a.dst[0].ptr, a.dst[0].C, a.dst[0].c0, a.dst[0].ncols = t.data_ptr(), cq, 0, cq
+            dsts, nd = [], 1
+        else:
+            dsts = [dst] if isinstance(dst, Dst) else list(dst)
+            nd = len(dsts)
         wp, bp = self._packed44[id(plan)]
-        a.nsrc, a.B, a.H, a.W, a.Npad, a.ndst = len(vsrcs), B, H, W, self._maps44[id(plan)]['Npad'], len(dsts)
+        a.nsrc, a.B, a.H, a.W, a.Npad, a.ndst = len(vsrcs), B, H, W, self._maps44[id(plan)]['Npad'], nd
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
         for i, d in enumerate(dsts):
             self._chk(d.t)

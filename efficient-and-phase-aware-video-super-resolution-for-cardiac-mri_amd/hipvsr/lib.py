@@ -77,7 +77,7 @@ class Wino44CellArgs(C.Structure):
 class Wino44ConvArgs(C.Structure):
     """rnh_wino44_conv_args_t"""
     _fields_ = [('v', C.c_void_p * 16), ('vchunks', C.c_int32 * 16), ('vblock_off', C.c_int32 * 16), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32),
-                ('W', C.c_int32), ('Npad', C.c_int32), ('_pad', C.c_int32 * 3), ('wp', C.c_void_p), ('bias', C.c_void_p), ('ndst', C.c_int32), ('_pad2', C.c_int32), ('dst', Dst * MAX_DST)]
+                ('W', C.c_int32), ('Npad', C.c_int32), ('_pad', C.c_int32 * 3), ('wp', C.c_void_p), ('bias', C.c_void_p), ('ndst', C.c_int32), ('ps_r', C.c_int32), ('ps_cq', C.c_int32), ('_pad2', C.c_int32), ('dst', Dst * MAX_DST)]
 
 
 class ConvArgs(C.Structure):

@@ -404,6 +404,8 @@ class NetPlans:
             ws = (r * r * C, C, 3, 3)
             fwd = ConvPlan_(f'up{i + 1}.fwd', wk, bk, ws, [KSeg(C, C, 0)], ps_colmap(C, r), epilogue=L.EPI_PS,
                            wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
+            # the PixelShuffle convolution's forward in F(4x4, 3x3) form (rnh_wino44_conv with the shuffle in its store) on one transform of its input
+            fwd.wino44 = (not bf) and fwd.wino and C % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0' and os.environ.get('RNH_WINO44_UP', '1') != '0'
             dgrad = ConvPlan_(f'up{i + 1}.dgrad', wk, None, ws, [KSeg(C, C, ij) for ij in range(r * r)], list(range(C)),
                              transposed=True, kstride=r * r,
                              wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')

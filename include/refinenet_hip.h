@@ -568,6 +568,9 @@ typedef struct rnh_wino44_conv_args {
     const float *wp;
     const float *bias;
     int32_t ndst;               /* destination segments as for rnh_conv_igemm's RNH_EPI_STORE: consecutive column ranges                 */
+    int32_t ps_r;               /* > 0: nn.PixelShuffle(ps_r) fused into the store as RNH_EPI_PS does (column n = (i*r+j)*ps_cq + c); ndst = 1,
+                                   dst[0].ptr = the (B, r H, r W, ps_cq) tensor                                                        */
+    int32_t ps_cq;
     int32_t _pad2;
     rnh_dst_t dst[RNH_MAX_DST];
 } rnh_wino44_conv_args_t;

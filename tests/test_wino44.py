@@ -383,3 +383,35 @@ def test_cell_data_gradient_in_f4x4_form_vs_float64(feat, B, H, W, monkeypatch):
         assert not torch.isnan(m).any(), nm
         err = float((m - want).abs().max())
         assert err <= 2e-5 * max(1.0, scale), (nm, err, scale)
+
+
+@pytest.mark.parametrize('B,H,W', [(3, 12, 20), (2, 32, 32)])
+def test_pixel_shuffle_conv_in_f4x4_form_vs_float64(B, H, W):
+    """The upsampler's first convolution with nn.PixelShuffle(2) fused into the store (reference refine_net.py:199-200) through rnh_wino44_transform +
+    rnh_wino44_conv against float64 pixel_shuffle(conv2d)."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    u = P.up[0]
+    plan = u['fwd']
+    assert plan.wino44 and u['r'] == 2
+    g = torch.Generator('cpu').manual_seed(H)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    w, b = R(*spec[plan.wkey]) * 0.05, R(*spec[plan.bkey]) * 0.1
+    ops.pack(plan, w.to(dev), b.to(dev))
+    x = R(B, H, W, 64)
+    ref = F.pixel_shuffle(F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1), 2).permute(0, 2, 3, 1)
+    v = ops.wino44_v(B, H, W, 64)[0]
+    ops.wino44_transform(Src(x.to(dev)), B, H, W, v)
+    y = torch.full((B, 2 * H, 2 * W, 64), float('nan'), device=dev)
+    ops.wino44_conv(plan, [(v, 0)], B, H, W, ps=(y, 2))
+    torch.cuda.synchronize()
+    m = y.cpu().double()
+    assert not torch.isnan(m).any()
+    err = float((m - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
