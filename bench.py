@@ -55,7 +55,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (the 5 PF headline figure in
 PEAK_HBM_TBS = 8.0
 
 
-def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False, refine44=False, up44=False):
+def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False, refine44=False, up44=False, refine_dgrad44=False):
     """Conv FLOPs (2*MAC) per LR pixel per sample.  executed=False: the reference's layer-by-layer formulation
      - what its PyTorch step computes and what `step_tflop` reports.  executed=True (x4 only):
     what this implementation issues - the last PixelShuffle conv + final conv (1 198 080 FLOP/LR pixel forward, twice
@@ -77,7 +77,8 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=Fa
     # conv1 in Winograd form (fwd, dgrad, wgrad); conv2 forward and data gradient in Winograd form over its 128 hidden-state
     # channels (channel 128 through the implicit GEMM), its weight gradient as pixel-contraction GEMM (direct)
     # refine44: conv1's forward in F(4x4, 3x3) form (rnh_wino44_conv on the transformed top-layer h')
-    ref_f, ref_b = (0.25 if executed and refine44 else w) * r1 + w * r2h + r2x, 2 * w * r1 + (w * r2h + r2x) + r2
+    # refine_dgrad44: its data gradient likewise (the weight gradient stays in F(2x2)-tile form)
+    ref_f, ref_b = (0.25 if executed and refine44 else w) * r1 + w * r2h + r2x, ((0.25 if executed and refine_dgrad44 else w) + w) * r1 + (w * r2h + r2x) + r2
     nfr, nwin = S * F, S * (F - 4)            # ConvLSTM frames per direction and refine windows, all stages
     if executed:                              # the last stage stops at the last refine window / computes the T supervised windows only
         nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
@@ -377,7 +378,8 @@ def run_case(args, dtype, dev, world, rank):
     cell44 = eng_.cells_f4x4(args.batch, args.size, args.size)
     refine44 = cell44 and eng_.refine_f4x4(args.batch, args.size, args.size, args.frames + 12)
     up44 = cell44 and eng_.up_f4x4(args.batch, args.size, args.size)
-    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44) * args.size * args.size * n_global
+    rd44 = cell44 and eng_.refine_dgrad_f4x4(args.batch, args.size, args.size, args.frames)
+    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44, refine_dgrad44=rd44) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages

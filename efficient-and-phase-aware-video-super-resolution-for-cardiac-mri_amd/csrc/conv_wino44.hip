@@ -79,8 +79,8 @@ __device__ __forceinline__ void w4_tile_xy(int t, int TX, int TY, int &img, int 
 }
 
 // U[s8][xi][n][kh][m] = (G g G^T)[xi] of (output column colmap[n], input channel kch[8 s8 + 4 kh + m]); transposed: of the data gradient's filter
-__global__ void wino44_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kch, const int *colmap, int K, int Npad, int Cin,
-                                   int transposed) {
+__global__ void wino44_pack_kernel(const float *w, const float *bias, float *wp, float *biasp, const int *kch, const int *kcoff, const int *colmap, int K, int Npad,
+                                   int Cin, int transposed) {
     const long total = (long)(K / 8) * 36 * Npad * 8;
     const float G[6][3] = {{0.25f, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
@@ -91,7 +91,8 @@ __global__ void wino44_pack_kernel(const float *w, const float *bias, float *wp,
             continue;
         }
         const int km = (int)(e & 7), n = (int)((e >> 3) % Npad), xi = (int)((e / (8L * Npad)) % 36), s8 = (int)(e / (8L * Npad * 36));
-        const int col = colmap[n], c = kch[8 * s8 + km];
+        // (kcoff: per K slot, added to the column's channel - rnh_pack_weights' kcoff: the window slot of refine conv1's data gradient)
+        const int col = colmap[n] < 0 ? -1 : colmap[n] + (kcoff ? kcoff[8 * s8 + km] : 0), c = kch[8 * s8 + km];
         float v = 0.f;
         if (col >= 0 && c >= 0) {
             // (transposed: the data gradient - the K slot is the forward weight's OUTPUT channel, the column its input channel, the taps flipped)
@@ -568,13 +569,13 @@ extern "C" int64_t rnh_wino44_v_floats(int B, int H, int W, int nch) {
     return ((ntiles + W4_TILES - 1) / W4_TILES) * ((nch + 15) / 16) * (int64_t)W4_BUF;
 }
 
-extern "C" int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *colmap, int K, int Npad,
-                                       int Cout, int Cin, int transposed, void *stream) {
+extern "C" int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *kcoff, const int32_t *colmap, int K,
+                                       int Npad, int Cout, int Cin, int transposed, void *stream) {
     if (!w || !wp || !kch || !colmap || K < 16 || Npad < 64 || Cout < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "rnh_wino44_pack_weights: bad arguments");
     if (K % 32) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_pack_weights: K must be a multiple of 32 (an even number of 16-channel chunks)");
     if (Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_pack_weights: Npad must be a multiple of 64");
-    hipLaunchKernelGGL(wino44_pack_kernel, dim3(w4_grid((long)(K / 8) * 36 * Npad * 8 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, biasp, kch, colmap, K,
-                       Npad, Cin, transposed);
+    hipLaunchKernelGGL(wino44_pack_kernel, dim3(w4_grid((long)(K / 8) * 36 * Npad * 8 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, biasp, kch, kcoff, colmap,
+                       K, Npad, Cin, transposed);
     RNH_CHECK_LAUNCH("rnh_wino44_pack_weights");
     return 0;
 }

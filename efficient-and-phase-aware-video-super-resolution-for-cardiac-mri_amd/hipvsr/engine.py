@@ -207,6 +207,12 @@ class RefineNetEngine:
         return (slots <= 0.08 * self.ops.total_memory() and (N * (H // 4) * (W // 4)) % 32 == 0 and
                 self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False))
 
+    def refine_dgrad_f4x4(self, N, H, W, T):
+        """Does refine conv1's data gradient over the hidden states run in F(4x4, 3x3) form at this shape (T supervised frames)?"""
+        P = self.plans
+        return (self.cells_f4x4(N, H, W) and P.pos and P.r1_wino and getattr(P.r1_dgrad_h, 'wino44', False) and (N * (H // 4) * (W // 4)) % 32 == 0 and
+                self.ops.wino44_ok(P.r1_dgrad_h, T * N, H, W, packed=False))
+
     def up_f4x4(self, N, H, W):
         """Does the first PixelShuffle convolution of the upsampler (the one in front of the collapsed tail) run in F(4x4, 3x3) form at this shape?"""
         P = self.plans
@@ -814,8 +820,17 @@ class RefineNetEngine:
             # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
             if P.r1_wino:
                 nm = P.r1_cols
-                ops.conv(P.r1_dgrad_h, [Src(gsrc, nch=nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
-                         dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+                if st.get('use44') and self.refine_dgrad_f4x4(N, H, W, T) and ops.wino44_ok(P.r1_dgrad_h, TN, H, W):
+                    # F(4x4, 3x3) form (rnh_wino44_conv): ONE transform of the zero-padded dR1, the window slots = the same image a frame apart
+                    nfr, mtf = T + 2 * hw, N * (H // 4) * (W // 4) // 32
+                    Vg = ops.wino44_v(nfr * N, H, W, nm)[0]
+                    ops.wino44_transform(Src(gsrc, nch=nm), nfr * N, H, W, Vg)
+                    ops.wino44_conv(P.r1_dgrad_h, [(Vg, (2 * hw - j) * mtf) for j in range(w)], TN, H, W,
+                                    [Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
+                    del Vg
+                else:
+                    ops.conv(P.r1_dgrad_h, [Src(gsrc, nch=nm, img_off=(2 * hw - j) * N) for j in range(w)], TN, H, W,
+                             dsts=[Dst(dHf, Cl, accumulate=True), Dst(dHb, Cl, accumulate=True)])
                 if Cl % 64 == 0:
                     ops.refine_xcol_dgrad(gsrc, params[k1], dHf, dHb, N, w, Cl)      # the last channel's contribution: a 45-tap stencil
                 else:

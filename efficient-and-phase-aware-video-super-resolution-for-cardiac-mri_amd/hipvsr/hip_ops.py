@@ -331,13 +331,14 @@ class HipOps:
             kch = [sg.kbase + c if c < sg.nvalid else -1 for sg in plan.ksegs for c in range(sg.nch)]
             # the cell's columns in blocks of 64 = the gates i, f | o, g of 16 hidden channels; any other plan's columns as they are, padded to 64
             cm = lstm_colmap64(plan.Cout // 4) if plan.epilogue == L.EPI_LSTM else list(plan.colmap) + [-1] * (-len(plan.colmap) % 64)
-            m = self._maps44[id(plan)] = dict(kch=self._i32(kch), colmap=self._i32(cm), K=len(kch), Npad=len(cm), _plan=plan)
+            kco = [sg.kcoff for sg in plan.ksegs for c in range(sg.nch)]
+            m = self._maps44[id(plan)] = dict(kch=self._i32(kch), kcoff=self._i32(kco) if any(kco) else None, colmap=self._i32(cm), K=len(kch), Npad=len(cm), _plan=plan)
         K, Npad = m['K'], m['Npad']
         buf = self._packed44.get(id(plan))
         if buf is None:
             buf = self._packed44[id(plan)] = (self.empty(K // 8 * 36 * Npad * 8), self.empty(Npad))
-        L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['colmap']), K, Npad, plan.Cout,
-                                                 plan.Cin, int(plan.transposed), self._stream()), f'rnh_wino44_pack_weights({plan.name})')
+        L.check(self.lib.rnh_wino44_pack_weights(_ptr(w), _ptr(b), _ptr(buf[0]), _ptr(buf[1]), _ptr(m['kch']), _ptr(m['kcoff']), _ptr(m['colmap']), K, Npad,
+                                                 plan.Cout, plan.Cin, int(plan.transposed), self._stream()), f'rnh_wino44_pack_weights({plan.name})')
 
     def wino44_conv(self, plan, vsrcs, B, H, W, dst=None, ps=None):
         """A plain-store convolution in F(4x4, 3x3) form on transformed sources (rnh_wino44_conv): ``vsrcs`` = (tensor of wino44_transform images,

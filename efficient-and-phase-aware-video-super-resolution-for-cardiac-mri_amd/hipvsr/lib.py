@@ -214,7 +214,7 @@ def load():
     lib.rnh_wino44_v_floats.argtypes = [i32, i32, i32, i32]
     lib.rnh_wino44_v_floats.restype = i64
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
-    lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_conv.argtypes = [C.POINTER(Wino44ConvArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

@@ -328,6 +328,9 @@ class NetPlans:
                 self.r1_wgrad_p = WgradPlan_('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_dgrad_h = ConvPlan_('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
                                            list(range(2 * Cl)), transposed=True, wino=True)
+                # ... and its data gradient over the hidden states (one transform of the zero-padded dR1, the five window slots as five sources)
+                self.r1_dgrad_h.wino44 = self.r1_fwd_h.wino44 and (C1 - 1) % 16 == 0 and (w * (C1 - 1)) % 32 == 0 and \
+                    os.environ.get('RNH_WINO44_REFINE_DGRAD', '1') != '0'
                 self.r1_dgrad_x = ConvPlan_('refine1.dgrad.x', k1, None, ws1,
                                            [KSeg(self.C1p - C1 + 1, 1, C1 - 1, kcoff=j * C1) for j in range(w)], list(range(2 * Cl)),
                                            transposed=True)

@@ -529,9 +529,10 @@ int rnh_wino44_transform(const float *x, int C, int c0, int nch, int B, int H, i
 /* wp[s8][xi][n][kh][m] = (G g G^T)[xi], g = the 3x3 filter w[colmap[n]][kch[8 s8 + 4 kh + m]] (w OIHW [Cout][Cin][3][3]; kch [K] = the
  * weight's input channel of every K slot in the order the transformed sources are passed to rnh_wino44_cell, colmap [Npad]; device int32
  * arrays, negative = zero); wp: K / 8 * 36 * Npad * 8 floats; biasp[n] = bias[colmap[n]].  K a multiple of 32, Npad of 64.
- * transposed (the data gradient, as rnh_pack_weights): g = w[kch[..]][colmap[n]] with the taps flipped, no bias. */
-int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *colmap, int K, int Npad,
-                            int Cout, int Cin, int transposed, void *stream);
+ * kcoff [K] or 0: per K slot, added to colmap[n] (rnh_pack_weights' kcoff).  transposed (the data gradient, as rnh_pack_weights):
+ * g = w[kch[..]][colmap[n] + kcoff[..]] with the taps flipped, no bias. */
+int rnh_wino44_pack_weights(const float *w, const float *bias, float *wp, float *biasp, const int32_t *kch, const int32_t *kcoff, const int32_t *colmap, int K,
+                            int Npad, int Cout, int Cin, int transposed, void *stream);
 typedef struct rnh_wino44_cell_args {
     const float *v[2];          /* transformed sources (rnh_wino44_transform) in K order: the cell's input x_t, its previous output h_{t-1} */
     int32_t vchunks[2];         /* their 16-channel chunks; the sum must be even                                                       */

@@ -415,3 +415,43 @@ def test_pixel_shuffle_conv_in_f4x4_form_vs_float64(B, H, W):
     assert not torch.isnan(m).any()
     err = float((m - ref).abs().max())
     assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+
+
+def test_refine_conv1_data_gradient_in_f4x4_form_vs_the_f2x2_launch():
+    """refine conv1's data gradient over the hidden states in gather form (frame f collects from the windows that used it in slot j: five sources =
+    the zero-padded dR1 a frame apart each, transposed weights with a per-slot channel offset, two accumulating destinations): rnh_wino44_transform
+    + rnh_wino44_conv against the rnh_conv_wino launch it replaces (itself held against the oracle by the training-step tests), 1e-4 of the largest
+    value, and against what was in the destinations before (accumulation)."""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.r1_dgrad_h
+    assert plan.wino44 and plan.transposed and len(plan.ksegs) == 5
+    N, T, H, W, hw, w_ = 2, 3, 16, 32, 2, 5
+    g = torch.Generator('cpu').manual_seed(11)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    wt = (R(*spec[plan.wkey]) * 0.02).to(dev)
+    ops.pack(plan, wt)
+    nfr = T + 2 * hw
+    gsrc = torch.zeros(nfr * N, H, W, P.C1p)
+    gsrc[hw * N:(hw + T) * N] = R(T * N, H, W, P.C1p)
+    gsrc = gsrc.to(dev)
+    base_f, base_b = R(T * N, H, W, 64).to(dev), R(T * N, H, W, 64).to(dev)
+    nm = P.r1_cols
+    a_f, a_b = base_f.clone(), base_b.clone()
+    ops.conv(plan, [Src(gsrc, nch=nm, img_off=(2 * hw - j) * N) for j in range(w_)], T * N, H, W,
+             dsts=[Dst(a_f, 64, accumulate=True), Dst(a_b, 64, accumulate=True)])
+    b_f, b_b = base_f.clone(), base_b.clone()
+    mtf = N * (H // 4) * (W // 4) // 32
+    v = ops.wino44_v(nfr * N, H, W, nm)[0]
+    ops.wino44_transform(Src(gsrc, nch=nm), nfr * N, H, W, v)
+    ops.wino44_conv(plan, [(v, (2 * hw - j) * mtf) for j in range(w_)], T * N, H, W, [Dst(b_f, 64, accumulate=True), Dst(b_b, 64, accumulate=True)])
+    torch.cuda.synchronize()
+    for nm_, a, b, base in (('dHf', a_f, b_f, base_f), ('dHb', a_b, b_b, base_b)):
+        scale = float((a - base).abs().max())
+        assert scale > 0.1
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (nm_, float((a - b).abs().max()), scale)
