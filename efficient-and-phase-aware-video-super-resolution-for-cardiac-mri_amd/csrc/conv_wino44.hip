@@ -213,8 +213,8 @@ __global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const i
     int src_i = 0, src_c = 0;
     auto chunk_src = [&](i32x4 &vd, int &blockoff) W4_INL {                    // descriptor and byte offset of that chunk's image; advances
         const int nl = P.vchunks[src_i];
-        vd = w4_desc(P.v[src_i]);
-        blockoff = (mt * nl + src_c) * (W4_BUF * 4);
+        vd = w4_desc(P.v[src_i] + (long)mt * nl * W4_BUF);                   // (the tile block's images: 64-bit, so a transformed tensor may be of any size)
+        blockoff = src_c * (W4_BUF * 4);
         if (++src_c == nl) {
             src_c = 0;
             src_i = src_i + 1 < P.nsrc ? src_i + 1 : src_i;                    // (past the end: never requested)
@@ -611,7 +611,6 @@ extern "C" int rnh_wino44_cell(const rnh_wino44_cell_args_t *args, void *stream)
     const int nchunks = a.vchunks[0] + (a.nsrc == 2 ? a.vchunks[1] : 0);
     if (a.vchunks[0] < 1 || (a.nsrc == 2 && a.vchunks[1] < 1) || (nchunks & 1)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: an even number of 16-channel chunks");
     if (a.hd < 16 || (a.hd & 15) || a.Npad != 4 * a.hd) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: hidden channels in multiples of 16, Npad = 4 hd (plans.lstm_colmap64)");
-    if ((long)MT * nchunks * W4_BUF * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: a transformed source of at most 2 GiB");
     if ((long)a.B * a.H * a.W * a.hd * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: a cell state of at most 2 GiB");
     w4_args p = {};
     for (int i = 0; i < a.nsrc; ++i) p.v[i] = a.v[i], p.vchunks[i] = a.vchunks[i];
@@ -644,8 +643,6 @@ extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream)
     int nchunks = 0;
     for (int i = 0; i < a.nsrc; ++i) {
         if (!a.v[i] || a.vchunks[i] < 1 || a.vblock_off[i] < 0) RNH_FAIL(RNH_E_ARG, "rnh_wino44_conv: bad source %d", i);
-        if ((long)MT * a.vchunks[i] * W4_BUF * 4 >= (1L << 31))
-            RNH_FAIL(RNH_E_RANGE, "rnh_wino44_conv: at most 2 GiB of a transformed source per launch");
         p.v[i] = a.v[i] + (long)a.vblock_off[i] * a.vchunks[i] * W4_BUF;        // (a transformed tensor may hold several frames: the launch starts at this tile block)
         p.vchunks[i] = a.vchunks[i];
         nchunks += a.vchunks[i];

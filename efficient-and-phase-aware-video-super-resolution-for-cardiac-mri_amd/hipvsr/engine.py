@@ -183,6 +183,10 @@ class RefineNetEngine:
             fwd_t += F * px * C * 9 + (slots if slots <= 0.08 * self.ops.total_memory() else 2 * min(F, 4) * sum(nf) * px * 9)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
+        if self.up_f4x4(N, H, W):
+            fwd_t += 3 * T * px * C * 9                         # the transformed input of the first PixelShuffle convolution (beside the next stage's wavefront)
+        if self.refine_dgrad_f4x4(N, H, W, T):
+            bwd_t += (T + 2 * hw) * px * getattr(P, 'r1_cols', 0) * 9      # the transformed dR1 of refine conv1's data gradient
         # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
         # joined, the stage's dgates and hidden states stay alive although the stage itself has been released
         dgates = 2 * sum(nf) * 4 * T * px * ea

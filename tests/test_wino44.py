@@ -455,3 +455,34 @@ def test_refine_conv1_data_gradient_in_f4x4_form_vs_the_f2x2_launch():
         scale = float((a - base).abs().max())
         assert scale > 0.1
         assert float((a - b).abs().max()) <= 1e-4 * scale, (nm_, float((a - b).abs().max()), scale)
+
+
+def test_transformed_source_larger_than_2_gib():
+    """BASELINE config 4's launches (16 x 256 x 256 images, 5 + 4 frames at once) hold more than 2 GiB of transformed input: the kernel addresses a
+    tile block's images from a 64-bit base.  80 images of 256 x 256 x 64 channels (3.0 GB transformed) through the PixelShuffle convolution in
+    both forms; the last images - the largest offsets - must agree."""
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.up[0]['fwd']
+    g = torch.Generator('cpu').manual_seed(2)
+    ops.pack(plan, (torch.randn(*spec[plan.wkey], generator=g) * 0.05).to(dev), (torch.randn(*spec[plan.bkey], generator=g) * 0.1).to(dev))
+    B, H, W = 80, 256, 256
+    x = torch.randn(B, H, W, 64, device=dev)
+    v = ops.wino44_v(B, H, W, 64)[0]
+    assert v.numel() * 4 > 2**31
+    ops.wino44_transform(Src(x), B, H, W, v)
+    y44 = torch.empty(B, 2 * H, 2 * W, 64, device=dev)
+    ops.wino44_conv(plan, [(v, 0)], B, H, W, ps=(y44, 2))
+    del v
+    y22 = torch.empty(B, 2 * H, 2 * W, 64, device=dev)
+    ops.conv(plan, [Src(x)], B, H, W, ps=(y22, 2))
+    torch.cuda.synchronize()
+    for img in (0, B // 2, B - 1):
+        a, b = y44[img], y22[img]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (img, float((a - b).abs().max()), scale)
