@@ -209,13 +209,13 @@ class RefineNetEngine:
             return False
         slots = 2 * F * sum(P.nf) * N * H * W * 9
         return (slots <= 0.08 * self.ops.total_memory() and (N * (H // 4) * (W // 4)) % 32 == 0 and
-                self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False))
+                self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False, dst_channels=P.C1p))
 
     def refine_dgrad_f4x4(self, N, H, W, T):
         """Does refine conv1's data gradient over the hidden states run in F(4x4, 3x3) form at this shape (T supervised frames)?"""
         P = self.plans
         return (self.cells_f4x4(N, H, W) and P.pos and P.r1_wino and getattr(P.r1_dgrad_h, 'wino44', False) and (N * (H // 4) * (W // 4)) % 32 == 0 and
-                self.ops.wino44_ok(P.r1_dgrad_h, T * N, H, W, packed=False))
+                self.ops.wino44_ok(P.r1_dgrad_h, (T + 2 * self.hw) * N, H, W, packed=False, dst_channels=P.Cl))
 
     def up_f4x4(self, N, H, W):
         """Does the first PixelShuffle convolution of the upsampler (the one in front of the collapsed tail) run in F(4x4, 3x3) form at this shape?"""

@@ -379,15 +379,21 @@ class HipOps:
             a.dst[i].ncols, a.dst[i].accumulate, a.dst[i].img_off = d.ncols, int(d.accumulate), d.img_off
         L.check(self.lib.rnh_wino44_conv(C.byref(a), self._stream()), f'rnh_wino44_conv({plan.name})')
 
-    def wino44_ok(self, plan, B, H, W, packed=True):
+    def wino44_ok(self, plan, B, H, W, packed=True, dst_channels=0):
         """Does the cell call (plan, B, H, W) run in F(4x4, 3x3) form?  The plan must be eligible and packed for it and the images whole 4x4
         tiles.  No size condition: measured against the F(2x2) kernel on one box each, the step is faster at every launch size tried - BASELINE
         config 4 (8192 workgroups per cell launch) 1742 -> 1495 ms, config 2 (1024) 304 -> 277, config 5 (576) 247.9 -> 230.7, the same at N = 4 /
         N = 2 (288 / 144) 127.8 -> 119.8 / 66.1 -> 62.4, the reference YAML's 16 crops of 32 x 32 (128, graph replay) 42.4 -> 40.8
         (profiles/r05_zb_*).  RNH_WINO44=0 switches the form off; RNH_WINO44_MIN=n asks for launches of at least n workgroups (A/B runs).
-        ``packed=False``: the question before the weights are packed (the engine's memory plan)."""
+        ``packed=False``: the question before the weights are packed (the engine's memory plan).  The kernels' own limits are part of the answer
+        (the engine falls back to the F(2x2) launch instead of meeting a refusal): fewer than 2^27 pixels per launch, and fewer than 2^31 elements in
+        a destination of ``dst_channels`` channels (the cell: its state, 4 bytes per element of hd channels)."""
         mode = os.environ.get('RNH_WINO44', '1')
         if mode == '0' or not getattr(plan, 'wino44', False) or (packed and id(plan) not in self._packed44) or (H & 3) or (W & 3):
+            return False
+        if plan.epilogue == L.EPI_LSTM:
+            dst_channels = max(dst_channels, plan.Cout)                        # (4 hd: the previous state is addressed in bytes)
+        if B * H * W >= 2 ** 27 or B * H * W * dst_channels >= 2 ** 31:
             return False
         wgs = -(-(B * (H // 4) * (W // 4)) // 32) * max(len(plan.colmap) // 64, 1)
         return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1'))
