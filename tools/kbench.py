@@ -68,6 +68,17 @@ xs, hs, gd = R(TN + N, H, W, 64), R(TN + N, H, W, 64), R(TN, H, W, 256)
 dw, db = ops.empty(256, 128, 3, 3), ops.empty(256)
 timeit('lstm.wgrad', lambda: ops.wgrad(pl['wgrad'], [Src(xs, img_off=N), Src(hs)], [Src(gd)], TN, H, W, dw, db), 2.0 * TN * H * W * 128 * 256 * 9)
 
+# upsampler conv1 at 128x128 (3 branches x T frames): the PixelShuffle convolution in front of the collapsed tail
+u0 = P.up[0]
+sb0 = R(3 * TN, H, W, 64)
+y0 = ops.empty(3 * TN, 2 * H, 2 * W, 64)
+timeit('up1.fwd(ps,128^2)', lambda: ops.conv(u0['fwd'], [Src(sb0)], 3 * TN, H, W, ps=(y0, 2)), 2.0 * 3 * TN * H * W * 256 * 576, 3)
+if getattr(u0['fwd'], 'wino44', False):
+    v0 = ops.wino44_v(3 * TN, H, W, 64)[0]
+    timeit('up1.fwd(ps,128^2,wino44)', lambda: (ops.wino44_transform(Src(sb0), 3 * TN, H, W, v0), ops.wino44_conv(u0['fwd'], [(v0, 0)], 3 * TN, H, W, ps=(y0, 2))),
+           2.0 * 3 * TN * H * W * 256 * 576, 3)
+    del v0
+del sb0, y0
 # upsampler conv2 at 256x256 (3 branches x T frames)
 B3 = 3 * TN
 u = P.up[1]
@@ -93,6 +104,16 @@ if P.r1_wino:
     timeit('refine1.fwd.phase-bias', lambda: ops.refine_phase_bias(R1, P4, params[P.r1_fwd_h.wkey], N, 5, 64, P.r1_cols), 2.0 * nwin * N * H * W * 128 * 5 * 9, 3)
 else:
     timeit('refine1.fwd', lambda: ops.conv(P.r1_fwd, srcs, nwin * N, H, W, dsts=[Dst(R1, P.r1_cols)]), 2.0 * nwin * N * H * W * 129 * 645 * 9, 3)
+if P.r1_wino and getattr(P.r1_fwd_h, 'wino44', False):
+    # the same launch in F(4x4, 3x3) form on the transformed hidden states (which the top layer's cells wrote anyway: no transform counted)
+    mtf44 = N * (H // 4) * (W // 4) // 32
+    vf44, vb44 = ops.wino44_v(N, H, W, 64, frames=F), ops.wino44_v(N, H, W, 64, frames=F)
+    for k in range(F):
+        ops.wino44_transform(Src(Hf, img_off=k * N), N, H, W, vf44[k])
+        ops.wino44_transform(Src(Hb, img_off=k * N), N, H, W, vb44[k])
+    timeit('refine1.fwd.h(wino44)', lambda: ops.wino44_conv(P.r1_fwd_h, [(v, j * mtf44) for j in range(5) for v in (vf44, vb44)], nwin * N, H, W, Dst(R1, P.r1_cols)),
+           2.0 * nwin * N * H * W * 128 * 640 * 9, 3)
+    del vf44, vb44
 if P.xcol:
     timeit('refine1.fwd.xcol', lambda: ops.refine_xcol_fwd([Hf, Hb, P4], params[P.r1_fwd.wkey], params[P.r1_fwd.bkey], R1, N, 5, 64), 2.0 * nwin * N * H * W * 645 * 9, 3)
 Rr = ops.empty(nwin * N, H, W, 64)
@@ -137,6 +158,13 @@ dHf, dHb = ops.zeros(TN, H, W, 64), ops.zeros(TN, H, W, 64)
 if P.r1_wino:
     timeit('refine1.dgrad.h(wino)', lambda: ops.conv(P.r1_dgrad_h, [Src(dR1p, nch=128, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
                                                      dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 640 * 9, 3)
+    if getattr(P.r1_dgrad_h, 'wino44', False):
+        vg44 = ops.wino44_v((T + 4) * N, H, W, 128)[0]
+        mtf44 = N * (H // 4) * (W // 4) // 32
+        timeit('refine1.dgrad.h(wino44)', lambda: (ops.wino44_transform(Src(dR1p, nch=128), (T + 4) * N, H, W, vg44),
+                                                   ops.wino44_conv(P.r1_dgrad_h, [(vg44, (4 - j) * mtf44) for j in range(5)], TN, H, W,
+                                                                   [Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)])), 2.0 * TN * H * W * 128 * 640 * 9, 3)
+        del vg44
     timeit('refine1.dgrad.x', lambda: ops.conv(P.r1_dgrad_x, [Src(dR1p, c0=128, nch=4, img_off=(4 - j) * N) for j in range(5)], TN, H, W,
                                                dsts=[Dst(dHf, 64, accumulate=True), Dst(dHb, 64, accumulate=True)]), 2.0 * TN * H * W * 128 * 5 * 9, 3)
 else:
