@@ -486,3 +486,46 @@ def test_transformed_source_larger_than_2_gib():
         a, b = y44[img], y22[img]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale, (img, float((a - b).abs().max()), scale)
+
+
+def test_conv_entry_refusals():
+    """rnh_wino44_conv refuses - with a message, before any launch - an odd number of chunks, more destination columns than Npad, a pixel-shuffle
+    destination beside others, an image that is not whole tiles; the wrapper refuses a source that does not hold the launch's tile blocks."""
+    import ctypes as C
+    from hipvsr import lib as L
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Dst, NetPlans
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    plan = P.up[0]['fwd']
+    ops.pack(plan, torch.zeros(*spec[plan.wkey], device=dev), torch.zeros(*spec[plan.bkey], device=dev))
+    B, H, W = 1, 8, 8
+    v = ops.wino44_v(B, H, W, 64)[0]
+    y = torch.empty(B, 2 * H, 2 * W, 64, device=dev)
+    with pytest.raises(L.HipKernelError):                                      # the source is one tile block short
+        ops.wino44_conv(plan, [(v, 1)], B, H, W, ps=(y, 2))
+    wp, bp = ops._packed44[id(plan)]
+
+    def args(**kw):
+        a = L.Wino44ConvArgs()
+        a.v[0], a.vchunks[0], a.nsrc, a.B, a.H, a.W, a.Npad = v.data_ptr(), 4, 1, B, H, W, 256
+        a.wp, a.bias, a.ndst = wp.data_ptr(), bp.data_ptr(), 1
+        a.dst[0].ptr, a.dst[0].C, a.dst[0].ncols = y.data_ptr(), 64, 64
+        for k, val in kw.items():
+            setattr(a, k, val)
+        return a
+    for a, word in ((args(H=10), 'multiples of 4'), (args(Npad=100), 'multiple of 64'), (args(ndst=5), 'destination count'), (args(ps_r=2, ps_cq=64, ndst=2), 'pixel-shuffle'),
+                    (args(ps_r=2, ps_cq=128), 'pixel-shuffle')):
+        rc = ops.lib.rnh_wino44_conv(C.byref(a), None)
+        assert rc < 0 and word in ops.lib.rnh_last_error().decode(), (rc, ops.lib.rnh_last_error().decode(), word)
+    a = args()
+    a.vchunks[0] = 3
+    assert ops.lib.rnh_wino44_conv(C.byref(a), None) < 0 and 'even number' in ops.lib.rnh_last_error().decode()
+    a = args()
+    a.dst[0].ncols = 300
+    a.dst[0].C = 300
+    assert ops.lib.rnh_wino44_conv(C.byref(a), None) < 0 and 'exceed Npad' in ops.lib.rnh_last_error().decode()
+    torch.cuda.synchronize()
