@@ -1,4 +1,5 @@
-// The ConvLSTM cell's 3x3 convolution in Winograd form F(4x4, 3x3) on fp32 MFMA for gfx950 - rnh_wino44_transform, rnh_wino44_cell.
+// 3x3 convolutions (padding 1) in Winograd form F(4x4, 3x3) on fp32 MFMA for gfx950: the ConvLSTM cell (rnh_wino44_cell) and, with a plain-store or
+// PixelShuffle epilogue, refine conv1's forward and data gradient and the upsampler's first convolution (rnh_wino44_conv); rnh_wino44_transform.
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 4x4 output tile, 6x6 input patch d, 3x3 filter g
 //
@@ -21,8 +22,14 @@
 //                         other 27 positions of those from its three partners through LDS, computes A^T M A, activates its gates; the gates
 //                         meet in LDS and the 512 threads finish (tile, pixel, 4 channels) items with 16-byte accesses - in two passes of
 //                         half the entries, because the exchange of all of them (221 KB) does not fit the LDS.
-// Replaces src/model/nets/refine_net.py:245-265 (ConvLSTMCell.forward: cat, conv, split, sigmoid / tanh, state update) where the plan selects
-// it (hipvsr/plans.py: H, W multiples of 4, 64-column gate layout, hidden and input channels multiples of 16).
+//   rnh_wino44_conv       the same matrix kernel (template argument EPI) with a store epilogue: bias, then columns -> up to four destination segments
+//                         (accumulating or not) or, PixelShuffle fused, -> the (B, rH, rW, cq) tensor; up to 16 transformed sources, each a number
+//                         of tile blocks into a tensor that holds several frames (a window's frames are whole tile blocks apart); transposed-
+//                         packed weights make it a data gradient.  Refine conv1's forward reads the transformed h' the top layer's cells wrote
+//                         anyway - no transform of its own.
+// Replaces src/model/nets/refine_net.py:245-265 (ConvLSTMCell.forward: cat, conv, split, sigmoid / tanh, state update), :149 + :170-181 (refine
+// conv1 over the window's hidden states) and its autograd, :199-200 (upsampler conv + PixelShuffle) where the plans select it (hipvsr/plans.py,
+// HipOps.wino44_ok: H, W multiples of 4, channel counts multiples of 16, an even number of 16-channel chunks).
 #include "rnh_common.h"
 #include <type_traits>
 #include <utility>
