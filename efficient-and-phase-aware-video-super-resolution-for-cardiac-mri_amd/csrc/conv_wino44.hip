@@ -190,14 +190,22 @@ struct w4_args {                          // the device view of rnh_wino44_cell_
     int ps_r, ps_cq;                      // > 0: nn.PixelShuffle(ps_r) fused into the store - column n = (i r + j) cq + c -> pixel (r y + i, r x + j), channel c of dst[0]
 };
 
+// PP, nA: ONE launch may serve TWO calls of equal geometry (rnh_wino44_cell_pair: the cells of the two directions at small images, where a call alone
+// leaves half the chip idle): workgroups [0, nA) belong to PP.call[0], the rest to PP.call[1] (an offset into the kernel-argument segment, no copy)
+struct w4_pair {
+    w4_args call[2];
+};
+
 template <int EPI>
-__global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_args P, const int MT, const int NT, const int TX, const int TY) {
+__global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_pair PP, const int nA, const int MT, const int NT, const int TX, const int TY) {
+    const int second = (int)blockIdx.x >= nA;
+    const w4_args &P = PP.call[second];
     __shared__ __attribute__((aligned(16))) float stage[2 * W4_BUF];          // 147 456 bytes: two staged chunks; the epilogue's exchange areas afterwards
     __shared__ int tpix[W4_TILES];                                            // top-left output pixel of the block's tiles, -1: no such tile
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, cg = wave >> 2;                                  // quarter of the transform domain, column group
-    const int bid = rnh_xcd_remap((int)blockIdx.x, MT * NT);                  // (column block fastest: the NT workgroups of a tile block share an L2)
+    const int bid = rnh_xcd_remap(second ? (int)blockIdx.x - nA : (int)blockIdx.x, MT * NT);                  // (column block fastest: the NT workgroups of a tile block share an L2)
     const int mt = bid / NT, nt = bid - mt * NT;
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX, m0 = mt * W4_TILES, nchunks = P.nchunks;
     if (tid < W4_TILES) {
@@ -600,31 +608,51 @@ extern "C" int rnh_wino44_transform(const float *x, int C, int c0, int nch, int 
     return 0;
 }
 
-static int w4_launch(const w4_args &p, int epi, int MT, int TX, int TY, hipStream_t st, const char *who) {
-    const int NT = p.Npad / 64;
-    if (epi == W4_EPI_LSTM) hipLaunchKernelGGL((wino44_kernel<W4_EPI_LSTM>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, p, MT, NT, TX, TY);
-    else hipLaunchKernelGGL((wino44_kernel<W4_EPI_STORE>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, p, MT, NT, TX, TY);
+static int w4_launch(const w4_args &p, int epi, int MT, int TX, int TY, hipStream_t st, const char *who, const w4_args *second = nullptr) {
+    const int NT = p.Npad / 64, nA = MT * NT;
+    w4_pair pp;
+    pp.call[0] = p;
+    pp.call[1] = second ? *second : p;
+    const dim3 grid((unsigned)(second ? 2 * nA : nA));
+    if (epi == W4_EPI_LSTM) hipLaunchKernelGGL((wino44_kernel<W4_EPI_LSTM>), grid, dim3(512), 0, st, pp, nA, MT, NT, TX, TY);
+    else hipLaunchKernelGGL((wino44_kernel<W4_EPI_STORE>), grid, dim3(512), 0, st, pp, nA, MT, NT, TX, TY);
     RNH_CHECK_LAUNCH(who);
+    return 0;
+}
+
+static int w4_cell_fill(const rnh_wino44_cell_args_t &a, w4_args &p, int &TX, int &TY, int &MT, const char *who) {
+    if (a.nsrc < 1 || a.nsrc > 2 || !a.v[0] || (a.nsrc == 2 && !a.v[1]) || !a.wp || !a.bias || !a.h_out || !a.c_out) RNH_FAIL(RNH_E_ARG, "%s: bad arguments", who);
+    long ntiles;
+    if (int rc = w4_geometry(a.B, a.H, a.W, who, TX, TY, ntiles, MT)) return rc;
+    const int nchunks = a.vchunks[0] + (a.nsrc == 2 ? a.vchunks[1] : 0);
+    if (a.vchunks[0] < 1 || (a.nsrc == 2 && a.vchunks[1] < 1) || (nchunks & 1)) RNH_FAIL(RNH_E_RANGE, "%s: an even number of 16-channel chunks", who);
+    if (a.hd < 16 || (a.hd & 15) || a.Npad != 4 * a.hd) RNH_FAIL(RNH_E_RANGE, "%s: hidden channels in multiples of 16, Npad = 4 hd (plans.lstm_colmap64)", who);
+    if ((long)a.B * a.H * a.W * a.hd * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "%s: a cell state of at most 2 GiB", who);
+    p = w4_args{};
+    for (int i = 0; i < a.nsrc; ++i) p.v[i] = a.v[i], p.vchunks[i] = a.vchunks[i];
+    p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
+    p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad, p.hd = a.hd;
+    p.c_prev = a.c_prev, p.h_out = a.h_out, p.c_out = a.c_out, p.gates_out = a.gates_out;
     return 0;
 }
 
 extern "C" int rnh_wino44_cell(const rnh_wino44_cell_args_t *args, void *stream) {
     if (!args) RNH_FAIL(RNH_E_ARG, "rnh_wino44_cell: null args");
-    const rnh_wino44_cell_args_t &a = *args;
-    if (a.nsrc < 1 || a.nsrc > 2 || !a.v[0] || (a.nsrc == 2 && !a.v[1]) || !a.wp || !a.bias || !a.h_out || !a.c_out) RNH_FAIL(RNH_E_ARG, "rnh_wino44_cell: bad arguments");
+    w4_args p;
     int TX, TY, MT;
-    long ntiles;
-    if (int rc = w4_geometry(a.B, a.H, a.W, "rnh_wino44_cell", TX, TY, ntiles, MT)) return rc;
-    const int nchunks = a.vchunks[0] + (a.nsrc == 2 ? a.vchunks[1] : 0);
-    if (a.vchunks[0] < 1 || (a.nsrc == 2 && a.vchunks[1] < 1) || (nchunks & 1)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: an even number of 16-channel chunks");
-    if (a.hd < 16 || (a.hd & 15) || a.Npad != 4 * a.hd) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: hidden channels in multiples of 16, Npad = 4 hd (plans.lstm_colmap64)");
-    if ((long)a.B * a.H * a.W * a.hd * 4 >= (1L << 31)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_cell: a cell state of at most 2 GiB");
-    w4_args p = {};
-    for (int i = 0; i < a.nsrc; ++i) p.v[i] = a.v[i], p.vchunks[i] = a.vchunks[i];
-    p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
-    p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad, p.hd = a.hd;
-    p.c_prev = a.c_prev, p.h_out = a.h_out, p.c_out = a.c_out, p.gates_out = a.gates_out;
+    if (int rc = w4_cell_fill(*args, p, TX, TY, MT, "rnh_wino44_cell")) return rc;
     return w4_launch(p, W4_EPI_LSTM, MT, TX, TY, (hipStream_t)stream, "rnh_wino44_cell");
+}
+
+extern "C" int rnh_wino44_cell_pair(const rnh_wino44_cell_args_t *args_a, const rnh_wino44_cell_args_t *args_b, void *stream) {
+    if (!args_a || !args_b) RNH_FAIL(RNH_E_ARG, "rnh_wino44_cell_pair: null args");
+    w4_args pa, pb;
+    int TX, TY, MT, TXb, TYb, MTb;
+    if (int rc = w4_cell_fill(*args_a, pa, TX, TY, MT, "rnh_wino44_cell_pair (first call)")) return rc;
+    if (int rc = w4_cell_fill(*args_b, pb, TXb, TYb, MTb, "rnh_wino44_cell_pair (second call)")) return rc;
+    if (pa.B != pb.B || pa.H != pb.H || pa.W != pb.W || pa.Npad != pb.Npad)
+        RNH_FAIL(RNH_E_ARG, "rnh_wino44_cell_pair: the two calls must agree in B, H, W and Npad");
+    return w4_launch(pa, W4_EPI_LSTM, MT, TX, TY, (hipStream_t)stream, "rnh_wino44_cell_pair", &pb);
 }
 
 extern "C" int rnh_wino44_conv(const rnh_wino44_conv_args_t *args, void *stream) {

@@ -434,12 +434,19 @@ class RefineNetEngine:
                 ref44 = R44 == F_s and self.refine_f4x4(N, H, W, F) and ops.wino44_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W)
             slot44 = lambda d, l, idx: (idx if d == 'forward' else F_s - 1 - idx) if ref44 and l == Lr - 1 else idx % R44   # noqa: E731
 
-            def cell44(d, l, idx):
+            def cell44_call(d, l, idx):
+                """(plan, transformed sources, lstm arguments) of cell (d, l) at wavefront slot idx in F(4x4, 3x3) form."""
                 plan, srcs, _, _, _, kw = cell_call(d, l, idx)
                 k = idx if d == 'forward' else F - 1 - idx
                 vx = VF[k] if l == 0 else VH[d][l - 1][slot44(d, l - 1, idx)]
                 vs = [vx] + ([VH[d][l][slot44(d, l, idx - 1)]] if cfg.memory and idx > 0 else [vx])[:len(srcs) - 1]
-                ops.wino44_cell(plan, vs, N, H, W, kw['lstm'])
+                return plan, vs, kw['lstm']
+
+            def cell44(d, l, idx, launch=True):
+                k = idx if d == 'forward' else F - 1 - idx
+                if launch:
+                    plan, vs, lstm = cell44_call(d, l, idx)
+                    ops.wino44_cell(plan, vs, N, H, W, lstm)
                 if l > 0 and idx + R44 < F_s:                                # (only with a ring: R44 < F_s)
                     read44[(d, l, idx)] = ops.record()                       # slot idx % R44 of the layer below has been read
                 if l + 1 < Lr or (cfg.memory and idx + 1 < F_s) or ref44:   # somebody reads this h' in transformed form (ref44: only the top layer gets here)
@@ -458,8 +465,10 @@ class RefineNetEngine:
                             if below is not None:
                                 ops.wait(below)
                             if use44:
+                                # (both directions' cells in one launch, then each direction's event / transform as behind a launch of its own)
+                                ops.wino44_cell_pair([cell44_call(d, l, idx) for d in dirs], N, H, W)
                                 for d in dirs:
-                                    cell44(d, l, idx)
+                                    cell44(d, l, idx, launch=False)
                             else:
                                 ops.conv_pair([cell_call(d, l, idx) for d in dirs])
                             below = ops.record() if l + 1 < Lr else None

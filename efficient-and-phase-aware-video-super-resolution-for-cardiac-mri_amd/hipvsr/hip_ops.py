@@ -414,9 +414,7 @@ class HipOps:
         L.check(self.lib.rnh_wino44_transform(t.data_ptr() + s.img_off * H * W * t.shape[-1] * 4, t.shape[-1], s.c0, nch, B, H, W, _ptr(out), self._stream()),
                 'rnh_wino44_transform')
 
-    def wino44_cell(self, plan, vsrcs, B, H, W, lstm):
-        """One ConvLSTM cell on its transformed sources ``vsrcs`` (tensors of wino44_transform, in the order of the plan's K segments);
-        ``lstm`` as for conv()."""
+    def _wino44_cell_args(self, plan, vsrcs, B, H, W, lstm):
         if id(plan) not in self._packed44:
             raise L.HipKernelError(f'{plan.name}: weights were not packed for the F(4x4, 3x3) form')
         if len(vsrcs) != len(plan.ksegs):
@@ -437,7 +435,19 @@ class HipOps:
         a.nsrc, a.B, a.H, a.W, a.Npad, a.hd = len(vsrcs), B, H, W, 4 * hd, hd
         a.wp, a.bias = wp.data_ptr(), bp.data_ptr()
         a.c_prev, a.h_out, a.c_out, a.gates_out = _ptr(lstm.get('c_prev')), _ptr(lstm['h_out']), _ptr(lstm['c_out']), _ptr(lstm.get('gates_out'))
+        return a
+
+    def wino44_cell(self, plan, vsrcs, B, H, W, lstm):
+        """One ConvLSTM cell on its transformed sources ``vsrcs`` (tensors of wino44_transform, in the order of the plan's K segments);
+        ``lstm`` as for conv()."""
+        a = self._wino44_cell_args(plan, vsrcs, B, H, W, lstm)
         L.check(self.lib.rnh_wino44_cell(C.byref(a), self._stream()), f'rnh_wino44_cell({plan.name})')
+
+    def wino44_cell_pair(self, calls, B, H, W):
+        """``calls``: two (plan, vsrcs, lstm) of wino44_cell at one geometry - ONE launch (rnh_wino44_cell_pair), the same results bit for bit."""
+        (pa, va, la), (pb, vb, lb) = calls
+        a, b = self._wino44_cell_args(pa, va, B, H, W, la), self._wino44_cell_args(pb, vb, B, H, W, lb)
+        L.check(self.lib.rnh_wino44_cell_pair(C.byref(a), C.byref(b), self._stream()), f'rnh_wino44_cell_pair({pa.name}, {pb.name})')
 
     def _pack(self, plan: ConvPlan, w, b=None):
         self._chk(w, b)

@@ -39,7 +39,7 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_conv_bf16', 'rnh_conv_bf16_pair', 'rnh_conv_wino_pair', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
            'rnh_phase_plane_m', 'rnh_struct_sizes_bf16',
            # F(4x4, 3x3) ConvLSTM cell (ABI 5)
-           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_conv']
+           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_cell_pair', 'rnh_wino44_conv']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -216,6 +216,7 @@ def load():
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
+    lib.rnh_wino44_cell_pair.argtypes = [C.POINTER(Wino44CellArgs), C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_conv.argtypes = [C.POINTER(Wino44ConvArgs), vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]

@@ -550,6 +550,9 @@ typedef struct rnh_wino44_cell_args {
  * h' = o tanh c') on its transformed inputs: 36 GEMMs on v_mfma_f32_32x32x2_f32 with V through LDS-DMA, output transform and gate math in the
  * epilogue.  Same results as rnh_conv_wino / rnh_conv_igemm with RNH_EPI_LSTM up to the rounding of the transforms. */
 int rnh_wino44_cell(const rnh_wino44_cell_args_t *args /* host */, void *stream);
+/* TWO cells of equal geometry in ONE launch (the cells of the forward- and the backward-direction ConvLSTM of a layer at the same wavefront slot, as
+ * rnh_conv_wino_pair): the same results as the two calls, bit for bit; the calls must agree in B, H, W and Npad (the number of chunks may differ). */
+int rnh_wino44_cell_pair(const rnh_wino44_cell_args_t *args_a /* host */, const rnh_wino44_cell_args_t *args_b /* host */, void *stream);
 
 /* A 3x3 convolution (padding 1) with a plain-store epilogue in the same F(4x4, 3x3) form, on transformed sources that already exist: refine
  * conv1's forward over the hidden states of the top ConvLSTM layer (reference refine_net.py:149, :170-181: torch.cat of the window's frames,

@@ -529,3 +529,49 @@ def test_conv_entry_refusals():
     a.dst[0].C = 300
     assert ops.lib.rnh_wino44_conv(C.byref(a), None) < 0 and 'exceed Npad' in ops.lib.rnh_last_error().decode()
     torch.cuda.synchronize()
+
+
+def test_paired_cells_equal_two_launches_bit_for_bit():
+    """rnh_wino44_cell_pair (the two directions' cells of a layer in one launch) against the two rnh_wino44_cell launches: gates, c', h' of both
+    calls bit for bit; different weights, sources and a different number of chunks per call (one call without previous state); mismatched
+    geometry is refused."""
+    from hipvsr import lib as L
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    from hipvsr.spec import state_dict_spec
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    spec = state_dict_spec(cfg)
+    B, H, W = 3, 24, 20
+    g = torch.Generator('cpu').manual_seed(21)
+    R = lambda *sh: torch.randn(*sh, generator=g).to(dev)                      # noqa: E731
+    calls = []
+    for d, kind in (('forward', 'full'), ('backward', 'first')):
+        plan = P.lstm[(d, 1)][kind]
+        ops.pack(plan, R(*spec[plan.wkey]) * 0.05, R(*spec[plan.bkey]) * 0.1)
+        vs = []
+        for _ in plan.ksegs:
+            v = ops.wino44_v(B, H, W, 64)[0]
+            ops.wino44_transform(Src(R(B, H, W, 64)), B, H, W, v)
+            vs.append(v)
+        calls.append((plan, vs, R(B, H, W, 64) if kind == 'full' else None))
+
+    def outs():
+        return [dict(hd=64, c_prev=c, h_out=torch.full((B, H, W, 64), float('nan'), device=dev), c_out=torch.full((B, H, W, 64), float('nan'), device=dev),
+                     gates_out=torch.full((B, H, W, 256), float('nan'), device=dev)) for _, _, c in calls]
+    single, paired = outs(), outs()
+    for (plan, vs, _), lstm in zip(calls, single):
+        ops.wino44_cell(plan, vs, B, H, W, lstm)
+    ops.wino44_cell_pair([(plan, vs, lstm) for (plan, vs, _), lstm in zip(calls, paired)], B, H, W)
+    torch.cuda.synchronize()
+    for a, b in zip(single, paired):
+        for k in ('h_out', 'c_out', 'gates_out'):
+            assert not torch.isnan(a[k]).any() and torch.equal(a[k], b[k]), k
+    with pytest.raises(L.HipKernelError):
+        v2 = ops.wino44_v(B, H, W + 4, 64)[0]
+        bad = dict(hd=64, c_prev=None, h_out=torch.empty(B, H, W + 4, 64, device=dev), c_out=torch.empty(B, H, W + 4, 64, device=dev), gates_out=None)
+        a = ops._wino44_cell_args(calls[1][0], [v2], B, H, W + 4, bad)
+        b = ops._wino44_cell_args(calls[0][0], calls[0][1], B, H, W, single[0])
+        L.check(ops.lib.rnh_wino44_cell_pair(__import__('ctypes').byref(b), __import__('ctypes').byref(a), None), 'pair')
+    assert 'must agree' in ops.lib.rnh_last_error().decode()
