@@ -713,9 +713,66 @@ class HipOps:
         L.check(self.lib.rnh_cast(_ptr(t), L.dt_of(t), _ptr(out), L.dt_of(out), t.numel(), self._stream()), 'rnh_cast')
         return out
 
+    def _wgrad44(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
+        """The weight gradient in Winograd form F(4x4, 3x3) over 4x4 tiles (csrc/wgrad_wino44.hip) - or False where this call is not one it takes:
+        fp32, 3x3, whole 4x4 tiles, the x sources in pairs of 64 channels (a pair = one block of 128 weight input channels at one image offset: h_fwd
+        | h_bwd of a window slot), every source tensor transformed ONCE over the frames its slots use, one dy source of 128 k channels."""
+        if os.environ.get('RNH_WINO44_WGRAD', '0') != '1' or not getattr(plan, 'wino44w', False) or plan.bf16 or (H & 3) or (W & 3):
+            return False
+        tpi = (H // 4) * (W // 4)                                           # tiles per image
+        if len(ysrcs) != 1 or len(xsrcs) % 2 or len(xsrcs) // 2 > 8 or (B * tpi) % 8 or B * H * W >= 2 ** 27:
+            return False
+        ys = ysrcs[0]
+        CO = ys.t.shape[-1] - ys.c0 if ys.nch is None else ys.nch
+        if CO % 128 or ys.scale != 1 or ys.add is not None or len(plan.ysegs) != 1 or plan.ysegs[0].co_base or plan.ysegs[0].stride != 1:
+            return False
+        probs, tensors = [], {}
+        for j in range(len(xsrcs) // 2):
+            pair = xsrcs[2 * j:2 * j + 2]
+            sg = plan.xsegs[2 * j:2 * j + 2]
+            if any(s.scale != 1 or s.add is not None or (s.t.shape[-1] - s.c0 if s.nch is None else s.nch) != 64 for s in pair) or \
+                    pair[0].img_off != pair[1].img_off or any(g.nch != 64 or g.nvalid != 64 for g in sg) or sg[1].ci_base != sg[0].ci_base + 64:
+                return False
+            for s in pair:
+                key = (s.t.data_ptr(), s.c0)
+                lo, hi, t = tensors.get(key, (s.img_off, s.img_off, s.t))
+                tensors[key] = (min(lo, s.img_off), max(hi, s.img_off), t)
+            probs.append((pair, sg[0].ci_base))
+        if any(((hi - lo) * tpi) % 8 or ((hi - lo + B) * tpi) % 8 for lo, hi, _ in tensors.values()):
+            return False
+        T8 = B * tpi // 8
+        ncb, nprob = CO // 128, len(probs)
+        want = max(1, 1280 // (nprob * 9 * ncb))                           # ~5 rounds of the chip
+        S = min((s_ for s_ in range(1, 129) if T8 % (2 * s_) == 0), key=lambda s_: abs(s_ - want))
+        st = self._stream()
+        vt = {}
+        for key, (lo, hi, t) in tensors.items():                           # one transform per source tensor over the frames its slots use
+            nimg = hi - lo + B
+            buf = self._workspace(f'w44_vt{len(vt)}', int(self.lib.rnh_wino44_tmajor_floats(nimg, H, W, 64)))
+            L.check(self.lib.rnh_wino44_tmajor(t.data_ptr() + lo * H * W * t.shape[-1] * 4, t.shape[-1], key[1], 64, nimg, H, W, 0, _ptr(buf), st), 'rnh_wino44_tmajor(x)')
+            vt[key] = (buf, nimg * tpi // 8, lo)
+        zt = self._workspace('w44_zt', int(self.lib.rnh_wino44_tmajor_floats(B, H, W, CO)))
+        L.check(self.lib.rnh_wino44_tmajor(ys.t.data_ptr() + ys.img_off * H * W * ys.t.shape[-1] * 4, ys.t.shape[-1], ys.c0, CO, B, H, W, 1, _ptr(zt), st), 'rnh_wino44_tmajor(dy)')
+        a = L.Wino44WgradArgs()
+        for i, (pair, _) in enumerate(probs):
+            for h_, s in enumerate(pair):
+                buf, k8, lo = vt[(s.t.data_ptr(), s.c0)]
+                a.a[i][h_], a.a_k8[i][h_], a.a_k80[i][h_] = buf.data_ptr(), k8, (s.img_off - lo) * tpi // 8
+        part = self._workspace('w44_part', S * nprob * 36 * 128 * CO)
+        a.z, a.z_k8, a.part, a.nprob, a.CO, a.T8, a.S = zt.data_ptr(), T8, part.data_ptr(), nprob, CO, T8, S
+        L.check(self.lib.rnh_wino44_wgrad_gemm(C.byref(a), st), f'rnh_wino44_wgrad_gemm({plan.name})')
+        rb = self._maps.setdefault(('w44_rowbase', id(plan)), self._i32([kb for _, kb in probs]))
+        ncol = sum(g.nvalid for g in plan.ysegs)
+        zpart = self._workspace('w44_zpart', 64 * CO) if db is not None else None
+        L.check(self.lib.rnh_wino44_wgrad_finish(C.byref(a), _ptr(rb), ncol, plan.Cin, _ptr(dw), _ptr(db), _ptr(zpart), 64, int(accumulate), st),
+                f'rnh_wino44_wgrad_finish({plan.name})')
+        return True
+
     def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
         m = self._plan_maps(plan)
         self._chk(dw, db)
+        if self._wgrad44(plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
+            return
         if plan.bf16:
             if len(xsrcs) != len(plan.xsegs) or len(ysrcs) != len(plan.ysegs):
                 raise L.HipKernelError(f'{plan.name}: source count')

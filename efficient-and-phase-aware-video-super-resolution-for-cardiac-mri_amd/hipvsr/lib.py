@@ -39,7 +39,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_conv_bf16', 'rnh_conv_bf16_pair', 'rnh_conv_wino_pair', 'rnh_pack_weights_bf16', 'rnh_wgrad_bf16', 'rnh_ew_add_m', 'rnh_lstm_gates_bwd_m', 'rnh_cast',
            'rnh_phase_plane_m', 'rnh_struct_sizes_bf16',
            # F(4x4, 3x3) ConvLSTM cell (ABI 5)
-           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_cell_pair', 'rnh_wino44_conv']
+           'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_cell_pair', 'rnh_wino44_conv',
+           'rnh_wino44_tmajor_floats', 'rnh_wino44_tmajor', 'rnh_wino44_wgrad_gemm', 'rnh_wino44_wgrad_finish']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -72,6 +73,12 @@ class Wino44CellArgs(C.Structure):
     _fields_ = [('v', C.c_void_p * 2), ('vchunks', C.c_int32 * 2), ('nsrc', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('Npad', C.c_int32), ('hd', C.c_int32), ('_pad', C.c_int32), ('wp', C.c_void_p), ('bias', C.c_void_p), ('c_prev', C.c_void_p),
                 ('h_out', C.c_void_p), ('c_out', C.c_void_p), ('gates_out', C.c_void_p)]
+
+
+class Wino44WgradArgs(C.Structure):
+    """rnh_wino44_wgrad_args_t"""
+    _fields_ = [('a', (C.c_void_p * 2) * 8), ('a_k8', (C.c_int64 * 2) * 8), ('a_k80', (C.c_int64 * 2) * 8), ('z', C.c_void_p), ('z_k8', C.c_int64),
+                ('part', C.c_void_p), ('nprob', C.c_int32), ('CO', C.c_int32), ('T8', C.c_int32), ('S', C.c_int32)]
 
 
 class Wino44ConvArgs(C.Structure):
@@ -218,6 +225,11 @@ def load():
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_cell_pair.argtypes = [C.POINTER(Wino44CellArgs), C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_conv.argtypes = [C.POINTER(Wino44ConvArgs), vp]
+    lib.rnh_wino44_tmajor_floats.argtypes = [i32, i32, i32, i32]
+    lib.rnh_wino44_tmajor_floats.restype = i64
+    lib.rnh_wino44_tmajor.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.rnh_wino44_wgrad_gemm.argtypes = [C.POINTER(Wino44WgradArgs), vp]
+    lib.rnh_wino44_wgrad_finish.argtypes = [C.POINTER(Wino44WgradArgs), vp, i32, i32, vp, vp, vp, i32, i32, vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
     lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]

@@ -325,6 +325,7 @@ class NetPlans:
                 self.r1_fwd_h.wino44 = Cl % 16 == 0 and (len(hsegs) * Cl) % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0' and \
                     os.environ.get('RNH_WINO44_REFINE', '1') != '0'
                 self.r1_wgrad_h = WgradPlan_('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
+                self.r1_wgrad_h.wino44w = not bf and Cl == 64          # F(4x4)-tile form (rnh_wino44_wgrad_*): opt-in, RNH_WINO44_WGRAD=1
                 self.r1_wgrad_p = WgradPlan_('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_dgrad_h = ConvPlan_('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
                                            list(range(2 * Cl)), transposed=True, wino=True)

@@ -580,6 +580,32 @@ typedef struct rnh_wino44_conv_args {
 } rnh_wino44_conv_args_t;
 int rnh_wino44_conv(const rnh_wino44_conv_args_t *args /* host */, void *stream);
 
+/* ---- Weight gradient in Winograd form F(4x4, 3x3) over 4x4 output tiles (csrc/wgrad_wino44.hip; ABI 5) ------------------------------------
+ * dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G: 36 GEMMs whose K dimension is the tile index, 2.25 multiplications per (pixel, ci, co).
+ * rnh_wino44_tmajor writes the transformed inputs (mode 0: B^T d B of the 6x6 patches of `nch` channels [c0, c0 + nch) of x [B][H][W][C], zero
+ * padding 1) or output gradients (mode 1: A dY A^T of the 4x4 tiles) tile-major, [36][nch / 32][K8][32][8] with K8 = B * H/4 * W/4 / 8
+ * (rnh_wino44_tmajor_floats floats; H, W multiples of 4, nch of 32, the tile count of 8).  A tensor may hold all frames of a source: a window
+ * slot that pairs frame f + j with the gradient of window f starts j * (tiles per frame) / 8 rows into it. */
+int64_t rnh_wino44_tmajor_floats(int B, int H, int W, int nch);
+int rnh_wino44_tmajor(const float *x, int C, int c0, int nch, int B, int H, int W, int mode, float *out, void *stream);
+typedef struct rnh_wino44_wgrad_args {
+    const float *a[8][2];       /* per problem (a block of 128 input channels against all CO outputs): its two 64-channel halves, tmajor tensors */
+    int64_t a_k8[8][2];         /* K8 of those tensors                                                                                          */
+    int64_t a_k80[8][2];        /* the problem's first k8 row in them                                                                            */
+    const float *z;             /* tmajor tensor (mode 1) of the CO gradient channels, K8 = z_k8 >= T8                                           */
+    int64_t z_k8;
+    float *part;                /* workspace [S][nprob][36][128][CO] floats: partial sums per K split                                            */
+    int32_t nprob, CO;          /* CO a multiple of 128                                                                                          */
+    int32_t T8, S;              /* k8 rows of the problem, K splits; T8 % (2 S) == 0                                                             */
+} rnh_wino44_wgrad_args_t;
+/* The 36 GEMMs on v_mfma_f32_32x32x2_f32 (a workgroup = four positions x a problem's two halves, 128 columns, one K split; operands straight from
+ * L2 into a register ring), then: K splits summed in order, dg = G^T dU G, dw[co][rowbase[p] + ci][3][3] (+)= dg for co < ncol (dw OIHW with Cin
+ * input channels), db[co] (+)= the tile sum of Z at position (1, 1) (zpart: nchunk * CO floats; z_k8 must equal T8).  Replaces the weight part of
+ * aten::convolution_backward for refine conv1 over the hidden states (reference refine_net.py:149; loss.backward(), trainer :46). */
+int rnh_wino44_wgrad_gemm(const rnh_wino44_wgrad_args_t *args /* host */, void *stream);
+int rnh_wino44_wgrad_finish(const rnh_wino44_wgrad_args_t *args /* host */, const int32_t *rowbase /* device [nprob] */, int ncol, int Cin, float *dw,
+                            float *db /* or 0 */, float *zpart, int nchunk, int accumulate, void *stream);
+
 const char *rnh_last_error(void);
 int rnh_abi_version(void);
 /* sizeof(rnh_src_t), sizeof(rnh_dst_t), sizeof(rnh_conv_args_t), sizeof(rnh_wgrad_args_t): lets a binding

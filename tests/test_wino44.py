@@ -575,3 +575,60 @@ def test_paired_cells_equal_two_launches_bit_for_bit():
         b = ops._wino44_cell_args(calls[0][0], calls[0][1], B, H, W, single[0])
         L.check(ops.lib.rnh_wino44_cell_pair(__import__('ctypes').byref(b), __import__('ctypes').byref(a), None), 'pair')
     assert 'must agree' in ops.lib.rnh_last_error().decode()
+
+
+def test_refine_conv1_weight_gradient_in_f4x4_tile_form(monkeypatch):
+    """refine conv1's weight gradient over the hidden states (10 sources = the five window slots x two directions, 128 gradient channels) through
+    rnh_wino44_tmajor (inputs and gradients tile-major, every source tensor transformed once over the frames its slots use), rnh_wino44_wgrad_gemm
+    and rnh_wino44_wgrad_finish against a float64 evaluation (autograd of conv2d over the concatenated window), and the bias gradient against the
+    pixel sum; accumulation into existing gradients."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    dev = _dev()
+    cfg = orc.exp1_x4_config()
+    P, ops = NetPlans(cfg), HipOps(dev)
+    plan = P.r1_wgrad_h
+    assert plan.wino44w and len(plan.xsegs) == 10
+    N, T, H, W = 2, 3, 16, 32
+    g = torch.Generator('cpu').manual_seed(31)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    nfr = T + 4
+    hf, hb = R(nfr * N, H, W, 64), R(nfr * N, H, W, 64)
+    dy = torch.zeros((T + 1) * N, H, W, P.C1p)
+    dy[N:] = R(T * N, H, W, P.C1p) * 0.1
+    hfd, hbd, dyd = hf.to(dev), hb.to(dev), dy.to(dev)
+    xs = []
+    for j in range(5):
+        xs += [Src(hfd, img_off=j * N), Src(hbd, img_off=j * N)]
+    ys = [Src(dyd, nch=128, img_off=N)]
+    C1 = 129
+    # float64: window f = frames f .. f + 4 of both directions, 645-channel layout slot j -> [j * 129, j * 129 + 128)
+    wz = torch.zeros(129, 645, 3, 3, dtype=torch.float64, requires_grad=True)
+    x64 = torch.zeros(T * N, 645, H, W, dtype=torch.float64)
+    for f in range(T):
+        for j in range(5):
+            x64[f * N:(f + 1) * N, j * C1:j * C1 + 64] = hf[(f + j) * N:(f + j + 1) * N].double().permute(0, 3, 1, 2)
+            x64[f * N:(f + 1) * N, j * C1 + 64:j * C1 + 128] = hb[(f + j) * N:(f + j + 1) * N].double().permute(0, 3, 1, 2)
+    out = F.conv2d(x64, wz, padding=1)
+    gy = torch.zeros_like(out)
+    gy[:, :128] = dy[N:, ..., :128].double().permute(0, 3, 1, 2)
+    out.backward(gy)
+    ref_dw, ref_db = wz.grad, gy.sum(dim=(0, 2, 3))
+    rows = torch.tensor([j * C1 + c for j in range(5) for c in range(128)])
+    base_w, base_b = R(129, 645, 3, 3).to(dev), R(129).to(dev)
+    for accumulate in (False, True):
+        monkeypatch.setenv('RNH_WINO44_WGRAD', '1')
+        dw, db = base_w.clone(), base_b.clone()
+        ops.wgrad(plan, xs, ys, T * N, H, W, dw, db, accumulate=accumulate)
+        torch.cuda.synchronize()
+        got_w = (dw - base_w if accumulate else dw).cpu().double()[:128][:, rows]
+        got_b = (db - base_b if accumulate else db).cpu().double()[:128]
+        want_w = ref_dw[:128][:, rows]
+        scale = float(want_w.abs().max())
+        assert float((got_w - want_w).abs().max()) <= 2e-4 * scale, (accumulate, float((got_w - want_w).abs().max()), scale)
+        assert float((got_b - ref_db[:128]).abs().max()) <= 1e-4 * float(ref_db.abs().max()), accumulate
+        if not accumulate:                                                     # the rows and columns this plan does not own are untouched
+            other = torch.ones(645, dtype=torch.bool)
+            other[rows] = False
+            assert torch.equal(dw[:, other], base_w[:, other]) and torch.equal(dw[128:], base_w[128:])

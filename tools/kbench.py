@@ -148,6 +148,11 @@ for j in range(5):
 dw1, db1 = ops.empty(129, 645, 3, 3), ops.empty(129)
 if P.r1_wino:
     timeit('refine1.wgrad.h(wino)', lambda: ops.wgrad(P.r1_wgrad_h, [sc for sc in xs1 if sc.t is not P4], [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 128 * 640 * 9, 3)
+    if getattr(P.r1_wgrad_h, 'wino44w', False):
+        os.environ['RNH_WINO44_WGRAD'] = '1'
+        timeit('refine1.wgrad.h(wino44)', lambda: ops.wgrad(P.r1_wgrad_h, [sc for sc in xs1 if sc.t is not P4], [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1),
+               2.0 * TN * H * W * 128 * 640 * 9, 3)
+        os.environ.pop('RNH_WINO44_WGRAD')
     timeit('refine1.wgrad.p', lambda: ops.wgrad(P.r1_wgrad_p, [sc for sc in xs1 if sc.t is P4], [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, None), 2.0 * TN * H * W * 128 * 5 * 9, 3)
 else:
     timeit('refine1.wgrad', lambda: ops.wgrad(P.r1_wgrad, xs1, [Src(dR1p, nch=P.r1_cols, img_off=2 * N)], TN, H, W, dw1, db1), 2.0 * TN * H * W * 129 * 645 * 9, 3)
