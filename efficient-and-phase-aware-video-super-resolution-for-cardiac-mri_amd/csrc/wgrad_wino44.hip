@@ -243,9 +243,19 @@ __global__ void __launch_bounds__(512, 1) wino44_wgrad_gemm_kernel(const wg4_gem
             }
 }
 
-// dw[colmap(co)][rowbase[prob] + ci][a][b] (+)= sum_{i, j} G[i][a] G[j][b] sum_splits part[split][prob][6 i + j][ci][co]; thread = (prob, ci, co)
-__global__ void __launch_bounds__(256) wino44_wgrad_finish_kernel(const float *part, const int S, const int nprob, const int CO, const int *rowbase, const int ncol,
-                                                                 const int Cin, float *dw, const int accumulate) {
+// the K splits summed in order, in place into split 0: thread = four consecutive elements of [nprob][36][128][CO]
+__global__ void __launch_bounds__(256) wino44_wgrad_splitsum_kernel(float *part, const int S, const long n4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4w *p = reinterpret_cast<f32x4w *>(part) + idx;
+    f32x4w u = p[0];
+    for (int s = 1; s < S; ++s) u += p[s * n4];
+    p[0] = u;
+}
+
+// dw[co][rowbase[prob] + ci][a][b] (+)= sum_{i, j} G[i][a] G[j][b] dU[prob][6 i + j][ci][co]; thread = (prob, ci, co)
+__global__ void __launch_bounds__(256) wino44_wgrad_finish_kernel(const float *part, const int nprob, const int CO, const int *rowbase, const int ncol, const int Cin,
+                                                                 float *dw, const int accumulate) {
     const long total = (long)nprob * 128 * CO;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -254,16 +264,18 @@ __global__ void __launch_bounds__(256) wino44_wgrad_finish_kernel(const float *p
     const float G[6][3] = {{0.25f, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                            {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
     float dg[3][3] = {};
-    const long pstride = 128L * CO, sstride = (long)nprob * 36 * pstride;
+    const long pstride = 128L * CO;
     const float *p0 = part + (long)prob * 36 * pstride + (long)ci * CO + co;
+    float u[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) u[xi] = p0[xi * pstride];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         float rowg[3] = {0.f, 0.f, 0.f};                                     // sum_j dU[i][j] G[j][b]
-        for (int j = 0; j < 6; ++j) {
-            float u = 0.f;
-            for (int s = 0; s < S; ++s) u += p0[s * sstride + (6 * i + j) * pstride];
 #pragma unroll
-            for (int bb = 0; bb < 3; ++bb) rowg[bb] = __builtin_fmaf(u, G[j][bb], rowg[bb]);
-        }
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) rowg[bb] = __builtin_fmaf(u[6 * i + j], G[j][bb], rowg[bb]);
 #pragma unroll
         for (int aa = 0; aa < 3; ++aa)
 #pragma unroll
@@ -355,9 +367,10 @@ extern "C" int rnh_wino44_wgrad_finish(const rnh_wino44_wgrad_args_t *args, cons
     if (!args || !rowbase || !dw || ncol < 1 || Cin < 1) RNH_FAIL(RNH_E_ARG, "rnh_wino44_wgrad_finish: bad arguments");
     const rnh_wino44_wgrad_args_t &a = *args;
     if (ncol > a.CO) RNH_FAIL(RNH_E_ARG, "rnh_wino44_wgrad_finish: more columns than the problem has");
-    const long total = (long)a.nprob * 128 * a.CO;
-    hipLaunchKernelGGL(wino44_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, a.S, a.nprob, a.CO, rowbase, ncol, Cin,
-                       dw, accumulate);
+    const long total = (long)a.nprob * 128 * a.CO, n4 = total * 36 / 4;
+    if (a.S > 1) hipLaunchKernelGGL(wino44_wgrad_splitsum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, a.S, n4);
+    hipLaunchKernelGGL(wino44_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, a.nprob, a.CO, rowbase, ncol, Cin, dw,
+                       accumulate);
     RNH_CHECK_LAUNCH("rnh_wino44_wgrad_finish");
     if (db) {
         if (!zpart || nchunk < 1) RNH_FAIL(RNH_E_ARG, "rnh_wino44_wgrad_finish: the bias gradient needs its workspace");

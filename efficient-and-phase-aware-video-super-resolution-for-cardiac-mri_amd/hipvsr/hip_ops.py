@@ -715,8 +715,8 @@ class HipOps:
 
     def _wgrad44(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
         """The weight gradient in Winograd form F(4x4, 3x3) over 4x4 tiles (csrc/wgrad_wino44.hip) - or False where this call is not one it takes:
-        fp32, 3x3, whole 4x4 tiles, the x sources in pairs of 64 channels (a pair = one block of 128 weight input channels at one image offset: h_fwd
-        | h_bwd of a window slot), every source tensor transformed ONCE over the frames its slots use, one dy source of 128 k channels."""
+        fp32, 3x3, whole 4x4 tiles, the x sources in pairs of 64 channels (a pair = one block of 128 weight input channels: h_fwd | h_bwd of a
+        window slot, each at its own image offset), every source tensor transformed ONCE over the frames its slots use, one dy source of 128 k channels."""
         if os.environ.get('RNH_WINO44_WGRAD', '0') != '1' or not getattr(plan, 'wino44w', False) or plan.bf16 or (H & 3) or (W & 3):
             return False
         tpi = (H // 4) * (W // 4)                                           # tiles per image
@@ -731,7 +731,7 @@ class HipOps:
             pair = xsrcs[2 * j:2 * j + 2]
             sg = plan.xsegs[2 * j:2 * j + 2]
             if any(s.scale != 1 or s.add is not None or (s.t.shape[-1] - s.c0 if s.nch is None else s.nch) != 64 for s in pair) or \
-                    pair[0].img_off != pair[1].img_off or any(g.nch != 64 or g.nvalid != 64 for g in sg) or sg[1].ci_base != sg[0].ci_base + 64:
+                    any(g.nch != 64 or g.nvalid != 64 for g in sg) or sg[1].ci_base != sg[0].ci_base + 64:
                 return False
             for s in pair:
                 key = (s.t.data_ptr(), s.c0)
