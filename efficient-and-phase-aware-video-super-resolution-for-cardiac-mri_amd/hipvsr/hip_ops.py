@@ -743,7 +743,10 @@ class HipOps:
         T8 = B * tpi // 8
         ncb, nprob = CO // 128, len(probs)
         want = max(1, 1280 // (nprob * 9 * ncb))                           # ~5 rounds of the chip
-        S = min((s_ for s_ in range(1, 129) if T8 % (2 * s_) == 0), key=lambda s_: abs(s_ - want))
+        splits = [s_ for s_ in range(1, 129) if T8 % (2 * s_) == 0]
+        if not splits:                                                      # (an odd number of k8 rows: the kernel's ring is two deep)
+            return False
+        S = min(splits, key=lambda s_: abs(s_ - want))
         st = self._stream()
         vt = {}
         for key, (lo, hi, t) in tensors.items():                           # one transform per source tensor over the frames its slots use
