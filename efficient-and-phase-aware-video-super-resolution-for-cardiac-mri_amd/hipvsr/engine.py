@@ -187,6 +187,11 @@ class RefineNetEngine:
             fwd_t += 3 * T * px * C * 9                         # the transformed input of the first PixelShuffle convolution (beside the next stage's wavefront)
         if self.refine_dgrad_f4x4(N, H, W, T):
             bwd_t += (T + 2 * hw) * px * getattr(P, 'r1_cols', 0) * 9      # the transformed dR1 of refine conv1's data gradient
+        # the opt-in forms' scratch (both off by default): the transformed gate gradients of every chain; refine conv1's tile-major operands
+        if os.environ.get('RNH_WINO44_DGRAD', '0') == '1' and self.cells_f4x4(N, H, W):
+            bwd_t += 2 * sum(nf) * 4 * px * 9
+        if os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and self.cells_f4x4(N, H, W) and P.pos and P.r1_wino:
+            bwd_t += (2 * (T + 2 * hw) * Cl + T * getattr(P, 'r1_cols', 0)) * px * 9 + 64 * w * 36 * 128 * 128 * 4
         # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
         # joined, the stage's dgates and hidden states stay alive although the stage itself has been released
         dgates = 2 * sum(nf) * 4 * T * px * ea
