@@ -29,6 +29,7 @@
 namespace {
 
 // wp[ks][n][kk] = W[o][i][tap] as bf16, index conventions of rnh_pack_weights (conv_igemm.hip), kk in natural order
+template <bool F16>
 __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned short *wp, float *biasp, const int *kbase, const int *knv,
                                  const int *ktap, const int *kcoff, const int *colmap, int nk, int Npad, int Cout, int Cin, int ntaps,
                                  int kstride, int transposed) {
@@ -46,8 +47,13 @@ __global__ void pack_bf16_kernel(const float *w, const float *bias, unsigned sho
             const int k = kbase[ks] + kk * kstride, c = col + (kcoff ? kcoff[ks] : 0), t = ktap[ks];
             v = transposed ? w[((long)k * Cin + c) * ntaps + (ntaps - 1 - t)] : w[((long)c * Cin + k) * ntaps + t];
         }
-        const __bf16 b = (__bf16)v;
-        wp[e] = __builtin_bit_cast(unsigned short, b);
+        if constexpr (F16) {
+            const _Float16 h = (_Float16)v;                         // v_cvt_f16_f32 (RNE)
+            wp[e] = __builtin_bit_cast(unsigned short, h);
+        } else {
+            const __bf16 b = (__bf16)v;
+            wp[e] = __builtin_bit_cast(unsigned short, b);
+        }
     }
 }
 
@@ -150,7 +156,9 @@ struct rnh_conv_bf16_pair_t {
 
 // PP, nA: ONE launch may serve TWO calls of equal geometry (rnh_conv_bf16_pair: the ConvLSTM cells of the two directions at small images, where a
 // call alone leaves half the chip idle): workgroups [0, nA) belong to PP.call[0], the rest to PP.call[1].  A single call passes nA = its workgroup count (call[1] is never read).
-template <int EPI, int NCOLS, int NTAPS, int KC = 16>
+// F16 (round 6; the upsampler's PixelShuffle convolutions in the forward): the packed weights are IEEE half (rnh_pack_weights_f16: 11 bits instead of
+// 8), the halo's bf16 values are converted to half on their way to LDS (exact) and the contraction runs on v_mfma_f32_32x32x16_f16 - the same rate.
+template <int EPI, int NCOLS, int NTAPS, int KC = 16, bool F16 = false>
 __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_pair_t PP, const int nA, const int TYn, const int TXn, const int NT) {
     const int second = (int)blockIdx.x >= nA;
     const rnh_conv_bf16_args_t &P = PP.call[second];                 // (an offset into the kernel-argument segment: no copy)
@@ -163,6 +171,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
     constexpr bool W8 = RNH_W8 && NCOLS == 128 && NTAPS == 9 && !M16;   // wave = (all 8 tile rows) x (32-column group `wave`)
     static_assert(NTAPS % 3 == 0 || NTAPS == 1, "the fragment ring has three sets");
     static_assert(KC == 16 || (KC == 32 && NTAPS == 9), "32-channel chunks serve the 3x3 kernels");
+    static_assert(!F16 || (KC == 32 && !M16 && !W8), "the f16 form is the 32-channel-chunk kernel's (bf16 sources through staging registers)");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
@@ -236,6 +245,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
         for (int i = 0; i < A_ITERS; ++i) {
             uint4 v = ra[i];
             if constexpr (KC == 16) v = ra_f32 ? pack8(__builtin_bit_cast(float4, ra[i]), __builtin_bit_cast(float4, rh[i])) : ra[i];
+            if constexpr (F16) v = bf2h8(v);
             if (i + 1 < A_ITERS || alast) *reinterpret_cast<uint4 *>(Ab + alds0 + i * ALDS_STEP) = v;
         }
     };
@@ -417,8 +427,12 @@ __global__ void __launch_bounds__(256, 2) conv_bf16d_kernel(const rnh_conv_bf16_
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (step & 1)][m],
-                                                                        __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
+                    if constexpr (F16)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[step & 1][m]),
+                                                                           __builtin_bit_cast(f16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
+                    else
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(RNH_EXP & 2) ? 0 : (step & 1)][m],
+                                                                            __builtin_bit_cast(bf16x8, bq[NTAPS == 9 ? step % RING : 0][n]), acc[m][n], 0, 0, 0);
             if constexpr (NTAPS == 1) bload(c + 1, 0, 0);
             if constexpr (NTAPS == 9) __builtin_amdgcn_sched_barrier(0);     // pin the issue order: hipcc otherwise sinks the weight loads to their first use
         }
@@ -903,9 +917,22 @@ extern "C" int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp
         RNH_FAIL(RNH_E_ARG, "rnh_pack_weights_bf16: bad arguments");
     if (ntaps != 9 && ntaps != 1) RNH_FAIL(RNH_E_RANGE, "rnh_pack_weights_bf16: ntaps must be 9 or 1");
     if (Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_pack_weights_bf16: Npad must be a multiple of 64");
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3(bgrid_for((long)nk * Npad * 16 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias,
+    hipLaunchKernelGGL(pack_bf16_kernel<false>, dim3(bgrid_for((long)nk * Npad * 16 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias,
                        (unsigned short *)wp, biasp, kbase, knv, ktap, kcoff, colmap, nk, Npad, Cout, Cin, ntaps, kstride, transposed);
     RNH_CHECK_LAUNCH("rnh_pack_weights_bf16");
+    return 0;
+}
+
+extern "C" int rnh_pack_weights_f16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase, const int32_t *knv,
+                                    const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk, int Npad, int Cout, int Cin,
+                                    int ntaps, int kstride, int transposed, void *stream) {
+    if (!w || !wp || !kbase || !knv || !ktap || !colmap || nk < 1 || Npad < 1 || Cout < 1 || Cin < 1 || kstride < 1)
+        RNH_FAIL(RNH_E_ARG, "rnh_pack_weights_f16: bad arguments");
+    if (ntaps != 9) RNH_FAIL(RNH_E_RANGE, "rnh_pack_weights_f16: the f16 form serves 3x3 convolutions");
+    if (Npad % 64) RNH_FAIL(RNH_E_RANGE, "rnh_pack_weights_f16: Npad must be a multiple of 64");
+    hipLaunchKernelGGL(pack_bf16_kernel<true>, dim3(bgrid_for((long)nk * Npad * 16 + Npad)), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       (unsigned short *)wp, biasp, kbase, knv, ktap, kcoff, colmap, nk, Npad, Cout, Cin, ntaps, kstride, transposed);
+    RNH_CHECK_LAUNCH("rnh_pack_weights_f16");
     return 0;
 }
 
@@ -939,6 +966,9 @@ int conv_bf16_check(const rnh_conv_bf16_args_t &a, BfGeo &g, const char *who) {
     g.k32 = a.ntaps == 9 && !(getenv("RNH_BF16_KC") && getenv("RNH_BF16_KC")[0] == '1');
     for (int i = 0; i < a.nsrc; ++i) g.k32 = g.k32 && a.src[i].dtype == RNH_DT_BF16 && a.src[i].nch % 32 == 0;
     const int NT = g.NT;
+    if (a.wp_f16 != 0 && a.wp_f16 != 1) RNH_FAIL(RNH_E_ARG, "%s: wp_f16 must be 0 or 1", who);
+    if (a.wp_f16 && !(a.epilogue == RNH_EPI_PS && g.k32))
+        RNH_FAIL(RNH_E_RANGE, "%s: f16 weights serve the pixel-shuffle epilogue over bf16 sources of 32-channel multiples", who);
     switch (a.epilogue) {
         case RNH_EPI_STORE:
             if (a.ndst < 1 || a.ndst > RNH_MAX_DST) RNH_FAIL(RNH_E_ARG, "%s: bad destination count", who);
@@ -1004,7 +1034,10 @@ int conv_bf16_launch(const rnh_conv_bf16_args_t &a, const rnh_conv_bf16_args_t &
             }
             break;
         case RNH_EPI_PS:
-            if (ncols == 128) RNH_LAUNCH9(RNH_EPI_PS, 128);
+            if (a.wp_f16) {                                           // (conv_bf16_check: 32-channel chunks)
+                if (ncols == 128) hipLaunchKernelGGL((conv_bf16d_kernel<RNH_EPI_PS, 128, 9, 32, true>), grid, block, 0, st, pp, nA, TYn, TXn, NT);
+                else hipLaunchKernelGGL((conv_bf16d_kernel<RNH_EPI_PS, 64, 9, 32, true>), grid, block, 0, st, pp, nA, TYn, TXn, NT);
+            } else if (ncols == 128) RNH_LAUNCH9(RNH_EPI_PS, 128);
             else RNH_LAUNCH9(RNH_EPI_PS, 64);
             break;
         case RNH_EPI_LSTM_BWD:
@@ -1038,7 +1071,7 @@ extern "C" int rnh_conv_bf16_pair(const rnh_conv_bf16_args_t *args_a, const rnh_
     if (int rc = conv_bf16_check(*args_b, gb, "rnh_conv_bf16_pair (second call)")) return rc;
     const rnh_conv_bf16_args_t &a = *args_a, &b = *args_b;
     if (a.B != b.B || a.H != b.H || a.W != b.W || a.Npad != b.Npad || a.ntaps != b.ntaps || a.epilogue != b.epilogue || ga.k32 != gb.k32 ||
-        a.src[0].scale != b.src[0].scale)
+        a.src[0].scale != b.src[0].scale || a.wp_f16 != b.wp_f16)
         RNH_FAIL(RNH_E_ARG, "rnh_conv_bf16_pair: the two calls must agree in B, H, W, Npad, ntaps, epilogue, source scale and chunk size");
     return conv_bf16_launch(a, b, true, ga, (hipStream_t)stream, "rnh_conv_bf16_pair");
 }

@@ -18,6 +18,13 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 __device__ __forceinline__ uint4 pack8(const float4 a, const float4 b) {
     return make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
 }
+// two / eight bf16 -> IEEE half (exact above 2^-14; v_cvt_pkrtz_f16_f32 has nothing to truncate there): the operands of the f16 MFMA forms
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned bf2h2(unsigned x) {
+    const float lo = __builtin_bit_cast(float, x << 16), hi = __builtin_bit_cast(float, x & 0xffff0000u);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+__device__ __forceinline__ uint4 bf2h8(uint4 v) { return make_uint4(bf2h2(v.x), bf2h2(v.y), bf2h2(v.z), bf2h2(v.w)); }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ void unpack8(const uint4 u, float *f) {

@@ -125,12 +125,17 @@ class FrameStore:
 
 
 class RefineNetEngine:
-    def __init__(self, cfg, ops, dtype='f32'):
+    STORAGE_CLASSES = ('feat', 'h', 'r1', 'r', 'sb', 'ys')
+
+    def __init__(self, cfg, ops, dtype='f32', storage=None):
         """dtype 'f32': everything fp32 (the reference's precision).  dtype 'bf16' (BASELINE.json configs[2]): the bf16-storage
         path - feature maps, hidden states, saved gates and the activation gradients between the big convolutions live in
         HBM as bf16 and all 3x3 convolutions run on bf16 MFMA with fp32 accumulators (rnh_conv_bf16 / rnh_wgrad_bf16);
         the cell state c and its gradient, the upsampler's inner feature map (which the collapsed tail kernels consume),
-        the outputs, the loss and every parameter gradient stay fp32; the state_dict is fp32 either way."""
+        the outputs, the loss and every parameter gradient stay fp32; the state_dict is fp32 either way.
+        ``storage``: {class: 'f32' | 'bf16'} overrides of the element type a class of forward tensors is STORED in under dtype 'bf16'
+        (STORAGE_CLASSES: the features across stages, the hidden states, refine conv1's / conv2's output, the upsampler's input sums, its
+        inner maps) - the numerical ablation of tools/bf16_ablation.py; the MFMA operands are rounded to bf16 either way."""
         import torch
         if dtype not in ('f32', 'bf16'):
             raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
@@ -138,7 +143,25 @@ class RefineNetEngine:
         self.bf16 = dtype == 'bf16'
         self.act = torch.bfloat16 if self.bf16 else torch.float32
         self.f32 = torch.float32
+        storage = dict(storage or {})
+        if set(storage) - set(self.STORAGE_CLASSES) or set(storage.values()) - {'f32', 'bf16'}:
+            raise ValueError(f'storage overrides must map {self.STORAGE_CLASSES} to f32 / bf16, got {storage!r}')
+        if storage and not self.bf16:
+            raise ValueError("storage overrides only exist under dtype 'bf16'")
+        self.storage = storage
+        self.st_dt = {k: (torch.float32 if storage.get(k) == 'f32' else self.act) for k in self.STORAGE_CLASSES}
         self.plans = NetPlans(cfg, bf16=self.bf16)
+        if self.bf16:
+            # The upsampler's PixelShuffle convolutions in the forward contract in IEEE half (plan.f16w: rnh_pack_weights_f16 + the f16 MFMA form of
+            # rnh_conv_bf16; the collapsed tail does the same inside rnh_uptail_fwd_bf16): the outputs are two linear maps away from these weights,
+            # and with 8-bit weights in exactly these layers the PSNR at trained weights moved by up to 0.014 + 0.009 dB - a fixed perturbation of
+            # the weights is a systematic shift, not noise (profiles/r06_a_bf16_psnr_ablation.txt, r06_b_bf16_weight_rounding.txt) - against
+            # 0.002 + 0.001 with 11 bits.  Where the convolution's input is bf16 in whole 32-channel chunks (the form's condition); else bf16 as before.
+            P = self.plans
+            tail_bf16 = len(P.up) > 1 and storage.get('ys') != 'f32' and ops.uptail_bf16_supported(P.C, P.up[-1]['r'], cfg.out_channels)
+            for i, u in enumerate(P.up):
+                src_dt = (self.f32 if len(P.up) == 1 else self.st_dt['sb']) if i == 0 else (self.st_dt['ys'] if tail_bf16 else self.f32)
+                u['fwd'].f16w = src_dt is torch.bfloat16 and P.C % 32 == 0 and os.environ.get('RNH_UP_F16', '1') != '0'
         self.hw = cfg.refine_window_size // 2
         if (3 if self.plans.pos else 2) * cfg.refine_window_size > L.MAX_SRC:
             raise ValueError(f'refine_window_size {cfg.refine_window_size} needs more than {L.MAX_SRC} conv sources')
@@ -342,21 +365,22 @@ class RefineNetEngine:
         # the features of the F frames, in pieces: the backward reads the T supervised frames again (first K source of layer 0's
         # weight gradient), the update frames on both sides only feed this stage's forward
         sup = (U, U + T) if need_grad else None
-        feat = FrameStore(ops, N, 0, F, sup, (H, W, C), act, alloc=False)
+        sdt = self.st_dt
+        feat = FrameStore(ops, N, 0, F, sup, (H, W, C), sdt['feat'], alloc=False)
         for a, b in ([(0, U), (U, U + T), (U + T, F)] if need_grad else [(0, F)]):
             y = ops.inconv_fwd(x_all[a * N:b * N], params['in_block.conv.weight'], params['in_block.conv.bias'],
                                params['in_block.prelu.weight'])
             if self.bf16:
-                y = ops.cast(y, act)                              # the input block's features cross into bf16 storage here
+                y = ops.cast(y, sdt['feat'])                      # the input block's features cross into bf16 storage here
             feat.put(a, b, y)
         P4 = (ops.phase_plane(pos_codes, N, F, H, W, dtype=act, channels=P.pw) if self.bf16 else
               ops.phase_plane(pos_codes, N, F, H, W)) if P.pos else None
         # the tail kernels read their input in fp32 (csrc/uptail.hip) or, for the x4 / x8 nets' r = 2 tail, in bf16
         # (csrc/uptail_bf16.hip): then every inner feature map of the upsampler and its gradient are bf16 too.  With a single
         # PixelShuffle stage the tail's input is Sb, kept fp32
-        tail_bf16 = self.bf16 and len(P.up) > 1 and ops.uptail_bf16_supported(C, P.up[-1]['r'], cfg.out_channels)
+        tail_bf16 = self.bf16 and len(P.up) > 1 and self.storage.get('ys') != 'f32' and ops.uptail_bf16_supported(C, P.up[-1]['r'], cfg.out_channels)
         ctx.tail_bf16 = tail_bf16
-        sb_dt = f32 if len(P.up) == 1 else act
+        sb_dt = f32 if len(P.up) == 1 else sdt['sb']
         ctx.P4 = P4
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
@@ -384,7 +408,7 @@ class RefineNetEngine:
                 # what the backward reads again: the supervised frames and, per direction, the frame in front of them (second K source of
                 # the weight gradient, previous cell state); the top layer's h feeds the refine windows and stays whole
                 keep = ((U - 1, U + T) if fwd else (U, U + T + 1)) if need_grad else None
-                st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), act) for l, hd in enumerate(nf)],
+                st[d] = dict(H=[FrameStore(ops, N, lo_d, hi_d, keep if l < Lr - 1 else (lo_d, hi_d), (H, W, hd), sdt['h']) for l, hd in enumerate(nf)],
                              C=[FrameStore(ops, N, lo_d, hi_d, keep, (H, W, hd), f32, ring=2, step=1 if fwd else -1) for hd in nf],
                              G=[ops.empty(TN, H, W, 4 * hd, dtype=act) for hd in nf] if need_grad and s >= n_rc else None)
             def cell_call(d, l, idx):
@@ -508,7 +532,7 @@ class RefineNetEngine:
 
             # ---- phase-aware refine block over all windows (refine_net.py:157-185) -----------------------
             w0, nwin = (U - hw, T) if last else (0, F - 2 * hw)     # first window computed, number of windows
-            R = ops.empty(nwin * N, H, W, Cl, dtype=act)
+            R = ops.empty(nwin * N, H, W, Cl, dtype=sdt['r'])
 
             def win_srcs(a):
                 out = []
@@ -526,7 +550,7 @@ class RefineNetEngine:
                         continue
                     nw = b - a
                     srcs = win_srcs(a)
-                    R1 = ops.empty(nw * N, H, W, P.C1p, dtype=act)
+                    R1 = ops.empty(nw * N, H, W, P.C1p, dtype=sdt['r1'])
                     hfs, hbs, p4s = HF.frames(a, b + w - 1), HB.frames(a, b + w - 1), P4[a * N:(b + w - 1) * N]   # the source frames of these windows
                     if P.r1_wino and VT is not None:
                         mtf = N * (H // 4) * (W // 4) // 32                 # tile blocks per frame
@@ -591,7 +615,7 @@ class RefineNetEngine:
             Yb, hh, ww = [], H, W
             for u in (P.up[:-1] if tail_u is not None else P.up) if nb else []:
                 hh, ww = hh * u['r'], ww * u['r']
-                Yb.append(ops.empty(nb * TN, hh, ww, C, dtype=act if tail_bf16 else f32))
+                Yb.append(ops.empty(nb * TN, hh, ww, C, dtype=sdt['ys'] if tail_bf16 else f32))
             if not need_grad and aside_keep:
                 # inference keeps nothing for a backward: the previous stage's upsampler (long finished: a whole ConvLSTM wavefront and refine block
                 # ago) is rejoined here, so that at most ONE stage's upsampler buffers are alive
@@ -627,7 +651,7 @@ class RefineNetEngine:
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
             if S > 1 and s < S - 1:
-                nfeat = FrameStore(ops, N, 0, F, sup, (H, W, C), act)
+                nfeat = FrameStore(ops, N, 0, F, sup, (H, W, C), sdt['feat'])
                 for lo_r, hi_r, other in ((0, hw, lambda a, b: HF.frames(a, b)), (hw, F - hw, lambda a, b: R[(a - hw) * N:(b - hw) * N]),
                                           (F - hw, F, lambda a, b: HB.frames(a, b))):
                     for a, b in nfeat.pieces(lo_r, hi_r):

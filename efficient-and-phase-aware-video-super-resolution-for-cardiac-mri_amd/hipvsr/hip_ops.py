@@ -463,10 +463,11 @@ class HipOps:
             self._packed[id(plan)] = buf
         wp, bp = buf
         if plan.bf16:
-            L.check(self.lib.rnh_pack_weights_bf16(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['kbase']), _ptr(m['knv']),
-                                                   _ptr(m['ktap']), _ptr(m['kcoff']), _ptr(m['colmap']), plan.nk, plan.Npad,
-                                                   plan.Cout, plan.Cin, plan.ntaps, plan.kstride, int(plan.transposed),
-                                                   self._stream()), f'rnh_pack_weights_bf16({plan.name})')
+            # (plan.f16w: IEEE-half weights for the f16 MFMA form of the launch - the upsampler's PixelShuffle convolutions in the forward)
+            fn, who = (self.lib.rnh_pack_weights_f16, 'rnh_pack_weights_f16') if getattr(plan, 'f16w', False) else \
+                (self.lib.rnh_pack_weights_bf16, 'rnh_pack_weights_bf16')
+            L.check(fn(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['kbase']), _ptr(m['knv']), _ptr(m['ktap']), _ptr(m['kcoff']), _ptr(m['colmap']),
+                       plan.nk, plan.Npad, plan.Cout, plan.Cin, plan.ntaps, plan.kstride, int(plan.transposed), self._stream()), f'{who}({plan.name})')
             return
         if plan.wino:
             L.check(self.lib.rnh_wino_pack_weights(_ptr(w), _ptr(b), _ptr(wp), _ptr(bp), _ptr(m['wkbase']), _ptr(m['wknv']),
@@ -624,6 +625,7 @@ class HipOps:
         a.nsrc, a.B, a.H, a.W, a.ntaps, a.nchunks = len(srcs), B, H, W, plan.ntaps, plan.nchunks
         a.wp, a.bias = wp.data_ptr(), (bp.data_ptr() if plan.bkey is not None else None)
         a.Npad, a.epilogue = plan.Npad, plan.epilogue
+        a.wp_f16 = int(bool(getattr(plan, 'f16w', False)))
         if lstm_bwd is not None:
             hd = lstm_bwd['hd']
             if plan.epilogue != L.EPI_STORE or len(dsts) != 1 or not self.lstm_bwd_fusable(plan, dsts[0].ncols, hd):

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
-ABI_VERSION = 5          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
+ABI_VERSION = 6          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -40,7 +40,9 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_phase_plane_m', 'rnh_struct_sizes_bf16',
            # F(4x4, 3x3) ConvLSTM cell (ABI 5)
            'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_cell_pair', 'rnh_wino44_conv',
-           'rnh_wino44_tmajor_floats', 'rnh_wino44_tmajor', 'rnh_wino44_wgrad_gemm', 'rnh_wino44_wgrad_finish']
+           'rnh_wino44_tmajor_floats', 'rnh_wino44_tmajor', 'rnh_wino44_wgrad_gemm', 'rnh_wino44_wgrad_finish',
+           # f16 weights for the upsampler's forward in the bf16-storage path (ABI 6)
+           'rnh_pack_weights_f16']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -121,7 +123,7 @@ class ConvBf16Args(C.Structure):
                 ('h_out', C.c_void_p), ('gates_out', C.c_void_p), ('h_dtype', C.c_int32), ('gates_dtype', C.c_int32),
                 ('bw_dh', C.c_void_p), ('bw_dc_next', C.c_void_p), ('bw_gates', C.c_void_p), ('bw_c_prev', C.c_void_p),
                 ('bw_c_next', C.c_void_p), ('bw_dgates', C.c_void_p), ('bw_dc_prev', C.c_void_p), ('bw_dh_dtype', C.c_int32),
-                ('bw_dgates_dtype', C.c_int32), ('bw_rec_dtype', C.c_int32), ('_pad2', C.c_int32)]
+                ('bw_dgates_dtype', C.c_int32), ('bw_rec_dtype', C.c_int32), ('wp_f16', C.c_int32)]
 
 
 class WgradBf16Args(C.Structure):
@@ -231,6 +233,7 @@ def load():
     lib.rnh_wino44_wgrad_gemm.argtypes = [C.POINTER(Wino44WgradArgs), vp]
     lib.rnh_wino44_wgrad_finish.argtypes = [C.POINTER(Wino44WgradArgs), vp, i32, i32, vp, vp, vp, i32, i32, vp]
     lib.rnh_pack_weights_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.rnh_pack_weights_f16.argtypes = lib.rnh_pack_weights_bf16.argtypes
     lib.rnh_wgrad_bf16.argtypes = [C.POINTER(WgradBf16Args), vp]
     lib.rnh_ew_add_m.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i64, i32, vp]
     lib.rnh_lstm_gates_bwd_m.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, i64, i32, vp]

@@ -80,6 +80,15 @@ class RefineNet(BaseNet):
         # the supervised frames for the backward, 'recompute' re-runs the cell launch there instead (bit-identical gradients, one more
         # launch per cell and frame), 'auto' recomputes only where the stored-gates step is estimated not to fit the device
         self.gate_memory = 'auto'
+        # bf16-storage path only: {class: 'f32'} overrides of the element type a class of forward tensors is stored in
+        # (hipvsr.engine.RefineNetEngine.STORAGE_CLASSES); {} = the path's own layout
+        self.storage = {}
+
+    def set_storage(self, storage):
+        """Storage-class overrides of the bf16-storage path (see RefineNetEngine); takes effect at the next forward."""
+        self.storage = dict(storage or {})
+        self._eng = None
+        return self
 
     def set_compute_dtype(self, dtype):
         """'f32' or 'bf16'; takes effect at the next forward (the engine and its packed weights are rebuilt)."""
@@ -103,7 +112,8 @@ class RefineNet(BaseNet):
                                    'There is no CPU path in this package.')
             from hipvsr.engine import RefineNetEngine
             from hipvsr.hip_ops import HipOps
-            self._eng = RefineNetEngine(self.cfg, HipOps(dev), dtype=self.compute_dtype)
+            self._eng = RefineNetEngine(self.cfg, HipOps(dev), dtype=self.compute_dtype,
+                                        storage=self.storage if self.compute_dtype == 'bf16' else None)
         self._eng.gate_memory = self.gate_memory
         return self._eng
 

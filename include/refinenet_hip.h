@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 5       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_* */
+#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16 */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -471,7 +471,9 @@ typedef struct rnh_conv_bf16_args {
     void *bw_dgates;            /* out [B][H][W][4*hd] of bw_dgates_dtype                                 */
     float *bw_dc_prev;          /* out fp32 [B][H][W][hd] or 0                                            */
     int32_t bw_dh_dtype, bw_dgates_dtype, bw_rec_dtype;
-    int32_t _pad2;
+    int32_t wp_f16;             /* 1: wp is IEEE half from rnh_pack_weights_f16 and the contraction runs on v_mfma_f32_32x32x16_f16 (the bf16 inputs
+                                 * convert exactly; values beyond 65504 would saturate to inf): RNH_EPI_PS over bf16 sources of 32-channel multiples
+                                 * only (ABI 6; the field was padding until then, 0 = the bf16 form) */
 } rnh_conv_bf16_args_t;
 
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA: one workgroup = 8 x 32 output pixels x 128 (64) columns; per
@@ -489,6 +491,13 @@ int rnh_conv_bf16_pair(const rnh_conv_bf16_args_t *args_a /* host */, const rnh_
 int rnh_pack_weights_bf16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,
                           const int32_t *knv, const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk,
                           int Npad, int Cout, int Cin, int ntaps, int kstride, int transposed, void *stream);
+
+/* The same slabs in IEEE half for calls with wp_f16 = 1 (ABI 6): the upsampler's PixelShuffle convolutions in the forward (reference
+ * src/model/nets/refine_net.py:199-204) - the network's outputs are two linear maps away from them, and at trained weights the 8-bit weights of
+ * exactly these layers moved the PSNR by more than the contract's 0.01 dB (profiles/r06_a_*, r06_b_*); 3x3 only. */
+int rnh_pack_weights_f16(const float *w, const float *bias, void *wp, float *biasp, const int32_t *kbase,
+                         const int32_t *knv, const int32_t *ktap, const int32_t *kcoff, const int32_t *colmap, int nk,
+                         int Npad, int Cout, int Cin, int ntaps, int kstride, int transposed, void *stream);
 
 typedef struct rnh_wgrad_bf16_args {
     rnh_msrc_t xs[RNH_MAX_SRC]; /* forward inputs (rows of dW): scale 1                                  */

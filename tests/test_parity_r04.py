@@ -312,9 +312,10 @@ def test_psnr_parity_with_trained_weights(trained, name, n, t, size):
     """the contract criterion at trained scale.  The weights the fp32 run ended with (saturating gates, a wider dynamic
     range than the default initialisation), BASELINE config 1 and config 2's geometry on the structured cine: PSNR of the fused group
     against the TRUE HR frames through the fp32 oracle (== reference) and through the HIP path: fp32 |delta| < 0.01 dB on every frame (the
-    contract's fp32 tolerance); bf16 storage |delta| < 0.03 dB - its deviation is a systematic shift that depends on the weights: 0.008-0.009
-    dB at the weights the round-4 fp32 run ended with, 0.016-0.021 dB at the (equally valid, training is chaotic) weights the fp32 run ends
-    with since the cells run in F(4x4, 3x3) form."""
+    contract's tolerance) in fp32 AND in the bf16-storage path.  (Round 5 had to relax the bf16 bound to 0.03 dB: a one-sided shift of 0.016-0.021 dB
+    at the weights the fp32 run ends with since the cells run in F(4x4, 3x3) form.  Round 6 found its source - the 8-bit WEIGHTS of the upsampler's
+    forward, a fixed perturbation one or two linear maps in front of the output, profiles/r06_a_*, r06_b_* - and took it away: those layers
+    contract in IEEE half, 0.002-0.005 dB.  The same criterion at three FROZEN weight sets: test_psnr_parity_at_frozen_trained_weights.)"""
     cfg, sd = trained['cfg'], trained['f32']['sd']
     inputs, targets, pos = orc.structured_cine(cfg, n, t, size, size, seed=71)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -333,9 +334,40 @@ def test_psnr_parity_with_trained_weights(trained, name, n, t, size):
         worst = max(abs(a - b) for a, b in zip(got, want))
         rel = max(float((o.cpu() - r).norm() / r.norm()) for o, r in zip(outs[-1], ref_last))
         msg.append(f'{dt}: worst frame |dPSNR| {worst:.1e} dB, worst output error {rel:.1e} rel. L2')
-        assert worst < (0.01 if dt == 'f32' else 0.03), (name, dt, got, want)
+        assert worst < 0.01, (name, dt, got, want)
         del net
     print(f'{name}, weights after {_TRAIN["steps"]} fp32 steps: PSNR vs true HR {sum(want) / len(want):.3f} dB (oracle); ' + '; '.join(msg))
+
+
+@pytest.mark.parametrize('name,n,t,size', [('config 1', 1, 3, 64), ('config 2 geometry', 2, 7, 128)])
+@pytest.mark.parametrize('wset', ['A', 'B', 'C'])
+def test_psnr_parity_at_frozen_trained_weights(golden_dir, wset, name, n, t, size):
+    """ADVICE r05 / VERDICT r05 item 1: the contract criterion |dPSNR| < 0.01 dB per frame, fp32 and bf16 storage, at three weight sets FROZEN as
+    fixtures (tests/golden/trained/weights_{A,B,C}.pt: 600 fp32 training steps each at the reference YAML's training shape - A: seed 61 in round
+    5's forms, the set at which the bf16 path showed +0.019 ... +0.024 dB; B: seed 61 with every Winograd launch in F(2x2) form, round 4's
+    trajectory; C: seed 161; made by tests/ablation/bf16_psnr_ablation.py train) - a kernel change is then judged at the same weights before and
+    after, not at wherever a chaotic training run happens to end.  Measured in round 6 (profiles/r06_c_bf16_f16_upsampler.txt): bf16 worst frame
+    0.0033 / 0.0049 (A), 0.0053 / 0.0044 (B), 0.0028 / 0.0024 dB (C)."""
+    w = torch.load(os.path.join(golden_dir, 'trained', f'weights_{wset}.pt'), weights_only=False)
+    cfg, sd = orc.exp1_x4_config(), w['sd']
+    inputs, targets, pos = orc.structured_cine(cfg, n, t, size, size, seed=71)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = orc.forward(orc.as_leaf_params(sd), cfg, [x.clone() for x in inputs], pos)
+    want = [float(sto.trainer_metrics([o.detach()], [y])[0]) for o, y in zip(ref[-1], targets)]
+    from src.model.metrics import PSNR, fused_metrics
+    dev = _dev()
+    msg = []
+    for dt in ('f32', 'bf16'):
+        net = _net(cfg, sd, dt).eval()
+        with torch.no_grad():
+            outs = net([x.to(dev) for x in inputs], pos.to(dev))
+            got = [float(x) for x in fused_metrics(outs[-1], [y.to(dev) for y in targets], [PSNR()], per_frame=True)[:, 0]]
+        worst = max(abs(a - b) for a, b in zip(got, want))
+        msg.append(f'{dt} worst frame |dPSNR| {worst:.1e} dB')
+        assert worst < 0.01, (wset, name, dt, got, want)
+        del net
+    print(f'frozen weights {wset} (seed {w["seed"]}, {w["env"] or "default forms"}), {name}: oracle {sum(want) / len(want):.3f} dB; ' + '; '.join(msg))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -104,7 +104,9 @@ class TorchOps:
 
     def pack(self, plan, w, b=None):
         weff = effective_weight(plan, w.detach())
-        if getattr(plan, 'bf16', False):
+        if getattr(plan, 'f16w', False):                      # (the f16 MFMA form: IEEE-half weights, the bf16 inputs convert exactly)
+            weff = weff.half().float()
+        elif getattr(plan, 'bf16', False):
             weff = weff.bfloat16().float()
         bp = None
         if b is not None and not plan.transposed:
