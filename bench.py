@@ -202,6 +202,8 @@ def lstm_kernel_roofline(net, dev, n, h, w, reps=200, warm=50):
                                     'bound': 'hbm', 'bytes_per_launch': int(4 * n * h * w * hd * 3.25), 'achieved_tbs': round(4 * n * h * w * hd * 3.25 / (t_ms * 1e-3) / 1e12, 3),
                                     'frac_of_8tbs': round(4 * n * h * w * hd * 3.25 / (t_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)},
                 'cell_plus_transform_ms': round(ms + t_ms, 4),
+                # the honest figure for "one ConvLSTM cell": the matrix kernel AND the transform launch it cannot run without, against the same peak
+                'frac_with_transform': round(flops_exec / ((ms + t_ms) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 'algorithmic_equiv_tflops_with_transform': round(flops / ((ms + t_ms) * 1e-3) / 1e12, 2)}
     # what the matrix cores execute: the Winograd F(2x2,3x3) kernel runs 16 GEMMs over n*h*w/4 tiles = 4/9 of it
     flops_exec = flops * 4.0 / 9.0 if wino else flops
@@ -374,16 +376,15 @@ def run_case(args, dtype, dev, world, rank):
     n_global = args.batch * world
     bf = dtype == 'bf16'
     flop_step = step_flops_per_lr_pixel(args.frames, scale=args.scale) * args.size * args.size * n_global
-    eng_ = net._engine()
-    cell44 = eng_.cells_f4x4(args.batch, args.size, args.size)
-    refine44 = cell44 and eng_.refine_f4x4(args.batch, args.size, args.size, args.frames + 12)
-    up44 = cell44 and eng_.up_f4x4(args.batch, args.size, args.size)
-    rd44 = cell44 and eng_.refine_dgrad_f4x4(args.batch, args.size, args.size, args.frames)
+    # the forms the timed steps ran in: the engine's own record (hipvsr/forms.py) at this shape and mode - incl. the F(2x2) fallback of a captured step at
+    # a shape whose F(4x4) cells need the transformed-h' ring
+    fm = net._engine().resolve_forms(args.batch, args.size, args.size, args.frames + 12, need_grad=True, capturing=args.graph == 'on')
+    cell44, refine44, up44, rd44 = fm.cells44, fm.refine_fwd44, bool(fm.up44 and fm.up44[0]), fm.refine_dgrad44
     flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44, refine_dgrad44=rd44) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages
-    n_rc = net._engine().recompute_stages(args.batch, args.size, args.size, args.frames + 12)
+    n_rc = fm.recompute
     flop_exec += n_rc * 2 * args.frames * 3 * 589824 * (1.0 if bf else (0.25 if cell44 else 4.0 / 9.0)) * args.size * args.size * n_global
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     prec = ('bf16 storage + bf16 MFMA, fp32 accumulate (BASELINE config 3 per GPU)' if bf else 'fp32')
@@ -414,6 +415,7 @@ def run_case(args, dtype, dev, world, rank):
                            round(flop_exec / world / (dt / args.steps) / 1e12 / peak, 4),
                        'final_loss': round(float(loss.detach()), 6),
                        'gates': gates_label(net, args),
+                       'forms': fm.describe(),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             'roofline': roof,
         }
@@ -446,6 +448,9 @@ def parse_args(argv=None):
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32: the headline (BASELINE config 2, the reference's precision) with the bf16-storage step of BASELINE "
                          "config 3 as `secondary` in the same line; bf16: that bf16 step alone as the line")
+    ap.add_argument('--allow-overrides', action='store_true',
+                    help='print the line although RNH_* A/B switches are set in the environment (hipvsr/forms.py: SWITCHES); they are listed in config.forms.env_overrides '
+                         'either way.  Without this flag a run with overrides is refused: a stray variable on a box must not silently change the headline')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU: the launch / rendezvous / barrier / max-over-ranks protocol over gloo with a stub step (what tests/ checks on CPU)')
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
@@ -605,6 +610,10 @@ def main(argv=None):
                              f'run `python bench.py --gpus {args.gpus}` (it starts the ranks itself) or torchrun with --nproc-per-node {args.gpus}')
     if args.dry_run:
         return dry_run(args, world, rank)
+    from hipvsr.forms import env_overrides
+    if env_overrides() and not args.allow_overrides:
+        raise SystemExit(f'bench.py: A/B switches are set in the environment ({", ".join(env_overrides())}): this would not be the product\'s own step. '
+                         f'Unset them, or pass --allow-overrides (they are then recorded in config.forms.env_overrides).')
     apply_rank_affinity(local)                    # (before the first GPU call of this process)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')

@@ -20,6 +20,7 @@ import os
 from collections import OrderedDict
 
 from . import lib as L
+from .forms import SLOT_FRACTION, Forms, wino44_launch_ok
 from .plans import Dst, NetPlans, Src
 
 
@@ -30,7 +31,7 @@ def _span_src(store, k0, n):
 
 class Context:
     """What the forward keeps for the backward."""
-    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad', 'tail_bf16', 'recompute')
+    __slots__ = ('N', 'H', 'W', 'F', 'T', 'x_all', 'P4', 'stages', 'packed_dgrad', 'tail_bf16', 'recompute', 'forms')
 
     def __init__(self):
         self.stages = []
@@ -199,21 +200,21 @@ class RefineNetEngine:
         o_all = 2 * S * 3 * T * px * cfg.upscale_factor ** 2 * cfg.out_channels * 4               # outputs and their gradient
         fwd_t = (2 * sum(nf[:-1]) * (F - T - 1) * px * ea + 4 * sum(nf) * 2 * px * 4 + (F - 2 * hw) * px * Cl * ea +
                  max(U - hw, 1) * px * c1p * ea + 2 * F * px * C * ea)
-        if self.cells_f4x4(N, H, W):
+        fm = self._conv_forms(N, H, W, F)                         # (the eager step's forms; a captured step at a ring shape runs F(2x2) cells: less)
+        if fm.cells44:
             # the cells in F(4x4, 3x3) form read transformed inputs, 2.25 x 4 bytes per element: the features of every frame and the h' of every cell -
-            # a slot per frame, or a ring of four where that would take more than 8 % of the card (forward_impl)
-            slots = 2 * F * sum(nf) * px * 9
-            fwd_t += F * px * C * 9 + (slots if slots <= 0.08 * self.ops.total_memory() else 2 * min(F, 4) * sum(nf) * px * 9)
+            # a slot per frame, or a ring of four where that would take more than 8 % of the card (resolve_forms)
+            fwd_t += F * px * C * 9 + 2 * (min(F, fm.ring) if fm.ring else F) * sum(nf) * px * 9
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
-        if self.up_f4x4(N, H, W):
+        if fm.up44 and fm.up44[0]:
             fwd_t += 3 * T * px * C * 9                         # the transformed input of the first PixelShuffle convolution (beside the next stage's wavefront)
-        if self.refine_dgrad_f4x4(N, H, W, T):
+        if fm.refine_dgrad44:
             bwd_t += (T + 2 * hw) * px * getattr(P, 'r1_cols', 0) * 9      # the transformed dR1 of refine conv1's data gradient
         # the opt-in forms' scratch (both off by default): the transformed gate gradients of every chain; refine conv1's tile-major operands
-        if os.environ.get('RNH_WINO44_DGRAD', '0') == '1' and self.cells_f4x4(N, H, W):
+        if fm.cell_dgrad44:
             bwd_t += 2 * sum(nf) * 4 * px * 9
-        if os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and self.cells_f4x4(N, H, W) and P.pos and P.r1_wino:
+        if os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and fm.cells44 and P.pos and P.r1_wino:
             bwd_t += (2 * (T + 2 * hw) * Cl + T * getattr(P, 'r1_cols', 0)) * px * 9 + 64 * w * 36 * 128 * 128 * 4
         # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
         # joined, the stage's dgates and hidden states stay alive although the stage itself has been released
@@ -224,32 +225,119 @@ class RefineNetEngine:
         return dict(per_stage=per, recomputing_stages=n_rc, kept=kept, outputs=o_all, forward_transient=fwd_t, backward_transient=bwd_t,
                     held_for_weight_gradients=held, peak=peak)
 
-    def cells_f4x4(self, N, H, W):
-        """Do the ConvLSTM cells of a forward at this shape run in Winograd form F(4x4, 3x3) (rnh_wino44_cell)?  All of them or none."""
-        ops, P = self.ops, self.plans
-        return (not self.bf16) and hasattr(ops, 'wino44_ok') and all(ops.wino44_ok(P.lstm[k][kind], N, H, W, packed=False) for k in P.lstm for kind in ('full', 'first'))
+    # ------------------------------------------------------------------------------------------------
+    # forms (hipvsr/forms.py): ONE decision per (shape, mode), read by the forward, the backward, memory_plan, _pack and bench.py
+    def resolve_forms(self, N, H, W, F, need_grad=True, last_only=False, capturing=False):
+        """Which form every big launch of a step at this shape takes.  fp32 path: the ConvLSTM cells in Winograd form F(4x4, 3x3) (rnh_wino44_cell)
+        wherever every cell plan of the net is eligible and the images are whole 4x4 tiles - all cells or none -, their transformed h' in a slot per
+        frame, or in a ring of four where the slots would take more than SLOT_FRACTION of the card (BASELINE config 4 at N = 16: 62 GB; the
+        device's TOTAL memory, not what is free right now: the decision must not change from one step to the next); under HIP-graph capture the
+        ring cannot be captured (hipStreamEndCapture, DESIGN section 8 hazard 3), so a capture at a ring shape falls back to F(2x2) cells
+        (``capture_fallback``: eager and graph steps differ in their low bits there, and only there).  Refine conv1's forward / data gradient
+        and the PixelShuffle convolutions follow the cells where their own launches qualify.  The result is cached per argument tuple."""
+        import copy
+        f = copy.copy(self._conv_forms(N, H, W, F, need_grad, last_only, capturing))
+        f.recompute = self.recompute_stages(N, H, W, F) if need_grad else 0           # (asks memory_plan, which reads the convolution forms)
+        return f
 
-    def refine_f4x4(self, N, H, W, F):
-        """Does refine conv1's forward over the hidden states run in F(4x4, 3x3) form (rnh_wino44_conv) at this shape?  It reads the transformed h'
-        the top layer's cells wrote: the cells must run in that form with a slot per frame (no ring), a frame must be whole tile blocks."""
-        P, cfg = self.plans, self.cfg
-        if not (self.cells_f4x4(N, H, W) and P.pos and P.r1_wino and getattr(P.r1_fwd_h, 'wino44', False)):
-            return False
-        slots = 2 * F * sum(P.nf) * N * H * W * 9
-        return (slots <= 0.08 * self.ops.total_memory() and (N * (H // 4) * (W // 4)) % 32 == 0 and
-                self.ops.wino44_ok(P.r1_fwd_h, (F - 2 * self.hw) * N, H, W, packed=False, dst_channels=P.C1p))
+    def _conv_forms(self, N, H, W, F, need_grad=True, last_only=False, capturing=False):
+        """resolve_forms without the gate-memory plan (which itself depends on these forms through memory_plan)."""
+        key = (N, H, W, F, bool(need_grad), bool(last_only), bool(capturing), os.environ.get('RNH_WINO44'), os.environ.get('RNH_WINO44_MIN'),
+               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'))
+        cache = self.__dict__.setdefault('_forms_cache', {})
+        if key in cache:
+            return cache[key]
+        ops, P, cfg = self.ops, self.plans, self.cfg
+        U, hw, w = cfg.num_updated_frames, self.hw, cfg.refine_window_size
+        T = F - 2 * U
+        nf, Lr = P.nf, P.L
+        f = Forms()
+        f.N, f.H, f.W, f.F, f.T, f.dtype, f.need_grad, f.last_only, f.capturing = N, H, W, F, T, self.dtype, bool(need_grad), bool(last_only), bool(capturing)
+        hip = hasattr(ops, 'wino44_cell')                        # (the CPU double of tests/ has no F(4x4) kernels: every launch in its plain form)
+        cell_plans = [P.lstm[k][kind] for k in P.lstm for kind in ('full', 'first')]
+        cells44 = (not self.bf16) and hip and all(wino44_launch_ok(pl, N, H, W) for pl in cell_plans)
+        total = ops.total_memory() if hasattr(ops, 'total_memory') else 0
+        slots = 2 * F * sum(nf) * N * H * W * 9               # a slot per frame: 2.25 x 4 bytes per element of every h'
+        ring = cells44 and bool(total) and slots > SLOT_FRACTION * total
+        f.capture_fallback = bool(cells44 and ring and capturing)
+        if f.capture_fallback:
+            cells44 = False
+        f.cells44, f.ring = bool(cells44), (4 if cells44 and ring else 0)
+        tiles32 = (N * (H // 4) * (W // 4)) % 32 == 0          # a frame = whole tile blocks (the window slots of refine conv1 are frames apart)
+        r1 = cells44 and P.pos and P.r1_wino
+        f.refine_fwd44 = bool(r1 and not f.ring and tiles32 and wino44_launch_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W, dst_channels=P.C1p))
+        f.refine_dgrad44 = bool(r1 and need_grad and tiles32 and wino44_launch_ok(P.r1_dgrad_h, (T + 2 * hw) * N, H, W, dst_channels=P.Cl)
+                                and wino44_launch_ok(P.r1_dgrad_h, T * N, H, W, dst_channels=P.Cl))
+        nb = (1 if last_only and not need_grad else 3)
+        n_up = len(P.up) - 1 if (hasattr(ops, 'uptail_fwd_supported') and ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)) else len(P.up)
+        f.up44 = [bool(cells44 and u['r'] == 2 and wino44_launch_ok(u['fwd'], nb * T * N, H * 2 ** i, W * 2 ** i)) for i, u in enumerate(P.up[:n_up])]
+        fused = bool(cfg.memory and hasattr(ops, 'lstm_bwd_fusable') and
+                     all(ops.lstm_bwd_fusable(P.lstm[k]['dgrad'], P.lstm[k]['cx'], P.lstm[k]['hd']) for k in P.lstm))
+        f.cell_dgrad_fused = fused
+        f.cell_dgrad44 = bool(cells44 and need_grad and not fused and all(wino44_launch_ok(P.lstm[k]['dgrad'], N, H, W) for k in P.lstm))
+        f.recompute = None
+        f.paired = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False
+        f.plans44 = set()
+        if cells44:
+            f.plans44 |= {id(pl) for pl in cell_plans}
+        if f.refine_fwd44:
+            f.plans44.add(id(P.r1_fwd_h))
+        if f.refine_dgrad44:
+            f.plans44.add(id(P.r1_dgrad_h))
+        f.plans44 |= {id(u['fwd']) for u, on in zip(P.up, f.up44) if on}
+        if f.cell_dgrad44:
+            f.plans44 |= {id(P.lstm[k]['dgrad']) for k in P.lstm}
+        # the names bench.py prints (config.forms)
+        pl0 = P.lstm[('forward', 0)]
 
-    def refine_dgrad_f4x4(self, N, H, W, T):
+        def conv_form(pl, on44):
+            if self.bf16:
+                return 'direct 3x3 on bf16 MFMA (rnh_conv_bf16)' + (', IEEE-half weights on the f16 MFMA form' if getattr(pl, 'f16w', False) else '')
+            if on44:
+                return 'Winograd F(4x4,3x3) on transformed inputs (rnh_wino44_*)'
+            return 'Winograd F(2x2,3x3) (rnh_conv_wino)' if getattr(pl, 'wino', False) else 'implicit GEMM (rnh_conv_igemm)'
+        cell = conv_form(pl0['full'], cells44)
+        if cells44:
+            cell += ', transformed h\' in a ring of 4' if f.ring else ', a transformed-h\' slot per frame'
+        if f.capture_fallback:
+            cell += " [capture fallback: the F(4x4) form's ring cannot be captured at this shape]"
+        names = dict(cell=cell,
+                     cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '')) if need_grad else None,
+                     cell_wgrad=('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
+                                 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)') if need_grad else None)
+        if P.pos:
+            r1p = P.r1_fwd_h if P.r1_wino else (P.r1_fwd_a if getattr(P, 'r1_split', False) else P.r1_fwd)
+            names['refine1_fwd'] = conv_form(r1p, f.refine_fwd44) + (' on the cells\' transformed h\'' if f.refine_fwd44 else '')
+            if need_grad:
+                names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
+                w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
+                names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else names['cell_wgrad'])
+        else:
+            names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
+        for i, u in enumerate(P.up[:n_up]):
+            names[f'up{i + 1}_fwd'] = conv_form(u['fwd'], f.up44[i]) + ', PixelShuffle in the store'
+        names['tail'] = ('last PixelShuffle conv + final conv collapsed (rnh_uptail_*' + ('_bf16: f16 MFMA, IEEE-half composed weights)' if self.bf16 and n_up and
+                         self.storage.get('ys') != 'f32' and ops.uptail_bf16_supported(P.C, P.up[-1]['r'], cfg.out_channels) else ')')) if n_up < len(P.up) else 'rnh_outconv_*'
+        f.names = names
+        cache[key] = f
+        return f
+
+    def cells_f4x4(self, N, H, W, F=None, capturing=False):
+        """Do the ConvLSTM cells of a training step at this shape run in Winograd form F(4x4, 3x3)?  (resolve_forms; F defaults to the smallest legal sequence)"""
+        return self._conv_forms(N, H, W, F if F is not None else 2 * self.cfg.num_updated_frames + 1, capturing=capturing).cells44
+
+    def refine_f4x4(self, N, H, W, F, capturing=False):
+        """Does refine conv1's forward over the hidden states run in F(4x4, 3x3) form (rnh_wino44_conv) at this shape?"""
+        return self._conv_forms(N, H, W, F, capturing=capturing).refine_fwd44
+
+    def refine_dgrad_f4x4(self, N, H, W, T, capturing=False):
         """Does refine conv1's data gradient over the hidden states run in F(4x4, 3x3) form at this shape (T supervised frames)?"""
-        P = self.plans
-        return (self.cells_f4x4(N, H, W) and P.pos and P.r1_wino and getattr(P.r1_dgrad_h, 'wino44', False) and (N * (H // 4) * (W // 4)) % 32 == 0 and
-                self.ops.wino44_ok(P.r1_dgrad_h, (T + 2 * self.hw) * N, H, W, packed=False, dst_channels=P.Cl))
+        return self._conv_forms(N, H, W, T + 2 * self.cfg.num_updated_frames, capturing=capturing).refine_dgrad44
 
-    def up_f4x4(self, N, H, W):
-        """Does the first PixelShuffle convolution of the upsampler (the one in front of the collapsed tail) run in F(4x4, 3x3) form at this shape?"""
-        P = self.plans
-        return (self.cells_f4x4(N, H, W) and len(P.up) > 1 and P.up[0]['r'] == 2 and getattr(P.up[0]['fwd'], 'wino44', False) and
-                self.ops.wino44_ok(P.up[0]['fwd'], N, H, W, packed=False))
+    def up_f4x4(self, N, H, W, F=None, capturing=False):
+        """Does the first PixelShuffle convolution of the upsampler run in F(4x4, 3x3) form at this shape?"""
+        fm = self._conv_forms(N, H, W, F if F is not None else 2 * self.cfg.num_updated_frames + 1, capturing=capturing)
+        return bool(fm.up44 and fm.up44[0])
 
     def _mem(self, label):
         """RNH_MEMLOG=1: (label, allocated bytes) at the engine's stage boundaries, in self.memlog (calibration of memory_plan)."""
@@ -315,12 +403,17 @@ class RefineNetEngine:
             params[P.r1x_key] = w1[P.C1 - 1].view(self.cfg.refine_window_size, P.C1, 3, 3)
         return params
 
-    def _pack(self, params, which):
+    def _pack(self, params, which, fm=None):
+        """Re-lay the weights of the forward's (which = 'fwd') or the backward's plans - for a plan that has a Winograd F(4x4, 3x3) form only the form
+        this step launches it in (``fm``: the step's resolved forms; None: every form the plan has)."""
         P = self.plans
         for pl in P.conv_plans():
             is_dgrad = pl.transposed
             if (which == 'fwd') == (not is_dgrad):
-                self.ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None)
+                kw = {}
+                if fm is not None and getattr(pl, 'wino44', False):
+                    kw = dict(f22=not fm.uses44(pl), f44=fm.uses44(pl))
+                self.ops.pack(pl, params[pl.wkey], params[pl.bkey] if pl.bkey else None, **kw)
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, params, inputs, pos_codes, need_grad, last_only=False):
@@ -356,11 +449,13 @@ class RefineNetEngine:
 
         ctx = Context()
         ctx.N, ctx.H, ctx.W, ctx.F, ctx.T = N, H, W, F, T
-        ctx.recompute = n_rc = self.recompute_stages(N, H, W, F) if need_grad else 0       # stages 0 .. n_rc-1 store no gates
+        # the form of every big launch of this step, decided once (hipvsr/forms.py): read here, by the backward (ctx.forms) and by _pack
+        fm = ctx.forms = self.resolve_forms(N, H, W, F, need_grad, last_only, bool(ops.capturing()) if hasattr(ops, 'capturing') else False)
+        ctx.recompute = n_rc = fm.recompute                    # stages 0 .. n_rc-1 store no gates
         params = self._views(params)
         x_all = ops.stack_inputs(inputs)                       # (F*N, H, W, Cin)
         ctx.x_all = x_all
-        self._pack(params, 'fwd')
+        self._pack(params, 'fwd', fm)
         act, f32 = self.act, self.f32
         # the features of the F frames, in pieces: the backward reads the T supervised frames again (first K source of layer 0's
         # weight gradient), the update frames on both sides only feed this stage's forward
@@ -385,7 +480,7 @@ class RefineNetEngine:
         O_all = ops.empty(S, 3, TN, s_up * H, s_up * W, cfg.out_channels)
 
         aside_keep = []
-        pair = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False      # the two directions' cells of a layer in one launch
+        pair = fm.paired                                        # the two directions' cells of a layer in one launch
 
         def run_stage(s, feat):
             """Stage s of the forward; returns the features the next stage starts from.  A function of its own so that the stage's transients die
@@ -438,11 +533,7 @@ class RefineNetEngine:
             # and the launch is large enough (HipOps.wino44_ok): the kernel reads its inputs in transform-domain form, written by a kernel of
             # its own - the features of every frame once, in front of the wavefront, and every cell's h' right behind the cell on the cell's
             # stream (the event the layer above waits for is recorded behind it): one transform serves both readers of an h'.
-            use44 = self.cells_f4x4(N, H, W) and all(ops.wino44_ok(P.lstm[(d, l)][kind], N, H, W) for d in dirs for l in range(Lr) for kind in ('full', 'first'))
-            v44_bytes = 2 * F_s * sum(nf) * N * H * W * 9 if use44 else 0        # a slot per frame: 2.25 x 4 bytes per element of every h'
-            if use44 and v44_bytes > 0.08 * ops.total_memory() and ops.capturing():
-                use44 = False
-            st['use44'] = use44
+            use44 = st['use44'] = fm.cells44
             ref44, R44 = False, 1
             if use44:
                 VF = ops.wino44_v(N, H, W, C, frames=F)
@@ -454,13 +545,13 @@ class RefineNetEngine:
                 # - only where a slot per frame would take more than 8 % of the card (BASELINE config 4 at N = 16: 62 GB), and not under HIP-graph
                 # capture: the layer's stream then waits on the stream above while that waits on it, and hipStreamEndCapture (ROCm 7.2) never
                 # returns from two streams that reference each other (hazard 3)
-                R44 = F_s if v44_bytes <= 0.08 * ops.total_memory() else min(F_s, 4)
+                R44 = min(F_s, fm.ring) if fm.ring else F_s
                 VH = {d: [ops.wino44_v(N, H, W, hd, frames=R44) for hd in nf] for d in dirs}
                 read44 = {}
                 # refine conv1's forward reads the top layer's h' of both directions (refine_net.py:170-181): in the same form
                 # (rnh_wino44_conv) it takes the transformed h' the cells wrote - every frame's then, the slots in frame order, and a window's
                 # frames whole tile blocks apart
-                ref44 = R44 == F_s and self.refine_f4x4(N, H, W, F) and ops.wino44_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W)
+                ref44 = fm.refine_fwd44
             slot44 = lambda d, l, idx: (idx if d == 'forward' else F_s - 1 - idx) if ref44 and l == Lr - 1 else idx % R44   # noqa: E731
 
             def cell44_call(d, l, idx):
@@ -622,8 +713,7 @@ class RefineNetEngine:
                 ops.rejoin()
                 aside_keep.clear()
             # (the PixelShuffle convolutions in F(4x4, 3x3) form where the cells run in it: one transform of the input, allocated here like Yb)
-            up44 = [bool(st.get('use44')) and getattr(u['fwd'], 'wino44', False) and ops.wino44_ok(u['fwd'], nb * TN, H * 2 ** i, W * 2 ** i) and u['r'] == 2
-                    for i, u in enumerate(P.up[:len(Yb)])] if nb else []
+            up44 = list(fm.up44[:len(Yb)]) if nb else []
             Vup = [ops.wino44_v(nb * TN, H * 2 ** i, W * 2 ** i, C)[0] if f44 else None for i, f44 in enumerate(up44)]
             with ops.aside('up_fwd'):
                 for i, (u, Y) in enumerate(zip(P.up, Yb)):
@@ -689,8 +779,9 @@ class RefineNetEngine:
         nf, Lr, C, Cl = P.nf, P.L, P.C, P.Cl
         TN = T * N
         act = self.act
+        fm = ctx.forms
         params = self._views(params)
-        self._pack(params, 'bwd')
+        self._pack(params, 'bwd', fm)
 
         grads, touched = OrderedDict(), set()
         off = 0
@@ -862,7 +953,7 @@ class RefineNetEngine:
             # data gradient in gather form: frame f collects from the windows f+hw-j that used it in slot j
             if P.r1_wino:
                 nm = P.r1_cols
-                if st.get('use44') and self.refine_dgrad_f4x4(N, H, W, T) and ops.wino44_ok(P.r1_dgrad_h, TN, H, W):
+                if fm.refine_dgrad44:
                     # F(4x4, 3x3) form (rnh_wino44_conv): ONE transform of the zero-padded dR1, the window slots = the same image a frame apart
                     nfr, mtf = T + 2 * hw, N * (H // 4) * (W // 4) // 32
                     Vg = ops.wino44_v(nfr * N, H, W, nm)[0]
@@ -898,8 +989,7 @@ class RefineNetEngine:
             # state gradients handed from a frame to the previous one of the same (direction, layer): two buffers each, used in
             # turn, allocated HERE on the main stream - an allocation inside a side-stream block would, under HIP-graph
             # capture, come from the graph's pool on a stream other than the capture's origin (the capture then fails)
-            fused = cfg.memory and all(ops.lstm_bwd_fusable(P.lstm[(d, l)]['dgrad'], P.lstm[(d, l)]['cx'], P.lstm[(d, l)]['hd'])
-                                       for d in dirs for l in range(Lr))
+            fused = fm.cell_dgrad_fused
             DCP = {d: [[ops.empty(N, H, W, hd) for _ in range(2)] for hd in nf] for d in dirs}
             DHP = {d: [[ops.empty(N, H, W, hd, dtype=act) for _ in range(2)] for hd in nf] for d in dirs} if cfg.memory and not fused else None
             TMP = None if cfg.memory else {d: [ops.empty(N, H, W, P.lstm[(d, l)]['cx'], dtype=act) for l in range(Lr)] for d in dirs}
@@ -933,7 +1023,7 @@ class RefineNetEngine:
                 return g
             RV = {d: [(ops.wino44_v(N, H, W, P.lstm[(d, l)]['cx'])[0], ops.wino44_v(N, H, W, hd)[0]) for l, hd in enumerate(nf)]
                   for d in dirs} if RG is not None and st.get('use44') else None
-            pair = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False      # (as the forward: small images)
+            pair = fm.paired                                    # (as the forward: small images)
             ops.fork(2 * Lr, bank=1)
             if fused:
                 # The gate backward of a frame rides in the epilogue of the data-gradient launch of the frame its chain processed just before
@@ -1024,8 +1114,7 @@ class RefineNetEngine:
 
             # the fp32 path's data gradients in F(4x4, 3x3) form where the forward's cells ran in it: one transform of the frame's gate gradients
             # (4 hd channels) into a scratch image per (direction, layer), then rnh_wino44_conv with the transposed weights
-            dg44 = (not fused and bool(st.get('use44')) and
-                    all(ops.wino44_ok(P.lstm[(d, l)]['dgrad'], N, H, W) for d in dirs for l in range(Lr)))
+            dg44 = fm.cell_dgrad44
             VG = {d: [ops.wino44_v(N, H, W, 4 * hd)[0] for hd in nf] for d in dirs} if dg44 else None
 
             def dgrad_launch(d, l, call):

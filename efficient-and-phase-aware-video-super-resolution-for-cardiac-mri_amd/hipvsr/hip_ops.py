@@ -316,11 +316,13 @@ class HipOps:
             self._maps[id(plan)] = m
         return m
 
-    def pack(self, plan: ConvPlan, w, b=None):
-        """Re-lay the OIHW weight (and bias) of ``plan`` into the kernel's [nk][Npad][16] slabs (and, for a ConvLSTM cell plan that may run in
-        F(4x4, 3x3) form, into that kernel's layout as well)."""
-        self._pack(plan, w, b)
-        if getattr(plan, 'wino44', False):
+    def pack(self, plan: ConvPlan, w, b=None, f22=True, f44=None):
+        """Re-lay the OIHW weight (and bias) of ``plan`` into the kernel's [nk][Npad][16] slabs (f22: the plan's own form - direct, F(2x2, 3x3) or
+        bf16) and / or into the F(4x4, 3x3) kernels' layout (f44; None = wherever the plan is eligible for that form).  The engine asks for the one
+        form the step launches the plan in (hipvsr/forms.py); a caller that packs a plan by hand gets both."""
+        if f22:
+            self._pack(plan, w, b)
+        if f44 if f44 is not None else getattr(plan, 'wino44', False):
             self._pack44(plan, w, b)
 
     # ---- the ConvLSTM cell in Winograd form F(4x4, 3x3): rnh_wino44_* (csrc/conv_wino44.hip) ---------------------------------------------
@@ -388,15 +390,8 @@ class HipOps:
         ``packed=False``: the question before the weights are packed (the engine's memory plan).  The kernels' own limits are part of the answer
         (the engine falls back to the F(2x2) launch instead of meeting a refusal): fewer than 2^27 pixels per launch, and fewer than 2^31 elements in
         a destination of ``dst_channels`` channels (the cell: its state, 4 bytes per element of hd channels)."""
-        mode = os.environ.get('RNH_WINO44', '1')
-        if mode == '0' or not getattr(plan, 'wino44', False) or (packed and id(plan) not in self._packed44) or (H & 3) or (W & 3):
-            return False
-        if plan.epilogue == L.EPI_LSTM:
-            dst_channels = max(dst_channels, plan.Cout)                        # (4 hd: the previous state is addressed in bytes)
-        if B * H * W >= 2 ** 27 or B * H * W * dst_channels >= 2 ** 31:
-            return False
-        wgs = -(-(B * (H // 4) * (W // 4)) // 32) * max(len(plan.colmap) // 64, 1)
-        return mode == 'force' or wgs >= int(os.environ.get('RNH_WINO44_MIN', '1'))
+        from .forms import wino44_launch_ok
+        return bool((not packed or id(plan) in self._packed44) and wino44_launch_ok(plan, B, H, W, dst_channels))
 
     def wino44_v(self, B, H, W, nch, frames=1):
         """Buffer(s) for the transformed form of ``frames`` tensors (B, H, W, nch): a (frames, floats) tensor."""
@@ -745,7 +740,7 @@ class HipOps:
         T8 = B * tpi // 8
         ncb, nprob = CO // 128, len(probs)
         want = max(1, 1280 // (nprob * 9 * ncb))                           # ~5 rounds of the chip
-        splits = [s_ for s_ in range(1, 129) if T8 % (2 * s_) == 0]
+        splits = [s_ for s_ in range(1, 65) if T8 % (2 * s_) == 0]             # (at most 64 K splits: the bound memory_plan budgets the partial sums with)
         if not splits:                                                      # (an odd number of k8 rows: the kernel's ring is two deep)
             return False
         S = min(splits, key=lambda s_: abs(s_ - want))

@@ -9,6 +9,7 @@ included, are one launch (src.model.metrics.fused_metrics); and under torch.dist
 averaged with one all-reduce before the optimizer step."""
 import functools
 import logging
+import os
 
 import numpy as np
 import torch
@@ -63,6 +64,12 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
     def train_step(self, inputs, targets, pos_codes):
         """forward + loss + backward (+ gradient all-reduce) + optimizer step; returns (outputs, loss, losses)."""
         use_graph = bool(getattr(self, 'graph', False))
+        if use_graph and dp.world() > 1 and os.environ.get('RNH_GRAPH_DP', '0') != '1':
+            # ADVICE r05: a capture beside a live RCCL communicator has only ever run with ONE rank (tests/test_parity_r05.py) - no node with
+            # more than one GPU has been available to this project: the watchdog with real peers, a first capture while another rank is still in
+            # its all-reduce and a static gradient buffer handed to RCCL are untested.  Refused until someone opts in and measures it.
+            raise RuntimeError('trainer kwarg graph=True under torch.distributed with more than one rank is untested on hardware: '
+                               'set RNH_GRAPH_DP=1 to try it, or run the eager step (graph=False)')
         if use_graph:
             if getattr(self, '_graphed', None) is None:
                 from hipvsr.graph import GraphedTrainStep

@@ -112,7 +112,7 @@ def run_double(cfg, sd, storage, inputs, pos, mode=''):
         return out.reshape(weff.shape)
 
     class Ops(TorchOps):
-        def pack(self, plan, w, b=None):
+        def pack(self, plan, w, b=None, **forms):
             super().pack(plan, w, b)
             weff, bp = self._w[id(plan)]
             exact = effective_weight(plan, w.detach())

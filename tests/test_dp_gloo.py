@@ -82,6 +82,17 @@ def _worker(rank, world, port, case_path, out_path):
     # epoch log: per-rank sums and counts become the whole split's (ReduceLROnPlateau / Monitor / early stop then agree)
     log, count = dp.allreduce_log({'Loss': 3.0 * (rank + 1), 'PSNR': 10.0 + rank}, 4 + rank, torch.device('cpu'))
     assert log == {'Loss': 9.0, 'PSNR': 21.0} and count == 9.0 and dp.rank() == rank
+    # HIP-graph replay of the step beside more than one rank has never run on hardware: refused unless RNH_GRAPH_DP=1 opts in -
+    # before anything touches a device
+    from src.runner.trainers import AcdcVSRRefineNetTrainer
+    tr = object.__new__(AcdcVSRRefineNetTrainer)
+    tr.graph, tr._graphed = True, None
+    os.environ.pop('RNH_GRAPH_DP', None)
+    try:
+        tr.train_step(None, None, None)
+        raise AssertionError('graph=True with two ranks was not refused')
+    except RuntimeError as e:
+        assert 'RNH_GRAPH_DP=1' in str(e), e
     if rank == 0:
         torch.save({k: (p.grad.clone() if p.grad is not None else None) for p, k in zip(net.params, net.names)}, out_path)
     dist.barrier()

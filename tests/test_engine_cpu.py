@@ -442,6 +442,69 @@ def test_auto_gate_plan_recomputes_only_where_the_stored_step_does_not_fit():
     assert RefineNetEngine(NetConfig(**orc.exp1_x4_config()), TorchOps('cpu')).recompute_gates(64, 512, 512, 19) is False    # no device: store
 
 
+def test_default_forms_at_the_benchmark_shapes(monkeypatch):
+    """VERDICT r05 item 6 / ADVICE r05: ONE record of the forms a step runs in (hipvsr/forms.py, RefineNetEngine.resolve_forms) - what the forward, the
+    backward, memory_plan, the weight packing and bench.py's `config.forms` all read.  Its defaults at the benchmark shapes on a 288 GB card are what
+    DESIGN section 4 says: fp32 cells in F(4x4, 3x3) form everywhere (whole 4x4 tiles), a transformed-h' slot per frame at configs 2, 5 and the YAML
+    shape, a ring of four at config 4 (62 GB of slots) - where a CAPTURED step falls back to F(2x2) cells and the record says so -, refine conv1 and
+    the first PixelShuffle convolution following the cells, the cell's data gradient in F(2x2) form; bf16: direct forms, IEEE-half weights in the
+    upsampler's forward.  An environment switch set to anything but the product's choice is listed."""
+    from hipvsr import forms
+    from oracle import refinenet_oracle as orc
+    for k in forms.SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+
+    class HipLike(TorchOps):                      # the double with the attributes resolve_forms asks a HIP backend for
+        wino44_cell = None
+
+        def total_memory(self):
+            return 288 * 10**9
+
+        def pair_cells(self, N, H, W):
+            return True
+    cases = {'config 2': (dict(), 8, 7, 128), 'config 4': (dict(upscale_factor=2), 16, 5, 256), 'config 5': (dict(), 8, 11, 96), 'yaml': (dict(), 16, 7, 32)}
+    got = {}
+    for name, (over, n, t, size) in cases.items():
+        eng = RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), HipLike('cpu'))
+        fm = got[name] = eng.resolve_forms(n, size, size, t + 12)
+        assert fm.cells44 and not fm.capture_fallback and not fm.cell_dgrad44 and fm.paired and fm.refine_dgrad44, name
+        assert all(fm.uses44(eng.plans.lstm[k][kind]) for k in eng.plans.lstm for kind in ('full', 'first'))
+        assert not any(fm.uses44(eng.plans.lstm[k]['dgrad']) for k in eng.plans.lstm)
+        d = fm.describe()
+        assert 'F(4x4,3x3)' in d['cell'] and 'F(2x2,3x3)' in d['cell_dgrad'] and d['env_overrides'] == [] and d['paired'] is True
+        # memory_plan reads the same record
+        assert eng.memory_plan(n, size, size, t + 12)['forward_transient'] > RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), TorchOps('cpu')).memory_plan(n, size, size, t + 12)['forward_transient']
+    for name in ('config 2', 'config 5', 'yaml'):
+        fm = got[name]
+        assert fm.ring == 0 and fm.refine_fwd44 and fm.up44 == [True] and fm.recompute == 0, name
+        assert "slot per frame" in fm.describe()['cell'] and 'F(4x4,3x3)' in fm.describe()['refine1_fwd'] and 'F(4x4,3x3)' in fm.describe()['up1_fwd']
+    fm4 = got['config 4']
+    assert fm4.ring == 4 and not fm4.refine_fwd44 and fm4.up44 == [] and fm4.recompute >= 1 and 'ring of 4' in fm4.describe()['cell']
+    assert 'F(2x2,3x3)' in fm4.describe()['refine1_fwd'] and 'recomputed in' in fm4.describe()['gates']
+    # a captured step at the ring shape: F(2x2) cells, said so; at a slot shape capture changes nothing
+    eng4 = RefineNetEngine(NetConfig(**orc.exp1_x4_config(upscale_factor=2)), HipLike('cpu'))
+    cap = eng4.resolve_forms(16, 256, 256, 17, capturing=True)
+    assert cap.capture_fallback and not cap.cells44 and not cap.plans44 and 'capture fallback' in cap.describe()['cell'] and cap.describe()['graph_capture']
+    eng2 = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'))
+    assert eng2.resolve_forms(8, 128, 128, 19, capturing=True).cells44
+    # images that are not whole 4x4 tiles: every launch in its F(2x2) form
+    odd = eng2.resolve_forms(2, 33, 20, 15)
+    assert not odd.cells44 and not odd.plans44 and 'F(2x2,3x3)' in odd.describe()['cell']
+    # bf16 storage: direct forms; the upsampler's forward with IEEE-half weights
+    engb = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'), dtype='bf16')
+    fb = engb.resolve_forms(8, 128, 128, 19)
+    db = fb.describe()
+    assert not fb.cells44 and not fb.plans44 and 'bf16 MFMA' in db['cell'] and 'IEEE-half' in db['up1_fwd'] and 'f16 MFMA' in db['tail']
+    assert engb.plans.up[0]['fwd'].f16w and not getattr(engb.plans.up[0]['dgrad'], 'f16w', False)
+    # an A/B switch shows up in the record (and makes bench.py refuse the line without --allow-overrides)
+    monkeypatch.setenv('RNH_WINO44', '0')
+    eng2b = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'))
+    off = eng2b.resolve_forms(8, 128, 128, 19)
+    assert not off.cells44 and off.describe()['env_overrides'] == ['RNH_WINO44=0']
+    monkeypatch.setenv('RNH_WINO44', '1')                     # (the product's own value: not an override)
+    assert forms.env_overrides() == []
+
+
 def test_input_block_width_outside_the_backward_kernels_set_plans_for_inference_only():
     """num_features[0] = 24: the forward kernels serve it, rnh_inconv_prelu_bwd does not (4, 8, ..., 256).  The net is planned and runs
     forward without gradients (a predict-only user must not be refused at construction); the first forward that is asked to

@@ -716,3 +716,37 @@ def test_bench_launch_geometry_n8_equals_replicated_n2(cell_form):
     for k, p in net8.named_parameters():
         if k in g2:
             _grad_close(p.grad, g2[k], k)
+
+
+def test_bench_timed_code_path_first_step_loss_vs_oracle(monkeypatch):
+    """the code path bench.py TIMES - bench.run_case at BASELINE config 2 (its net, its synthetic batch, its trainer step, the
+    forms the engine resolves by itself), one step, no warm-up - is itself pinned to the oracle: the step's loss (`config.final_loss`, the training
+    loss of the N = 8 batch at the initial weights) against the CPU oracle's (== reference, acdc_vsr_refinenet_trainer.py:83-94) on the same net and
+    batch, evaluated two samples at a time (every term is a mean over samples: the mean of the four pair losses), 1e-5 relative; and the line carries
+    the resolved forms.  (A second step would need the oracle's backward at N = 8 on the CPU: minutes; the trajectory tests of test_parity_r04.py
+    cover the optimizer's side at a smaller shape.)"""
+    import bench
+    from hipvsr import forms
+    for k in forms.SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    dev = _dev()
+    args = bench.parse_args(['--steps', '1', '--warmup', '0', '--no-secondary', '--no-cpu-baseline'])
+    out = bench.run_case(args, 'f32', dev, 1, 0)
+    fm = out['config']['forms']
+    assert 'F(4x4,3x3)' in fm['cell'] and fm['env_overrides'] == [] and fm['gates'] == 'stored' and out['roofline']['frac_with_transform'] < out['roofline']['frac']
+    net = bench.make_net(dev, seed=0, scale=4)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    inputs, targets, pos = bench.synthetic_batch(dev, args.batch, args.frames, args.size, args.size, seed=20200526 + 2, s=4)
+    inputs, targets, pos = [x.cpu() for x in inputs], [y.cpu() for y in targets], pos.cpu()
+    del net
+    cfg = orc.exp1_x4_config()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    losses = []
+    with torch.no_grad():
+        for q in range(0, args.batch, 2):
+            outs = orc.forward(orc.as_leaf_params(sd), cfg, [x[q:q + 2].clone() for x in inputs], pos[q:q + 2])
+            losses.append(float(orc.training_loss(outs, [y[q:q + 2] for y in targets])))
+    want = sum(losses) / len(losses)
+    got = out['config']['final_loss']
+    assert abs(got - want) <= 1e-5 * abs(want) + 1e-6, (got, want)          # (+ the 6 decimals the line rounds to)
+    print(f'bench.run_case, config 2, first step: loss {got:.6f}, oracle {want:.6f}')

@@ -59,6 +59,11 @@ _VARIANTS = {
     'x8': (dict(upscale_factor=8), 1, 2, 24, 20),
     'no_phase_code': (dict(positional_encoding=False), 1, 2, 33, 20),
     'no_memory': (dict(memory=False), 1, 2, 33, 20),
+    # the reference YAMLs' own 32 x 32 crops at x3 / x2 (configs/train/refine_net/exp2_x3.yaml:22-23, exp3_x2.yaml): whole 4x4 tiles, so the fp32 step
+    # runs the F(4x4, 3x3) cells and refine conv1 TOGETHER with the collapsed r = 3 / r = 2 tail (the only full-width x3 case
+    # was 33 x 20, which never takes that path)
+    'x3_crop32': (dict(upscale_factor=3), 2, 2, 32, 32),
+    'x2_crop32': (dict(upscale_factor=2), 2, 2, 32, 32),
 }
 
 
@@ -86,6 +91,9 @@ def test_full_width_variant_fp32_vs_oracle(variant_refs, name):
     cfg, sd, inputs, targets, pos, ref_out, ref_loss, ref_grads = variant_refs(name)
     net, tr, outs, loss = _module_step(dict(cfg), sd, inputs, targets, pos, 'f32')
     assert list(net.state_dict().keys()) == list(sd.keys())
+    if name.endswith('crop32'):                               # (the forms this case is here for)
+        fm = net._engine().resolve_forms(inputs[0].shape[0], 32, 32, len(inputs))
+        assert fm.cells44 and fm.refine_fwd44 and fm.refine_dgrad44 and not fm.ring, fm.describe()
     s = cfg['upscale_factor']
     assert len(outs) == len(ref_out) == 3 * cfg['num_stages']
     worst = 0.0

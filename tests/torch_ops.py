@@ -102,7 +102,7 @@ class TorchOps:
         Fr, N, Cin, H, W = x.shape
         return x.permute(0, 1, 3, 4, 2).reshape(Fr * N, H, W, Cin).contiguous()
 
-    def pack(self, plan, w, b=None):
+    def pack(self, plan, w, b=None, **forms):                 # (forms: which kernel layouts HipOps packs - the double has one)
         weff = effective_weight(plan, w.detach())
         if getattr(plan, 'f16w', False):                      # (the f16 MFMA form: IEEE-half weights, the bf16 inputs convert exactly)
             weff = weff.half().float()
