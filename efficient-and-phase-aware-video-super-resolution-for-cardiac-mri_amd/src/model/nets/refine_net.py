@@ -112,7 +112,13 @@ class RefineNet(BaseNet):
                                    'There is no CPU path in this package.')
             from hipvsr.engine import RefineNetEngine
             from hipvsr.hip_ops import HipOps
-            self._eng = RefineNetEngine(self.cfg, HipOps(dev), dtype=self.compute_dtype,
+            ops = HipOps(dev)
+            if os.environ.get('RNH_CHECK', '0') == '1':
+                # debugging mode: every big launch is held against float64 right behind the launch (hipvsr/check_ops.py) - a checker around the
+                # HIP path, not a path of its own
+                from hipvsr.check_ops import CheckedOps
+                ops = CheckedOps(ops)
+            self._eng = RefineNetEngine(self.cfg, ops, dtype=self.compute_dtype,
                                         storage=self.storage if self.compute_dtype == 'bf16' else None)
         self._eng.gate_memory = self.gate_memory
         return self._eng

@@ -11,39 +11,8 @@ import torch
 import torch.nn.functional as F
 
 from hipvsr import lib as L
+from hipvsr.check_ops import effective_weight, gather_src      # noqa: F401  (shared with the RNH_CHECK=1 checker; re-exported)
 from hipvsr.plans import ConvPlan, Dst, WgradPlan
-
-
-def gather_src(s, B):
-    """(B, H, W, nch) NHWC slice described by a plans.Src."""
-    t = s.t[s.img_off:s.img_off + B]
-    if s.add is not None:
-        t = t + s.add[s.img_off:s.img_off + B]
-    if s.scale > 1:
-        t = t[:, s.sub[0]::s.scale, s.sub[1]::s.scale]
-    nch = t.shape[-1] - s.c0 if s.nch is None else s.nch
-    return t[..., s.c0:s.c0 + nch]
-
-
-def effective_weight(plan: ConvPlan, w):
-    """[Npad][Ktot][kh][kw] weight equivalent to what rnh_pack_weights builds for ``plan``."""
-    kh = 3 if plan.ntaps == 9 else 1
-    ktot = sum(sg.nch for sg in plan.ksegs)
-    weff = torch.zeros(plan.Npad, ktot, kh, kh, dtype=w.dtype, device=w.device)
-    koff = 0
-    for sg in plan.ksegs:
-        for n, cm in enumerate(plan.colmap):
-            if cm < 0:
-                continue
-            cme = cm + sg.kcoff
-            for kk in range(sg.nvalid):
-                kidx = sg.kbase + kk * plan.kstride
-                if plan.transposed:
-                    weff[n, koff + kk] = torch.flip(w[kidx, cme], dims=(0, 1))
-                else:
-                    weff[n, koff + kk] = w[cme, kidx]
-        koff += sg.nch
-    return weff
 
 
 class TorchOps:
