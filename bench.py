@@ -444,7 +444,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-secondary', action='store_true', help='skip the bf16-storage run that rides along as `secondary`')
     ap.add_argument('--graph', choices=['on', 'off'], default='off',
                     help='replay forward + loss + backward of the step from a HIP graph (hipvsr.graph.GraphedTrainStep, opt-in: no '
-                         'measured gain at any benchmarked shape, profiles/r02_l_train_shape.txt)')
+                         'measured gain at any benchmarked shape, profiles/ARCHIVE/r02_l_train_shape.txt)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32: the headline (BASELINE config 2, the reference's precision) with the bf16-storage step of BASELINE "
                          "config 3 as `secondary` in the same line; bf16: that bf16 step alone as the line")

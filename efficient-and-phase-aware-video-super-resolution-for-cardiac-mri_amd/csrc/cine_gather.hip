@@ -17,7 +17,7 @@ namespace {
 // enqueued), RNH_CINE_CHUNK samples per launch.  An earlier version uploaded them with hipMemcpyAsync from the caller's
 // pageable array, which the Python binding frees (and the next batch re-fills) as soon as rnh_cine_gather returns: correct
 // only as long as the runtime stages pageable copies before returning.  ROCm 7.2 on MI355X does (tools/pageable_async_probe.hip:
-// 0 of 400 copies saw later host writes, profiles/r02_a_pageable_probe.txt), so this was a latent dependence on
+// 0 of 400 copies saw later host writes, profiles/ARCHIVE/r02_a_pageable_probe.txt), so this was a latent dependence on
 // unspecified behaviour, not an observed fault; by-value arguments remove it and the descriptor buffer.
 constexpr int RNH_CINE_CHUNK = 32;
 struct cine_chunk_t {

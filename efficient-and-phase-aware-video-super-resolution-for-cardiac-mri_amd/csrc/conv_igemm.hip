@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256, (min_waves<MI, NI, DIRECT>())) conv_igemm
         // among the younger ones; round 4 widened that to any masked lane while hunting wrong steps - whose cause turned out to be the copied tail
         // registers described at the K loop below, most likely round 1's too.  Vector-memory operations of a wave complete in issue order, masked or
         // not (MI355X_MICROARCH.md; tools/probes/oob_order.hip, tools/probes/lds_dma_oob.hip), and the build without the drain is exact in 3000 cold
-        // steps on one box (round 4, profiles/r04_at_*), 3700 on a second (round 5, profiles/r05_u_*) and passes the GPU suite: since round 5 the
+        // steps on one box (round 4, profiles/ARCHIVE/r04_at_*), 3700 on a second (round 5, profiles/r05_u_*) and passes the GPU suite: since round 5 the
         // counted waits stand alone.  -DRNH_IGEMM_MASK_DRAIN brings the drain back (diagnostic build).
         fm_prev = fm_cur;
         fm_cur = false;

@@ -90,7 +90,7 @@ class GraphedTrainStep:
     HIP-graph"; reference src/runner/trainers/acdc_vsr_refinenet_trainer.py:41-46: ``net(inputs, pos_codes)``,
     ``_compute_losses``, ``loss.backward()``).
 
-    Measured (profiles/r02_e_train_shape.txt, r02_l_train_shape.txt): at the reference's own training shape
+    Measured (profiles/ARCHIVE/r02_e_train_shape.txt, r02_l_train_shape.txt): at the reference's own training shape
     (configs/train/refine_net/exp1_x4.yaml:21-33: batch 16, 32 x 32 crops) the step is GPU-bound, not launch-bound - fp32 50.9 ms
     eager against 51.3 ms replayed, bf16 24.2 against 27.0 (slower) - so the trainer does NOT use this class unless asked to
     (trainer kwarg ``graph: true``); it is kept for smaller batches, where a step is ~1 500 launches of a few microseconds each.

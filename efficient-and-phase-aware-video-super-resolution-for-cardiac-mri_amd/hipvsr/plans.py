@@ -173,7 +173,7 @@ class WgradPlan:
         one's staging latency hides behind the other's MFMAs)."""
         tiles = (self.xrows_pad64 // 64) * (self.ycols_pad64 // 64)
         # floor, not ceil: 22 tiles x 24 splits = 528 workgroups on 512 slots ran as two rounds, the second one nearly empty (refine conv1's
-        # weight gradient 2.03 -> see profiles/r04_k; the ConvLSTM's 8 tiles x 64 were exact already)
+        # weight gradient 2.03 -> see profiles/ARCHIVE/r04_k; the ConvLSTM's 8 tiles x 64 were exact already)
         return int(max(1, min(nitems, 256, 512 // tiles)))
 
     def nsplit(self, npix):
@@ -358,7 +358,7 @@ class NetPlans:
                                            [XSeg(Cl, Cl, 0), XSeg(Cl, Cl, Cl), XSeg(pw, 1, 2 * Cl)], [YSeg(8, w, 0)])
                 # rows: the 2*w hidden-state sources first, the w phase planes behind them (NOT slot by slot: rnh_wgrad_bf16 works on 64-row
                 # tiles, and an 8-channel plane in front of a hidden-state source shifts it off the tile grid - every 128-byte pixel
-                # line of that source is then fetched by two row tiles: 2.10 -> see profiles/r04_k for the launch at config 2)
+                # line of that source is then fetched by two row tiles: 2.10 -> see profiles/ARCHIVE/r04_k for the launch at config 2)
                 self.r1_wgrad_a = WgradPlan_('refine1.wgrad.a', k1, b1, ws1,
                                             [sg for i, sg in enumerate(xsegs) if i % 3 != 2] + [sg for i, sg in enumerate(xsegs) if i % 3 == 2],
                                             [YSeg(C1 - 1, C1 - 1, 0)])

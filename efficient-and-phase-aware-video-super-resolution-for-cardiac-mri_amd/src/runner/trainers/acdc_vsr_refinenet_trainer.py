@@ -26,7 +26,7 @@ class AcdcVSRRefineNetTrainer(BaseTrainer):
     # graph: replay forward + loss + backward of a step from a HIP graph (hipvsr.graph.GraphedTrainStep).  OFF unless asked for
     # (trainer kwarg ``graph: true`` in the YAML, ``bench.py --graph on``): no measured shape gains from it - at the reference
     # YAML's 16 crops of 32 x 32 the step is GPU-bound either way (fp32 59.4 ms eager / 59.5 ms replayed, bf16 25.1 / 27.4:
-    # tools/train_shape_bench.py, profiles/r02_e_train_shape.txt, r02_l_train_shape.txt) - and the graphed step behaves
+    # tools/train_shape_bench.py, profiles/ARCHIVE/r02_e_train_shape.txt, r02_l_train_shape.txt) - and the graphed step behaves
     # differently (static gradient tensors, no zero_grad, one capture per batch shape).  Under torch.distributed the graph holds
     # forward + loss + backward only: the gradient all-reduce and the optimizer step stay outside it, as in the single-rank step
     # (the capture runs in thread-local error mode, so RCCL's watchdog thread cannot invalidate it;

@@ -241,7 +241,7 @@ def test_full_size_baseline_configs(name, over, t, size, n_bwd, n_fwd, n_bf16, m
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cols', ['64', '128'])
 def test_lstm_cell_gates_config2_size_vs_float64(cols):
-    """(tools/debug/lstm_mismatch.py as a test.)  One ConvLSTM cell launch at N = 8, 128 x 128 - 2048 / 4096 workgroups, several
+    """(The round-3 mismatch hunt as a test.)  One ConvLSTM cell launch at N = 8, 128 x 128 - 2048 / 4096 workgroups, several
     of which write disjoint pieces of the same 128-byte lines of the gate tensor - in the 64-column (two workgroups per CU) and
     the 128-column (8-wave) geometry of conv_winoh_kernel: gates, c' and h' of EVERY pixel against a float64 evaluation of
     reference refine_net.py:247-267; no NaN left from the poison fill.  Repeated 5 times (the corruption was intermittent)."""

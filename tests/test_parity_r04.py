@@ -281,7 +281,7 @@ def trained():
 def test_bf16_training_run_tracks_the_fp32_run(trained):
     """where the bf16-storage run ends up against where the fp32 run ends up.  Training is chaotic: an fp32 run whose
     initialisation differs by 1e-6 relative leaves the fp32 run after ~150 steps and from then on sits 1-2 % away in the 25-step loss
-    windows and 0.05-0.2 dB away in validation PSNR (profiles/r04_e_training_trajectories.txt; the size of that drift itself varies by
+    windows and 0.05-0.2 dB away in validation PSNR (profiles/ARCHIVE/r04_e_training_trajectories.txt; the size of that drift itself varies by
     2-3 x from one realisation to the next: a change of the summation order in one reduction kernel moved it) - so "within 1 % / 0.05 dB
     of the fp32 run" is not a property even fp32 has.  Asserted instead: (1) before the trajectories decorrelate (the first 125 steps,
     loss 6.4 -> 0.5, PSNR 25 -> 30 dB) the bf16 run follows the fp32 run to 1e-3 in every loss window and 0.02 dB in PSNR; (2) over the
@@ -464,7 +464,7 @@ def test_cold_training_steps_repeat_bit_for_bit_beside_the_helper_stream(dtype, 
     repetition's.  RNH_POISON fills every new buffer on its stream (timing noise, and NaN wherever something unwritten is read); the weight gradients
     stream on the helper stream meanwhile.  With the direct implicit-GEMM kernel of rounds 1-3 (two loop tails that hipcc folded behind copies of
     operand registers whose loads were still in flight) 1.2-2 % of these steps came out wrong at either size
-    (tools/probes/flake_width16.py, profiles/r04_ab_*): 160 / 120 repetitions miss that with probability < 10 %."""
+    (tools/probes/flake_width16.py, profiles/ARCHIVE/r04_ab_*): 160 / 120 repetitions miss that with probability < 10 %."""
     monkeypatch.setenv('RNH_POISON', '1')
     monkeypatch.setenv('RNH_ASIDE_OFF', 'up_fwd')
     cfg = orc.Config(in_channels=1, out_channels=1, num_features=[width, width], num_stages=3, refine_window_size=5, upscale_factor=4,
