@@ -171,6 +171,123 @@ __global__ void __launch_bounds__(256) wino44_transform_kernel(const float *x, c
     }
 }
 
+// The gate backward of a ConvLSTM cell (rnh_lstm_gates_bwd: autograd of reference src/model/nets/refine_net.py:258-265) AND V = B^T dG B of the gate
+// gradients it produces, in one launch (round 6): the cell's data gradient in F(4x4, 3x3) form (rnh_wino44_conv on transposed weights) reads its 4 hd input
+// channels in transform-domain form, and a rnh_wino44_transform launch of their own re-read all of them from HBM (107 us at BASELINE config 2, which ate
+// the 126 us the form saves).  Here a workgroup owns HALF a tile block - 16 tiles = 8 x 32 pixels of one image - and 16 hidden channels: phase 1 computes
+// the four gate gradients of its 10 x 34 HALO'd pixels (1.33 x the element-wise work: the 6x6 patches of neighbouring tiles overlap; zeros outside the
+// image = the convolution's padding) into LDS, and stores those of its own 8 x 32 pixels (and dc_prev) to the tensors the weight gradient and the chain's
+// next frame read; phase 2 = wino44_transform_kernel's arithmetic on the LDS image: wave = gate, lane = (tile, 4-channel piece), every store a contiguous
+// kilobyte of the image rnh_wino44_conv copies to LDS.  The blocked tile geometry only (W % 32 == 0, H % 16 == 0: rnh_wino44_gates_bwd_supported).
+constexpr int W4G_PITCH = 68, W4G_COLS = 34, W4G_ROWS = 10, W4G_PX = W4G_COLS * W4G_ROWS;       // floats per LDS pixel: 4 gates x 16 channels + 4 (conflict-free 16-byte reads)
+
+__global__ void __launch_bounds__(256) wino44_gates_bwd_kernel(const float *__restrict__ dh, const float *__restrict__ dh2, const float *__restrict__ dcn,
+                                                               const float *__restrict__ gates, const float *__restrict__ cprev, const float *__restrict__ cnext,
+                                                               float *__restrict__ dgates, float *__restrict__ dcprev, float *__restrict__ V, const int H, const int W,
+                                                               const int hd, const int TX, const int TY, const int nblocks) {
+    __shared__ __attribute__((aligned(16))) float sm[W4G_PX * W4G_PITCH];         // 92 480 bytes
+    const int tid = threadIdx.x, ncg = hd >> 4;
+    const int bid = rnh_xcd_remap((int)blockIdx.x, nblocks);                        // (the channel groups of a half block on one XCD: they share every 256-byte pixel row)
+    const int cg = bid % ncg, half = (bid / ncg) & 1, mt = bid / (2 * ncg);
+    const int t0 = mt * W4_TILES, img = t0 / (TX * TY), rem = t0 - img * TX * TY, bi = rem >> 5, bpr = TX >> 3, by = bi / bpr, bx = bi - by * bpr;
+    const int y0 = (by * 4 + 2 * half) * 4, x0 = bx * 32;                           // this half block's 8 x 32 pixels
+    // ---- phase 1: item = (halo pixel, 4-channel piece), 1360 of them: up to six per thread.  ALL of a thread's loads are requested before the first
+    // value is used (one workgroup of four waves per CU - the LDS image is 92 KB - hides no latency by occupancy: 54 requests of 16 bytes in flight per lane do)
+    constexpr int NIT = (W4G_PX * 4 + 255) / 256;
+    f32x4w vdh[NIT], vd2[NIT], vdc[NIT], vcp[NIT], vcn[NIT], gi[NIT], gf[NIT], go[NIT], gg[NIT];
+    long oo[NIT];
+    int pp[NIT];
+    const f32x4w z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+        const int it = tid + 256 * r, q = it & 3, p = it >> 2, pr = p / W4G_COLS, pc = p - pr * W4G_COLS;
+        const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+        const bool in = it < W4G_PX * 4 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const long pix = ((long)img * H + (in ? y : 0)) * W + (in ? x : 0);
+        const long o = pix * hd + cg * 16 + q * 4, og = pix * 4 * hd + cg * 16 + q * 4;
+        oo[r] = in ? o : -1;
+        pp[r] = it < W4G_PX * 4 ? (p | ((pr >= 1 && pr <= 8 && pc >= 1 && pc <= 32) ? 0x10000 : 0)) : -1;      // halo pixel | "one of this workgroup's own"
+        vdh[r] = vd2[r] = vdc[r] = vcp[r] = vcn[r] = gi[r] = gf[r] = go[r] = gg[r] = z4;
+        if (in) {
+            vdh[r] = *reinterpret_cast<const f32x4w *>(dh + o);
+            vcn[r] = *reinterpret_cast<const f32x4w *>(cnext + o);
+            gi[r] = *reinterpret_cast<const f32x4w *>(gates + og);
+            gf[r] = *reinterpret_cast<const f32x4w *>(gates + og + hd);
+            go[r] = *reinterpret_cast<const f32x4w *>(gates + og + 2 * hd);
+            gg[r] = *reinterpret_cast<const f32x4w *>(gates + og + 3 * hd);
+            if (dh2) vd2[r] = *reinterpret_cast<const f32x4w *>(dh2 + o);
+            if (dcn) vdc[r] = *reinterpret_cast<const f32x4w *>(dcn + o);
+            if (cprev) vcp[r] = *reinterpret_cast<const f32x4w *>(cprev + o);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+        if (pp[r] < 0) continue;
+        const int p = pp[r] & 0xffff, q = (tid + 256 * r) & 3;
+        f32x4w di, df, dgo, dg, dcp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                               // (the expressions of gates_bwd_m_kernel, mixed_kernels.hip; zeros outside the image)
+            const float d = vdh[r][e] + vd2[r][e];
+            const float th = tanhf(vcn[r][e]);
+            const float d_o = d * th;
+            const float dct = vdc[r][e] + d * go[r][e] * (1.f - th * th);
+            di[e] = dct * gg[r][e] * gi[r][e] * (1.f - gi[r][e]);
+            df[e] = dct * vcp[r][e] * gf[r][e] * (1.f - gf[r][e]);
+            dgo[e] = d_o * go[r][e] * (1.f - go[r][e]);
+            dg[e] = dct * gi[r][e] * (1.f - gg[r][e] * gg[r][e]);
+            dcp[e] = dct * gf[r][e];
+        }
+        if ((pp[r] & 0x10000) && oo[r] >= 0) {                                       // this workgroup's own pixels
+            const long o = oo[r], og = (o - (cg * 16 + q * 4)) * 4 + cg * 16 + q * 4;
+            *reinterpret_cast<f32x4w *>(dgates + og) = di;
+            *reinterpret_cast<f32x4w *>(dgates + og + hd) = df;
+            *reinterpret_cast<f32x4w *>(dgates + og + 2 * hd) = dgo;
+            *reinterpret_cast<f32x4w *>(dgates + og + 3 * hd) = dg;
+            if (dcprev) *reinterpret_cast<f32x4w *>(dcprev + o) = dcp;
+        }
+        float *l = sm + p * W4G_PITCH + q * 4;
+        *reinterpret_cast<f32x4w *>(l) = di;
+        *reinterpret_cast<f32x4w *>(l + 16) = df;
+        *reinterpret_cast<f32x4w *>(l + 32) = dgo;
+        *reinterpret_cast<f32x4w *>(l + 48) = dg;
+    }
+    __syncthreads();
+    // ---- phase 2: wave = gate, lane = (tile of the half block, piece) ----
+    const int gate = tid >> 6, lane = tid & 63, tile = lane >> 2, piece = lane & 3, tr = tile >> 3, tc = tile & 7;
+    const float *lp = sm + ((4 * tr) * W4G_COLS + 4 * tc) * W4G_PITCH + gate * 16 + piece * 4;
+    f32x4w d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = *reinterpret_cast<const f32x4w *>(lp + (i * W4G_COLS + j) * W4G_PITCH);
+    auto bt6 = [](const f32x4w d0, const f32x4w d1, const f32x4w d2, const f32x4w d3, const f32x4w d4, const f32x4w d5, f32x4w *r) W4_INL {
+        const f32x4w a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = d3 - d1;
+        r[0] = 4.f * d0 - 5.f * d2 + d4;
+        r[1] = a + b;
+        r[2] = a - b;
+        r[3] = c + 2.f * e;
+        r[4] = c - 2.f * e;
+        r[5] = 4.f * d1 - 5.f * d3 + d5;
+    };
+    f32x4w tq[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4w r[6];
+        bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tq[i][j] = r[i];
+    }
+    const int tb = half * 16 + tile, nchunks = 4 * ncg, chunk = gate * ncg + cg;
+    float *o = V + ((long)mt * nchunks + chunk) * W4_BUF + tb * 16 + ((piece ^ ((tb >> 2) & 3)) * 4);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4w r[6];
+        bt6(tq[i][0], tq[i][1], tq[i][2], tq[i][3], tq[i][4], tq[i][5], r);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4w *>(o + (6 * i + j) * (W4_TILES * 16)) = r[j];
+    }
+}
+
 constexpr int W4_MAX_SRC = 16;
 constexpr int W4_EPI_LSTM = 0, W4_EPI_STORE = 1;
 
@@ -633,6 +750,23 @@ static int w4_cell_fill(const rnh_wino44_cell_args_t &a, w4_args &p, int &TX, in
     p.nsrc = a.nsrc, p.nchunks = nchunks, p.B = a.B, p.H = a.H, p.W = a.W;
     p.wp = a.wp, p.bias = a.bias, p.Npad = a.Npad, p.hd = a.hd;
     p.c_prev = a.c_prev, p.h_out = a.h_out, p.c_out = a.c_out, p.gates_out = a.gates_out;
+    return 0;
+}
+
+extern "C" int rnh_wino44_gates_bwd_supported(int H, int W, int hd) { return H > 0 && W > 0 && hd >= 16 && !(H & 15) && !(W & 31) && !(hd & 15); }
+
+extern "C" int rnh_wino44_gates_bwd(const float *dh, const float *dh2, const float *dc_next, const float *gates, const float *c_prev, const float *c_next,
+                                    float *dgates, float *dc_prev, float *v, int B, int H, int W, int hd, void *stream) {
+    if (!dh || !gates || !c_next || !dgates || !v || B < 1) RNH_FAIL(RNH_E_ARG, "rnh_wino44_gates_bwd: bad arguments");
+    if (!rnh_wino44_gates_bwd_supported(H, W, hd)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_gates_bwd: H %% 16 == 0, W %% 32 == 0, hd %% 16 == 0 (whole 8 x 4 blocks of 4x4 tiles)");
+    int TX, TY, MT;
+    long ntiles;
+    if (int rc = w4_geometry(B, H, W, "rnh_wino44_gates_bwd", TX, TY, ntiles, MT)) return rc;
+    const long nblocks = (long)MT * 2 * (hd / 16);
+    if (nblocks >= (1L << 30)) RNH_FAIL(RNH_E_RANGE, "rnh_wino44_gates_bwd: grid too large");
+    hipLaunchKernelGGL(wino44_gates_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, dh, dh2, dc_next, gates, c_prev, c_next, dgates, dc_prev, v,
+                       H, W, hd, TX, TY, (int)nblocks);
+    RNH_CHECK_LAUNCH("rnh_wino44_gates_bwd");
     return 0;
 }
 

@@ -10,7 +10,7 @@ magnitude and keeps a copy of every tensor that went through rnh_wino44_transfor
 tests/ (tests/torch_ops.py shares ``gather_src`` / ``effective_weight`` with it).  It does not import oracle/.
 
 Checked: conv() in every epilogue (plain store with segments / accumulation, PixelShuffle store, the fused ConvLSTM gates; of the fused gate backward
-the data-gradient columns), conv_pair(), wino44_cell() / wino44_cell_pair(), wino44_conv(), wgrad(), lstm_gates_bwd().  Passed through unchecked: the
+the data-gradient columns), conv_pair(), wino44_cell() / wino44_cell_pair(), wino44_conv(), wgrad(), lstm_gates_bwd() / wino44_gates_bwd().  Passed through unchecked: the
 small element-wise / side-path / tail kernels (tests/ hold them against their references one by one).
 """
 import torch
@@ -306,6 +306,19 @@ class CheckedOps:
     def lstm_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=None):
         self._no_capture()
         self.inner.lstm_gates_bwd(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2=dh2)
+        self._check_gates_bwd('rnh_lstm_gates_bwd', dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2)
+
+    def wino44_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2, v):
+        """The gate backward that also writes the transformed gate gradients: its dgates / dc_prev are checked here, its transformed image by the
+        F(4x4) data gradient that reads it (recorded, like a rnh_wino44_transform, as the image of what float64 says the gate gradients are)."""
+        self._no_capture()
+        self.inner.wino44_gates_bwd(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2, v)
+        want = self._check_gates_bwd('rnh_wino44_gates_bwd', dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2)
+        lo, nb = v.data_ptr(), v.numel() * v.element_size()
+        self._vsrc = [r for r in self._vsrc if r[0] + r[1] <= lo or r[0] >= lo + nb]
+        self._vsrc.append((lo, nb, dh.shape[0], want.shape[-1], want.float()))
+
+    def _check_gates_bwd(self, who, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2):
         hd = dh.shape[-1]
         d = dh.double() + (dh2.double() if dh2 is not None else 0)
         g = gates.double()
@@ -316,8 +329,9 @@ class CheckedOps:
         want = torch.cat([dct * gg * gi * (1 - gi), dct * cp * gf * (1 - gf), d * th * go * (1 - go), dct * gi * (1 - gg * gg)], dim=-1)
 
         class _P:                                           # (no plan: a name for the message)
-            name = 'rnh_lstm_gates_bwd'
+            name = who
         B, H, W = dh.shape[:3]
         self._cmp('gate backward', _P, B, H, W, 'element-wise', 'dgates', dgates, want)
         if dc_prev is not None:
             self._cmp('gate backward', _P, B, H, W, 'element-wise', 'dc_prev', dc_prev, dct * gf)
+        return want

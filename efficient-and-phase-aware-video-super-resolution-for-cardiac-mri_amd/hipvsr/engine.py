@@ -243,7 +243,7 @@ class RefineNetEngine:
     def _conv_forms(self, N, H, W, F, need_grad=True, last_only=False, capturing=False):
         """resolve_forms without the gate-memory plan (which itself depends on these forms through memory_plan)."""
         key = (N, H, W, F, bool(need_grad), bool(last_only), bool(capturing), os.environ.get('RNH_WINO44'), os.environ.get('RNH_WINO44_MIN'),
-               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'))
+               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'), os.environ.get('RNH_WINO44_DGRAD'))
         cache = self.__dict__.setdefault('_forms_cache', {})
         if key in cache:
             return cache[key]
@@ -274,7 +274,12 @@ class RefineNetEngine:
         fused = bool(cfg.memory and hasattr(ops, 'lstm_bwd_fusable') and
                      all(ops.lstm_bwd_fusable(P.lstm[k]['dgrad'], P.lstm[k]['cx'], P.lstm[k]['hd']) for k in P.lstm))
         f.cell_dgrad_fused = fused
-        f.cell_dgrad44 = bool(cells44 and need_grad and not fused and all(wino44_launch_ok(P.lstm[k]['dgrad'], N, H, W) for k in P.lstm))
+        # the cell's data gradient in F(4x4, 3x3) form wherever the gate backward can write the transformed gate gradients itself (rnh_wino44_gates_bwd:
+        # whole 8 x 4 blocks of tiles); with a transform launch of its own the form barely pays (RNH_WINO44_DGRAD=force asks for it anyway)
+        gt = bool(hasattr(ops, 'wino44_gates_bwd_supported') and all(ops.wino44_gates_bwd_supported(H, W, P.lstm[k]['hd']) for k in P.lstm))
+        f.cell_dgrad44 = bool(cells44 and need_grad and not fused and all(wino44_launch_ok(P.lstm[k]['dgrad'], N, H, W) for k in P.lstm) and
+                              (gt or os.environ.get('RNH_WINO44_DGRAD') == 'force'))
+        f.gates_bwd44 = bool(f.cell_dgrad44 and gt)
         f.recompute = None
         f.paired = bool(ops.pair_cells(N, H, W)) if hasattr(ops, 'pair_cells') else False
         f.plans44 = set()
@@ -302,7 +307,8 @@ class RefineNetEngine:
         if f.capture_fallback:
             cell += " [capture fallback: the F(4x4) form's ring cannot be captured at this shape]"
         names = dict(cell=cell,
-                     cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '')) if need_grad else None,
+                     cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '') +
+                                 (', transformed gate gradients written by the gate backward (rnh_wino44_gates_bwd)' if f.gates_bwd44 else '')) if need_grad else None,
                      cell_wgrad=('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
                                  'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)') if need_grad else None)
         if P.pos:
@@ -1098,7 +1104,10 @@ class RefineNetEngine:
                 c_prev = Cb[l].view(prevk) if 0 <= prevk < F else None
                 dg = Gd[d][l][fi * N:(fi + 1) * N]
                 dcp = DCP[d][l][idx & 1] if prev_grad else None
-                ops.lstm_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg, dcp, dh2=dh_next[d][l])
+                if fm.gates_bwd44:                       # (the gate backward writes the transformed gate gradients the F(4x4) data gradient reads)
+                    ops.wino44_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg, dcp, dh_next[d][l], VG[d][l])
+                else:
+                    ops.lstm_gates_bwd(dh, dc_next[d][l], gates_of(d, l, k), c_prev, Cb[l].view(k), dg, dcp, dh2=dh_next[d][l])
                 dxbuf = (DX[d][l] if l > 0 else dfeat_d[d])[fi * N:(fi + 1) * N]
                 dhp, tmp = None, None
                 if cfg.memory:
@@ -1120,7 +1129,8 @@ class RefineNetEngine:
             def dgrad_launch(d, l, call):
                 plan, srcs, _, _, _, kw = call
                 if dg44:
-                    ops.wino44_transform(srcs[0], N, H, W, VG[d][l])
+                    if not fm.gates_bwd44:
+                        ops.wino44_transform(srcs[0], N, H, W, VG[d][l])
                     ops.wino44_conv(plan, [(VG[d][l], 0)], N, H, W, kw['dsts'])
                 else:
                     ops.conv(plan, srcs, N, H, W, **kw)

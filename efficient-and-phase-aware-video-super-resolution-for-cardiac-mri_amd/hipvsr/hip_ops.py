@@ -1075,6 +1075,24 @@ class HipOps:
         L.check(self.lib.rnh_lstm_gates_bwd(_ptr(dh), _ptr(dh2), _ptr(dc_next), _ptr(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates),
                                             _ptr(dc_prev), npix, hd, self._stream()), 'rnh_lstm_gates_bwd')
 
+    def wino44_gates_bwd_supported(self, H, W, hd):
+        """Does rnh_wino44_gates_bwd (the gate backward + the transform of its gate gradients in one launch) serve cells of this shape?"""
+        return bool(self.lib.rnh_wino44_gates_bwd_supported(H, W, hd))
+
+    def wino44_gates_bwd(self, dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2, v):
+        """lstm_gates_bwd(...) and wino44_transform(Src(dgates), ..., v) in ONE launch (fp32; rnh_wino44_gates_bwd)."""
+        self._chk(dh, dc_next, gates, c_prev, c_next, dgates, dc_prev, dh2, v)
+        B, H, W, hd = dh.shape
+        for t in (dc_next, c_prev, c_next, dc_prev, dh2):
+            if t is not None and t.shape != dh.shape:
+                raise L.HipKernelError('wino44_gates_bwd: state shapes')
+        if tuple(gates.shape) != (B, H, W, 4 * hd) or tuple(dgates.shape) != (B, H, W, 4 * hd):
+            raise L.HipKernelError('wino44_gates_bwd: gate shapes')
+        if v.numel() != int(self.lib.rnh_wino44_v_floats(B, H, W, 4 * hd)):
+            raise L.HipKernelError('wino44_gates_bwd: size of the transformed image')
+        L.check(self.lib.rnh_wino44_gates_bwd(_ptr(dh), _ptr(dh2), _ptr(dc_next), _ptr(gates), _ptr(c_prev), _ptr(c_next), _ptr(dgates), _ptr(dc_prev),
+                                              _ptr(v), B, H, W, hd, self._stream()), 'rnh_wino44_gates_bwd')
+
     def add(self, out, a, b=None, c=None, accumulate=False):
         n = out.numel()
         for t in (a, b, c):

@@ -42,7 +42,9 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            'rnh_wino44_v_floats', 'rnh_wino44_transform', 'rnh_wino44_pack_weights', 'rnh_wino44_cell', 'rnh_wino44_cell_pair', 'rnh_wino44_conv',
            'rnh_wino44_tmajor_floats', 'rnh_wino44_tmajor', 'rnh_wino44_wgrad_gemm', 'rnh_wino44_wgrad_finish',
            # f16 weights for the upsampler's forward in the bf16-storage path (ABI 6)
-           'rnh_pack_weights_f16']
+           'rnh_pack_weights_f16',
+           # gate backward + transform of the gate gradients in one launch (ABI 6)
+           'rnh_wino44_gates_bwd_supported', 'rnh_wino44_gates_bwd']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -223,6 +225,8 @@ def load():
     lib.rnh_wino44_v_floats.argtypes = [i32, i32, i32, i32]
     lib.rnh_wino44_v_floats.restype = i64
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.rnh_wino44_gates_bwd_supported.argtypes = [i32, i32, i32]
+    lib.rnh_wino44_gates_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, vp]
     lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_cell_pair.argtypes = [C.POINTER(Wino44CellArgs), C.POINTER(Wino44CellArgs), vp]

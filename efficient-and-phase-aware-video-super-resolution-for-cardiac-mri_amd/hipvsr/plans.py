@@ -283,10 +283,12 @@ class NetPlans:
                                   and sum(sg.nch for sg in pl_.ksegs) % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0')
                 dgrad = ConvPlan_(f'{d}{l}.dgrad', wk, None, ws, [KSeg(4 * hd, 4 * hd, 0)], list(range(cin)), transposed=True,
                                  wino=os.environ.get('RNH_WINO_DGRAD', '1') != '0' and wino)
-                # the data gradient in F(4x4, 3x3) form (rnh_wino44_conv on the transformed gate gradients): opt-in (RNH_WINO44_DGRAD=1).  Correct
-                # (tests/test_wino44.py) but barely faster: the transform of the 4 hd = 256 gate-gradient channels costs 107 us of the 281 the
-                # F(2x2) launch takes (transform + F(4x4) 263 us; step 265.8 -> 263.6 ms, profiles/r05_zd_*), for 0.3 GB of scratch per chain
-                dgrad.wino44 = bool(full.wino44) and dgrad.wino and (4 * hd) % 32 == 0 and os.environ.get('RNH_WINO44_DGRAD', '0') == '1'
+                # the data gradient in F(4x4, 3x3) form (rnh_wino44_conv on the transformed gate gradients): 177 against 281-303 us at BASELINE config 2.
+                # With a transform launch of its own over the 4 hd = 256 gate-gradient channels (107 us) that was barely a gain (round 5: step 265.8 ->
+                # 263.6 ms, an opt-in); since round 6 the gate backward writes the transformed image itself (rnh_wino44_gates_bwd) and the form is the
+                # engine's choice wherever that launch serves the shape (hipvsr/forms.py; RNH_WINO44_DGRAD=0: off, =force: also with the separate
+                # transform launch); 0.3 GB of scratch per chain
+                dgrad.wino44 = bool(full.wino44) and dgrad.wino and (4 * hd) % 32 == 0 and os.environ.get('RNH_WINO44_DGRAD', '1') != '0'
                 wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
                                   [YSeg(4 * hd, 4 * hd, 0)])
                 self.lstm[(d, l)] = dict(full=full, first=first, dgrad=dgrad, wgrad=wgrad, cx=cx, hd=hd, second=second)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16 */
+#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16, rnh_wino44_gates_bwd[_supported] */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -535,6 +535,13 @@ int rnh_phase_plane_m(const float *pos /* [N][F] */, void *out, int out_dt, int 
  * refine_net.py:88-93: the next frame of its layer, the same frame of the next layer). */
 int64_t rnh_wino44_v_floats(int B, int H, int W, int nch);
 int rnh_wino44_transform(const float *x, int C, int c0, int nch, int B, int H, int W, float *v, void *stream);
+/* rnh_lstm_gates_bwd (autograd of reference src/model/nets/refine_net.py:258-265) AND rnh_wino44_transform of the 4 hd gate gradients it writes, in ONE
+ * launch (ABI 6): dgates / dc_prev exactly as rnh_lstm_gates_bwd's (all tensors fp32), v = B^T dgates B as rnh_wino44_transform(dgates, 4 hd, 0, 4 hd, ...)
+ * would write it - the input of the cell's data gradient in F(4x4, 3x3) form (rnh_wino44_conv on transposed weights), without the second pass over the
+ * gate gradients.  H % 16 == 0, W % 32 == 0, hd % 16 == 0 (rnh_wino44_gates_bwd_supported); dh2, dc_next, c_prev, dc_prev may be 0 as there. */
+int rnh_wino44_gates_bwd_supported(int H, int W, int hd);
+int rnh_wino44_gates_bwd(const float *dh, const float *dh2, const float *dc_next, const float *gates, const float *c_prev, const float *c_next,
+                         float *dgates, float *dc_prev, float *v, int B, int H, int W, int hd, void *stream);
 /* wp[s8][xi][n][kh][m] = (G g G^T)[xi], g = the 3x3 filter w[colmap[n]][kch[8 s8 + 4 kh + m]] (w OIHW [Cout][Cin][3][3]; kch [K] = the
  * weight's input channel of every K slot in the order the transformed sources are passed to rnh_wino44_cell, colmap [Npad]; device int32
  * arrays, negative = zero); wp: K / 8 * 36 * Npad * 8 floats; biasp[n] = bias[colmap[n]].  K a multiple of 32, Npad of 64.

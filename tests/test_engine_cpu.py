@@ -447,7 +447,8 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
     backward, memory_plan, the weight packing and bench.py's `config.forms` all read.  Its defaults at the benchmark shapes on a 288 GB card are what
     DESIGN section 4 says: fp32 cells in F(4x4, 3x3) form everywhere (whole 4x4 tiles), a transformed-h' slot per frame at configs 2, 5 and the YAML
     shape, a ring of four at config 4 (62 GB of slots) - where a CAPTURED step falls back to F(2x2) cells and the record says so -, refine conv1 and
-    the first PixelShuffle convolution following the cells, the cell's data gradient in F(2x2) form; bf16: direct forms, IEEE-half weights in the
+    the first PixelShuffle convolution following the cells, the cell's data gradient in F(4x4) form on the transformed gate gradients the gate backward
+    writes (round 6; where the tiles come in whole 8 x 4 blocks - every benchmark shape); bf16: direct forms, IEEE-half weights in the
     upsampler's forward.  An environment switch set to anything but the product's choice is listed."""
     from hipvsr import forms
     from oracle import refinenet_oracle as orc
@@ -462,16 +463,19 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
 
         def pair_cells(self, N, H, W):
             return True
+
+        def wino44_gates_bwd_supported(self, H, W, hd):          # (rnh_wino44_gates_bwd_supported)
+            return H % 16 == 0 and W % 32 == 0 and hd % 16 == 0
     cases = {'config 2': (dict(), 8, 7, 128), 'config 4': (dict(upscale_factor=2), 16, 5, 256), 'config 5': (dict(), 8, 11, 96), 'yaml': (dict(), 16, 7, 32)}
     got = {}
     for name, (over, n, t, size) in cases.items():
         eng = RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), HipLike('cpu'))
         fm = got[name] = eng.resolve_forms(n, size, size, t + 12)
-        assert fm.cells44 and not fm.capture_fallback and not fm.cell_dgrad44 and fm.paired and fm.refine_dgrad44, name
+        assert fm.cells44 and not fm.capture_fallback and fm.cell_dgrad44 and fm.gates_bwd44 and fm.paired and fm.refine_dgrad44, name
         assert all(fm.uses44(eng.plans.lstm[k][kind]) for k in eng.plans.lstm for kind in ('full', 'first'))
-        assert not any(fm.uses44(eng.plans.lstm[k]['dgrad']) for k in eng.plans.lstm)
+        assert all(fm.uses44(eng.plans.lstm[k]['dgrad']) for k in eng.plans.lstm)
         d = fm.describe()
-        assert 'F(4x4,3x3)' in d['cell'] and 'F(2x2,3x3)' in d['cell_dgrad'] and d['env_overrides'] == [] and d['paired'] is True
+        assert 'F(4x4,3x3)' in d['cell'] and 'F(4x4,3x3)' in d['cell_dgrad'] and 'rnh_wino44_gates_bwd' in d['cell_dgrad'] and d['env_overrides'] == [] and d['paired'] is True
         # memory_plan reads the same record
         assert eng.memory_plan(n, size, size, t + 12)['forward_transient'] > RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), TorchOps('cpu')).memory_plan(n, size, size, t + 12)['forward_transient']
     for name in ('config 2', 'config 5', 'yaml'):
@@ -487,9 +491,12 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
     assert cap.capture_fallback and not cap.cells44 and not cap.plans44 and 'capture fallback' in cap.describe()['cell'] and cap.describe()['graph_capture']
     eng2 = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'))
     assert eng2.resolve_forms(8, 128, 128, 19, capturing=True).cells44
-    # images that are not whole 4x4 tiles: every launch in its F(2x2) form
+    # images that are not whole 4x4 tiles: every launch in its F(2x2) form; whole tiles but not whole 8 x 4 blocks of them (the fused gate backward's
+    # geometry): the cells in F(4x4) form, their data gradient in F(2x2) form
     odd = eng2.resolve_forms(2, 33, 20, 15)
     assert not odd.cells44 and not odd.plans44 and 'F(2x2,3x3)' in odd.describe()['cell']
+    t44 = eng2.resolve_forms(2, 24, 40, 15)
+    assert t44.cells44 and not t44.cell_dgrad44 and not t44.gates_bwd44 and 'F(2x2,3x3)' in t44.describe()['cell_dgrad']
     # bf16 storage: direct forms; the upsampler's forward with IEEE-half weights
     engb = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'), dtype='bf16')
     fb = engb.resolve_forms(8, 128, 128, 19)

@@ -356,7 +356,7 @@ def test_cell_data_gradient_in_f4x4_form_vs_float64(feat, B, H, W, monkeypatch):
     from hipvsr.hip_ops import HipOps
     from hipvsr.plans import Dst, NetPlans, Src
     from hipvsr.spec import state_dict_spec
-    monkeypatch.setenv('RNH_WINO44_DGRAD', '1')                                # (opt-in: measured barely faster than the F(2x2) launch)
+    monkeypatch.setenv('RNH_WINO44_DGRAD', 'force')                            # (the plan flag; where the engine takes the form: hipvsr/forms.py)
     dev = _dev()
     cfg = orc.exp1_x4_config()
     cfg.num_features = [feat, feat]
@@ -383,6 +383,58 @@ def test_cell_data_gradient_in_f4x4_form_vs_float64(feat, B, H, W, monkeypatch):
         assert not torch.isnan(m).any(), nm
         err = float((m - want).abs().max())
         assert err <= 2e-5 * max(1.0, scale), (nm, err, scale)
+
+
+@pytest.mark.parametrize('hd,B,H,W,full', [(64, 2, 32, 64, True), (16, 3, 16, 32, False), (32, 1, 48, 96, True), (64, 8, 128, 128, True)])
+def test_gate_backward_that_writes_the_transformed_gate_gradients(hd, B, H, W, full):
+    """rnh_wino44_gates_bwd (round 6): the gate backward of a ConvLSTM cell (autograd of reference refine_net.py:258-265) and B^T dG B of the gate
+    gradients it produces in ONE launch.  dgates and dc_prev against the float64 formulas (and against rnh_lstm_gates_bwd, the launch it replaces, 1e-6);
+    the transformed image against rnh_wino44_transform of those gate gradients - the launch it saves - to 1e-6 of the largest value (the same
+    arithmetic on the same values; hipcc may contract a product-sum differently in the two kernels); with and without the optional operands
+    (first frame of a chain: no dc_next, no dh2; cell without a predecessor: no c_prev / dc_prev); image borders (the zero padding of the patches),
+    several images, BASELINE config 2's launch.  Refused where the tiles do not come in whole 8 x 4 blocks."""
+    from hipvsr import lib as L
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import Src
+    dev = _dev()
+    ops = HipOps(dev)
+    assert ops.wino44_gates_bwd_supported(H, W, hd) and not ops.wino44_gates_bwd_supported(H + 4, W, hd) and not ops.wino44_gates_bwd_supported(H, W + 16, hd)
+    g = torch.Generator('cpu').manual_seed(hd + W)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    dh, cn = R(B, H, W, hd), R(B, H, W, hd)
+    gates = torch.rand(B, H, W, 4 * hd, generator=g)
+    gates[..., 3 * hd:] = gates[..., 3 * hd:] * 2 - 1                          # (the candidate gate is a tanh)
+    dh2, dcn, cp = (R(B, H, W, hd) if full else None for _ in range(3))
+    d = lambda t: t.to(dev) if t is not None else None                         # noqa: E731
+    dg, dcp = torch.full((B, H, W, 4 * hd), float('nan'), device=dev), (torch.full((B, H, W, hd), float('nan'), device=dev) if full else None)
+    v = torch.full_like(ops.wino44_v(B, H, W, 4 * hd)[0], float('nan'))
+    ops.wino44_gates_bwd(d(dh), d(dcn), d(gates), d(cp), d(cn), dg, dcp, d(dh2), v)
+    # the two launches it replaces
+    dg2, dcp2 = torch.full_like(dg, float('nan')), (torch.full_like(dcp, float('nan')) if full else None)
+    ops.lstm_gates_bwd(d(dh), d(dcn), d(gates), d(cp), d(cn), dg2, dcp2, dh2=d(dh2))
+    v2 = torch.full_like(v, float('nan'))
+    ops.wino44_transform(Src(dg), B, H, W, v2)
+    torch.cuda.synchronize()
+    # float64
+    dd = dh.double() + (dh2.double() if full else 0)
+    gi, gf, go, gg = (gates.double()[..., k * hd:(k + 1) * hd] for k in range(4))
+    th = torch.tanh(cn.double())
+    dct = dd * go * (1 - th * th) + (dcn.double() if full else 0)
+    cpv = cp.double() if full else torch.zeros_like(dd)
+    want = torch.cat([dct * gg * gi * (1 - gi), dct * cpv * gf * (1 - gf), dd * th * go * (1 - go), dct * gi * (1 - gg * gg)], dim=-1)
+    assert not torch.isnan(dg).any() and not torch.isnan(v).any()
+    scale = float(want.abs().max())
+    assert float((dg.cpu().double() - want).abs().max()) <= 1e-5 * scale
+    assert float((dg - dg2).abs().max()) <= 1e-6 * scale
+    if full:
+        assert float((dcp.cpu().double() - dct * gf).abs().max()) <= 1e-5 * float((dct * gf).abs().max())
+        assert float((dcp - dcp2).abs().max()) <= 1e-6 * scale
+    vs = float(v2.abs().max())
+    assert vs > 0 and float((v - v2).abs().max()) <= 1e-6 * vs, (float((v - v2).abs().max()), vs)
+    with pytest.raises(L.HipKernelError):
+        bad = torch.zeros(1, 20, 32, hd, device=dev)
+        ops.wino44_gates_bwd(bad, None, torch.zeros(1, 20, 32, 4 * hd, device=dev), None, bad, torch.zeros(1, 20, 32, 4 * hd, device=dev), None, None,
+                             ops.wino44_v(1, 20, 32, 4 * hd)[0])
 
 
 @pytest.mark.parametrize('B,H,W', [(3, 12, 20), (2, 32, 32)])

@@ -64,6 +64,15 @@ if hasattr(ops, 'wino44_cell') and getattr(pl['full'], 'wino44', False):
 dg = R(N, H, W, 256)
 dx, dh = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64)
 timeit('lstm.dgrad', lambda: ops.conv(pl['dgrad'], [Src(dg)], N, H, W, dsts=[Dst(dx, 64), Dst(dh, 64)]), 2.0 * N * H * W * 128 * 2304, 20)
+# the gate backward, alone (rnh_lstm_gates_bwd) and with the transformed gate gradients written by the same launch (rnh_wino44_gates_bwd), the separate
+# transform of the 256 gate-gradient channels it replaces, and the data gradient in F(4x4, 3x3) form on that image
+dhh, dh2, dcn, gts, cpv, cnx, dgo_, dcp = R(N, H, W, 64), R(N, H, W, 64), R(N, H, W, 64), torch.rand(N, H, W, 256, device=dev), R(N, H, W, 64), R(N, H, W, 64), ops.empty(N, H, W, 256), ops.empty(N, H, W, 64)
+timeit('lstm.gates_bwd', lambda: ops.lstm_gates_bwd(dhh, dcn, gts, cpv, cnx, dgo_, dcp, dh2=dh2), 0.0, 20)
+if hasattr(ops, 'wino44_gates_bwd') and getattr(pl['dgrad'], 'wino44', False):
+    vg = ops.wino44_v(N, H, W, 256)[0]
+    timeit('lstm44.gates_bwd+transform', lambda: ops.wino44_gates_bwd(dhh, dcn, gts, cpv, cnx, dgo_, dcp, dh2, vg), 0.0, 20)
+    timeit('lstm44.transform(256ch)', lambda: ops.wino44_transform(Src(dgo_), N, H, W, vg), 0.0, 20)
+    timeit('lstm44.dgrad', lambda: ops.wino44_conv(pl['dgrad'], [(vg, 0)], N, H, W, [Dst(dx, 64), Dst(dh, 64)]), 2.0 * N * H * W * 128 * 2304, 20)
 xs, hs, gd = R(TN + N, H, W, 64), R(TN + N, H, W, 64), R(TN, H, W, 256)
 dw, db = ops.empty(256, 128, 3, 3), ops.empty(256)
 timeit('lstm.wgrad', lambda: ops.wgrad(pl['wgrad'], [Src(xs, img_off=N), Src(hs)], [Src(gd)], TN, H, W, dw, db), 2.0 * TN * H * W * 128 * 256 * 9)
