@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OBJ="$(mktemp -d "${TMPDIR:-/tmp}/rnh_build.XXXXXX")"
 trap 'rm -rf "$OBJ"' EXIT
 mkdir -p "$(dirname "$OUT")"
-SRCS=(conv_igemm conv_wino conv_wino44 wgrad_wino44 conv_wgrad wgrad_wino small_kernels uptail uptail_bf16 cine_gather step_tail conv_bf16 wgrad_bf16 mixed_kernels)
+SRCS=(conv_igemm conv_wino conv_wino44 wgrad_wino44 wgrad_wino44f conv_wgrad wgrad_wino small_kernels uptail uptail_bf16 cine_gather step_tail conv_bf16 wgrad_bf16 mixed_kernels)
 # RNH_PERSISTENT=1: also build the persistent form of the bf16 convolution (csrc/experiments/conv_bf16p.hip: measured slower in round 5, kept for A/B runs)
 if [ "${RNH_PERSISTENT:-0}" = 1 ]; then SRCS+=(experiments/conv_bf16p); set -- "$@" -DRNH_WITH_PERSISTENT; mkdir -p "$OBJ/experiments"; fi
 pids=()

@@ -1,0 +1,389 @@
+// Weight gradient of a 3x3 convolution in Winograd form F(3x3, 4x4) over 4x4 output tiles on fp32 MFMA, BOTH transforms fused - rnh_wino44f_wgrad (round 6).
+//
+//   dg = G^T [ sum_tiles (B^T d B) .* (A dY A^T) ] G        d: 6x6 input patch, dY: 4x4 output-gradient tile, G, B, A of F(4x4, 3x3) (conv_wino44.hip)
+//
+// 36 GEMMs dU_xi[ci][co] = sum_tiles V_xi[tile][ci] * Z_xi[tile][co] (contraction over tiles, two per v_mfma_f32_32x32x2_f32): 2.25 multiplications per
+// (pixel, ci, co) where the F(2x2)-tile form (wgrad_wino.hip) needs 4 and the pixel contraction (conv_wgrad.hip) 9 - for the ConvLSTM cell's weight gradient
+// (autograd of reference src/model/nets/refine_net.py:234-239, :256; 128 x 256 channels over T N H W pixels) 135 instead of 240 GFLOP per launch, the largest
+// single item of the fp32 step (profiles/r05_zv_*).  Round 5 measured the matrix part alone at 0.92 of the fp32 MFMA peak on operands a separate launch had
+// transformed (tools/probes/wino44_wgrad_gemm.hip) and found the materialised transforms - 2.25 x the bytes of both operands through HBM, beside kernels that
+// want the same bandwidth - to cost what the form saves (csrc/wgrad_wino44.hip, opt-in).  Here nothing transformed ever leaves the CU:
+//
+//   workgroup = 16 waves = one 32 (ci) x 64 (co) block of all 36 dU_xi, over a range of tile QUADS (4 tiles side by side = 4 x 16 pixels; K split over
+//     workgroups, partial sums summed in fixed order by the finish kernel);
+//   12 CONSUMER waves (3 per SIMD): wave = (row pg of the 6x6 transform domain: positions 6 pg .. 6 pg + 5) x (column half): 96 accumulator registers;
+//     per quad and position one ds_read2_b32 per operand and two MFMAs - nothing else;
+//   4 PRODUCER waves (1 per SIMD): two compute V = B^T d B of a quad's four tiles (lane = 2 input channels x tile, so that every transform instruction is a
+//     packed v_pk_*_f32 on two channels: 144 for the 36 positions), two compute Z = A dY A^T (lane = 2 output channels x tile, two passes of 90), each for every
+//     OTHER quad, straight from the raw tensors (buffer_load_dwordx2: 128-byte rows of 32 channels per tile; scalar offsets, no address arithmetic) into the LDS
+//     image of the next quad - [xi][tile][32 channels], the layout in which both the producers' 8-byte writes and the consumers' reads are conflict-free; a
+//     producer requests its raw values in one interval between barriers and transforms them in the next.  ONE barrier per quad (LDS counter only: the requests
+//     stay in flight across it).  What the form costs on this chip: a non-MFMA vector instruction takes ~9 cycles of matrix-core time from the SIMD it is issued
+//     on, WHICHEVER wave issues it (measured: iteration = 36 MFMAs + 8.7 cycles x the transform instructions of the busiest SIMD, profiles/r06_n_*).
+//
+// No border cases: the inputs are first gathered into one zero-padded tensor xp (B, H+2, W+2, Cx) (as rnh_wino_wgrad does).  The bias gradient is the tile sum
+// of dY = Z at position (1, 1), accumulated by the Z producers.  rnh_wino44f_wgrad_supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 in 32-channel
+// multiples, ONE dy source of scale 1 with a multiple of 64 channels, every tensor below 2 GiB.
+#include "rnh_common.h"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// raw-buffer descriptor over 2 GiB from a wave-uniform pointer (the convention of conv_wino44.hip: the quad's base goes here, every further offset is a scalar)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_desc(const float *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(u & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f2 wf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+constexpr int WF_V = 36 * 4 * 32;                 // floats of a stage's V image  [xi][tile 4][ci 32]
+constexpr int WF_Z = 36 * 2 * 4 * 32;             // ... and of its Z image       [xi][column half 2][tile 4][co 32]
+constexpr int WF_STAGE = WF_V + WF_Z;             // 13 824 floats = 55 296 bytes; two stages
+
+// one workgroup per padded image row: zero border, interior gathered from the sources (16 bytes per thread) - wgrad_wino.hip's wino_pad_kernel
+__global__ void __launch_bounds__(256) wf_pad_kernel(const rnh_wgrad_args_t P, float *xp, int Cx) {
+    const int H = P.H, W = P.W, Hp = H + 2, Wp = W + 2, C4 = Cx >> 2;
+    const int row = blockIdx.x, b = row / Hp, y = row - b * Hp - 1;
+    float *dst = xp + (long)row * Wp * Cx;
+    const bool inside = (unsigned)y < (unsigned)H;
+    for (int e = threadIdx.x; e < Wp * C4; e += 256) {
+        const int xq = e / C4, c = (e - xq * C4) * 4, x = xq - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside && (unsigned)x < (unsigned)W) {
+            int cc = c, s = 0;
+            while (cc >= P.xs[s].nch) cc -= P.xs[s++].nch;
+            const rnh_src_t &S = P.xs[s];
+            v = rnh_ld4(S.ptr + ((((long)b + S.img_off) * H + y) * W + x) * S.C + S.c0 + cc);
+        }
+        rnh_st4(dst + (long)e * 4, v);
+    }
+}
+
+// B^T of F(4x4, 3x3) applied to six values (conv_wino44.hip's bt6)
+__device__ __forceinline__ void wf_bt6(const f2 d0, const f2 d1, const f2 d2, const f2 d3, const f2 d4, const f2 d5, f2 *r) {
+    const f2 a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = d3 - d1;
+    r[0] = 4.f * d0 - 5.f * d2 + d4;
+    r[1] = a + b;
+    r[2] = a - b;
+    r[3] = c + 2.f * e;
+    r[4] = c - 2.f * e;
+    r[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+// A (6x4: the adjoint of the output transform A^T) applied to four values
+__device__ __forceinline__ void wf_a4(const f2 v0, const f2 v1, const f2 v2, const f2 v3, f2 *r) {
+    const f2 s = v0 + v2, u = v1 + v3, c = v0 + 4.f * v2, d = 2.f * (v1 + 4.f * v3);
+    r[0] = v0;
+    r[1] = s + u;
+    r[2] = s - u;
+    r[3] = c + d;
+    r[4] = c - d;
+    r[5] = v3;
+}
+
+// The workgroup barrier of the quad loop: LDS traffic drained, s_barrier - and NOT the vmcnt(0) a __syncthreads() carries: the producers' global loads
+// for the quad after next stay in flight across it (with __syncthreads() every iteration waited out a full HBM latency: 2.4 instead of 1.2 us per quad)
+#define WF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// diagnostic builds (-DWF_EXP=<mask>; results WRONG, only the time is of interest): 1: the producers load their first quad only, 2: the consumers skip their MFMAs,
+// 4: the producers skip the transform arithmetic and the LDS writes
+#ifndef WF_EXP
+#define WF_EXP 0
+#endif
+
+// y: the dy tensor at (image offset, first channel); Yc its channels per pixel.  part [S][36][Cx][Cy], bpart [S][Cy / 64][4][64].
+__global__ void __launch_bounds__(1024) wf_wgrad_kernel(const float *__restrict__ xp, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
+                                                        const int H, const int W, const int nquads, const int nper, float *__restrict__ part,
+                                                        float *__restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * WF_STAGE];                 // 110 592 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RT = Cx >> 5, CT = Cy >> 6;
+    const int bid = rnh_xcd_remap((int)blockIdx.x, (int)gridDim.x);                 // (the blocks of one K range share their operands through one L2)
+    const int s = bid / (RT * CT), rc = bid - s * RT * CT, rt = rc / CT, ct = rc - rt * CT;
+    const int q0 = s * nper, n = max(0, min(nquads, q0 + nper) - q0);
+    const int Hp = H + 2, Wp = W + 2, QX = W >> 4, TY = H >> 2;
+
+    if (wave < 12) {
+        // ---------------- consumers ----------------
+        const int pg = wave % 6, ch = wave / 6, l31 = lane & 31, kh = lane >> 5;
+        f16v acc[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+        const int voff = (6 * pg * 4 + kh) * 32 + l31, zoff = WF_V + ((6 * pg * 2 + ch) * 4 + kh) * 32 + l31;
+        WF_BARRIER();
+        for (int it = 0; it < n; ++it) {
+            const float *st = sm + (it & 1) * WF_STAGE;
+            float a0[6], a1[6], b0[6], b1[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                a0[p] = st[voff + p * 128];
+                a1[p] = st[voff + p * 128 + 64];
+                b0[p] = st[zoff + p * 256];
+                b1[p] = st[zoff + p * 256 + 64];
+            }
+            if (!(WF_EXP & 2)) {
+#pragma unroll
+                for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[p], b0[p], acc[p], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[p], b1[p], acc[p], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 6; ++p) acc[p][0] += a0[p] * b0[p] + a1[p] * b1[p];
+            }
+            WF_BARRIER();
+        }
+        // D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
+        float *o = part + ((long)s * 36 * Cx + rt * 32) * Cy + ct * 64 + ch * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[((long)(6 * pg + p) * Cx + (v & 3) + 8 * (v >> 2) + 4 * kh) * Cy] = acc[p][v];
+        return;
+    }
+
+    // ---------------- producers ----------------
+    // Waves 12 / 15 compute V = B^T d B of a quad's four tiles (lane = (channel pair cp of the block's 32, tile t)), waves 13 / 14 compute Z = A dY A^T (tiles 0-1,
+    // then tiles 2-3: lane = (channel pair cp of the block's 64, tile of the pair)) - each for every OTHER quad (`par`): in one interval between barriers a producer
+    // requests the raw values of its next quad, in the next it transforms them into the LDS image the consumers read the iteration after.  A request is therefore a
+    // whole iteration (>= 36 MFMAs per SIMD) old at its first use - with one register set (128 registers per lane at 16 waves) and every producer working on every
+    // quad, the requests were issued one barrier before their use and every iteration began with a memory latency plus the 47 KB burst through the CU's 64 B/clk L2
+    // port (2.25 ms for the cell's problem against 0.95 for its matrix instructions alone; profiles/r06_n_*).
+    // Barriers: B_0 in front of iteration 0, B_k at the end of iteration k - 1 (k = 1 .. n); the image of quad j must stand at B_j, its raw values are requested in
+    // the interval before B_(j-1).  Every request is issued unconditionally (past the range: the last quad again) so that the register set has ONE definition per
+    // loop body and no copies (hipcc spilled 80-200 registers around a conditional redefinition).
+    const int pr = wave - 12;
+    const int par = (pr == 0 || pr == 1) ? 0 : 1;
+    auto run = [&](auto &&load, auto &&transform) {
+        if (n <= 0) {
+            WF_BARRIER();
+            return;
+        }
+        if (par == 0) {
+            load(q0);
+            if (!(WF_EXP & 4)) transform(sm);
+            WF_BARRIER();                                                           // B_0
+            for (int j = 2; j - 1 <= n; j += 2) {
+                if (!((WF_EXP & 1))) load(q0 + min(j, n - 1));
+                WF_BARRIER();                                                       // B_(j-1)
+                if (j > n) break;
+                if (j < n && !(WF_EXP & 4)) transform(sm);                         // (j even: stage 0)
+                WF_BARRIER();                                                       // B_j
+            }
+        } else {
+            load(q0 + min(1, n - 1));
+            WF_BARRIER();                                                           // B_0
+            for (int j = 1; j <= n; j += 2) {
+                if (j < n && !(WF_EXP & 4)) transform(sm + WF_STAGE);               // (j odd: stage 1)
+                WF_BARRIER();                                                       // B_j
+                if (j + 1 > n) break;
+                if (!((WF_EXP & 1))) load(q0 + min(j + 2, n - 1));
+                WF_BARRIER();                                                       // B_(j+1)
+            }
+        }
+    };
+    if (pr == 0 || pr == 3) {
+        // ---- V: lane = (channel pair cp of the block's 32, tile t of the quad) ----
+        const int cp = lane & 15, t = lane >> 4;
+        const int xlane = ((4 * t) * Cx + rt * 32 + 2 * cp) * 4;                    // this lane's bytes inside the quad's patch rows
+        f2 d[6][6];
+        run([&](int q) {
+                const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+                const __amdgpu_buffer_rsrc_t rs = wf_desc(xp + (((long)img * Hp + 4 * ty) * Wp + 16 * tx4) * Cx);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) d[i][j] = wf_ld2(rs, xlane, (i * Wp + j) * Cx * 4);
+            },
+            [&](float *st) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {                                       // B^T d, column by column, in place
+                    f2 r[6];
+                    wf_bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) d[i][j] = r[i];
+                    __builtin_amdgcn_sched_barrier(0);                              // (one column at a time: hipcc otherwise interleaves all six and spills)
+                }
+                float *o = st + t * 32 + 2 * cp;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    f2 r[6];
+                    wf_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 128) = r[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        return;
+    }
+    // ---- Z: lane = (channel pair cp of the block's 64, tile t of a pair); pass a = tiles 0-1, pass b = tiles 2-3 ----
+    const int cp = lane & 31, t = lane >> 5;
+    const int ylane = ((4 * t) * Yc + ct * 64 + 2 * cp) * 4;
+    f2 ya[4][4], yb[4][4];
+    f2 bsum = {0.f, 0.f};
+    auto zpass = [&](float *st, f2 (&in)[4][4], int tile) {
+        f2 M[6][4];                                                                 // A dY: column by column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f2 r[6];
+            wf_a4(in[0][j], in[1][j], in[2][j], in[3][j], r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) M[i][j] = r[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float *o = st + WF_V + (((cp >> 4) * 4 + tile) * 32) + 2 * (cp & 15);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            f2 r[6];
+            wf_a4(M[i][0], M[i][1], M[i][2], M[i][3], r);
+            if (i == 1) bsum += r[1];                                               // Z at (1, 1) = the sum of the tile's 16 pixels
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 256) = r[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    run([&](int q) {
+            const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+            const __amdgpu_buffer_rsrc_t rs = wf_desc(y + (((long)img * H + 4 * ty) * W + 16 * tx4) * Yc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ya[i][j] = wf_ld2(rs, ylane, (i * W + j) * Yc * 4);
+                    yb[i][j] = wf_ld2(rs, ylane, (i * W + j + 8) * Yc * 4);
+                }
+        },
+        [&](float *st) {
+            zpass(st, ya, t);
+            __builtin_amdgcn_sched_barrier(0);
+            zpass(st, yb, 2 + t);
+        });
+    if (rt == 0 && bpart) {                                                         // bias partial sums: [s][ct][2 par + tile lane][64] (each lane: tiles t and 2 + t of its quads)
+        float *o = bpart + (((long)s * CT + ct) * 4 + 2 * par + t) * 64 + 2 * cp;
+        *reinterpret_cast<f2 *>(o) = bsum;
+    }
+}
+
+// dw[(colmap[j] Cin + rowmap[i]) 9 + 3 p + q] (+)= sum_{a, b} G[a][p] G[b][q] sum_s part[s][6 a + b][i][j];  db[colmap[j]] (+)= sum_s sum_k bpart[s][j / 64][k][j % 64].
+// A workgroup = 64 consecutive (i, j) entries x 4 groups of 9 positions: the K-split sums of a position group by one wave (coalesced 256-byte rows), the four
+// groups meet in LDS, then G^T . G per entry.  Fixed order: deterministic.
+__global__ void __launch_bounds__(256) wf_finish_kernel(const float *__restrict__ part, const float *__restrict__ bpart, const int S, const int Cx, const int Cy,
+                                                        const int *__restrict__ rowmap, const int *__restrict__ colmap, const int Cin, float *dw, float *db,
+                                                        const int accumulate) {
+    __shared__ float us[36][65];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;                                    // (Cx Cy is a multiple of 64)
+    const int j = (int)(e % Cy), i = (int)(e / Cy);
+    for (int k = 0; k < 9; ++k) {
+        const int xi = 9 * grp + k;
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[(((long)s * 36 + xi) * Cx + i) * Cy + j];
+        us[xi][lane] = a;
+    }
+    __syncthreads();
+    if (grp) return;
+    const int co = colmap[j], ci = rowmap[i];
+    if (i == 0 && db && co >= 0) {
+        float b = 0.f;
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < 4; ++k) b += bpart[(((long)s * (Cy >> 6) + (j >> 6)) * 4 + k) * 64 + (j & 63)];
+        db[co] = accumulate ? db[co] + b : b;
+    }
+    if (co < 0 || ci < 0) return;
+    const float G[6][3] = {{0.25f, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float u[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) u[xi] = us[xi][lane];
+    float *o = dw + ((long)co * Cin + ci) * 9;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float g = 0.f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float row = 0.f;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) row += u[6 * a + b] * G[b][q];
+                g += G[a][p] * row;
+            }
+            o[3 * p + q] = accumulate ? o[3 * p + q] + g : g;
+        }
+}
+
+struct WfGeo {
+    int Cx, Cy, S, nquads, nper;
+};
+
+int wf_check(const rnh_wgrad_args_t &a, WfGeo &g, bool quiet) {
+#define WF_NO(msg)                                        \
+    do {                                                  \
+        if (quiet) return 1;                              \
+        RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad: " msg); \
+    } while (0)
+    if (a.ntaps != 9 || a.B < 1 || a.H < 4 || a.W < 16 || (a.H & 3) || (a.W & 15)) WF_NO("3x3, H % 4 == 0, W % 16 == 0");
+    if (a.nxs < 1 || a.nxs > RNH_MAX_SRC || a.nys != 1) WF_NO("1..16 x sources, ONE dy source");
+    int Cx = 0;
+    for (int i = 0; i < a.nxs; ++i) {
+        const rnh_src_t &s = a.xs[i];
+        if (!s.ptr || s.ptr2 || s.scale != 1 || s.nch < 4 || (s.nch & 3) || (s.C & 3) || (s.c0 & 3)) WF_NO("x sources: scale 1, no second operand, channels in fours");
+        Cx += s.nch;
+    }
+    const rnh_src_t &y = a.ys[0];
+    if (!y.ptr || y.ptr2 || y.scale != 1 || (y.nch & 63) || (y.C & 1) || (y.c0 & 1)) WF_NO("the dy source: scale 1, no second operand, a multiple of 64 channels");
+    if (Cx & 31) WF_NO("input channels in multiples of 32");
+    if ((long)a.B * a.H * a.W >= (1L << 27)) WF_NO("too many pixels");
+    g.Cx = Cx, g.Cy = y.nch;
+    g.nquads = a.B * (a.H >> 2) * (a.W >> 4);
+    const int blocks = (Cx >> 5) * (g.Cy >> 6);
+    int S = (256 + blocks - 1) / blocks;                          // one workgroup per CU (16 waves, 108 KB of LDS); at least two quads per workgroup
+    if (S > g.nquads / 2) S = g.nquads / 2 > 0 ? g.nquads / 2 : 1;
+    if (S > 64) S = 64;
+    g.nper = (g.nquads + S - 1) / S;
+    g.S = (g.nquads + g.nper - 1) / g.nper;
+    return 0;
+#undef WF_NO
+}
+
+}  // namespace
+
+extern "C" int rnh_wino44f_wgrad_supported(const rnh_wgrad_args_t *args) {
+    WfGeo g;
+    return args && wf_check(*args, g, true) == 0;
+}
+
+extern "C" int rnh_wino44f_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t *out3) {
+    if (!args || !out3) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad_ws_floats: null argument");
+    WfGeo g;
+    if (int rc = wf_check(*args, g, false)) return rc;
+    out3[0] = (int64_t)args->B * (args->H + 2) * (args->W + 2) * g.Cx;
+    out3[1] = (int64_t)g.S * 36 * g.Cx * g.Cy;
+    out3[2] = (int64_t)g.S * (g.Cy >> 6) * 4 * 64;
+    return 0;
+}
+
+extern "C" int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args, float *xp, float *part, float *bpart, const int32_t *rowmap, const int32_t *colmap, int Cin,
+                                 float *dw, float *db, int accumulate, void *stream) {
+    if (!args || !xp || !part || !rowmap || !colmap || !dw || Cin < 1 || (db && !bpart)) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad: bad arguments");
+    const rnh_wgrad_args_t &a = *args;
+    WfGeo g;
+    if (int rc = wf_check(a, g, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wf_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, g.Cx);
+    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad(pad)");
+    const rnh_src_t &y = a.ys[0];
+    const float *yp = y.ptr + (long)y.img_off * a.H * a.W * y.C + y.c0;
+    const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
+    hipLaunchKernelGGL(wf_wgrad_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, xp, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
+    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad");
+    hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
+                       db, accumulate);
+    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad(finish)");
+    return 0;
+}

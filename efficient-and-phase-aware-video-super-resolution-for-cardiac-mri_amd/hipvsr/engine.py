@@ -243,7 +243,7 @@ class RefineNetEngine:
     def _conv_forms(self, N, H, W, F, need_grad=True, last_only=False, capturing=False):
         """resolve_forms without the gate-memory plan (which itself depends on these forms through memory_plan)."""
         key = (N, H, W, F, bool(need_grad), bool(last_only), bool(capturing), os.environ.get('RNH_WINO44'), os.environ.get('RNH_WINO44_MIN'),
-               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'), os.environ.get('RNH_WINO44_DGRAD'))
+               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'), os.environ.get('RNH_WINO44_DGRAD'), os.environ.get('RNH_WINO44F_WGRAD'))
         cache = self.__dict__.setdefault('_forms_cache', {})
         if key in cache:
             return cache[key]
@@ -306,18 +306,23 @@ class RefineNetEngine:
             cell += ', transformed h\' in a ring of 4' if f.ring else ', a transformed-h\' slot per frame'
         if f.capture_fallback:
             cell += " [capture fallback: the F(4x4) form's ring cannot be captured at this shape]"
+        # the cell's weight gradient in F(4x4)-tile form with both transforms fused (rnh_wino44f_wgrad) where the kernel takes the call (HipOps.wgrad asks
+        # rnh_wino44f_wgrad_supported per call: the cell's sources always qualify, the image must be whole quads of tiles)
+        w44f = bool(hip and not self.bf16 and getattr(pl0['wgrad'], 'wino44f', False) and os.environ.get('RNH_WINO44F_WGRAD', '1') != '0' and
+                    H % 4 == 0 and W % 16 == 0 and os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0')
+        f22w = 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)'
         names = dict(cell=cell,
                      cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '') +
                                  (', transformed gate gradients written by the gate backward (rnh_wino44_gates_bwd)' if f.gates_bwd44 else '')) if need_grad else None,
                      cell_wgrad=('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
-                                 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)') if need_grad else None)
+                                 'Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' if w44f else f22w) if need_grad else None)
         if P.pos:
             r1p = P.r1_fwd_h if P.r1_wino else (P.r1_fwd_a if getattr(P, 'r1_split', False) else P.r1_fwd)
             names['refine1_fwd'] = conv_form(r1p, f.refine_fwd44) + (' on the cells\' transformed h\'' if f.refine_fwd44 else '')
             if need_grad:
                 names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
                 w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
-                names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else names['cell_wgrad'])
+                names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else f22w))
         else:
             names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
         for i, u in enumerate(P.up[:n_up]):

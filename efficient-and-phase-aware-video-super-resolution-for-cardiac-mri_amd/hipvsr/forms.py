@@ -16,7 +16,7 @@ SWITCHES = {
     'RNH_WINO': '1', 'RNH_WINO_COLS': '128', 'RNH_WINO_DGRAD': '1', 'RNH_WINO_REFINE': '1', 'RNH_WINO_REFINE2': '1', 'RNH_WINO_UP': '1',
     'RNH_WINO_WGRAD': '1', 'RNH_XCOL': '1', 'RNH_XCOL_M': '1', 'RNH_R1_SPLIT': '1', 'RNH_R2_WGRAD_SPLIT': '1', 'RNH_LSTM_TILE': None,
     'RNH_WINO44': '1', 'RNH_WINO44_MIN': '1', 'RNH_WINO44_REFINE': '1', 'RNH_WINO44_REFINE_DGRAD': '1', 'RNH_WINO44_UP': '1',
-    'RNH_WINO44_DGRAD': '1', 'RNH_WINO44_WGRAD': '0', 'RNH_UP_F16': '1',
+    'RNH_WINO44_DGRAD': '1', 'RNH_WINO44_WGRAD': '0', 'RNH_WINO44F_WGRAD': '1', 'RNH_UP_F16': '1',
     'RNH_PAIR': '1', 'RNH_FUSE_GATES_BWD': '1', 'RNH_FUSE_ANY': None, 'RNH_DEFER_WGRAD': '1', 'RNH_ASIDE': '1', 'RNH_ASIDE_OFF': None,
     'RNH_ASIDE_CAPTURE': '1', 'RNH_ASIDE_DELAY': None, 'RNH_LSTM_STREAMS': 'layer', 'RNH_SHARED_STREAMS': '1', 'RNH_STREAM_TOUCH': None,
     'RNH_DIRECT': '1', 'RNH_DIRECT_PS': '1', 'RNH_BF16_KC': None, 'RNH_WGRAD_TILE': None, 'RNH_WGRAD_NSPLIT': None, 'RNH_GRAPH_DP': '0',

@@ -768,6 +768,13 @@ class HipOps:
                 f'rnh_wino44_wgrad_finish({plan.name})')
         return True
 
+    @staticmethod
+    def wino44f_wgrad_on(plan):
+        """Is the F(4x4)-tile fused weight gradient (rnh_wino44f_wgrad) wanted for this plan?  RNH_WINO44F_WGRAD: '1' (default) = the plans it was measured
+        faster for (hipvsr/plans.py: plan.wino44f), 'all' = wherever the kernel takes the call, '0' = nowhere (A/B runs)."""
+        mode = os.environ.get('RNH_WINO44F_WGRAD', '1')
+        return mode == 'all' or (mode != '0' and bool(getattr(plan, 'wino44f', False)))
+
     def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
         m = self._plan_maps(plan)
         self._chk(dw, db)
@@ -791,8 +798,18 @@ class HipOps:
                 raise L.HipKernelError(f'{plan.name}: dy source {i} channels')
             self._check_src_range(a.ys[i], s.t, B, H, W, plan.name)
         a.B, a.H, a.W, a.ntaps, a.nxs, a.nys = B, H, W, plan.ntaps, len(xsrcs), len(ysrcs)
-        if self.wino_wgrad and all(sg.nvalid == sg.nch for sg in plan.xsegs) and all(sg.nvalid == sg.nch for sg in plan.ysegs) and \
-                self.lib.rnh_wino_wgrad_supported(C.byref(a)):
+        whole = all(sg.nvalid == sg.nch for sg in plan.xsegs) and all(sg.nvalid == sg.nch for sg in plan.ysegs)
+        if self.wino_wgrad and whole and self.wino44f_wgrad_on(plan) and self.lib.rnh_wino44f_wgrad_supported(C.byref(a)):
+            # Winograd form F(3x3, 4x4) over 4x4 tiles, both transforms fused (csrc/wgrad_wino44f.hip): 36 GEMMs over the tiles, fixed-order reduction
+            sz = (C.c_int64 * 3)()
+            L.check(self.lib.rnh_wino44f_wgrad_ws_floats(C.byref(a), sz), 'rnh_wino44f_wgrad_ws_floats')
+            xp = self._workspace('wino_xp', sz[0])
+            part = self._workspace('w44f_part', sz[1])
+            bpart = self._workspace('w44f_bpart', sz[2])
+            L.check(self.lib.rnh_wino44f_wgrad(C.byref(a), _ptr(xp), _ptr(part), _ptr(bpart), _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
+                                               int(accumulate), self._stream()), f'rnh_wino44f_wgrad({plan.name})')
+            return
+        if self.wino_wgrad and whole and self.lib.rnh_wino_wgrad_supported(C.byref(a)):
             # Winograd form F(3x3, 2x2): zero-padded gathered copy of the inputs, 16 GEMMs over tiles, fixed-order reduction
             sz = (C.c_int64 * 3)()
             L.check(self.lib.rnh_wino_wgrad_ws_floats(C.byref(a), sz), 'rnh_wino_wgrad_ws_floats')

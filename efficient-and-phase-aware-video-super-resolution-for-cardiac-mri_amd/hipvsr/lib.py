@@ -44,7 +44,9 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            # f16 weights for the upsampler's forward in the bf16-storage path (ABI 6)
            'rnh_pack_weights_f16',
            # gate backward + transform of the gate gradients in one launch (ABI 6)
-           'rnh_wino44_gates_bwd_supported', 'rnh_wino44_gates_bwd']
+           'rnh_wino44_gates_bwd_supported', 'rnh_wino44_gates_bwd',
+           # weight gradient in F(4x4)-tile Winograd form, both transforms fused (ABI 6)
+           'rnh_wino44f_wgrad_supported', 'rnh_wino44f_wgrad_ws_floats', 'rnh_wino44f_wgrad']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -227,6 +229,9 @@ def load():
     lib.rnh_wino44_transform.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.rnh_wino44_gates_bwd_supported.argtypes = [i32, i32, i32]
     lib.rnh_wino44_gates_bwd.argtypes = [vp] * 9 + [i32, i32, i32, i32, vp]
+    lib.rnh_wino44f_wgrad_supported.argtypes = [vp]
+    lib.rnh_wino44f_wgrad_ws_floats.argtypes = [vp, vp]
+    lib.rnh_wino44f_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_cell_pair.argtypes = [C.POINTER(Wino44CellArgs), C.POINTER(Wino44CellArgs), vp]

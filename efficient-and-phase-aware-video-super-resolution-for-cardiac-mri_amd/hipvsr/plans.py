@@ -291,6 +291,9 @@ class NetPlans:
                 dgrad.wino44 = bool(full.wino44) and dgrad.wino and (4 * hd) % 32 == 0 and os.environ.get('RNH_WINO44_DGRAD', '1') != '0'
                 wgrad = WgradPlan_(f'{d}{l}.wgrad', wk, bk, ws, [XSeg(cx, cx, 0), XSeg(second, second, cx)],
                                   [YSeg(4 * hd, 4 * hd, 0)])
+                # the weight gradient in F(4x4)-tile Winograd form with both transforms fused (rnh_wino44f_wgrad, round 6) where the kernel takes the call
+                # (fp32, whole 32-channel row blocks and 64-channel column blocks, H % 4 == 0, W % 16 == 0: checked per call)
+                wgrad.wino44f = not bf
                 self.lstm[(d, l)] = dict(full=full, first=first, dgrad=dgrad, wgrad=wgrad, cx=cx, hd=hd, second=second)
 
         Cl, w = self.Cl, cfg.refine_window_size

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16, rnh_wino44_gates_bwd[_supported] */
+#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16, rnh_wino44_gates_bwd[_supported], rnh_wino44f_wgrad* */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -191,6 +191,17 @@ int rnh_wino_wgrad_supported(const rnh_wgrad_args_t *args /* host */);
 int rnh_wino_wgrad_ws_floats(const rnh_wgrad_args_t *args /* host */, int64_t *out3 /* host: xp, slab, bslab */);
 int rnh_wino_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, const int32_t *rowmap, const int32_t *colmap, int Cin,
                    float *dw, float *db, int accumulate, void *stream);
+
+/* The same weight gradient in Winograd form F(3x3, 4x4) over 4x4 output tiles with BOTH transforms fused (ABI 6; csrc/wgrad_wino44f.hip): 36 GEMMs over
+ * the tiles, 2.25 multiplications per (pixel, ci, co) instead of the 4 of rnh_wino_wgrad - the ConvLSTM cell's weight gradient (autograd of reference
+ * src/model/nets/refine_net.py:234-239, :256), refine conv1's and conv2's (:149-151).  Supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 whose
+ * channel counts add up to a multiple of 32, ONE dy source of scale 1 with a multiple of 64 channels.  Workspaces (floats): xp (zero-padded gathered copy of
+ * the inputs), part (K-split partial sums [S][36][Cx][Cy]), bpart (bias partial sums).  Scatter as rnh_wgrad_reduce:
+ * dw[(colmap[j] * Cin + rowmap[i]) * 9 + tap], db[colmap[j]]; fixed summation order (deterministic). */
+int rnh_wino44f_wgrad_supported(const rnh_wgrad_args_t *args /* host */);
+int rnh_wino44f_wgrad_ws_floats(const rnh_wgrad_args_t *args /* host */, int64_t *out3 /* host: xp, part, bpart */);
+int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, float *part, float *bpart, const int32_t *rowmap, const int32_t *colmap, int Cin,
+                      float *dw, float *db, int accumulate, void *stream);
 
 /* Sum the partial slabs and scatter into the reference-layout gradient:
  *   dw[(colmap[j]*Cin + rowmap[i])*ntaps + tap] (+)= sum_s slab[s][tap][i][j]   (rowmap/colmap < 0: skipped)

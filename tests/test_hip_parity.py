@@ -615,8 +615,9 @@ def test_weight_gradient_kernels_vs_torch_float64(which, B, H, W):
         rb[:128] = rb128
         sel = True
     res = {}
-    old = {k: os.environ.get(k) for k in ('RNH_WGRAD_LDS', 'RNH_WGRAD_HALF')}
+    old = {k: os.environ.get(k) for k in ('RNH_WGRAD_LDS', 'RNH_WGRAD_HALF', 'RNH_WINO44F_WGRAD')}
     try:
+        os.environ['RNH_WINO44F_WGRAD'] = '0'                 # (the F(2x2)-tile variants: the fused F(4x4)-tile form has its own test, tests/test_wino44.py)
         # 'half' = the product's choice where W % 32 == 0 (two workgroups per CU, each half of the transform domain), 'lds' = one workgroup
         # per CU with all 16 positions, 'lane' = no LDS sharing, 'pixel' = the direct (non-Winograd) kernel
         for name, wino, lds, half in (('half', True, '1', '1'), ('lds', True, '1', '0'), ('lane', True, '0', '1'), ('pixel', False, '1', '1')):

@@ -698,3 +698,82 @@ def test_refine_conv1_weight_gradient_in_f4x4_tile_form(monkeypatch):
             other = torch.ones(645, dtype=torch.bool)
             other[rows] = False
             assert torch.equal(dw[:, other], base_w[:, other]) and torch.equal(dw[128:], base_w[128:])
+
+
+@pytest.mark.parametrize('which,B,H,W,accumulate', [('lstm', 3, 8, 16, False), ('lstm', 2, 4, 64, True), ('lstm', 5, 16, 32, False), ('lstm', 1, 12, 48, True),
+                                                     ('refine1', 3, 8, 32, False), ('refine2', 2, 16, 16, True), ('lstm', 14, 128, 128, False)])
+def test_fused_f4x4_tile_weight_gradient_vs_float64(which, B, H, W, accumulate, monkeypatch):
+    """rnh_wino44f_wgrad (round 6, csrc/wgrad_wino44f.hip): the weight gradient in Winograd form F(3x3, 4x4) over 4x4 tiles with both transforms computed
+    in the workgroup (producer waves -> LDS -> consumer waves' MFMAs), K split over workgroups, fixed-order finish with G^T . G and the bias gradient
+    from Z(1, 1) - against float64 autograd of conv2d (reference refine_net.py:234-239, :149-151 and loss.backward()): the ConvLSTM cell (two 64-channel
+    sources a frame apart, 256 columns), refine conv1's hidden-state rows (ten sources with frame offsets, 128 of 132 gradient channels, a scatter into
+    the 645-channel weight) and refine conv2's; one quad per tile row up to several quads and images per workgroup, an odd number of quads, accumulation
+    into what the gradient held, entries the plan does not map untouched; the config-2-sized cell launch (14 of its 56 images) against the F(2x2)-tile
+    kernel it replaces as well."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    monkeypatch.setenv('RNH_WINO44F_WGRAD', 'all')
+    dev = _dev()
+    P, ops = NetPlans(orc.exp1_x4_config()), HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(B * 100 + W)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    n64 = lambda t: t.double().permute(0, 3, 1, 2)                             # noqa: E731
+    big = B * H * W > 100000
+
+    def ref_wgrad(x_nchw, dy_nchw, cout, cin):
+        w0 = torch.zeros(cout, cin, 3, 3, dtype=torch.float32 if big else torch.float64, requires_grad=True)
+        F.conv2d(x_nchw.to(w0.dtype), w0, padding=1).backward(dy_nchw.to(w0.dtype))
+        return w0.grad.double(), dy_nchw.double().sum(dim=(0, 2, 3))
+    hidx = None
+    if which == 'lstm':
+        plan = P.lstm[('backward', 2)]['wgrad']
+        x, h, dy = R(B + 1, H, W, 64), R(B + 1, H, W, 64), R(B, H, W, 256)
+        xs, ys, shape = [Src(x.to(dev), img_off=1), Src(h.to(dev))], [Src(dy.to(dev))], (256, 128, 3, 3)
+        rw, rb = (None, None) if big else ref_wgrad(torch.cat([n64(x[1:]), n64(h[:B])], 1), n64(dy), 256, 128)
+    elif which == 'refine1':
+        plan = P.r1_wgrad_h
+        Hf, Hb, dy = R(B + 4, H, W, 64), R(B + 4, H, W, 64), R(B, H, W, 132)
+        Hfd, Hbd = Hf.to(dev), Hb.to(dev)
+        xs = [s_ for j in range(5) for s_ in (Src(Hfd, img_off=j), Src(Hbd, img_off=j))]
+        ys, shape = [Src(dy.to(dev), nch=128)], (129, 645, 3, 3)
+        g640, rb128 = ref_wgrad(torch.cat([torch.cat([n64(Hf[j:j + B]), n64(Hb[j:j + B])], 1) for j in range(5)], 1), n64(dy[..., :128]), 128, 640)
+        hidx = [j * 129 + c for j in range(5) for c in range(128)]
+        rw, rb = torch.zeros(shape, dtype=torch.float64), torch.zeros(129, dtype=torch.float64)
+        rw[:128, hidx], rb[:128] = g640, rb128
+    else:
+        plan = P.r2_wgrad_h
+        r1, dy = R(B, H, W, 132), R(B, H, W, 64)
+        xs, ys, shape = [Src(r1.to(dev), nch=128)], [Src(dy.to(dev))], (64, 129, 3, 3)
+        g128, rb = ref_wgrad(n64(r1[..., :128]), n64(dy), 64, 128)
+        rw = torch.zeros(shape, dtype=torch.float64)
+        rw[:, :128] = g128
+        hidx = None
+    base_w, base_b = (R(*shape), R(shape[0])) if accumulate else (torch.zeros(shape), torch.zeros(shape[0]))
+    dw, db = base_w.clone().to(dev), base_b.clone().to(dev)
+    calls = []
+    orig = ops.lib.rnh_wino44f_wgrad
+    monkeypatch.setattr(ops.lib, 'rnh_wino44f_wgrad', lambda *a: calls.append(1) or orig(*a))
+    ops.wgrad(plan, xs, ys, B, H, W, dw, db, accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert calls, 'the call did not take the fused F(4x4)-tile form'
+    if big:
+        # against the F(2x2)-tile kernel (itself held against float64 at smaller sizes, tests/test_hip_parity.py): 1e-4 of the largest value
+        monkeypatch.setenv('RNH_WINO44F_WGRAD', '0')
+        dw2, db2 = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
+        ops.wgrad(plan, xs, ys, B, H, W, dw2, db2)
+        torch.cuda.synchronize()
+        sc = float(dw2.abs().max())
+        assert float((dw - dw2).abs().max()) <= 1e-4 * sc and float((db - db2).abs().max()) <= 1e-4 * float(db2.abs().max())
+        return
+    want_w, want_b = rw + base_w.double(), rb + base_b.double()
+    if which == 'refine1':
+        mask = torch.ones(shape, dtype=torch.bool)
+        mask[:128, hidx] = False
+        assert torch.equal(dw.cpu()[mask], base_w[mask])                       # entries the plan does not map keep what they held
+        want_b[128] = base_b[128]
+    elif which == 'refine2':
+        assert torch.equal(dw.cpu()[:, 128:], base_w[:, 128:])
+    ew = float((dw.cpu().double() - want_w).abs().max())
+    eb = float((db.cpu().double() - want_b).abs().max())
+    assert ew <= 2e-5 * float(want_w.abs().max()) and eb <= 2e-5 * float(want_b.abs().max()), (ew, float(want_w.abs().max()), eb, float(want_b.abs().max()))
