@@ -9,17 +9,20 @@
 // transformed (tools/probes/wino44_wgrad_gemm.hip) and found the materialised transforms - 2.25 x the bytes of both operands through HBM, beside kernels that
 // want the same bandwidth - to cost what the form saves (csrc/wgrad_wino44.hip, opt-in).  Here nothing transformed ever leaves the CU:
 //
-//   workgroup = 16 waves = one 32 (ci) x 64 (co) block of all 36 dU_xi, over a range of tile QUADS (4 tiles side by side = 4 x 16 pixels; K split over
+//   workgroup = 12 waves = one 32 (ci) x 64 (co) block of all 36 dU_xi, over a range of tile QUADS (4 tiles side by side = 4 x 16 pixels; K split over
 //     workgroups, partial sums summed in fixed order by the finish kernel);
-//   12 CONSUMER waves (3 per SIMD): wave = (row pg of the 6x6 transform domain: positions 6 pg .. 6 pg + 5) x (column half): 96 accumulator registers;
-//     per quad and position one ds_read2_b32 per operand and two MFMAs - nothing else;
-//   4 PRODUCER waves (1 per SIMD): two compute V = B^T d B of a quad's four tiles (lane = 2 input channels x tile, so that every transform instruction is a
-//     packed v_pk_*_f32 on two channels: 144 for the 36 positions), two compute Z = A dY A^T (lane = 2 output channels x tile, two passes of 90), each for every
-//     OTHER quad, straight from the raw tensors (buffer_load_dwordx2: 128-byte rows of 32 channels per tile; scalar offsets, no address arithmetic) into the LDS
-//     image of the next quad - [xi][tile][32 channels], the layout in which both the producers' 8-byte writes and the consumers' reads are conflict-free; a
-//     producer requests its raw values in one interval between barriers and transforms them in the next.  ONE barrier per quad (LDS counter only: the requests
-//     stay in flight across it).  What the form costs on this chip: a non-MFMA vector instruction takes ~9 cycles of matrix-core time from the SIMD it is issued
-//     on, WHICHEVER wave issues it (measured: iteration = 36 MFMAs + 8.7 cycles x the transform instructions of the busiest SIMD, profiles/r06_n_*).
+//   8 CONSUMER waves (2 per SIMD): wave = (9 positions of the 6x6 transform domain) x (column half): 144 accumulator registers; per quad and position one
+//     ds_read2_b32 per operand and two MFMAs - nothing else;
+//   4 PRODUCER waves (1 per SIMD), each with TWO register sets of raw values: waves 8 / 11 compute V rows 0-2 / 3-5 of the quad's four tiles (lane = 2 input
+//     channels x tile, so that every transform instruction is a packed v_pk_*_f32 on two channels: 72 for 18 positions), waves 9 / 10 compute Z of tiles 0-1 /
+//     2-3 (lane = 2 output channels x tile: 90 for 36 positions), straight from the raw tensors (buffer_load_dwordx2: 128-byte rows of 32 channels per tile;
+//     scalar offsets, no address arithmetic) into the LDS image of the NEXT quad - [xi][tile][32 channels], the layout in which both the producers' 8-byte writes
+//     and the consumers' reads are conflict-free.  Iteration it requests quad it + 2 into the set that held quad it, then transforms quad it + 1 from the other:
+//     every request is a whole iteration old at its first use.  ONE barrier per quad (LDS counter only: the requests stay in flight across it).
+//   What the form costs on this chip (profiles/r06_n_*): a non-MFMA vector instruction takes ~9 cycles of matrix-core time from the SIMD it is issued on,
+//   WHICHEVER wave issues it - hence the even split of the transforms over the four SIMDs; earlier versions (16 waves, one register set) lost a memory latency
+//   per quad or carried a whole quad's transform on one SIMD.  1.91 ms for the ConvLSTM cell's problem at BASELINE config 2 against 2.37 of the F(2x2)-tile
+//   kernel (matrix instructions alone: 0.95).
 //
 // No border cases: the inputs are first gathered into one zero-padded tensor xp (B, H+2, W+2, Cx) (as rnh_wino_wgrad does).  The bias gradient is the tile sum
 // of dY = Z at position (1, 1), accumulated by the Z producers.  rnh_wino44f_wgrad_supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 in 32-channel
@@ -96,138 +99,141 @@ __device__ __forceinline__ void wf_a4(const f2 v0, const f2 v1, const f2 v2, con
 #endif
 
 // y: the dy tensor at (image offset, first channel); Yc its channels per pixel.  part [S][36][Cx][Cy], bpart [S][Cy / 64][4][64].
-__global__ void __launch_bounds__(1024) wf_wgrad_kernel(const float *__restrict__ xp, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
-                                                        const int H, const int W, const int nquads, const int nper, float *__restrict__ part,
-                                                        float *__restrict__ bpart) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * WF_STAGE];                 // 110 592 bytes
+// 3 waves per SIMD = 168 registers per lane: 144 accumulators + 12 operands in a consumer, two sets of raw values in a producer.
+__global__ void __launch_bounds__(768) wf12_wgrad_kernel(const float *__restrict__ xp, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
+                                                         const int H, const int W, const int nquads, const int nper, float *__restrict__ part,
+                                                         float *__restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * WF_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RT = Cx >> 5, CT = Cy >> 6;
-    const int bid = rnh_xcd_remap((int)blockIdx.x, (int)gridDim.x);                 // (the blocks of one K range share their operands through one L2)
+    const int bid = rnh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int s = bid / (RT * CT), rc = bid - s * RT * CT, rt = rc / CT, ct = rc - rt * CT;
     const int q0 = s * nper, n = max(0, min(nquads, q0 + nper) - q0);
     const int Hp = H + 2, Wp = W + 2, QX = W >> 4, TY = H >> 2;
 
-    if (wave < 12) {
-        // ---------------- consumers ----------------
-        const int pg = wave % 6, ch = wave / 6, l31 = lane & 31, kh = lane >> 5;
-        f16v acc[6];
+    if (wave < 8) {
+        // ---------------- consumers: positions 9 pg .. 9 pg + 8, column half ch ----------------
+        const int pg = wave & 3, ch = wave >> 2, l31 = lane & 31, kh = lane >> 5;
+        f16v acc[9];
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = 0; p < 9; ++p)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
-        const int voff = (6 * pg * 4 + kh) * 32 + l31, zoff = WF_V + ((6 * pg * 2 + ch) * 4 + kh) * 32 + l31;
+        const int voff = (9 * pg * 4 + kh) * 32 + l31, zoff = WF_V + ((9 * pg * 2 + ch) * 4 + kh) * 32 + l31;
         WF_BARRIER();
         for (int it = 0; it < n; ++it) {
             const float *st = sm + (it & 1) * WF_STAGE;
-            float a0[6], a1[6], b0[6], b1[6];
+            // three positions at a time: 12 operand registers beside the 144 accumulators
 #pragma unroll
-            for (int p = 0; p < 6; ++p) {
-                a0[p] = st[voff + p * 128];
-                a1[p] = st[voff + p * 128 + 64];
-                b0[p] = st[zoff + p * 256];
-                b1[p] = st[zoff + p * 256 + 64];
-            }
-            if (!(WF_EXP & 2)) {
+            for (int g = 0; g < 3; ++g) {
+                float a0[3], a1[3], b0[3], b1[3];
 #pragma unroll
-                for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[p], b0[p], acc[p], 0, 0, 0);
+                for (int p = 0; p < 3; ++p) {
+                    a0[p] = st[voff + (3 * g + p) * 128];
+                    a1[p] = st[voff + (3 * g + p) * 128 + 64];
+                    b0[p] = st[zoff + (3 * g + p) * 256];
+                    b1[p] = st[zoff + (3 * g + p) * 256 + 64];
+                }
+                if (!(WF_EXP & 2)) {
 #pragma unroll
-                for (int p = 0; p < 6; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[p], b1[p], acc[p], 0, 0, 0);
-            } else {
+                    for (int p = 0; p < 3; ++p) acc[3 * g + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[p], b0[p], acc[3 * g + p], 0, 0, 0);
 #pragma unroll
-                for (int p = 0; p < 6; ++p) acc[p][0] += a0[p] * b0[p] + a1[p] * b1[p];
+                    for (int p = 0; p < 3; ++p) acc[3 * g + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[p], b1[p], acc[3 * g + p], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) acc[3 * g + p][0] += a0[p] * b0[p] + a1[p] * b1[p];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             WF_BARRIER();
         }
-        // D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
         float *o = part + ((long)s * 36 * Cx + rt * 32) * Cy + ct * 64 + ch * 32 + l31;
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = 0; p < 9; ++p)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[((long)(6 * pg + p) * Cx + (v & 3) + 8 * (v >> 2) + 4 * kh) * Cy] = acc[p][v];
+            for (int v = 0; v < 16; ++v) o[((long)(9 * pg + p) * Cx + (v & 3) + 8 * (v >> 2) + 4 * kh) * Cy] = acc[p][v];
         return;
     }
 
-    // ---------------- producers ----------------
-    // Waves 12 / 15 compute V = B^T d B of a quad's four tiles (lane = (channel pair cp of the block's 32, tile t)), waves 13 / 14 compute Z = A dY A^T (tiles 0-1,
-    // then tiles 2-3: lane = (channel pair cp of the block's 64, tile of the pair)) - each for every OTHER quad (`par`): in one interval between barriers a producer
-    // requests the raw values of its next quad, in the next it transforms them into the LDS image the consumers read the iteration after.  A request is therefore a
-    // whole iteration (>= 36 MFMAs per SIMD) old at its first use - with one register set (128 registers per lane at 16 waves) and every producer working on every
-    // quad, the requests were issued one barrier before their use and every iteration began with a memory latency plus the 47 KB burst through the CU's 64 B/clk L2
-    // port (2.25 ms for the cell's problem against 0.95 for its matrix instructions alone; profiles/r06_n_*).
-    // Barriers: B_0 in front of iteration 0, B_k at the end of iteration k - 1 (k = 1 .. n); the image of quad j must stand at B_j, its raw values are requested in
-    // the interval before B_(j-1).  Every request is issued unconditionally (past the range: the last quad again) so that the register set has ONE definition per
-    // loop body and no copies (hipcc spilled 80-200 registers around a conditional redefinition).
-    const int pr = wave - 12;
-    const int par = (pr == 0 || pr == 1) ? 0 : 1;
-    auto run = [&](auto &&load, auto &&transform) {
+    const int pr = wave - 8;
+    if (pr == 0 || pr == 3) {
+        // ---- V rows 0-2 (patch rows 0..4) / rows 3-5 (patch rows 1..5): lane = (channel pair cp of the block's 32, tile t) ----
+        const int cp = lane & 15, t = lane >> 4, r0 = pr == 3 ? 1 : 0;
+        const int xlane = ((4 * t) * Cx + rt * 32 + 2 * cp) * 4;
+        f2 dA[5][6], dB[5][6];
+        auto load = [&](f2 (&d)[5][6], int q) {
+            const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+            const __amdgpu_buffer_rsrc_t rs = wf_desc(xp + (((long)img * Hp + 4 * ty + r0) * Wp + 16 * tx4) * Cx);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d[i][j] = wf_ld2(rs, xlane, (i * Wp + j) * Cx * 4);
+        };
+        auto transform = [&](f2 (&d)[5][6], float *st) {
+            // three rows of B^T d, column by column, in place (d[0..2][j])
+            if (pr == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const f2 a = d[4][j] - 4.f * d[2][j], b = d[3][j] - 4.f * d[1][j];
+                    d[0][j] = 4.f * d[0][j] - 5.f * d[2][j] + d[4][j];
+                    d[1][j] = a + b;
+                    d[2][j] = a - b;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const f2 c = d[3][j] - d[1][j], e = d[2][j] - d[0][j], r5 = 4.f * d[0][j] - 5.f * d[2][j] + d[4][j];
+                    d[0][j] = c + 2.f * e;
+                    d[1][j] = c - 2.f * e;
+                    d[2][j] = r5;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            float *o = st + (((pr == 3 ? 18 : 0) * 4 + t) * 32) + 2 * cp;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f2 r[6];
+                wf_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 128) = r[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if (n <= 0) {
             WF_BARRIER();
             return;
         }
-        if (par == 0) {
-            load(q0);
-            if (!(WF_EXP & 4)) transform(sm);
-            WF_BARRIER();                                                           // B_0
-            for (int j = 2; j - 1 <= n; j += 2) {
-                if (!((WF_EXP & 1))) load(q0 + min(j, n - 1));
-                WF_BARRIER();                                                       // B_(j-1)
-                if (j > n) break;
-                if (j < n && !(WF_EXP & 4)) transform(sm);                         // (j even: stage 0)
-                WF_BARRIER();                                                       // B_j
-            }
-        } else {
-            load(q0 + min(1, n - 1));
-            WF_BARRIER();                                                           // B_0
-            for (int j = 1; j <= n; j += 2) {
-                if (j < n && !(WF_EXP & 4)) transform(sm + WF_STAGE);               // (j odd: stage 1)
-                WF_BARRIER();                                                       // B_j
-                if (j + 1 > n) break;
-                if (!((WF_EXP & 1))) load(q0 + min(j + 2, n - 1));
-                WF_BARRIER();                                                       // B_(j+1)
-            }
+        load(dA, q0);
+        load(dB, q0 + min(1, n - 1));
+        transform(dA, sm);
+        WF_BARRIER();                                                               // B_0
+        for (int it = 0; it < n; it += 2) {
+            if (!(WF_EXP & 1)) load(dA, q0 + min(it + 2, n - 1));                   // iteration it (even): request quad it + 2, transform quad it + 1 (set B)
+            if (it + 1 < n && !(WF_EXP & 4)) transform(dB, sm + WF_STAGE);
+            WF_BARRIER();                                                           // B_(it+1)
+            if (it + 1 >= n) break;
+            if (!(WF_EXP & 1)) load(dB, q0 + min(it + 3, n - 1));                   // iteration it + 1: request quad it + 3, transform quad it + 2 (set A)
+            if (it + 2 < n && !(WF_EXP & 4)) transform(dA, sm);
+            WF_BARRIER();                                                           // B_(it+2)
         }
-    };
-    if (pr == 0 || pr == 3) {
-        // ---- V: lane = (channel pair cp of the block's 32, tile t of the quad) ----
-        const int cp = lane & 15, t = lane >> 4;
-        const int xlane = ((4 * t) * Cx + rt * 32 + 2 * cp) * 4;                    // this lane's bytes inside the quad's patch rows
-        f2 d[6][6];
-        run([&](int q) {
-                const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
-                const __amdgpu_buffer_rsrc_t rs = wf_desc(xp + (((long)img * Hp + 4 * ty) * Wp + 16 * tx4) * Cx);
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) d[i][j] = wf_ld2(rs, xlane, (i * Wp + j) * Cx * 4);
-            },
-            [&](float *st) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {                                       // B^T d, column by column, in place
-                    f2 r[6];
-                    wf_bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) d[i][j] = r[i];
-                    __builtin_amdgcn_sched_barrier(0);                              // (one column at a time: hipcc otherwise interleaves all six and spills)
-                }
-                float *o = st + t * 32 + 2 * cp;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    f2 r[6];
-                    wf_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 128) = r[j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
         return;
     }
-    // ---- Z: lane = (channel pair cp of the block's 64, tile t of a pair); pass a = tiles 0-1, pass b = tiles 2-3 ----
-    const int cp = lane & 31, t = lane >> 5;
+    // ---- Z of tiles 0-1 (wave 9) / 2-3 (wave 10): lane = (channel pair cp of the block's 64, tile of the pair) ----
+    const int cp = lane & 31, tl = lane >> 5, t = 2 * (pr - 1) + tl;
     const int ylane = ((4 * t) * Yc + ct * 64 + 2 * cp) * 4;
-    f2 ya[4][4], yb[4][4];
+    f2 yA[4][4], yB[4][4];
     f2 bsum = {0.f, 0.f};
-    auto zpass = [&](float *st, f2 (&in)[4][4], int tile) {
-        f2 M[6][4];                                                                 // A dY: column by column
+    auto load = [&](f2 (&d)[4][4], int q) {
+        const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+        const __amdgpu_buffer_rsrc_t rs = wf_desc(y + (((long)img * H + 4 * ty) * W + 16 * tx4) * Yc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = wf_ld2(rs, ylane, (i * W + j) * Yc * 4);
+    };
+    auto transform = [&](f2 (&in)[4][4], float *st) {
+        f2 M[6][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f2 r[6];
@@ -236,35 +242,36 @@ __global__ void __launch_bounds__(1024) wf_wgrad_kernel(const float *__restrict_
             for (int i = 0; i < 6; ++i) M[i][j] = r[i];
             __builtin_amdgcn_sched_barrier(0);
         }
-        float *o = st + WF_V + (((cp >> 4) * 4 + tile) * 32) + 2 * (cp & 15);
+        float *o = st + WF_V + (((cp >> 4) * 4 + t) * 32) + 2 * (cp & 15);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             f2 r[6];
             wf_a4(M[i][0], M[i][1], M[i][2], M[i][3], r);
-            if (i == 1) bsum += r[1];                                               // Z at (1, 1) = the sum of the tile's 16 pixels
+            if (i == 1) bsum += r[1];
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 256) = r[j];
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    run([&](int q) {
-            const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
-            const __amdgpu_buffer_rsrc_t rs = wf_desc(y + (((long)img * H + 4 * ty) * W + 16 * tx4) * Yc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ya[i][j] = wf_ld2(rs, ylane, (i * W + j) * Yc * 4);
-                    yb[i][j] = wf_ld2(rs, ylane, (i * W + j + 8) * Yc * 4);
-                }
-        },
-        [&](float *st) {
-            zpass(st, ya, t);
-            __builtin_amdgcn_sched_barrier(0);
-            zpass(st, yb, 2 + t);
-        });
-    if (rt == 0 && bpart) {                                                         // bias partial sums: [s][ct][2 par + tile lane][64] (each lane: tiles t and 2 + t of its quads)
-        float *o = bpart + (((long)s * CT + ct) * 4 + 2 * par + t) * 64 + 2 * cp;
+    if (n <= 0) {
+        WF_BARRIER();
+    } else {
+        load(yA, q0);
+        load(yB, q0 + min(1, n - 1));
+        transform(yA, sm);
+        WF_BARRIER();
+        for (int it = 0; it < n; it += 2) {
+            if (!(WF_EXP & 1)) load(yA, q0 + min(it + 2, n - 1));
+            if (it + 1 < n && !(WF_EXP & 4)) transform(yB, sm + WF_STAGE);
+            WF_BARRIER();
+            if (it + 1 >= n) break;
+            if (!(WF_EXP & 1)) load(yB, q0 + min(it + 3, n - 1));
+            if (it + 2 < n && !(WF_EXP & 4)) transform(yA, sm);
+            WF_BARRIER();
+        }
+    }
+    if (rt == 0 && bpart) {                                                         // bias partial sums: [s][ct][tile of the quad][64]
+        float *o = bpart + (((long)s * CT + ct) * 4 + t) * 64 + 2 * cp;
         *reinterpret_cast<f2 *>(o) = bsum;
     }
 }
@@ -380,7 +387,7 @@ extern "C" int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args, float *xp, float 
     const rnh_src_t &y = a.ys[0];
     const float *yp = y.ptr + (long)y.img_off * a.H * a.W * y.C + y.c0;
     const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
-    hipLaunchKernelGGL(wf_wgrad_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, xp, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
+    hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xp, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
     RNH_CHECK_LAUNCH("rnh_wino44f_wgrad");
     hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
                        db, accumulate);

@@ -380,6 +380,7 @@ class NetPlans:
                 # ... and its weight gradient (round 4; until then one pixel-contraction GEMM over all C1p rows, 2 % of the fp32 step): the 2*Cl
                 # hidden-state rows in Winograd form, the row of the phase channel (and the pad rows behind it) through the pixel contraction
                 self.r2_wgrad_h = WgradPlan_('refine2.wgrad.h', k2, b2, ws2, [XSeg(2 * Cl, 2 * Cl, 0)], [YSeg(Cl, Cl, 0)])
+                self.r2_wgrad_h.wino44f = not bf                    # (rnh_wino44f_wgrad: 1.81 -> 1.64 ms at BASELINE config 2; refine conv1's is SLOWER in that form: 5.5 -> 7.9)
                 self.r2_wgrad_x = WgradPlan_('refine2.wgrad.x', k2, None, ws2, [XSeg(self.C1p - 2 * Cl, C1 - 2 * Cl, 2 * Cl)], [YSeg(Cl, Cl, 0)])
             self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],
