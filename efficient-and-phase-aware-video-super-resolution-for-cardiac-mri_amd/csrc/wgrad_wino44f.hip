@@ -24,8 +24,10 @@
 //   per quad or carried a whole quad's transform on one SIMD.  1.91 ms for the ConvLSTM cell's problem at BASELINE config 2 against 2.37 of the F(2x2)-tile
 //   kernel (matrix instructions alone: 0.95).
 //
-// No border cases: the inputs are first gathered into one zero-padded tensor xp (B, H+2, W+2, Cx) (as rnh_wino_wgrad does).  The bias gradient is the tile sum
-// of dY = Z at position (1, 1), accumulated by the Z producers.  rnh_wino44f_wgrad_supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 in 32-channel
+// The borders of the 6x6 patches cost no copy and no branch: a V producer reads its 32-channel block straight from the source tensor that holds it (a block
+// never straddles two sources), a patch row above / below the image and the column left / right of it are requested at offset -1 - outside the buffer range,
+// which reads as zero (the convention of conv_wino44.hip; the first version gathered the inputs into a zero-padded copy first: 0.17 ms and 0.25-2.7 GB of
+// workspace per launch).  The bias gradient is the tile sum of dY = Z at position (1, 1), accumulated by the Z producers.  rnh_wino44f_wgrad_supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 in 32-channel
 // multiples, ONE dy source of scale 1 with a multiple of 64 channels, every tensor below 2 GiB.
 #include "rnh_common.h"
 
@@ -48,25 +50,6 @@ __device__ __forceinline__ f2 wf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int sof
 constexpr int WF_V = 36 * 4 * 32;                 // floats of a stage's V image  [xi][tile 4][ci 32]
 constexpr int WF_Z = 36 * 2 * 4 * 32;             // ... and of its Z image       [xi][column half 2][tile 4][co 32]
 constexpr int WF_STAGE = WF_V + WF_Z;             // 13 824 floats = 55 296 bytes; two stages
-
-// one workgroup per padded image row: zero border, interior gathered from the sources (16 bytes per thread) - wgrad_wino.hip's wino_pad_kernel
-__global__ void __launch_bounds__(256) wf_pad_kernel(const rnh_wgrad_args_t P, float *xp, int Cx) {
-    const int H = P.H, W = P.W, Hp = H + 2, Wp = W + 2, C4 = Cx >> 2;
-    const int row = blockIdx.x, b = row / Hp, y = row - b * Hp - 1;
-    float *dst = xp + (long)row * Wp * Cx;
-    const bool inside = (unsigned)y < (unsigned)H;
-    for (int e = threadIdx.x; e < Wp * C4; e += 256) {
-        const int xq = e / C4, c = (e - xq * C4) * 4, x = xq - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (inside && (unsigned)x < (unsigned)W) {
-            int cc = c, s = 0;
-            while (cc >= P.xs[s].nch) cc -= P.xs[s++].nch;
-            const rnh_src_t &S = P.xs[s];
-            v = rnh_ld4(S.ptr + ((((long)b + S.img_off) * H + y) * W + x) * S.C + S.c0 + cc);
-        }
-        rnh_st4(dst + (long)e * 4, v);
-    }
-}
 
 // B^T of F(4x4, 3x3) applied to six values (conv_wino44.hip's bt6)
 __device__ __forceinline__ void wf_bt6(const f2 d0, const f2 d1, const f2 d2, const f2 d3, const f2 d4, const f2 d5, f2 *r) {
@@ -100,7 +83,15 @@ __device__ __forceinline__ void wf_a4(const f2 v0, const f2 v1, const f2 v2, con
 
 // y: the dy tensor at (image offset, first channel); Yc its channels per pixel.  part [S][36][Cx][Cy], bpart [S][Cy / 64][4][64].
 // 3 waves per SIMD = 168 registers per lane: 144 accumulators + 12 operands in a consumer, two sets of raw values in a producer.
-__global__ void __launch_bounds__(768) wf12_wgrad_kernel(const float *__restrict__ xp, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
+struct wf_xsrc {                           // the x source of one 32-channel row block: tensor (at its first image), channels per pixel, first channel of the block
+    const float *ptr;
+    int C, c0;
+};
+struct wf_xsrcs {
+    wf_xsrc blk[RNH_MAX_SRC * 8];          // (up to 16 sources x 256 channels)
+};
+
+__global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
                                                          const int H, const int W, const int nquads, const int nper, float *__restrict__ part,
                                                          float *__restrict__ bpart) {
     __shared__ __attribute__((aligned(16))) float sm[2 * WF_STAGE];
@@ -109,7 +100,7 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const float *__restrict
     const int bid = rnh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int s = bid / (RT * CT), rc = bid - s * RT * CT, rt = rc / CT, ct = rc - rt * CT;
     const int q0 = s * nper, n = max(0, min(nquads, q0 + nper) - q0);
-    const int Hp = H + 2, Wp = W + 2, QX = W >> 4, TY = H >> 2;
+    const int QX = W >> 4, TY = H >> 2;
 
     if (wave < 8) {
         // ---------------- consumers: positions 9 pg .. 9 pg + 8, column half ch ----------------
@@ -159,15 +150,22 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const float *__restrict
     if (pr == 0 || pr == 3) {
         // ---- V rows 0-2 (patch rows 0..4) / rows 3-5 (patch rows 1..5): lane = (channel pair cp of the block's 32, tile t) ----
         const int cp = lane & 15, t = lane >> 4, r0 = pr == 3 ? 1 : 0;
-        const int xlane = ((4 * t) * Cx + rt * 32 + 2 * cp) * 4;
+        const wf_xsrc &X = XS.blk[rt];                                              // (an offset into the kernel-argument segment)
+        const float *xb = X.ptr + X.c0;
+        const int XC = X.C, xlane = ((4 * t) * XC + 2 * cp) * 4;
         f2 dA[5][6], dB[5][6];
         auto load = [&](f2 (&d)[5][6], int q) {
             const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
-            const __amdgpu_buffer_rsrc_t rs = wf_desc(xp + (((long)img * Hp + 4 * ty + r0) * Wp + 16 * tx4) * Cx);
+            // the descriptor starts at the patch's first pixel (4 ty - 1 + r0, 16 tx4 - 1) - possibly in front of the tensor: only pixels inside the image are
+            // ever requested through it; the others at offset -1 (out of range -> zero)
+            const __amdgpu_buffer_rsrc_t rs = wf_desc(xb + (((long)img * H + 4 * ty - 1 + r0) * W + 16 * tx4 - 1) * XC);
+            const int vl = (t == 0 && tx4 == 0) ? -1 : xlane, vr = (t == 3 && tx4 == QX - 1) ? -1 : xlane;
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 5; ++i) {
+                const bool out = (ty == 0 && r0 + i == 0) || (ty == TY - 1 && r0 + i == 5);     // (wave-uniform)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) d[i][j] = wf_ld2(rs, xlane, (i * Wp + j) * Cx * 4);
+                for (int j = 0; j < 6; ++j) d[i][j] = wf_ld2(rs, out ? -1 : (j == 0 ? vl : (j == 5 ? vr : xlane)), (i * W + j) * XC * 4);
+            }
         };
         auto transform = [&](f2 (&d)[5][6], float *st) {
             // three rows of B^T d, column by column, in place (d[0..2][j])
@@ -339,7 +337,7 @@ int wf_check(const rnh_wgrad_args_t &a, WfGeo &g, bool quiet) {
     int Cx = 0;
     for (int i = 0; i < a.nxs; ++i) {
         const rnh_src_t &s = a.xs[i];
-        if (!s.ptr || s.ptr2 || s.scale != 1 || s.nch < 4 || (s.nch & 3) || (s.C & 3) || (s.c0 & 3)) WF_NO("x sources: scale 1, no second operand, channels in fours");
+        if (!s.ptr || s.ptr2 || s.scale != 1 || s.nch < 32 || (s.nch & 31) || (s.C & 1) || (s.c0 & 1)) WF_NO("x sources: scale 1, no second operand, 32-channel multiples");
         Cx += s.nch;
     }
     const rnh_src_t &y = a.ys[0];
@@ -369,7 +367,7 @@ extern "C" int rnh_wino44f_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t
     if (!args || !out3) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad_ws_floats: null argument");
     WfGeo g;
     if (int rc = wf_check(*args, g, false)) return rc;
-    out3[0] = (int64_t)args->B * (args->H + 2) * (args->W + 2) * g.Cx;
+    out3[0] = 4;                                                  // (no padded copy of the inputs since the producers read the sources themselves)
     out3[1] = (int64_t)g.S * 36 * g.Cx * g.Cy;
     out3[2] = (int64_t)g.S * (g.Cy >> 6) * 4 * 64;
     return 0;
@@ -377,17 +375,25 @@ extern "C" int rnh_wino44f_wgrad_ws_floats(const rnh_wgrad_args_t *args, int64_t
 
 extern "C" int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args, float *xp, float *part, float *bpart, const int32_t *rowmap, const int32_t *colmap, int Cin,
                                  float *dw, float *db, int accumulate, void *stream) {
-    if (!args || !xp || !part || !rowmap || !colmap || !dw || Cin < 1 || (db && !bpart)) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad: bad arguments");
+    (void)xp;                                                     // (kept in the signature: ABI 6 was published with it; nothing is written there)
+    if (!args || !part || !rowmap || !colmap || !dw || Cin < 1 || (db && !bpart)) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad: bad arguments");
     const rnh_wgrad_args_t &a = *args;
     WfGeo g;
     if (int rc = wf_check(a, g, false)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wf_pad_kernel, dim3((unsigned)(a.B * (a.H + 2))), dim3(256), 0, st, a, xp, g.Cx);
-    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad(pad)");
+    wf_xsrcs xs;
+    int nb = 0;
+    for (int i = 0; i < a.nxs; ++i)
+        for (int c = 0; c < a.xs[i].nch; c += 32) {
+            if (nb >= RNH_MAX_SRC * 8) RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad: more than %d row blocks", RNH_MAX_SRC * 8);
+            xs.blk[nb].ptr = a.xs[i].ptr + (long)a.xs[i].img_off * a.H * a.W * a.xs[i].C;
+            xs.blk[nb].C = a.xs[i].C;
+            xs.blk[nb++].c0 = a.xs[i].c0 + c;
+        }
     const rnh_src_t &y = a.ys[0];
     const float *yp = y.ptr + (long)y.img_off * a.H * a.W * y.C + y.c0;
     const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
-    hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xp, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
+    hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xs, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
     RNH_CHECK_LAUNCH("rnh_wino44f_wgrad");
     hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
                        db, accumulate);

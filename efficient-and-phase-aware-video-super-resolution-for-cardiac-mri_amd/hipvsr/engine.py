@@ -215,8 +215,8 @@ class RefineNetEngine:
         if fm.cell_dgrad44:
             bwd_t += 2 * sum(nf) * 4 * px * 9
         if (not self.bf16) and H % 4 == 0 and W % 16 == 0 and os.environ.get('RNH_WINO44F_WGRAD', '1') != '0':
-            # the cell's weight gradient in F(4x4)-tile form (rnh_wino44f_wgrad): the zero-padded gathered copy of its inputs over the T frames + the K-split partial sums
-            bwd_t += T * N * (H + 2) * (W + 2) * max(P.lstm[k]['cx'] + P.lstm[k]['second'] for k in P.lstm) * 4 + 64 * 36 * 128 * 256 * 4
+            # the cell's weight gradient in F(4x4)-tile form (rnh_wino44f_wgrad): the K-split partial sums (its inputs are read in place)
+            bwd_t += 64 * 36 * 128 * 256 * 4
         if os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and fm.cells44 and P.pos and P.r1_wino:
             bwd_t += (2 * (T + 2 * hw) * Cl + T * getattr(P, 'r1_cols', 0)) * px * 9 + 64 * w * 36 * 128 * 128 * 4
         # the weight gradients of a stage run beside the next (earlier) stage's backward (engine.backward): until that stage's chains are
