@@ -347,7 +347,7 @@ int wf_check(const rnh_wgrad_args_t &a, WfGeo &g, bool quiet) {
     g.Cx = Cx, g.Cy = y.nch;
     g.nquads = a.B * (a.H >> 2) * (a.W >> 4);
     const int blocks = (Cx >> 5) * (g.Cy >> 6);
-    int S = (256 + blocks - 1) / blocks;                          // one workgroup per CU (16 waves, 108 KB of LDS); at least two quads per workgroup
+    int S = blocks >= 256 ? 1 : 256 / blocks;                     // ONE round of workgroups on the 256 CUs (12 waves, 108 KB of LDS: one per CU); at least two quads each
     if (S > g.nquads / 2) S = g.nquads / 2 > 0 ? g.nquads / 2 : 1;
     if (S > 64) S = 64;
     g.nper = (g.nquads + S - 1) / S;

@@ -325,7 +325,8 @@ class RefineNetEngine:
             if need_grad:
                 names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
                 w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
-                names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else f22w))
+                names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
+                                          (names['cell_wgrad'] if w44f and P.r1_wino else f22w)))
         else:
             names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
         for i, u in enumerate(P.up[:n_up]):

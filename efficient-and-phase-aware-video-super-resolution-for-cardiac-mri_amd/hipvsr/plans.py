@@ -330,7 +330,8 @@ class NetPlans:
                 self.r1_fwd_h.wino44 = Cl % 16 == 0 and (len(hsegs) * Cl) % 32 == 0 and os.environ.get('RNH_WINO44', '1') != '0' and \
                     os.environ.get('RNH_WINO44_REFINE', '1') != '0'
                 self.r1_wgrad_h = WgradPlan_('refine1.wgrad.h', k1, b1, ws1, [sg for sg in xsegs if sg.nch == Cl], [YSeg(C1 - 1, C1 - 1, 0)])
-                self.r1_wgrad_h.wino44w = not bf and Cl == 64          # F(4x4)-tile form (rnh_wino44_wgrad_*): opt-in, RNH_WINO44_WGRAD=1
+                self.r1_wgrad_h.wino44w = not bf and Cl == 64          # F(4x4)-tile form on materialised transforms (rnh_wino44_wgrad_*): opt-in, RNH_WINO44_WGRAD=1
+                self.r1_wgrad_h.wino44f = not bf                        # F(4x4)-tile form, both transforms fused (rnh_wino44f_wgrad): 5.54 -> 4.53 ms at BASELINE config 2
                 self.r1_wgrad_p = WgradPlan_('refine1.wgrad.p', k1, None, ws1, [sg for sg in xsegs if sg.nch == 4], [YSeg(C1 - 1, C1 - 1, 0)])
                 self.r1_dgrad_h = ConvPlan_('refine1.dgrad.h', k1, None, ws1, [KSeg(C1 - 1, C1 - 1, 0, kcoff=j * C1) for j in range(w)],
                                            list(range(2 * Cl)), transposed=True, wino=True)
@@ -380,7 +381,7 @@ class NetPlans:
                 # ... and its weight gradient (round 4; until then one pixel-contraction GEMM over all C1p rows, 2 % of the fp32 step): the 2*Cl
                 # hidden-state rows in Winograd form, the row of the phase channel (and the pad rows behind it) through the pixel contraction
                 self.r2_wgrad_h = WgradPlan_('refine2.wgrad.h', k2, b2, ws2, [XSeg(2 * Cl, 2 * Cl, 0)], [YSeg(Cl, Cl, 0)])
-                self.r2_wgrad_h.wino44f = not bf                    # (rnh_wino44f_wgrad: 1.81 -> 1.64 ms at BASELINE config 2; refine conv1's is SLOWER in that form: 5.5 -> 7.9)
+                self.r2_wgrad_h.wino44f = not bf                    # (rnh_wino44f_wgrad: 1.81 -> 1.55 ms at BASELINE config 2)
                 self.r2_wgrad_x = WgradPlan_('refine2.wgrad.x', k2, None, ws2, [XSeg(self.C1p - 2 * Cl, C1 - 2 * Cl, 2 * Cl)], [YSeg(Cl, Cl, 0)])
             self.r2_fwd = ConvPlan_('refine2.fwd', k2, b2, ws2, [KSeg(self.C1p, C1, 0)], list(range(Cl)))
             self.r2_dgrad = ConvPlan_('refine2.dgrad', k2, None, ws2, [KSeg(Cl, Cl, 0)],

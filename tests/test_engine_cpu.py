@@ -476,7 +476,7 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
         assert all(fm.uses44(eng.plans.lstm[k]['dgrad']) for k in eng.plans.lstm)
         d = fm.describe()
         assert 'F(4x4,3x3)' in d['cell'] and 'F(4x4,3x3)' in d['cell_dgrad'] and 'rnh_wino44_gates_bwd' in d['cell_dgrad'] and d['env_overrides'] == [] and d['paired'] is True
-        assert 'rnh_wino44f_wgrad' in d['cell_wgrad'] and 'F(2x2,3x3)' in d['refine1_wgrad']
+        assert 'rnh_wino44f_wgrad' in d['cell_wgrad'] and 'rnh_wino44f_wgrad' in d['refine1_wgrad']
         # memory_plan reads the same record
         assert eng.memory_plan(n, size, size, t + 12)['forward_transient'] > RefineNetEngine(NetConfig(**orc.exp1_x4_config(**over)), TorchOps('cpu')).memory_plan(n, size, size, t + 12)['forward_transient']
     for name in ('config 2', 'config 5', 'yaml'):
