@@ -55,7 +55,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (the 5 PF headline figure in
 PEAK_HBM_TBS = 8.0
 
 
-def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False, refine44=False, up44=False, refine_dgrad44=False):
+def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False, refine44=False, up44=False, refine_dgrad44=False, cell_dgrad44=False,
+                            cell_wgrad44=False, refine1_wgrad44=False, refine2_wgrad44=False):
     """Conv FLOPs (2*MAC) per LR pixel per sample.  executed=False: the reference's layer-by-layer formulation
      - what its PyTorch step computes and what `step_tflop` reports.  executed=True (x4 only):
     what this implementation issues - the last PixelShuffle conv + final conv (1 198 080 FLOP/LR pixel forward, twice
@@ -71,14 +72,20 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=Fa
         out_f, out_b = 12800, 16384                                           # the whole upsampler IS the collapsed tail (one PixelShuffle stage)
     # fwd, dgrad, wgrad in Winograd F(2x2, 3x3) form; cell44: the forward cell in F(4x4, 3x3) form (rnh_wino44_cell: 36 products per 16 outputs,
     # 1/4 of the direct FLOPs) where the engine selects it (HipOps.wino44_ok)
-    lstm_f, lstm_b = (0.25 if executed and cell44 else w) * 589824, 2 * w * 589824
+    # cell_dgrad44 / cell_wgrad44 (round 6): the cell's data gradient (rnh_wino44_conv on the transformed gate gradients) and its weight gradient
+    # (rnh_wino44f_wgrad: F(4x4)-tile form, both transforms fused) at 1/4 of the direct FLOPs as well
+    lstm_f = (0.25 if executed and cell44 else w) * 589824
+    lstm_b = ((0.25 if executed and cell_dgrad44 else w) + (0.25 if executed and cell_wgrad44 else w)) * 589824
     r1, r2 = 645 * 129 * 18, 129 * 64 * 18                                    # refine conv1 / conv2, 2*MAC per pixel
     r2h, r2x = 128 * 64 * 18, 1 * 64 * 18                                     # conv2: the 128 hidden-state channels / channel 128
     # conv1 in Winograd form (fwd, dgrad, wgrad); conv2 forward and data gradient in Winograd form over its 128 hidden-state
     # channels (channel 128 through the implicit GEMM), its weight gradient as pixel-contraction GEMM (direct)
     # refine44: conv1's forward in F(4x4, 3x3) form (rnh_wino44_conv on the transformed top-layer h')
     # refine_dgrad44: its data gradient likewise (the weight gradient stays in F(2x2)-tile form)
-    ref_f, ref_b = (0.25 if executed and refine44 else w) * r1 + w * r2h + r2x, ((0.25 if executed and refine_dgrad44 else w) + w) * r1 + (w * r2h + r2x) + r2
+    # refine1_wgrad44 / refine2_wgrad44 (round 6): their weight gradients over the hidden-state rows in the fused F(4x4)-tile form
+    ref_f = (0.25 if executed and refine44 else w) * r1 + w * r2h + r2x
+    ref_b = ((0.25 if executed and refine_dgrad44 else w) + (0.25 if executed and refine1_wgrad44 else w)) * r1 + (w * r2h + r2x) + \
+        ((0.25 * r2h + r2x) if executed and refine2_wgrad44 else r2)
     nfr, nwin = S * F, S * (F - 4)            # ConvLSTM frames per direction and refine windows, all stages
     if executed:                              # the last stage stops at the last refine window / computes the T supervised windows only
         nfr, nwin = (S - 1) * F + (U + T + 2), (S - 1) * (F - 4) + T
@@ -380,7 +387,9 @@ def run_case(args, dtype, dev, world, rank):
     # a shape whose F(4x4) cells need the transformed-h' ring
     fm = net._engine().resolve_forms(args.batch, args.size, args.size, args.frames + 12, need_grad=True, capturing=args.graph == 'on')
     cell44, refine44, up44, rd44 = fm.cells44, fm.refine_fwd44, bool(fm.up44 and fm.up44[0]), fm.refine_dgrad44
-    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44, refine_dgrad44=rd44) * args.size * args.size * n_global
+    flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44, refine_dgrad44=rd44,
+                                        cell_dgrad44=fm.cell_dgrad44, cell_wgrad44=fm.cell_wgrad44f, refine1_wgrad44=fm.refine1_wgrad44f,
+                                        refine2_wgrad44=fm.refine2_wgrad44f) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages

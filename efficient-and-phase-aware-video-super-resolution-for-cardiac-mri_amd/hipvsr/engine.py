@@ -311,8 +311,12 @@ class RefineNetEngine:
             cell += " [capture fallback: the F(4x4) form's ring cannot be captured at this shape]"
         # the cell's weight gradient in F(4x4)-tile form with both transforms fused (rnh_wino44f_wgrad) where the kernel takes the call (HipOps.wgrad asks
         # rnh_wino44f_wgrad_supported per call: the cell's sources always qualify, the image must be whole quads of tiles)
-        w44f = bool(hip and not self.bf16 and getattr(pl0['wgrad'], 'wino44f', False) and os.environ.get('RNH_WINO44F_WGRAD', '1') != '0' and
-                    H % 4 == 0 and W % 16 == 0 and os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0')
+        w44f_ok = bool(hip and not self.bf16 and need_grad and os.environ.get('RNH_WINO44F_WGRAD', '1') != '0' and H % 4 == 0 and W % 16 == 0 and
+                       os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_WGRAD', '1') != '0')
+        allw = os.environ.get('RNH_WINO44F_WGRAD') == 'all'
+        w44f = f.cell_wgrad44f = bool(w44f_ok and (allw or getattr(pl0['wgrad'], 'wino44f', False)))
+        f.refine1_wgrad44f = bool(w44f_ok and P.pos and P.r1_wino and (allw or getattr(P.r1_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_WINO44_WGRAD', '0') != '1')
+        f.refine2_wgrad44f = bool(w44f_ok and P.pos and P.r2_wino and (allw or getattr(P.r2_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0')
         f22w = 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)'
         names = dict(cell=cell,
                      cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '') +
@@ -326,7 +330,7 @@ class RefineNetEngine:
                 names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
                 w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
                 names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
-                                          (names['cell_wgrad'] if w44f and P.r1_wino else f22w)))
+                                          ('Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' if f.refine1_wgrad44f else f22w)))
         else:
             names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
         for i, u in enumerate(P.up[:n_up]):
