@@ -322,6 +322,13 @@ __global__ void __launch_bounds__(512, 1) wino44_kernel(const w4_pair PP, const 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, cg = wave >> 2;                                  // quarter of the transform domain, column group
+#ifdef W4_STAGGER
+    // experiment (round 6; never defined in the product build): every other workgroup of the FIRST round starts W4_STAGGER x 64 x 100 cycles late, so that
+    // afterwards half the CUs run their epilogue (stores) while the other half run their main loop
+    if (blockIdx.x < 256 && (blockIdx.x & 8)) {
+        for (int i = 0; i < W4_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     const int bid = rnh_xcd_remap(second ? (int)blockIdx.x - nA : (int)blockIdx.x, MT * NT);                  // (column block fastest: the NT workgroups of a tile block share an L2)
     const int mt = bid / NT, nt = bid - mt * NT;
     const int H = P.H, W = P.W, ntiles = P.B * TY * TX, m0 = mt * W4_TILES, nchunks = P.nchunks;
