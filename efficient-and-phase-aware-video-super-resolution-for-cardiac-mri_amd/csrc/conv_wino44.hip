@@ -9,7 +9,7 @@
 //
 // Unlike conv_wino.hip the input transform is NOT fused into the matrix kernel: with 36 positions a wave's share of the transform domain
 // is 9 positions x 32 tiles x 32 columns = 144 accumulator registers, and the 60 staging registers + 144 transform instructions per chunk
-// that a fused B^T d B needs do not fit beside them.  Instead
+// that a fused B^T d B needs do not fit beside them (docs/HISTORY.md, round 5).  Instead
 //   rnh_wino44_transform  writes V = B^T d B of an NHWC tensor to HBM (2.25 x its bytes; memory-bound, ~20 us per 64-channel tensor of config 2)
 //                         in exactly the order the matrix kernel wants it in LDS; every cell output h is transformed ONCE and read by both of
 //                         its consumers (the same layer's next frame, the next layer's same frame);
