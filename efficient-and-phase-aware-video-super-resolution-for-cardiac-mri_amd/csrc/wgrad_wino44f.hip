@@ -147,6 +147,20 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
     }
 
     const int pr = wave - 8;
+    // the quad a request is for: a cursor (tx4, ty, img) advanced by one per request - no division in the loop - and held at the range's last quad
+    int ctx = q0 % QX, cty = (q0 / QX) % TY, cimg = q0 / (QX * TY), cleft = n;      // (cleft: quads not yet requested, this one included)
+    auto advance = [&]() {
+        if (cleft > 1) {
+            --cleft;
+            if (++ctx == QX) {
+                ctx = 0;
+                if (++cty == TY) {
+                    cty = 0;
+                    ++cimg;
+                }
+            }
+        }
+    };
     if (pr == 0 || pr == 3) {
         // ---- V rows 0-2 (patch rows 0..4) / rows 3-5 (patch rows 1..5): lane = (channel pair cp of the block's 32, tile t) ----
         const int cp = lane & 15, t = lane >> 4, r0 = pr == 3 ? 1 : 0;
@@ -154,8 +168,9 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
         const float *xb = X.ptr + X.c0;
         const int XC = X.C, xlane = ((4 * t) * XC + 2 * cp) * 4;
         f2 dA[5][6], dB[5][6];
-        auto load = [&](f2 (&d)[5][6], int q) {
-            const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+        auto load = [&](f2 (&d)[5][6]) {
+            const int tx4 = ctx, ty = cty, img = cimg;
+            advance();
             // the descriptor starts at the patch's first pixel (4 ty - 1 + r0, 16 tx4 - 1) - possibly in front of the tensor: only pixels inside the image are
             // ever requested through it; the others at offset -1 (out of range -> zero)
             const __amdgpu_buffer_rsrc_t rs = wf_desc(xb + (((long)img * H + 4 * ty - 1 + r0) * W + 16 * tx4 - 1) * XC);
@@ -202,16 +217,16 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
             WF_BARRIER();
             return;
         }
-        load(dA, q0);
-        load(dB, q0 + min(1, n - 1));
+        load(dA);
+        load(dB);
         transform(dA, sm);
         WF_BARRIER();                                                               // B_0
         for (int it = 0; it < n; it += 2) {
-            if (!(WF_EXP & 1)) load(dA, q0 + min(it + 2, n - 1));                   // iteration it (even): request quad it + 2, transform quad it + 1 (set B)
+            if (!(WF_EXP & 1)) load(dA);                                            // iteration it (even): request quad it + 2, transform quad it + 1 (set B)
             if (it + 1 < n && !(WF_EXP & 4)) transform(dB, sm + WF_STAGE);
             WF_BARRIER();                                                           // B_(it+1)
             if (it + 1 >= n) break;
-            if (!(WF_EXP & 1)) load(dB, q0 + min(it + 3, n - 1));                   // iteration it + 1: request quad it + 3, transform quad it + 2 (set A)
+            if (!(WF_EXP & 1)) load(dB);                                            // iteration it + 1: request quad it + 3, transform quad it + 2 (set A)
             if (it + 2 < n && !(WF_EXP & 4)) transform(dA, sm);
             WF_BARRIER();                                                           // B_(it+2)
         }
@@ -222,8 +237,9 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
     const int ylane = ((4 * t) * Yc + ct * 64 + 2 * cp) * 4;
     f2 yA[4][4], yB[4][4];
     f2 bsum = {0.f, 0.f};
-    auto load = [&](f2 (&d)[4][4], int q) {
-        const int tx4 = q % QX, rest = q / QX, ty = rest % TY, img = rest / TY;
+    auto load = [&](f2 (&d)[4][4]) {
+        const int tx4 = ctx, ty = cty, img = cimg;
+        advance();
         const __amdgpu_buffer_rsrc_t rs = wf_desc(y + (((long)img * H + 4 * ty) * W + 16 * tx4) * Yc);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -254,16 +270,16 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
     if (n <= 0) {
         WF_BARRIER();
     } else {
-        load(yA, q0);
-        load(yB, q0 + min(1, n - 1));
+        load(yA);
+        load(yB);
         transform(yA, sm);
         WF_BARRIER();
         for (int it = 0; it < n; it += 2) {
-            if (!(WF_EXP & 1)) load(yA, q0 + min(it + 2, n - 1));
+            if (!(WF_EXP & 1)) load(yA);
             if (it + 1 < n && !(WF_EXP & 4)) transform(yB, sm + WF_STAGE);
             WF_BARRIER();
             if (it + 1 >= n) break;
-            if (!(WF_EXP & 1)) load(yB, q0 + min(it + 3, n - 1));
+            if (!(WF_EXP & 1)) load(yB);
             if (it + 2 < n && !(WF_EXP & 4)) transform(yA, sm);
             WF_BARRIER();
         }
