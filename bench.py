@@ -56,7 +56,7 @@ PEAK_HBM_TBS = 8.0
 
 
 def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=False, refine44=False, up44=False, refine_dgrad44=False, cell_dgrad44=False,
-                            cell_wgrad44=False, refine1_wgrad44=False, refine2_wgrad44=False):
+                            cell_wgrad44=False, refine1_wgrad44=False, refine2_wgrad44=False, up_wgrad44=False):
     """Conv FLOPs (2*MAC) per LR pixel per sample.  executed=False: the reference's layer-by-layer formulation
      - what its PyTorch step computes and what `step_tflop` reports.  executed=True (x4 only):
     what this implementation issues - the last PixelShuffle conv + final conv (1 198 080 FLOP/LR pixel forward, twice
@@ -67,7 +67,8 @@ def step_flops_per_lr_pixel(T, U=6, S=3, L=3, scale=4, executed=False, cell44=Fa
     w = 4.0 / 9.0 if executed else 1.0        # convolutions that run in Winograd form execute 4/9 of their direct FLOPs
     if executed and scale == 4:
         # first PixelShuffle conv: fwd, dgrad, wgrad Winograd (up44: the forward in F(4x4, 3x3) form); tail collapsed
-        out_f, out_b = (0.25 if up44 else w) * 294912 + 51200, 2 * w * 294912 + 65536
+        # (up_wgrad44, round 6: its weight gradient in the fused F(4x4)-tile form)
+        out_f, out_b = (0.25 if up44 else w) * 294912 + 51200, (w + (0.25 if up_wgrad44 else w)) * 294912 + 65536
     elif executed and scale == 2:
         out_f, out_b = 12800, 16384                                           # the whole upsampler IS the collapsed tail (one PixelShuffle stage)
     # fwd, dgrad, wgrad in Winograd F(2x2, 3x3) form; cell44: the forward cell in F(4x4, 3x3) form (rnh_wino44_cell: 36 products per 16 outputs,
@@ -389,7 +390,7 @@ def run_case(args, dtype, dev, world, rank):
     cell44, refine44, up44, rd44 = fm.cells44, fm.refine_fwd44, bool(fm.up44 and fm.up44[0]), fm.refine_dgrad44
     flop_exec = step_flops_per_lr_pixel(args.frames, scale=args.scale, executed=True, cell44=cell44, refine44=refine44, up44=up44, refine_dgrad44=rd44,
                                         cell_dgrad44=fm.cell_dgrad44, cell_wgrad44=fm.cell_wgrad44f, refine1_wgrad44=fm.refine1_wgrad44f,
-                                        refine2_wgrad44=fm.refine2_wgrad44f) * args.size * args.size * n_global
+                                        refine2_wgrad44=fm.refine2_wgrad44f, up_wgrad44=fm.up_wgrad44f) * args.size * args.size * n_global
     if bf:      # direct-form convolutions on bf16 MFMA; only the collapsed tail and the skipped dead cells reduce the work
         flop_exec = step_flops_bf16(args.frames, scale=args.scale) * args.size * args.size * n_global
     # gate recomputation: one more cell launch per cell and supervised frame of the recomputing stages

@@ -28,7 +28,7 @@
 // never straddles two sources), a patch row above / below the image and the column left / right of it are requested at offset -1 - outside the buffer range,
 // which reads as zero (the convention of conv_wino44.hip; the first version gathered the inputs into a zero-padded copy first: 0.17 ms and 0.25-2.7 GB of
 // workspace per launch).  The bias gradient is the tile sum of dY = Z at position (1, 1), accumulated by the Z producers.  rnh_wino44f_wgrad_supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 in 32-channel
-// multiples, ONE dy source of scale 1 with a multiple of 64 channels, every tensor below 2 GiB.
+// multiples, dy sources of one common scale (a scale r gathers the sub-pixel planes of an r x larger tensor: the PixelShuffle convolutions) in 64-channel multiples.
 #include "rnh_common.h"
 
 namespace {
@@ -90,8 +90,16 @@ struct wf_xsrc {                           // the x source of one 32-channel row
 struct wf_xsrcs {
     wf_xsrc blk[RNH_MAX_SRC * 8];          // (up to 16 sources x 256 channels)
 };
+struct wf_ysrc {                           // the dy source of one 64-channel column block: the tensor at (first image, sub-pixel, first channel of the block) and its
+    const float *ptr;                      // strides in floats - a source of scale r gathers every r-th pixel of an r x larger tensor (the pixel-unshuffle of a
+    int pix, row;                          // PixelShuffle convolution's output gradient, reference refine_net.py:199-200)
+    long img;
+};
+struct wf_ysrcs {
+    wf_ysrc blk[RNH_MAX_SRC * 4];
+};
 
-__global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, const int Cx, const float *__restrict__ y, const int Yc, const int Cy,
+__global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, const int Cx, const wf_ysrcs YS, const int Cy,
                                                          const int H, const int W, const int nquads, const int nper, float *__restrict__ part,
                                                          float *__restrict__ bpart) {
     __shared__ __attribute__((aligned(16))) float sm[2 * WF_STAGE];
@@ -234,17 +242,18 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
     }
     // ---- Z of tiles 0-1 (wave 9) / 2-3 (wave 10): lane = (channel pair cp of the block's 64, tile of the pair) ----
     const int cp = lane & 31, tl = lane >> 5, t = 2 * (pr - 1) + tl;
-    const int ylane = ((4 * t) * Yc + ct * 64 + 2 * cp) * 4;
+    const wf_ysrc &Y = YS.blk[ct];
+    const int ypix = Y.pix, yrow = Y.row, ylane = ((4 * t) * ypix + 2 * cp) * 4;
     f2 yA[4][4], yB[4][4];
     f2 bsum = {0.f, 0.f};
     auto load = [&](f2 (&d)[4][4]) {
         const int tx4 = ctx, ty = cty, img = cimg;
         advance();
-        const __amdgpu_buffer_rsrc_t rs = wf_desc(y + (((long)img * H + 4 * ty) * W + 16 * tx4) * Yc);
+        const __amdgpu_buffer_rsrc_t rs = wf_desc(Y.ptr + (long)img * Y.img + (long)(4 * ty) * yrow + (long)(16 * tx4) * ypix);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = wf_ld2(rs, ylane, (i * W + j) * Yc * 4);
+            for (int j = 0; j < 4; ++j) d[i][j] = wf_ld2(rs, ylane, (i * yrow + j * ypix) * 4);
     };
     auto transform = [&](f2 (&in)[4][4], float *st) {
         f2 M[6][4];
@@ -349,18 +358,25 @@ int wf_check(const rnh_wgrad_args_t &a, WfGeo &g, bool quiet) {
         RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad: " msg); \
     } while (0)
     if (a.ntaps != 9 || a.B < 1 || a.H < 4 || a.W < 16 || (a.H & 3) || (a.W & 15)) WF_NO("3x3, H % 4 == 0, W % 16 == 0");
-    if (a.nxs < 1 || a.nxs > RNH_MAX_SRC || a.nys != 1) WF_NO("1..16 x sources, ONE dy source");
+    if (a.nxs < 1 || a.nxs > RNH_MAX_SRC || a.nys < 1 || a.nys > RNH_MAX_SRC) WF_NO("1..16 x sources, 1..16 dy sources");
     int Cx = 0;
     for (int i = 0; i < a.nxs; ++i) {
         const rnh_src_t &s = a.xs[i];
         if (!s.ptr || s.ptr2 || s.scale != 1 || s.nch < 32 || (s.nch & 31) || (s.C & 1) || (s.c0 & 1)) WF_NO("x sources: scale 1, no second operand, 32-channel multiples");
         Cx += s.nch;
     }
-    const rnh_src_t &y = a.ys[0];
-    if (!y.ptr || y.ptr2 || y.scale != 1 || (y.nch & 63) || (y.C & 1) || (y.c0 & 1)) WF_NO("the dy source: scale 1, no second operand, a multiple of 64 channels");
+    int Cy = 0;
+    for (int i = 0; i < a.nys; ++i) {
+        const rnh_src_t &y = a.ys[i];
+        if (!y.ptr || y.ptr2 || y.scale < 1 || y.scale != a.ys[0].scale || y.sub_y < 0 || y.sub_x < 0 || y.sub_y >= y.scale || y.sub_x >= y.scale || y.nch < 64 || (y.nch & 63) ||
+            (y.C & 1) || (y.c0 & 1))
+            WF_NO("dy sources: one common scale, no second operand, 64-channel multiples");
+        Cy += y.nch;
+    }
+    if (Cy > RNH_MAX_SRC * 4 * 64) WF_NO("too many output channels");
     if (Cx & 31) WF_NO("input channels in multiples of 32");
     if ((long)a.B * a.H * a.W >= (1L << 27)) WF_NO("too many pixels");
-    g.Cx = Cx, g.Cy = y.nch;
+    g.Cx = Cx, g.Cy = Cy;
     g.nquads = a.B * (a.H >> 2) * (a.W >> 4);
     const int blocks = (Cx >> 5) * (g.Cy >> 6);
     int S = blocks >= 256 ? 1 : 256 / blocks;                     // ONE round of workgroups on the 256 CUs (12 waves, 108 KB of LDS: one per CU); at least two quads each
@@ -406,10 +422,20 @@ extern "C" int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args, float *xp, float 
             xs.blk[nb].C = a.xs[i].C;
             xs.blk[nb++].c0 = a.xs[i].c0 + c;
         }
-    const rnh_src_t &y = a.ys[0];
-    const float *yp = y.ptr + (long)y.img_off * a.H * a.W * y.C + y.c0;
+    wf_ysrcs ys;
+    nb = 0;
+    for (int i = 0; i < a.nys; ++i) {
+        const rnh_src_t &y = a.ys[i];
+        const long Hs = (long)a.H * y.scale, Ws = (long)a.W * y.scale;
+        for (int c = 0; c < y.nch; c += 64) {
+            ys.blk[nb].ptr = y.ptr + ((long)y.img_off * Hs + y.sub_y) * Ws * y.C + (long)y.sub_x * y.C + y.c0 + c;
+            ys.blk[nb].pix = y.scale * y.C;
+            ys.blk[nb].row = (int)(y.scale * Ws * y.C);
+            ys.blk[nb++].img = Hs * Ws * y.C;
+        }
+    }
     const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
-    hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xs, g.Cx, yp, y.C, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
+    hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xs, g.Cx, ys, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
     RNH_CHECK_LAUNCH("rnh_wino44f_wgrad");
     hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
                        db, accumulate);

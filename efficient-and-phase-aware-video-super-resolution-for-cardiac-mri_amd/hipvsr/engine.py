@@ -317,6 +317,7 @@ class RefineNetEngine:
         w44f = f.cell_wgrad44f = bool(w44f_ok and (allw or getattr(pl0['wgrad'], 'wino44f', False)))
         f.refine1_wgrad44f = bool(w44f_ok and P.pos and P.r1_wino and (allw or getattr(P.r1_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_WINO44_WGRAD', '0') != '1')
         f.refine2_wgrad44f = bool(w44f_ok and P.pos and P.r2_wino and (allw or getattr(P.r2_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0')
+        f.up_wgrad44f = bool(w44f_ok and n_up > 0 and P.C % 64 == 0 and (allw or getattr(P.up[0]['wgrad'], 'wino44f', False)))
         f22w = 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)'
         names = dict(cell=cell,
                      cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '') +
@@ -335,6 +336,8 @@ class RefineNetEngine:
             names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
         for i, u in enumerate(P.up[:n_up]):
             names[f'up{i + 1}_fwd'] = conv_form(u['fwd'], f.up44[i]) + ', PixelShuffle in the store'
+        if n_up and need_grad and not self.bf16:
+            names['up_wgrad'] = 'Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' if f.up_wgrad44f else f22w
         names['tail'] = ('last PixelShuffle conv + final conv collapsed (rnh_uptail_*' + ('_bf16: f16 MFMA, IEEE-half composed weights)' if self.bf16 and n_up and
                          self.storage.get('ys') != 'f32' and ops.uptail_bf16_supported(P.C, P.up[-1]['r'], cfg.out_channels) else ')')) if n_up < len(P.up) else 'rnh_outconv_*'
         f.names = names

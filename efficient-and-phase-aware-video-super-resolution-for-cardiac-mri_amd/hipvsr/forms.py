@@ -57,7 +57,7 @@ def wino44_launch_ok(plan, B, H, W, dst_channels=0):
 class Forms:
     """The resolved forms of one step at (N, H, W, F) - see RefineNetEngine.resolve_forms."""
     __slots__ = ('N', 'H', 'W', 'F', 'T', 'dtype', 'need_grad', 'last_only', 'capturing', 'cells44', 'capture_fallback', 'ring', 'refine_fwd44',
-                 'refine_dgrad44', 'up44', 'cell_dgrad44', 'gates_bwd44', 'cell_dgrad_fused', 'cell_wgrad44f', 'refine1_wgrad44f', 'refine2_wgrad44f', 'recompute', 'paired', 'plans44', 'names')
+                 'refine_dgrad44', 'up44', 'cell_dgrad44', 'gates_bwd44', 'cell_dgrad_fused', 'cell_wgrad44f', 'refine1_wgrad44f', 'refine2_wgrad44f', 'up_wgrad44f', 'recompute', 'paired', 'plans44', 'names')
 
     def uses44(self, plan):
         """Is this plan launched in F(4x4, 3x3) form in this step?"""

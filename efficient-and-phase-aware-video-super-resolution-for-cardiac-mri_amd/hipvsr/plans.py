@@ -421,6 +421,7 @@ class NetPlans:
                              transposed=True, kstride=r * r,
                              wino=os.environ.get('RNH_WINO', '1') != '0' and os.environ.get('RNH_WINO_UP', '1') != '0')
             wgrad = WgradPlan_(f'up{i + 1}.wgrad', wk, bk, ws, [XSeg(C, C, 0)], [YSeg(C, C, ij, r * r) for ij in range(r * r)])
+            wgrad.wino44f = not bf                                   # (rnh_wino44f_wgrad on the r*r gathered sub-pixel planes of the output gradient)
             self.up.append(dict(r=r, fwd=fwd, dgrad=dgrad, wgrad=wgrad))
         self.last_w, self.last_b = f'out_block.conv{len(rs) + 1}.weight', f'out_block.conv{len(rs) + 1}.bias'
         # collapsed tail backward (csrc/uptail.hip): wgrad of the last PixelShuffle conv's input against the expanded

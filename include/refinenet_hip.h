@@ -194,8 +194,9 @@ int rnh_wino_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, const int
 
 /* The same weight gradient in Winograd form F(3x3, 4x4) over 4x4 output tiles with BOTH transforms fused (ABI 6; csrc/wgrad_wino44f.hip): 36 GEMMs over
  * the tiles, 2.25 multiplications per (pixel, ci, co) instead of the 4 of rnh_wino_wgrad - the ConvLSTM cell's weight gradient (autograd of reference
- * src/model/nets/refine_net.py:234-239, :256), refine conv1's and conv2's (:149-151).  Supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 whose
- * channel counts are multiples of 32, ONE dy source of scale 1 with a multiple of 64 channels.  Workspaces (floats): xp (4: unused - the sources are read in
+ * src/model/nets/refine_net.py:234-239, :256), refine conv1's and conv2's (:149-151), the PixelShuffle convolutions' (:199-204).  Supported: 3x3, H % 4 == 0, W % 16 == 0, x sources of scale 1 whose
+ * channel counts are multiples of 32, dy sources of one common scale with channel counts in multiples of 64 (scale r: the pixel-unshuffle gather of a PixelShuffle
+ * convolution's output gradient).  Workspaces (floats): xp (4: unused - the sources are read in
  * place, zero padding by out-of-range buffer offsets), part (K-split partial sums [S][36][Cx][Cy]), bpart (bias partial sums).  Scatter as rnh_wgrad_reduce:
  * dw[(colmap[j] * Cin + rowmap[i]) * 9 + tap], db[colmap[j]]; fixed summation order (deterministic). */
 int rnh_wino44f_wgrad_supported(const rnh_wgrad_args_t *args /* host */);

@@ -701,13 +701,14 @@ def test_refine_conv1_weight_gradient_in_f4x4_tile_form(monkeypatch):
 
 
 @pytest.mark.parametrize('which,B,H,W,accumulate', [('lstm', 3, 8, 16, False), ('lstm', 2, 4, 64, True), ('lstm', 5, 16, 32, False), ('lstm', 1, 12, 48, True),
-                                                     ('refine1', 3, 8, 32, False), ('refine2', 2, 16, 16, True), ('lstm', 14, 128, 128, False)])
+                                                     ('refine1', 3, 8, 32, False), ('refine2', 2, 16, 16, True), ('up', 3, 8, 32, False), ('up', 2, 12, 16, True),
+                                                     ('lstm', 14, 128, 128, False)])
 def test_fused_f4x4_tile_weight_gradient_vs_float64(which, B, H, W, accumulate, monkeypatch):
     """rnh_wino44f_wgrad (round 6, csrc/wgrad_wino44f.hip): the weight gradient in Winograd form F(3x3, 4x4) over 4x4 tiles with both transforms computed
     in the workgroup (producer waves -> LDS -> consumer waves' MFMAs), K split over workgroups, fixed-order finish with G^T . G and the bias gradient
     from Z(1, 1) - against float64 autograd of conv2d (reference refine_net.py:234-239, :149-151 and loss.backward()): the ConvLSTM cell (two 64-channel
     sources a frame apart, 256 columns), refine conv1's hidden-state rows (ten sources with frame offsets, 128 of 132 gradient channels, a scatter into
-    the 645-channel weight) and refine conv2's; one quad per tile row up to several quads and images per workgroup, an odd number of quads, accumulation
+    the 645-channel weight), refine conv2's and the PixelShuffle convolution's (dy = four sub-pixel planes gathered from the 2x larger tensor); one quad per tile row up to several quads and images per workgroup, an odd number of quads, accumulation
     into what the gradient held, entries the plan does not map untouched; the config-2-sized cell launch (14 of its 56 images) against the F(2x2)-tile
     kernel it replaces as well."""
     import torch.nn.functional as F
@@ -741,6 +742,13 @@ def test_fused_f4x4_tile_weight_gradient_vs_float64(which, B, H, W, accumulate, 
         hidx = [j * 129 + c for j in range(5) for c in range(128)]
         rw, rb = torch.zeros(shape, dtype=torch.float64), torch.zeros(129, dtype=torch.float64)
         rw[:128, hidx], rb[:128] = g640, rb128
+    elif which == 'up':
+        # the PixelShuffle convolution: dy gathered from the 2x larger tensor (four sub-pixel planes = four sources of scale 2), strided column map
+        plan = P.up[0]['wgrad']
+        x, bigt = R(B, H, W, 64), R(B, 2 * H, 2 * W, 64)
+        bigd = bigt.to(dev)
+        xs, ys, shape = [Src(x.to(dev))], [Src(bigd, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)], (256, 64, 3, 3)
+        rw, rb = ref_wgrad(n64(x), F.pixel_unshuffle(n64(bigt), 2), 256, 64)
     else:
         plan = P.r2_wgrad_h
         r1, dy = R(B, H, W, 132), R(B, H, W, 64)

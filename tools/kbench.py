@@ -88,8 +88,15 @@ if getattr(u0['fwd'], 'wino44', False):
            2.0 * 3 * TN * H * W * 256 * 576, 3)
     del v0
 del sb0, y0
-# upsampler conv2 at 256x256 (3 branches x T frames)
+# the first PixelShuffle convolution's gradients at 128x128 (what the x4 step runs: the second one is part of the collapsed tail)
 B3 = 3 * TN
+sb1, dy256 = R(B3, H, W, 64), R(B3, 2 * H, 2 * W, 64)
+ys1 = [Src(dy256, scale=2, sub=(ij // 2, ij % 2)) for ij in range(4)]
+dw1u, db1u, dsb = ops.empty(256, 64, 3, 3), ops.empty(256), ops.empty(B3, H, W, 64)
+timeit('up1.dgrad', lambda: ops.conv(u0['dgrad'], ys1, B3, H, W, dsts=[Dst(dsb, 64)]), 2.0 * B3 * H * W * 64 * 2304, 3)
+timeit('up1.wgrad', lambda: ops.wgrad(u0['wgrad'], [Src(sb1)], ys1, B3, H, W, dw1u, db1u), 2.0 * B3 * H * W * 64 * 256 * 9, 3)
+del sb1, dy256, ys1, dsb
+# upsampler conv2 at 256x256 (3 branches x T frames)
 u = P.up[1]
 y1 = R(B3, 2 * H, 2 * W, 64)
 y2 = ops.empty(B3, 4 * H, 4 * W, 64)
