@@ -125,3 +125,16 @@ def test_one_rank_under_torchrun_goes_through_rccl():
     out = _line(r.stdout)
     assert out['n_gpus'] == 1 and out['config']['rccl_world'] == 1 and out['value'] > 0 and out['config']['gates'] == 'stored'
     assert out['config']['rank_ms_per_step_median_min_max'][0] > 0 and 'grad_allreduce_ms_min_max' in out['config']
+
+
+def test_committed_pmc_records_belong_to_the_committed_kernel_sources():
+    """bench.py quotes `roofline.traffic` out of profiles/*_hbm_bytes.json only while the record's sha256 is that of the kernel source it was measured
+    on - a one-line comment edit after the PMC pass silently turns the traffic of the driver's line into null (it happened in round 6).  The records
+    bench.py reads at config 2 (the fp32 headline's F(4x4) cell, the bf16 secondary's cell) must match the tree."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for record, source in (('lstm44_kernel_hbm_bytes.json', 'conv_wino44.hip'), ('lstm_bf16_kernel_hbm_bytes.json', 'conv_bf16.hip')):
+        rec = json.load(open(os.path.join(ROOT, 'profiles', record)))
+        assert rec['kernel_source_sha256'] == bench.kernel_source_sha256(source), f'{record} was measured on another revision of {source}: re-run tools/prof_pmc_*.sh'
+        traffic, src = bench.quoted_traffic(record, source, (8, 128, 128))
+        assert traffic and traffic > rec['algorithmic_bytes_per_launch'] * 0.9 and src['command']
