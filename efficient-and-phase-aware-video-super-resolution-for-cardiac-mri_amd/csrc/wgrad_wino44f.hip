@@ -299,6 +299,238 @@ __global__ void __launch_bounds__(768) wf12_wgrad_kernel(const wf_xsrcs XS, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with the V operand taken from the TRANSFORMED images the forward pass already holds (rnh_wino44f_wgrad_v, ABI 7): the F(4x4)
+// cells and refine conv1 read their inputs in transform-domain form V = B^T d B (rnh_wino44_transform: [tile block][16-channel chunk][xi][tile 32][16]),
+// and where the engine keeps those images until the backward, the V producers' whole job - 30 requests, 72 packed transform instructions, 18 LDS writes per
+// quad and wave, all of them matrix-core time on this chip (see the header) - becomes 18 LDS-DMA requests per quad and workgroup: lane = (position of a
+// pair, tile of the quad, chunk of the block's two, 4-channel piece) lands 16 bytes at LDS offset 16 lane, which IS the consumers' [xi][tile][32 ci] image
+// (the image's piece swizzle is undone in the source offset: one v_xor per quad).  All four producer waves now transform Z: wave = (tile pair) x (rows 0-2 /
+// 3-5 of A dY A^T), ~45 packed instructions + 18 LDS writes each instead of 90 + 36 on two SIMDs.  Three V stages (a DMA for quad it + 2 is issued in
+// iteration it, behind the transform, and waited for - by count - in front of the barrier of iteration it + 1), two Z stages: 129 KB of LDS.
+constexpr int WF_W4_BUF = 36 * 32 * 16;          // floats of one (tile block, chunk) of a transformed image (conv_wino44.hip: W4_BUF)
+constexpr int WFV_Z0 = 3 * WF_V;                 // float offset of the first Z stage
+
+struct wf_vsrc {                                 // the transformed image of one 32-channel row block: frame 0 at its first chunk, floats between frames (signed),
+    const float *v;                              // 16-channel chunks of the image's tensor
+    long frame;
+    int nchunks, pad;
+};
+struct wf_vsrcs {
+    wf_vsrc blk[RNH_MAX_SRC * 8];
+};
+
+__global__ void __launch_bounds__(768) wf12v_wgrad_kernel(const wf_vsrcs VS, const int Cx, const wf_ysrcs YS, const int Cy, const int H, const int W,
+                                                          const int NF, const int nquads, const int nper, float *__restrict__ part,
+                                                          float *__restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) float sm[3 * WF_V + 2 * WF_Z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RT = Cx >> 5, CT = Cy >> 6;
+    const int bid = rnh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int s = bid / (RT * CT), rc = bid - s * RT * CT, rt = rc / CT, ct = rc - rt * CT;
+    const int q0 = s * nper, n = max(0, min(nquads, q0 + nper) - q0);
+    const int QX = W >> 4, TY = H >> 2;
+
+    if (wave < 8) {
+        // ---------------- consumers (as wf12_wgrad_kernel's; V stage it % 3, Z stage it & 1) ----------------
+        const int pg = wave & 3, ch = wave >> 2, l31 = lane & 31, kh = lane >> 5;
+        f16v acc[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+        const int voff = (9 * pg * 4 + kh) * 32 + l31, zoff = WFV_Z0 + ((9 * pg * 2 + ch) * 4 + kh) * 32 + l31;
+        WF_BARRIER();
+        int vs = 0;
+        for (int it = 0; it < n; ++it) {
+            const float *sv = sm + vs * WF_V, *sz = sm + (it & 1) * WF_Z;
+            vs = vs == 2 ? 0 : vs + 1;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a0[p] = sv[voff + (3 * g + p) * 128];
+                    a1[p] = sv[voff + (3 * g + p) * 128 + 64];
+                    b0[p] = sz[zoff + (3 * g + p) * 256];
+                    b1[p] = sz[zoff + (3 * g + p) * 256 + 64];
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acc[3 * g + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[p], b0[p], acc[3 * g + p], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acc[3 * g + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[p], b1[p], acc[3 * g + p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WF_BARRIER();
+        }
+        float *o = part + ((long)s * 36 * Cx + rt * 32) * Cy + ct * 64 + ch * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[((long)(9 * pg + p) * Cx + (v & 3) + 8 * (v >> 2) + 4 * kh) * Cy] = acc[p][v];
+        return;
+    }
+
+    // ---------------- producers: wave 8 + pr = (tile pair tp of the quad) x (row half rh of Z) + a share of the quad's 18 V requests ----------------
+    const int pr = wave - 8, tp = pr & 1, rh = pr >> 1;
+    // the quad a request is for: cursor (tx4, ty, image of the frame, frame), advanced by one per request round, held at the range's last quad
+    int ctx = q0 % QX, cty = (q0 / QX) % TY, cimg = q0 / (QX * TY), cleft = n;
+    int cfn = cimg % NF, cfr = cimg / NF;
+    auto advance = [&]() {
+        if (cleft > 1) {
+            --cleft;
+            if (++ctx == QX) {
+                ctx = 0;
+                if (++cty == TY) {
+                    cty = 0;
+                    ++cimg;
+                    if (++cfn == NF) {
+                        cfn = 0;
+                        ++cfr;
+                    }
+                }
+            }
+        }
+    };
+    const int cp = lane & 31, tl = lane >> 5, t = 2 * tp + tl;
+    const wf_ysrc &Y = YS.blk[ct];
+    const int ypix = Y.pix, yrow = Y.row, ylane = ((4 * t) * ypix + 2 * cp) * 4;
+    const wf_vsrc &VB = VS.blk[rt];
+    const float *vbase = VB.v;
+    const long vframe = VB.frame;
+    const int vnch = VB.nchunks;
+    const bool blocked = !((W >> 2) & 7) && !(TY & 3);
+    // V request lane = (position of the pair, tile, chunk, piece): byte offset inside the (tile block, chunk 0) image of the quad's first tile
+    const int vlane0 = ((lane >> 2) & 1) * (WF_W4_BUF * 4) + (lane >> 5) * 2048 + ((lane >> 3) & 3) * 64 + (lane & 3) * 16;
+    const unsigned sm_lds = (unsigned)(unsigned long long)(&sm[0]);
+    f2 yA[4][4], yB[4][4];
+    f2 bsum = {0.f, 0.f};
+    int qtx = 0, qty = 0, qfn = 0, qfr = 0;                                          // the quad of the current request round
+    // The dy requests are inline asm and so are their waits: hipcc counts only the loads it knows, and with LDS-DMA requests it does not know in the same
+    // queue its own s_waitcnt would sit out requests issued moments ago (vector-memory requests return in order).  Every wait here is the same count: the
+    // 16 dy requests + 5 V requests of the newest request round stay in flight, everything older has landed.
+    typedef int i32x4q __attribute__((ext_vector_type(4)));
+    auto desc = [&](const float *b) {
+        const unsigned long long u = (unsigned long long)b;
+        i32x4q rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+        rs[1] = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+        rs[2] = 0x7fffffff;
+        rs[3] = 0x00020000;
+        return rs;
+    };
+    auto load = [&](f2 (&d)[4][4]) {
+        qtx = ctx, qty = cty, qfn = cfn, qfr = cfr;
+        const int img = cimg;
+        advance();
+        const i32x4q rs = desc(Y.ptr + (long)img * Y.img + (long)(4 * qty) * yrow + (long)(16 * qtx) * ypix);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int so = (i * yrow + j * ypix) * 4;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(d[i][j]) : "v"(ylane), "s"(rs), "s"(so) : "memory");
+            }
+    };
+    // (every producer wave issues FIVE V requests per quad - waves 2 and 3 request the last position pair once more - so that every wait is the same
+    // instruction: with two counts behind an if, hipcc merged the tied registers of the two asm statements through copies placed in FRONT of one of them)
+    auto landed = [&](f2 (&d)[4][4]) {                                              // the set's values are there (the wait is tied to the registers it guards)
+        asm volatile("s_waitcnt vmcnt(21)" : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]), "+v"(d[1][2]), "+v"(d[1][3])::"memory");
+        asm volatile("" : "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[2][2]), "+v"(d[2][3]), "+v"(d[3][0]), "+v"(d[3][1]), "+v"(d[3][2]), "+v"(d[3][3])::"memory");
+    };
+    auto older_landed = [&]() { asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); };
+    // the V requests of the quad `load` was last called for, into V stage vst: this wave's position pairs pr, pr + 4, ...
+    auto dma = [&](int vst) {
+        const int TXt = W >> 2;
+        int tq;                                                                     // tile index (in its frame) of the quad's first tile
+        if (blocked) {
+            const int bpr = TXt >> 3, tx = 4 * qtx;
+            tq = qfn * TXt * TY + (((qty >> 2) * bpr + (tx >> 3)) << 5) + ((qty & 3) << 3) + (tx & 7);
+        } else {
+            tq = (qfn * TY + qty) * TXt + 4 * qtx;
+        }
+        const i32x4q rs = desc(vbase + (long)qfr * vframe + (long)(tq >> 5) * vnch * WF_W4_BUF + (tq & 31) * 16);
+        const int voff = vlane0 ^ ((((tq & 31) >> 2) & 3) << 4);
+        const unsigned l0 = sm_lds + vst * (WF_V * 4);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int pp = min(pr + 4 * p, 17);                                     // (wave-uniform; waves 2, 3: pair 17 again - the same bytes to the same place)
+            const unsigned ld = __builtin_amdgcn_readfirstlane(l0 + pp * 1024);
+            const int so = __builtin_amdgcn_readfirstlane(pp * 4096);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ld), "v"(voff), "s"(rs), "s"(so) : "memory");
+        }
+    };
+    auto transform = [&](f2 (&in)[4][4], float *sz) {
+        f2 M[3][4];
+        if (rh == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2 sa = in[0][j] + in[2][j], ua = in[1][j] + in[3][j];
+                M[0][j] = in[0][j];
+                M[1][j] = sa + ua;
+                M[2][j] = sa - ua;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2 c = in[0][j] + 4.f * in[2][j], dd = 2.f * (in[1][j] + 4.f * in[3][j]);
+                M[0][j] = c + dd;
+                M[1][j] = c - dd;
+                M[2][j] = in[3][j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float *o = sz + (((cp >> 4) * 4 + t) * 32) + 2 * (cp & 15) + 18 * rh * 256;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            f2 r[6];
+            wf_a4(M[i][0], M[i][1], M[i][2], M[i][3], r);
+            if (i == 1 && rh == 0) bsum += r[1];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f2 *>(o + (6 * i + j) * 256) = r[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    float *const Z0 = sm + WFV_Z0, *const Z1 = Z0 + WF_Z;
+    if (n <= 0) {
+        WF_BARRIER();
+    } else {
+        load(yA);                                                                   // quad 0
+        dma(0);
+        load(yB);                                                                   // quad 1
+        dma(1);
+        landed(yA);                                                                 // (and quad 0's V requests with it)
+        transform(yA, Z0);
+        WF_BARRIER();                                                               // B_0
+        int vs = 2;                                                                 // V stage of the next request round (quad it + 2)
+        for (int it = 0; it < n; it += 2) {
+            // iteration it (even): request dy of quad it + 2 (set A), transform quad it + 1 (set B), request V of quad it + 2; in front of the barrier that
+            // publishes quad it + 1 its V requests - issued an iteration ago - are waited for
+            load(yA);
+            landed(yB);
+            if (it + 1 < n) transform(yB, Z1);
+            dma(vs);
+            vs = vs == 2 ? 0 : vs + 1;
+            older_landed();
+            WF_BARRIER();
+            if (it + 1 >= n) break;
+            load(yB);
+            landed(yA);
+            if (it + 2 < n) transform(yA, Z0);
+            dma(vs);
+            vs = vs == 2 ? 0 : vs + 1;
+            older_landed();
+            WF_BARRIER();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (no LDS-DMA request outlives the workgroup)
+    }
+    if (rt == 0 && bpart && rh == 0) {                                              // bias partial sums: [s][ct][tile of the quad][64]
+        float *o = bpart + (((long)s * CT + ct) * 4 + t) * 64 + 2 * cp;
+        *reinterpret_cast<f2 *>(o) = bsum;
+    }
+}
+
 // dw[(colmap[j] Cin + rowmap[i]) 9 + 3 p + q] (+)= sum_{a, b} G[a][p] G[b][q] sum_s part[s][6 a + b][i][j];  db[colmap[j]] (+)= sum_s sum_k bpart[s][j / 64][k][j % 64].
 // A workgroup = 64 consecutive (i, j) entries x 4 groups of 9 positions: the K-split sums of a position group by one wave (coalesced 256-byte rows), the four
 // groups meet in LDS, then G^T . G per entry.  Fixed order: deterministic.
@@ -388,6 +620,38 @@ int wf_check(const rnh_wgrad_args_t &a, WfGeo &g, bool quiet) {
 #undef WF_NO
 }
 
+void wf_fill_ysrcs(const rnh_wgrad_args_t &a, wf_ysrcs &ys) {
+    int nb = 0;
+    for (int i = 0; i < a.nys; ++i) {
+        const rnh_src_t &y = a.ys[i];
+        const long Hs = (long)a.H * y.scale, Ws = (long)a.W * y.scale;
+        for (int c = 0; c < y.nch; c += 64) {
+            ys.blk[nb].ptr = y.ptr + ((long)y.img_off * Hs + y.sub_y) * Ws * y.C + (long)y.sub_x * y.C + y.c0 + c;
+            ys.blk[nb].pix = y.scale * y.C;
+            ys.blk[nb].row = (int)(y.scale * Ws * y.C);
+            ys.blk[nb++].img = Hs * Ws * y.C;
+        }
+    }
+}
+
+// the V-operand form: every x source comes with the transformed image of its tensor (all its channels, NF images per frame); source channels in chunk
+// multiples, whole frames
+int wfv_check(const rnh_wgrad_args_t &a, const rnh_wino44_vsrc_t *vs, int NF, bool quiet) {
+#define WFV_NO(msg)                                         \
+    do {                                                    \
+        if (quiet) return 1;                                \
+        RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad_v: " msg); \
+    } while (0)
+    if (!vs || NF < 1 || a.B % NF) WFV_NO("whole frames of NF images");
+    for (int i = 0; i < a.nxs; ++i) {
+        if (!vs[i].v || vs[i].nchunks < 2 || vs[i].nchunks * 16 != a.xs[i].C || (a.xs[i].c0 & 15) || a.xs[i].img_off)
+            WFV_NO("x sources: the transformed image of the whole tensor (nchunks = C / 16), c0 a multiple of 16, img_off 0 (the frame pointer carries it)");
+        if ((vs[i].frame_stride < 0 ? -vs[i].frame_stride : vs[i].frame_stride) >= (1L << 40)) WFV_NO("frame stride");
+    }
+    return 0;
+#undef WFV_NO
+}
+
 }  // namespace
 
 extern "C" int rnh_wino44f_wgrad_supported(const rnh_wgrad_args_t *args) {
@@ -423,22 +687,47 @@ extern "C" int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args, float *xp, float 
             xs.blk[nb++].c0 = a.xs[i].c0 + c;
         }
     wf_ysrcs ys;
-    nb = 0;
-    for (int i = 0; i < a.nys; ++i) {
-        const rnh_src_t &y = a.ys[i];
-        const long Hs = (long)a.H * y.scale, Ws = (long)a.W * y.scale;
-        for (int c = 0; c < y.nch; c += 64) {
-            ys.blk[nb].ptr = y.ptr + ((long)y.img_off * Hs + y.sub_y) * Ws * y.C + (long)y.sub_x * y.C + y.c0 + c;
-            ys.blk[nb].pix = y.scale * y.C;
-            ys.blk[nb].row = (int)(y.scale * Ws * y.C);
-            ys.blk[nb++].img = Hs * Ws * y.C;
-        }
-    }
+    wf_fill_ysrcs(a, ys);
     const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
     hipLaunchKernelGGL(wf12_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, xs, g.Cx, ys, g.Cy, a.H, a.W, g.nquads, g.nper, part, db ? bpart : nullptr);
     RNH_CHECK_LAUNCH("rnh_wino44f_wgrad");
     hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
                        db, accumulate);
     RNH_CHECK_LAUNCH("rnh_wino44f_wgrad(finish)");
+    return 0;
+}
+
+extern "C" int rnh_wino44f_wgrad_v_supported(const rnh_wgrad_args_t *args, const rnh_wino44_vsrc_t *vsrcs, int images_per_frame) {
+    WfGeo g;
+    return args && wf_check(*args, g, true) == 0 && wfv_check(*args, vsrcs, images_per_frame, true) == 0;
+}
+
+extern "C" int rnh_wino44f_wgrad_v(const rnh_wgrad_args_t *args, const rnh_wino44_vsrc_t *vsrcs, int images_per_frame, float *part, float *bpart,
+                                   const int32_t *rowmap, const int32_t *colmap, int Cin, float *dw, float *db, int accumulate, void *stream) {
+    if (!args || !vsrcs || !part || !rowmap || !colmap || !dw || Cin < 1 || (db && !bpart)) RNH_FAIL(RNH_E_ARG, "rnh_wino44f_wgrad_v: bad arguments");
+    const rnh_wgrad_args_t &a = *args;
+    WfGeo g;
+    if (int rc = wf_check(a, g, false)) return rc;
+    if (int rc = wfv_check(a, vsrcs, images_per_frame, false)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    wf_vsrcs vs;
+    int nb = 0;
+    for (int i = 0; i < a.nxs; ++i)
+        for (int c = 0; c < a.xs[i].nch; c += 32) {
+            if (nb >= RNH_MAX_SRC * 8) RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad_v: more than %d row blocks", RNH_MAX_SRC * 8);
+            vs.blk[nb].v = vsrcs[i].v + (long)((a.xs[i].c0 + c) >> 4) * WF_W4_BUF;
+            vs.blk[nb].frame = vsrcs[i].frame_stride;
+            vs.blk[nb].nchunks = vsrcs[i].nchunks;
+            vs.blk[nb++].pad = 0;
+        }
+    wf_ysrcs ys;
+    wf_fill_ysrcs(a, ys);
+    const int blocks = (g.Cx >> 5) * (g.Cy >> 6) * g.S;
+    hipLaunchKernelGGL(wf12v_wgrad_kernel, dim3((unsigned)blocks), dim3(768), 0, st, vs, g.Cx, ys, g.Cy, a.H, a.W, images_per_frame, g.nquads, g.nper, part,
+                       db ? bpart : nullptr);
+    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad_v");
+    hipLaunchKernelGGL(wf_finish_kernel, dim3((unsigned)((long)g.Cx * g.Cy / 64)), dim3(256), 0, st, part, bpart, g.S, g.Cx, g.Cy, rowmap, colmap, Cin, dw,
+                       db, accumulate);
+    RNH_CHECK_LAUNCH("rnh_wino44f_wgrad_v(finish)");
     return 0;
 }

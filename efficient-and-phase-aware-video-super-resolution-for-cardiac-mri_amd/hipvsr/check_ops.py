@@ -271,11 +271,11 @@ class CheckedOps:
         self._check_conv('convolution', plan, xs, B, H, W, dsts, ps, None, before, self._form(plan, True))
 
     # ---- weight gradients -----------------------------------------------------------------------------------------------------------------
-    def wgrad(self, plan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
+    def wgrad(self, plan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False, vsrcs=None, vN=None):
         self._no_capture()
         dw0 = dw.double().clone() if accumulate else None
         db0 = db.double().clone() if accumulate and db is not None else None
-        self.inner.wgrad(plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate=accumulate)
+        self.inner.wgrad(plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate=accumulate, vsrcs=vsrcs, vN=vN)   # (held against the RAW sources below)
         x = torch.cat([self._round(gather_src(s, B), plan) for s in xsrcs], dim=-1).permute(0, 3, 1, 2)
         dy = torch.cat([self._round(gather_src(s, B), plan) for s in ysrcs], dim=-1).permute(0, 3, 1, 2)
         kh = 3 if plan.ntaps == 9 else 1

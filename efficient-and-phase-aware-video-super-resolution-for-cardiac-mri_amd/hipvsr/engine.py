@@ -20,7 +20,7 @@ import os
 from collections import OrderedDict
 
 from . import lib as L
-from .forms import SLOT_FRACTION, Forms, wino44_launch_ok
+from .forms import VKEEP_FRACTION, SLOT_FRACTION, Forms, wino44_launch_ok
 from .plans import Dst, NetPlans, Src
 
 
@@ -205,6 +205,9 @@ class RefineNetEngine:
             # the cells in F(4x4, 3x3) form read transformed inputs, 2.25 x 4 bytes per element: the features of every frame and the h' of every cell -
             # a slot per frame, or a ring of four where that would take more than 8 % of the card (resolve_forms)
             fwd_t += F * px * C * 9 + 2 * (min(F, fm.ring) if fm.ring else F) * sum(nf) * px * 9
+        if fm.wgrad_v:
+            # ... and kept by every stage until its weight gradients have run: they copy their x operand from these images (rnh_wino44f_wgrad_v)
+            kept += S * (F * C + 2 * F * sum(nf)) * px * 9
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
         if fm.up44 and fm.up44[0]:
@@ -246,7 +249,7 @@ class RefineNetEngine:
     def _conv_forms(self, N, H, W, F, need_grad=True, last_only=False, capturing=False):
         """resolve_forms without the gate-memory plan (which itself depends on these forms through memory_plan)."""
         key = (N, H, W, F, bool(need_grad), bool(last_only), bool(capturing), os.environ.get('RNH_WINO44'), os.environ.get('RNH_WINO44_MIN'),
-               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'), os.environ.get('RNH_WINO44_DGRAD'), os.environ.get('RNH_WINO44F_WGRAD'))
+               os.environ.get('RNH_PAIR'), os.environ.get('RNH_FUSE_GATES_BWD'), os.environ.get('RNH_WINO44_WGRAD'), os.environ.get('RNH_WINO44_DGRAD'), os.environ.get('RNH_WINO44F_WGRAD'), os.environ.get('RNH_WINO44F_V'))
         cache = self.__dict__.setdefault('_forms_cache', {})
         if key in cache:
             return cache[key]
@@ -318,12 +321,20 @@ class RefineNetEngine:
         f.refine1_wgrad44f = bool(w44f_ok and P.pos and P.r1_wino and (allw or getattr(P.r1_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_WINO44_WGRAD', '0') != '1')
         f.refine2_wgrad44f = bool(w44f_ok and P.pos and P.r2_wino and (allw or getattr(P.r2_wgrad_h, 'wino44f', False)) and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0')
         f.up_wgrad44f = bool(w44f_ok and n_up > 0 and P.C % 64 == 0 and (allw or getattr(P.up[0]['wgrad'], 'wino44f', False)))
+        # ... with the x operand COPIED from the transformed images the forward's cells and refine conv1 read (rnh_wino44f_wgrad_v) instead of transformed
+        # again - where every frame's image has a slot of its own (no ring) and keeping the images of ALL stages until the backward takes at most
+        # VKEEP_FRACTION of the card (BASELINE config 2: 23.8 GB); the frame in front of the supervised ones must exist (U >= 1)
+        vkeep = cfg.num_stages * (F * P.C + 2 * F * sum(nf)) * N * H * W * 9
+        f.wgrad_v = bool(w44f and cells44 and not f.ring and U >= 1 and hasattr(ops, '_wgrad44f_v') and os.environ.get('RNH_WINO44F_V', '1') != '0' and
+                         bool(total) and vkeep <= VKEEP_FRACTION * total and P.C % 32 == 0 and all(h % 32 == 0 for h in nf))
+        f.refine1_wgrad_v = bool(f.wgrad_v and f.refine1_wgrad44f and f.refine_fwd44)
+        vnote = ", x operand copied from the forward's transformed images (rnh_wino44f_wgrad_v)"
         f22w = 'Winograd F(2x2,3x3) tiles (rnh_wino_wgrad; pixel contraction where it does not take the call)'
         names = dict(cell=cell,
                      cell_dgrad=(conv_form(pl0['dgrad'], f.cell_dgrad44) + (' + the next frame\'s gate backward in its epilogue' if fused else '') +
                                  (', transformed gate gradients written by the gate backward (rnh_wino44_gates_bwd)' if f.gates_bwd44 else '')) if need_grad else None,
                      cell_wgrad=('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
-                                 'Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' if w44f else f22w) if need_grad else None)
+                                 'Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' + (vnote if f.wgrad_v else '') if w44f else f22w) if need_grad else None)
         if P.pos:
             r1p = P.r1_fwd_h if P.r1_wino else (P.r1_fwd_a if getattr(P, 'r1_split', False) else P.r1_fwd)
             names['refine1_fwd'] = conv_form(r1p, f.refine_fwd44) + (' on the cells\' transformed h\'' if f.refine_fwd44 else '')
@@ -331,7 +342,7 @@ class RefineNetEngine:
                 names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
                 w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
                 names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
-                                          ('Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' if f.refine1_wgrad44f else f22w)))
+                                          ('Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' + (vnote if f.refine1_wgrad_v else '') if f.refine1_wgrad44f else f22w)))
         else:
             names['refine1_fwd'] = '1x1 ' + conv_form(P.r1_fwd, False)
         for i, u in enumerate(P.up[:n_up]):
@@ -634,6 +645,9 @@ class RefineNetEngine:
             VT = None
             if use44:
                 VT = {d: VH[d][-1] for d in dirs} if ref44 else None      # the top layer's transformed h', slot = frame - first frame of the direction
+                if need_grad and fm.wgrad_v:
+                    # the weight gradients of this stage copy their x operand from these images (rnh_wino44f_wgrad_v): row of (direction, layer, frame)
+                    st['V44'] = dict(VF=VF, VH=VH, row=lambda d, l, k: slot44(d, l, k if d == 'forward' else F - 1 - k))
                 del VF, VH
             self._mem(f'fwd stage {s}: wavefront done')
             for d in dirs:                                      # the wavefront has passed: only what the backward reads stays
@@ -948,7 +962,11 @@ class RefineNetEngine:
                         ops.put_scalar(grads[b1][P.C1 - 1:P.C1], dbx[0:1], a)
                     elif P.r1_wino:
                         # hidden-state rows in Winograd form; the five phase-plane rows through the pixel-contraction kernel
-                        ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a)
+                        v44 = st.get('V44') if fm.refine1_wgrad_v else None
+                        vs_ = None
+                        if v44 is not None:                  # (the top layer's transformed h' of both directions, rows in frame order)
+                            vs_ = [(v44['VH'][d][-1], v44['row'](d, Lr - 1, U - hw + j), 1) for j in range(w) for d in ('forward', 'backward')]
+                        ops.wgrad(P.r1_wgrad_h, [sc for sc in xs if sc.t is not ctx.P4], ysrc, TN, H, W, grads[k1], grads[b1], accumulate=a, vsrcs=vs_, vN=N)
                         if Cl % 64 == 0 and (P.r1_cols // 4) in (8, 16, 32, 64):
                             # the five phase-plane rows from border-class sums of the gradient (rnh_phase_wgrad)
                             lo, hi = (U - hw) * N, (U - hw + T + w - 1) * N
@@ -1205,8 +1223,16 @@ class RefineNetEngine:
                         wk, bk = pl['wgrad'].wkey, pl['wgrad'].bkey
                         a = acc(wk)
                         acc(bk)
+                        v44 = st.get('V44') if fm.wgrad_v else None
+                        vs_ = None
+                        if v44 is not None:
+                            def vspan(Vt, dd, ll, k0, row=v44['row']):
+                                r0 = row(dd, ll, k0)
+                                return (Vt, r0, (row(dd, ll, k0 + 1) - r0) if T > 1 else 1)
+                            vx = (v44['VF'], U, 1) if l == 0 else vspan(v44['VH'][d][l - 1], d, l - 1, U)
+                            vs_ = [vx, vspan(v44['VH'][d][l], d, l, U - step) if cfg.memory else vx]
                         ops.wgrad(pl['wgrad'], [_span_src(xin, U, T), second], [Src(Gd[d][l])], TN, H, W, grads[wk], grads[bk],
-                                  accumulate=a)
+                                  accumulate=a, vsrcs=vs_, vN=N)
             if defer:
                 for ev in chains_done:
                     ops.wait(ev)

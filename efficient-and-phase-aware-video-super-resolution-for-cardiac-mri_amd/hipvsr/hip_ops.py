@@ -775,7 +775,11 @@ class HipOps:
         mode = os.environ.get('RNH_WINO44F_WGRAD', '1')
         return mode == 'all' or (mode != '0' and bool(getattr(plan, 'wino44f', False)))
 
-    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
+    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False, vsrcs=None, vN=None):
+        """dw (+)= the weight gradient of the plan's convolution over B images.  ``vsrcs`` (optional, one entry per x source): (V, first, step) - the
+        (frames, floats) tensor of transformed images (wino44_v / wino44_transform of the source's WHOLE tensor, ``vN`` images per frame), the row of the
+        frame that holds the launch's first vN images, and the row step per frame (+1 / -1): where the fused F(4x4)-tile kernel takes the call it then copies
+        the x operand from those images instead of transforming the raw tensor again (rnh_wino44f_wgrad_v); otherwise they are ignored."""
         m = self._plan_maps(plan)
         self._chk(dw, db)
         if self._wgrad44(plan, xsrcs, ysrcs, B, H, W, dw, db, accumulate):
@@ -806,6 +810,8 @@ class HipOps:
             xp = self._workspace('wino_xp', sz[0])
             part = self._workspace('w44f_part', sz[1])
             bpart = self._workspace('w44f_bpart', sz[2])
+            if vsrcs is not None and self._wgrad44f_v(plan, a, xsrcs, vsrcs, vN, B, H, W, part, bpart, m, dw, db, accumulate):
+                return
             L.check(self.lib.rnh_wino44f_wgrad(C.byref(a), _ptr(xp), _ptr(part), _ptr(bpart), _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
                                                int(accumulate), self._stream()), f'rnh_wino44f_wgrad({plan.name})')
             return
@@ -833,6 +839,32 @@ class HipOps:
         L.check(self.lib.rnh_wgrad_reduce(_ptr(slab), _ptr(bslab), nsplit, plan.ntaps, plan.xcols_pad, plan.ycols_pad,
                                           _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
                                           int(accumulate), st), f'rnh_wgrad_reduce({plan.name})')
+
+    def _wgrad44f_v(self, plan, a, xsrcs, vsrcs, vN, B, H, W, part, bpart, m, dw, db, accumulate):
+        """The fused F(4x4)-tile weight gradient with its x operand copied from transformed images (rnh_wino44f_wgrad_v); False = the call does not qualify
+        (the caller launches the form that transforms the raw tensors)."""
+        if os.environ.get('RNH_WINO44F_V', '1') == '0' or not vN or len(vsrcs) != len(xsrcs) or B % vN:
+            return False
+        nfr = B // vN
+        vs = (L.Wino44VSrc * len(vsrcs))()
+        keep = []
+        for i, ((V, first, step), sx) in enumerate(zip(vsrcs, xsrcs)):
+            self._chk(V)
+            Cs = sx.t.shape[-1]
+            last = first + step * (nfr - 1)
+            if V.dim() != 2 or V.dtype != torch.float32 or Cs % 16 or not (0 <= first < V.shape[0] and 0 <= last < V.shape[0]) or \
+                    V.shape[1] != int(self.lib.rnh_wino44_v_floats(vN, H, W, Cs)):
+                raise L.HipKernelError(f'{plan.name}: transformed image {i}: a (frames, rnh_wino44_v_floats(vN, H, W, C)) fp32 tensor holding rows {first}..{last}')
+            vs[i].v, vs[i].frame_stride, vs[i].nchunks = V.data_ptr() + first * V.shape[1] * 4, step * V.shape[1], Cs // 16
+            keep.append(a.xs[i].img_off)
+            a.xs[i].img_off = 0                               # (the frame pointer carries it)
+        ok = bool(self.lib.rnh_wino44f_wgrad_v_supported(C.byref(a), vs, vN))
+        if ok:
+            L.check(self.lib.rnh_wino44f_wgrad_v(C.byref(a), vs, vN, _ptr(part), _ptr(bpart), _ptr(m['rowmap']), _ptr(m['colmap']), plan.Cin, _ptr(dw), _ptr(db),
+                                                 int(accumulate), self._stream()), f'rnh_wino44f_wgrad_v({plan.name})')
+        for i, o in enumerate(keep):
+            a.xs[i].img_off = o
+        return ok
 
     # ---- small kernels ------------------------------------------------------------------------------
     def inconv_fwd(self, x, w, b, slope):

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (first: the process must bind ONE HIP runtime - torc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'librefinenet_hip.so')
-ABI_VERSION = 6          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
+ABI_VERSION = 7          # RNH_ABI_VERSION of include/refinenet_hip.h this binding was written against
 
 MAX_SRC, MAX_DST = 16, 4
 EPI_STORE, EPI_PS, EPI_LSTM, EPI_LSTM_BWD = 0, 1, 2, 3
@@ -46,7 +46,8 @@ EXPORTS = ['rnh_conv_igemm', 'rnh_pack_weights', 'rnh_conv_wgrad', 'rnh_wgrad_re
            # gate backward + transform of the gate gradients in one launch (ABI 6)
            'rnh_wino44_gates_bwd_supported', 'rnh_wino44_gates_bwd',
            # weight gradient in F(4x4)-tile Winograd form, both transforms fused (ABI 6)
-           'rnh_wino44f_wgrad_supported', 'rnh_wino44f_wgrad_ws_floats', 'rnh_wino44f_wgrad']
+           'rnh_wino44f_wgrad_supported', 'rnh_wino44f_wgrad_ws_floats', 'rnh_wino44f_wgrad',
+           'rnh_wino44f_wgrad_v_supported', 'rnh_wino44f_wgrad_v']
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -100,6 +101,11 @@ class ConvArgs(C.Structure):
                 ('dst', Dst * MAX_DST), ('ps_r', C.c_int32), ('ps_cq', C.c_int32), ('hd', C.c_int32),
                 ('_pad', C.c_int32), ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
                 ('gates_out', C.c_void_p)]
+
+
+class Wino44VSrc(C.Structure):
+    """rnh_wino44_vsrc_t: the transformed image that stands for one x source of rnh_wino44f_wgrad_v."""
+    _fields_ = [('v', C.c_void_p), ('frame_stride', C.c_int64), ('nchunks', C.c_int32), ('reserved', C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -232,6 +238,8 @@ def load():
     lib.rnh_wino44f_wgrad_supported.argtypes = [vp]
     lib.rnh_wino44f_wgrad_ws_floats.argtypes = [vp, vp]
     lib.rnh_wino44f_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+    lib.rnh_wino44f_wgrad_v_supported.argtypes = [vp, vp, i32]
+    lib.rnh_wino44f_wgrad_v.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.rnh_wino44_pack_weights.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rnh_wino44_cell.argtypes = [C.POINTER(Wino44CellArgs), vp]
     lib.rnh_wino44_cell_pair.argtypes = [C.POINTER(Wino44CellArgs), C.POINTER(Wino44CellArgs), vp]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RNH_ABI_VERSION 6       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16, rnh_wino44_gates_bwd[_supported], rnh_wino44f_wgrad* */
+#define RNH_ABI_VERSION 7       /* 2 (round 4): the argument constraints of rnh_inconv_prelu_bwd / rnh_wgrad_reduce (narrowed in round 3) are part of the contract; 3: + rnh_outconv_fwd_ld; 4 (round 5): + rnh_conv_bf16_pair, rnh_conv_wino_pair; 5: + rnh_wino44_*; 6 (round 6): + rnh_pack_weights_f16, rnh_conv_bf16_args_t.wp_f16 (was padding), rnh_uptail_fwd_bf16 contracts in f16, rnh_wino44_gates_bwd[_supported], rnh_wino44f_wgrad*; 7: + rnh_wino44f_wgrad_v[_supported] */
 
 #define RNH_E_ARG      (-1)   /* null pointer / non-positive size                                  */
 #define RNH_E_ALIGN    (-2)   /* channel count / offset / stride not a multiple of 4               */
@@ -203,6 +203,22 @@ int rnh_wino44f_wgrad_supported(const rnh_wgrad_args_t *args /* host */);
 int rnh_wino44f_wgrad_ws_floats(const rnh_wgrad_args_t *args /* host */, int64_t *out3 /* host: xp, part, bpart */);
 int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, float *part, float *bpart, const int32_t *rowmap, const int32_t *colmap, int Cin,
                       float *dw, float *db, int accumulate, void *stream);
+/* The same launch with its x operand taken from TRANSFORMED images that already exist (ABI 7): the forward's F(4x4) cells and refine conv1 read their
+ * inputs as V = B^T d B (rnh_wino44_transform), and where the caller has kept those images the kernel copies them to LDS (LDS-DMA) instead of transforming the
+ * raw tensor again - on this chip every vector instruction of a transform is matrix-core time.  vsrcs[i] belongs to args->xs[i]: `v` = the transformed image of
+ * the WHOLE tensor (all its C channels: nchunks = C / 16) of the frame that holds the launch's first `images_per_frame` images, frame f (images f *
+ * images_per_frame ...) at v + f * frame_stride floats (signed: the backward direction's frames sit in descending slots); xs[i].c0 (a multiple of 16) and
+ * nch select the channels, xs[i].img_off must be 0, xs[i].ptr is not read (non-null).  args->B a multiple of images_per_frame; the images were transformed
+ * as rnh_wino44_transform(x, C, 0, C, images_per_frame, H, W, ...).  Everything else as rnh_wino44f_wgrad (same workspaces part / bpart, same finish). */
+typedef struct rnh_wino44_vsrc {
+    const float *v;
+    int64_t frame_stride;
+    int32_t nchunks;
+    int32_t reserved;
+} rnh_wino44_vsrc_t;
+int rnh_wino44f_wgrad_v_supported(const rnh_wgrad_args_t *args /* host */, const rnh_wino44_vsrc_t *vsrcs /* host, args->nxs entries */, int images_per_frame);
+int rnh_wino44f_wgrad_v(const rnh_wgrad_args_t *args /* host */, const rnh_wino44_vsrc_t *vsrcs /* host */, int images_per_frame, float *part, float *bpart,
+                        const int32_t *rowmap, const int32_t *colmap, int Cin, float *dw, float *db, int accumulate, void *stream);
 
 /* Sum the partial slabs and scatter into the reference-layout gradient:
  *   dw[(colmap[j]*Cin + rowmap[i])*ntaps + tap] (+)= sum_s slab[s][tap][i][j]   (rowmap/colmap < 0: skipped)

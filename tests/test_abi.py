@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_struct_layout_and_version():
     lib = L.load()
-    assert lib.rnh_abi_version() == L.ABI_VERSION == 6
+    assert lib.rnh_abi_version() == L.ABI_VERSION == 7
     sizes = (ctypes.c_int32 * 4)()
     lib.rnh_struct_sizes(ctypes.byref(sizes))
     assert list(sizes) == [ctypes.sizeof(L.Src), ctypes.sizeof(L.Dst), ctypes.sizeof(L.ConvArgs), ctypes.sizeof(L.WgradArgs)]

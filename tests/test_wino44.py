@@ -785,3 +785,82 @@ def test_fused_f4x4_tile_weight_gradient_vs_float64(which, B, H, W, accumulate, 
     ew = float((dw.cpu().double() - want_w).abs().max())
     eb = float((db.cpu().double() - want_b).abs().max())
     assert ew <= 2e-5 * float(want_w.abs().max()) and eb <= 2e-5 * float(want_b.abs().max()), (ew, float(want_w.abs().max()), eb, float(want_b.abs().max()))
+
+
+@pytest.mark.parametrize('which,vN,nfr,H,W,accumulate', [('lstm', 1, 3, 8, 16, False), ('lstm', 2, 3, 16, 32, True), ('lstm', 3, 2, 12, 48, False), ('lstm', 2, 2, 32, 64, False),
+                                                         ('refine1', 2, 2, 16, 32, False), ('refine1', 1, 3, 8, 32, True), ('lstm', 8, 2, 128, 128, False)])
+def test_fused_f4x4_tile_weight_gradient_from_transformed_images_vs_float64(which, vN, nfr, H, W, accumulate, monkeypatch):
+    """rnh_wino44f_wgrad_v (round 6, ABI 7): the same weight gradient with its x operand copied (LDS-DMA) from the transformed images the forward's F(4x4)
+    cells read (rnh_wino44_transform of vN images per frame) instead of transformed again from the raw tensor - against float64 autograd of conv2d.  The
+    ConvLSTM cell: x from ascending rows, h_{t-1} from DESCENDING rows (the backward direction's slots) of a tensor with more rows than the launch uses;
+    blocked (W % 32 == 0, H % 16 == 0) and linear tile orders, tile blocks that straddle images (vN = 3 at 12 x 48: 36 tiles per image); refine conv1's
+    hidden-state rows: ten sources = five frame offsets into the two directions' images; a config-2-sized frame (8 images of 128 x 128) against the form
+    that transforms the raw tensors (itself held against float64 above)."""
+    import torch.nn.functional as F
+    from hipvsr.hip_ops import HipOps
+    from hipvsr.plans import NetPlans, Src
+    monkeypatch.setenv('RNH_WINO44F_WGRAD', 'all')
+    dev = _dev()
+    P, ops = NetPlans(orc.exp1_x4_config()), HipOps(dev)
+    g = torch.Generator('cpu').manual_seed(vN * 1000 + nfr * 100 + W)
+    R = lambda *sh: torch.randn(*sh, generator=g)                              # noqa: E731
+    n64 = lambda t: t.double().permute(0, 3, 1, 2)                             # noqa: E731
+    B = vN * nfr
+    big = B * H * W > 100000
+
+    def ref_wgrad(x_nchw, dy_nchw, cout, cin):
+        w0 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x_nchw, w0, padding=1).backward(dy_nchw)
+        return w0.grad, dy_nchw.sum(dim=(0, 2, 3))
+
+    def images(t, rows, order):
+        """The (rows, floats) tensor of transformed images of ``t``'s frames: frame f of t lives in row order[f] (the others hold noise)."""
+        V = ops.wino44_v(vN, H, W, t.shape[-1], frames=rows)
+        V.normal_()
+        for f, r in enumerate(order):
+            ops.wino44_transform(Src(t, img_off=f * vN), vN, H, W, V[r])
+        return V
+    if which == 'lstm':
+        plan = P.lstm[('backward', 2)]['wgrad']
+        x, h, dy = R(B, H, W, 64).to(dev), R(B, H, W, 64).to(dev), R(B, H, W, 256)
+        xs, ys, shape = [Src(x), Src(h)], [Src(dy.to(dev))], (256, 128, 3, 3)
+        Vx = images(x, nfr + 2, [1 + f for f in range(nfr)])                   # ascending from row 1
+        Vh = images(h, nfr + 3, [nfr + 1 - f for f in range(nfr)])             # descending from row nfr + 1
+        vsrcs = [(Vx, 1, 1), (Vh, nfr + 1, -1)]
+        rw, rb = (None, None) if big else ref_wgrad(torch.cat([n64(x.cpu()), n64(h.cpu())], 1), n64(dy), 256, 128)
+        hidx = None
+    else:
+        plan = P.r1_wgrad_h
+        Hf, Hb, dy = R(B + 4 * vN, H, W, 64).to(dev), R(B + 4 * vN, H, W, 64).to(dev), R(B, H, W, 132)
+        xs = [s_ for j in range(5) for s_ in (Src(Hf, img_off=j * vN), Src(Hb, img_off=j * vN))]
+        ys, shape = [Src(dy.to(dev), nch=128)], (129, 645, 3, 3)
+        Vf, Vb = images(Hf, nfr + 4, list(range(nfr + 4))), images(Hb, nfr + 4, list(range(nfr + 4)))
+        vsrcs = [v_ for j in range(5) for v_ in ((Vf, j, 1), (Vb, j, 1))]
+        g640, rb128 = ref_wgrad(torch.cat([torch.cat([n64(Hf.cpu()[j * vN:j * vN + B]), n64(Hb.cpu()[j * vN:j * vN + B])], 1) for j in range(5)], 1), n64(dy[..., :128]), 128, 640)
+        hidx = [j * 129 + c for j in range(5) for c in range(128)]
+        rw, rb = torch.zeros(shape, dtype=torch.float64), torch.zeros(129, dtype=torch.float64)
+        rw[:128, hidx], rb[:128] = g640, rb128
+    base_w, base_b = (R(*shape), R(shape[0])) if accumulate else (torch.zeros(shape), torch.zeros(shape[0]))
+    dw, db = base_w.clone().to(dev), base_b.clone().to(dev)
+    calls = []
+    orig = ops.lib.rnh_wino44f_wgrad_v
+    monkeypatch.setattr(ops.lib, 'rnh_wino44f_wgrad_v', lambda *a: calls.append(1) or orig(*a))
+    ops.wgrad(plan, xs, ys, B, H, W, dw, db, accumulate=accumulate, vsrcs=vsrcs, vN=vN)
+    torch.cuda.synchronize()
+    assert calls, 'the call did not take the transformed images'
+    if big:
+        dw2, db2 = torch.zeros(shape, device=dev), torch.zeros(shape[0], device=dev)
+        ops.wgrad(plan, xs, ys, B, H, W, dw2, db2)
+        torch.cuda.synchronize()
+        sc = float(dw2.abs().max())
+        assert float((dw - dw2).abs().max()) <= 2e-5 * sc and float((db - db2).abs().max()) <= 2e-5 * float(db2.abs().max())
+        return
+    want_w, want_b = rw + base_w.double(), rb + base_b.double()
+    if which == 'refine1':
+        mask = torch.ones(shape, dtype=torch.bool)
+        mask[:128, hidx] = False
+        assert torch.equal(dw.cpu()[mask], base_w[mask])
+        want_b[128] = base_b[128]
+    ew = float((dw.cpu().double() - want_w).abs().max())
+    eb = float((db.cpu().double() - want_b).abs().max())
+    assert ew <= 2e-5 * float(want_w.abs().max()) and eb <= 2e-5 * float(want_b.abs().max()), (ew, float(want_w.abs().max()), eb, float(want_b.abs().max()))

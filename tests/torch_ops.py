@@ -152,7 +152,7 @@ class TorchOps:
             if lstm.get('gates_out') is not None:
                 lstm['gates_out'].copy_(torch.cat([gi, gf, go, gg], dim=-1))
 
-    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False):
+    def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False, vsrcs=None, vN=None):
         bf = getattr(plan, 'bf16', False)
         x = torch.cat([self._r(gather_src(s, B), bf) for s in xsrcs], dim=-1).permute(0, 3, 1, 2)
         dy = torch.cat([self._r(gather_src(s, B), bf) for s in ysrcs], dim=-1).permute(0, 3, 1, 2)

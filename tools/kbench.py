@@ -60,6 +60,9 @@ if hasattr(ops, 'wino44_cell') and getattr(pl['full'], 'wino44', False):
     ops.wino44_transform(Src(hp), N, H, W, vh)
     timeit('lstm44.fwd', lambda: ops.wino44_cell(pl['full'], [vx, vh], N, H, W, dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=go)),
            2.0 * N * H * W * 256 * 1152, 20)
+    # the launch class of the frames nobody differentiates (192 of the 318 cell launches of a config-2 step): no 134 MB gate store
+    timeit('lstm44.fwd(no gate store)', lambda: ops.wino44_cell(pl['full'], [vx, vh], N, H, W, dict(hd=64, c_prev=cp, h_out=ho, c_out=co, gates_out=None)),
+           2.0 * N * H * W * 256 * 1152, 20)
     timeit('lstm44.transform', lambda: ops.wino44_transform(Src(hp), N, H, W, vh), 0.0, 20)
 dg = R(N, H, W, 256)
 dx, dh = ops.empty(N, H, W, 64), ops.empty(N, H, W, 64)
@@ -76,6 +79,15 @@ if hasattr(ops, 'wino44_gates_bwd') and getattr(pl['dgrad'], 'wino44', False):
 xs, hs, gd = R(TN + N, H, W, 64), R(TN + N, H, W, 64), R(TN, H, W, 256)
 dw, db = ops.empty(256, 128, 3, 3), ops.empty(256)
 timeit('lstm.wgrad', lambda: ops.wgrad(pl['wgrad'], [Src(xs, img_off=N), Src(hs)], [Src(gd)], TN, H, W, dw, db), 2.0 * TN * H * W * 128 * 256 * 9)
+if hasattr(ops, 'wino44_v') and getattr(pl['wgrad'], 'wino44f', False):
+    # the same launch with its x operand copied from the transformed images the forward's cells read (rnh_wino44f_wgrad_v)
+    T_ = TN // N
+    vxs, vhs = ops.wino44_v(N, H, W, 64, frames=T_ + 1), ops.wino44_v(N, H, W, 64, frames=T_ + 1)
+    for f_ in range(T_ + 1):
+        ops.wino44_transform(Src(xs, img_off=f_ * N), N, H, W, vxs[f_])
+        ops.wino44_transform(Src(hs, img_off=f_ * N), N, H, W, vhs[f_])
+    timeit('lstm.wgrad(x from transformed images)', lambda: ops.wgrad(pl['wgrad'], [Src(xs, img_off=N), Src(hs)], [Src(gd)], TN, H, W, dw, db,
+                                                                     vsrcs=[(vxs, 1, 1), (vhs, 0, 1)], vN=N), 2.0 * TN * H * W * 128 * 256 * 9)
 
 # upsampler conv1 at 128x128 (3 branches x T frames): the PixelShuffle convolution in front of the collapsed tail
 u0 = P.up[0]
