@@ -208,6 +208,8 @@ class RefineNetEngine:
         if fm.wgrad_v:
             # ... and kept by every stage until its weight gradients have run: they copy their x operand from these images (rnh_wino44f_wgrad_v)
             kept += S * (F * C + 2 * F * sum(nf)) * px * 9
+            if fm.up_wgrad44f and fm.up44 and fm.up44[0]:
+                kept += S * 3 * T * px * C * 9                  # (and the first PixelShuffle convolution's transformed input)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
                  4 * T * px * C * ea + (2 * sum(nf) * 6 * px * 4 if n_rc else 0))
         if fm.up44 and fm.up44[0]:
@@ -773,6 +775,8 @@ class RefineNetEngine:
                 Ys = Ys[:-1]                                  # the tail's output is not needed by the collapsed backward
             if need_grad:
                 st['Sb'], st['Ys'] = Sb, Ys
+                if fm.wgrad_v and fm.up_wgrad44f and nb == 3:
+                    st['Vup'] = list(Vup)                       # the PixelShuffle convolutions' transformed inputs (None where a launch ran in another form)
                 ctx.stages.append(st)
 
             # ---- feature update (refine_net.py:118-133), out of place ---------------------------------------
@@ -893,9 +897,10 @@ class RefineNetEngine:
                 a = acc(u['wgrad'].wkey)
                 acc(u['wgrad'].bkey)
                 hold.append(dcur)
+                vup = (st.get('Vup') or [None] * len(P.up))[ui] if fm.wgrad_v else None      # this convolution's input as the forward transformed it
                 with ops.aside('up_w'):
                     ops.wgrad(u['wgrad'], [Src(xin)], ysrcs, 3 * TN, h_in, w_in, grads[u['wgrad'].wkey], grads[u['wgrad'].bkey],
-                              accumulate=a)
+                              accumulate=a, vsrcs=[(vup.view(1, -1), 0, 1)] if vup is not None else None, vN=3 * TN)
                 dnext = ops.empty(3 * TN, h_in, w_in, C, dtype=act)
                 ops.conv(u['dgrad'], ysrcs, 3 * TN, h_in, w_in, dsts=[Dst(dnext, C)])
                 dcur = dnext
