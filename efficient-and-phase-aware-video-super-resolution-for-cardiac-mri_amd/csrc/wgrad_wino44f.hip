@@ -507,18 +507,18 @@ __global__ void __launch_bounds__(768) wf12v_wgrad_kernel(const wf_vsrcs VS, con
         for (int it = 0; it < n; it += 2) {
             // iteration it (even): request dy of quad it + 2 (set A), transform quad it + 1 (set B), request V of quad it + 2; in front of the barrier that
             // publishes quad it + 1 its V requests - issued an iteration ago - are waited for
-            load(yA);
+            if (!(WF_EXP & 1)) load(yA);                                            // (diagnostic masks: 1 no dy requests, 4 no Z transform, 8 no V requests)
             landed(yB);
-            if (it + 1 < n) transform(yB, Z1);
-            dma(vs);
+            if (it + 1 < n && !(WF_EXP & 4)) transform(yB, Z1);
+            if (!(WF_EXP & 8)) dma(vs);
             vs = vs == 2 ? 0 : vs + 1;
             older_landed();
             WF_BARRIER();
             if (it + 1 >= n) break;
-            load(yB);
+            if (!(WF_EXP & 1)) load(yB);
             landed(yA);
-            if (it + 2 < n) transform(yA, Z0);
-            dma(vs);
+            if (it + 2 < n && !(WF_EXP & 4)) transform(yA, Z0);
+            if (!(WF_EXP & 8)) dma(vs);
             vs = vs == 2 ? 0 : vs + 1;
             older_landed();
             WF_BARRIER();
@@ -530,6 +530,12 @@ __global__ void __launch_bounds__(768) wf12v_wgrad_kernel(const wf_vsrcs VS, con
         *reinterpret_cast<f2 *>(o) = bsum;
     }
 }
+
+// (Measured and not kept, profiles/r06_y_*: the same kernel with 64 (ci) x 32 (co) blocks - Z of 32 columns is half the work, shared by the four producer waves as
+// the four quadrants of A dY A^T, ~30 packed instructions each instead of ~61 - runs in the same time, 1.549 against 1.540 ms: its V image is twice the bytes
+// (36 requests per quad) and all four waves request the whole dy tile.  Diagnostic builds of THIS kernel (-DWF_EXP, masks 1 / 4 / 8 = no dy requests / no Z
+// transform / no V requests): 1.73 -> 1.53 / 1.45 / 1.50 ms, all three off 1.18 - the three cost about the same, and what they cost follows the bytes they bring
+// into the CU (20 KB of V, 32 KB of dy per quad) as much as the instructions they issue.)
 
 // dw[(colmap[j] Cin + rowmap[i]) 9 + 3 p + q] (+)= sum_{a, b} G[a][p] G[b][q] sum_s part[s][6 a + b][i][j];  db[colmap[j]] (+)= sum_s sum_k bpart[s][j / 64][k][j % 64].
 // A workgroup = 64 consecutive (i, j) entries x 4 groups of 9 positions: the K-split sums of a position group by one wave (coalesced 256-byte rows), the four
