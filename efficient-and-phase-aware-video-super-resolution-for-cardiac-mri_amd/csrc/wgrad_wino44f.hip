@@ -650,8 +650,9 @@ int wfv_check(const rnh_wgrad_args_t &a, const rnh_wino44_vsrc_t *vs, int NF, bo
     } while (0)
     if (!vs || NF < 1 || a.B % NF) WFV_NO("whole frames of NF images");
     for (int i = 0; i < a.nxs; ++i) {
-        if (!vs[i].v || vs[i].nchunks < 2 || vs[i].nchunks * 16 != a.xs[i].C || (a.xs[i].c0 & 15) || a.xs[i].img_off)
-            WFV_NO("x sources: the transformed image of the whole tensor (nchunks = C / 16), c0 a multiple of 16, img_off 0 (the frame pointer carries it)");
+        const int rel = a.xs[i].c0 - vs[i].c_first;
+        if (!vs[i].v || vs[i].nchunks < 2 || rel < 0 || (rel & 15) || rel + a.xs[i].nch > vs[i].nchunks * 16 || a.xs[i].img_off)
+            WFV_NO("x sources: channels [c0, c0 + nch) inside the image's [c_first, c_first + 16 nchunks), whole chunks, img_off 0 (the frame pointer carries it)");
         if ((vs[i].frame_stride < 0 ? -vs[i].frame_stride : vs[i].frame_stride) >= (1L << 40)) WFV_NO("frame stride");
     }
     return 0;
@@ -721,7 +722,7 @@ extern "C" int rnh_wino44f_wgrad_v(const rnh_wgrad_args_t *args, const rnh_wino4
     for (int i = 0; i < a.nxs; ++i)
         for (int c = 0; c < a.xs[i].nch; c += 32) {
             if (nb >= RNH_MAX_SRC * 8) RNH_FAIL(RNH_E_RANGE, "rnh_wino44f_wgrad_v: more than %d row blocks", RNH_MAX_SRC * 8);
-            vs.blk[nb].v = vsrcs[i].v + (long)((a.xs[i].c0 + c) >> 4) * WF_W4_BUF;
+            vs.blk[nb].v = vsrcs[i].v + (long)((a.xs[i].c0 - vsrcs[i].c_first + c) >> 4) * WF_W4_BUF;
             vs.blk[nb].frame = vsrcs[i].frame_stride;
             vs.blk[nb].nchunks = vsrcs[i].nchunks;
             vs.blk[nb++].pad = 0;

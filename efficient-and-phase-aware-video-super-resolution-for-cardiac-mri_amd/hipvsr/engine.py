@@ -208,6 +208,8 @@ class RefineNetEngine:
         if fm.wgrad_v:
             # ... and kept by every stage until its weight gradients have run: they copy their x operand from these images (rnh_wino44f_wgrad_v)
             kept += S * (F * C + 2 * F * sum(nf)) * px * 9
+            if fm.refine2_fwd44 and fm.refine2_wgrad44f:
+                kept += S * T * px * 2 * Cl * 9                 # (and R1's hidden-state channels as refine conv2 read them)
             if fm.up_wgrad44f and fm.up44 and fm.up44[0]:
                 kept += S * 3 * T * px * C * 9                  # (and the first PixelShuffle convolution's transformed input)
         bwd_t = (2 * sum(nf) * 4 * T * px * ea + 2 * sum(nf[:-1]) * T * px * ea + 3 * T * px * C * ea * (1 + scale * scale) + (T + 2 * hw) * px * c1p * ea +
@@ -216,6 +218,10 @@ class RefineNetEngine:
             fwd_t += 3 * T * px * C * 9                         # the transformed input of the first PixelShuffle convolution (beside the next stage's wavefront)
         if fm.refine_dgrad44:
             bwd_t += (T + 2 * hw) * px * getattr(P, 'r1_cols', 0) * 9      # the transformed dR1 of refine conv1's data gradient
+        if fm.refine2_fwd44:
+            fwd_t += (F - 2 * hw) * px * 2 * Cl * 9              # R1's hidden-state channels, transformed for refine conv2
+        if fm.refine2_dgrad44:
+            bwd_t += T * px * Cl * 9                            # the transformed dR of refine conv2's data gradient
         # the opt-in forms' scratch (both off by default): the transformed gate gradients of every chain; refine conv1's tile-major operands
         if fm.cell_dgrad44:
             bwd_t += 2 * sum(nf) * 4 * px * 9
@@ -276,6 +282,9 @@ class RefineNetEngine:
         f.refine_fwd44 = bool(r1 and not f.ring and tiles32 and wino44_launch_ok(P.r1_fwd_h, (F - 2 * hw) * N, H, W, dst_channels=P.C1p))
         f.refine_dgrad44 = bool(r1 and need_grad and tiles32 and wino44_launch_ok(P.r1_dgrad_h, (T + 2 * hw) * N, H, W, dst_channels=P.Cl)
                                 and wino44_launch_ok(P.r1_dgrad_h, T * N, H, W, dst_channels=P.Cl))
+        r2 = cells44 and P.pos and getattr(P, 'r2_wino', False)
+        f.refine2_fwd44 = bool(r2 and wino44_launch_ok(P.r2_fwd_h, (F - 2 * hw) * N, H, W, dst_channels=P.Cl) and wino44_launch_ok(P.r2_fwd_h, N, H, W, dst_channels=P.Cl))
+        f.refine2_dgrad44 = bool(r2 and need_grad and wino44_launch_ok(P.r2_dgrad_h, T * N, H, W, dst_channels=P.C1p))
         nb = (1 if last_only and not need_grad else 3)
         n_up = len(P.up) - 1 if (hasattr(ops, 'uptail_fwd_supported') and ops.uptail_fwd_supported(P.up[-1]['r'], cfg.out_channels)) else len(P.up)
         f.up44 = [bool(cells44 and u['r'] == 2 and wino44_launch_ok(u['fwd'], nb * T * N, H * 2 ** i, W * 2 ** i)) for i, u in enumerate(P.up[:n_up])]
@@ -297,6 +306,10 @@ class RefineNetEngine:
             f.plans44.add(id(P.r1_fwd_h))
         if f.refine_dgrad44:
             f.plans44.add(id(P.r1_dgrad_h))
+        if f.refine2_fwd44:
+            f.plans44.add(id(P.r2_fwd_h))
+        if f.refine2_dgrad44:
+            f.plans44.add(id(P.r2_dgrad_h))
         f.plans44 |= {id(u['fwd']) for u, on in zip(P.up, f.up44) if on}
         if f.cell_dgrad44:
             f.plans44 |= {id(P.lstm[k]['dgrad']) for k in P.lstm}
@@ -340,8 +353,12 @@ class RefineNetEngine:
         if P.pos:
             r1p = P.r1_fwd_h if P.r1_wino else (P.r1_fwd_a if getattr(P, 'r1_split', False) else P.r1_fwd)
             names['refine1_fwd'] = conv_form(r1p, f.refine_fwd44) + (' on the cells\' transformed h\'' if f.refine_fwd44 else '')
+            if getattr(P, 'r2_wino', False):
+                names['refine2_fwd'] = conv_form(P.r2_fwd_h, f.refine2_fwd44)
             if need_grad:
                 names['refine1_dgrad'] = conv_form(P.r1_dgrad_h if P.r1_wino else P.r1_dgrad, f.refine_dgrad44) + ', gather form'
+                if getattr(P, 'r2_wino', False):
+                    names['refine2_dgrad'] = conv_form(P.r2_dgrad_h, f.refine2_dgrad44)
                 w44 = (not self.bf16) and cells44 and os.environ.get('RNH_WINO44_WGRAD', '0') == '1' and P.r1_wino
                 names['refine1_wgrad'] = ('F(4x4)-tile Winograd (rnh_wino44_wgrad_*)' if w44 else ('bf16 MFMA over LDS-DMA rows (rnh_wgrad_bf16)' if self.bf16 else
                                           ('Winograd F(4x4,3x3) tiles, both transforms fused (rnh_wino44f_wgrad)' + (vnote if f.refine1_wgrad_v else '') if f.refine1_wgrad44f else f22w)))
@@ -710,7 +727,17 @@ class RefineNetEngine:
                         # (the small launch stores, the Winograd launch accumulates: the read-modify-write of R then rides in the
                         # MFMA-bound kernel instead of doubling the traffic of the HBM-bound one; a + b = b + a, the bits are the same)
                         ops.conv(P.r2_fwd_x, [Src(R1, c0=2 * Cl, nch=P.C1p - 2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
-                        ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, accumulate=True, img_off=ro)])
+                        if fm.refine2_fwd44:
+                            # (F(4x4, 3x3) form on one transform of R1's 2 Cl hidden-state channels; the supervised windows' image also serves conv2's
+                            # weight gradient in the backward)
+                            VR1 = ops.wino44_v(nw * N, H, W, 2 * Cl)
+                            ops.wino44_transform(Src(R1, nch=2 * Cl), nw * N, H, W, VR1[0])
+                            ops.wino44_conv(P.r2_fwd_h, [(VR1[0], 0)], nw * N, H, W, Dst(R, Cl, accumulate=True, img_off=ro))
+                            if need_grad and a == U - hw and fm.wgrad_v and fm.refine2_wgrad44f:
+                                st['VR1'] = VR1
+                            del VR1
+                        else:
+                            ops.conv(P.r2_fwd_h, [Src(R1, nch=2 * Cl)], nw * N, H, W, dsts=[Dst(R, Cl, accumulate=True, img_off=ro)])
                     else:
                         ops.conv(P.r2_fwd, [Src(R1)], nw * N, H, W, dsts=[Dst(R, Cl, img_off=ro)])
                     if need_grad and a == U - hw:
@@ -928,7 +955,13 @@ class RefineNetEngine:
                 # the T middle frames are written by conv2's data gradient, the window halo on both sides stays zero
                 dR1p = ops.halo_buffer('dR1p', ((T + 2 * hw) * N, H, W, P.C1p), act, hw * N, (hw + T) * N)
                 if P.r2_wino:
-                    ops.conv(P.r2_dgrad_h, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
+                    if fm.refine2_dgrad44:
+                        VdR = ops.wino44_v(TN, H, W, Cl)[0]
+                        ops.wino44_transform(Src(dR), TN, H, W, VdR)
+                        ops.wino44_conv(P.r2_dgrad_h, [(VdR, 0)], TN, H, W, Dst(dR1p, 2 * Cl, img_off=hw * N))
+                        hold.append(VdR)
+                    else:
+                        ops.conv(P.r2_dgrad_h, [Src(dR)], TN, H, W, dsts=[Dst(dR1p, 2 * Cl, img_off=hw * N)])
                     # (the one real column of the rest: a 9-tap, Cl-channel stencil, HBM-bound - not a 64-column GEMM launch)
                     ops.conv_to_column(dR, params[P.r2_fwd.wkey], 2 * Cl, dR1p[hw * N:(hw + T) * N], 2 * Cl, yzero=P.C1p - P.C1)
                 elif P.r1_split:
@@ -948,8 +981,9 @@ class RefineNetEngine:
                     hold += [E, dbx]
                 with ops.aside('refine_w'):                  # the refine block's weight gradients (behind conv2's data gradient above)
                     if P.r2_wino and os.environ.get('RNH_R2_WGRAD_SPLIT', '1') != '0':
+                        vr1 = st.get('VR1') if fm.wgrad_v else None          # (R1's 2 Cl channels as conv2's forward transformed them)
                         ops.wgrad(P.r2_wgrad_h, [Src(st['R1'], nch=2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], grads[P.r2_wgrad.bkey],
-                                  accumulate=a)
+                                  accumulate=a, vsrcs=[(vr1, 0, 1, 2 * Cl, 0)] if vr1 is not None else None, vN=TN)
                         ops.wgrad(P.r2_wgrad_x, [Src(st['R1'], c0=2 * Cl, nch=P.C1p - 2 * Cl)], [Src(dR)], TN, H, W, grads[P.r2_wgrad.wkey], None,
                                   accumulate=a)                     # (its own rows of the gradient: the same store / accumulate mode)
                     else:

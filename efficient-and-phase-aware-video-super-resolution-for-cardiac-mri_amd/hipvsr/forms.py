@@ -15,7 +15,7 @@ SWITCHES = {
     'RNH_DTYPE': 'f32', 'RNH_GATES': 'auto',
     'RNH_WINO': '1', 'RNH_WINO_COLS': '128', 'RNH_WINO_DGRAD': '1', 'RNH_WINO_REFINE': '1', 'RNH_WINO_REFINE2': '1', 'RNH_WINO_UP': '1',
     'RNH_WINO_WGRAD': '1', 'RNH_XCOL': '1', 'RNH_XCOL_M': '1', 'RNH_R1_SPLIT': '1', 'RNH_R2_WGRAD_SPLIT': '1', 'RNH_LSTM_TILE': None,
-    'RNH_WINO44': '1', 'RNH_WINO44_MIN': '1', 'RNH_WINO44_REFINE': '1', 'RNH_WINO44_REFINE_DGRAD': '1', 'RNH_WINO44_UP': '1',
+    'RNH_WINO44': '1', 'RNH_WINO44_MIN': '1', 'RNH_WINO44_REFINE': '1', 'RNH_WINO44_REFINE2': '0', 'RNH_WINO44_REFINE_DGRAD': '1', 'RNH_WINO44_UP': '1',
     'RNH_WINO44_DGRAD': '1', 'RNH_WINO44_WGRAD': '0', 'RNH_WINO44F_WGRAD': '1', 'RNH_WINO44F_V': '1', 'RNH_UP_F16': '1',
     'RNH_PAIR': '1', 'RNH_FUSE_GATES_BWD': '1', 'RNH_FUSE_ANY': None, 'RNH_DEFER_WGRAD': '1', 'RNH_ASIDE': '1', 'RNH_ASIDE_OFF': None,
     'RNH_ASIDE_CAPTURE': '1', 'RNH_ASIDE_DELAY': None, 'RNH_LSTM_STREAMS': 'layer', 'RNH_SHARED_STREAMS': '1', 'RNH_STREAM_TOUCH': None,
@@ -58,7 +58,7 @@ def wino44_launch_ok(plan, B, H, W, dst_channels=0):
 class Forms:
     """The resolved forms of one step at (N, H, W, F) - see RefineNetEngine.resolve_forms."""
     __slots__ = ('N', 'H', 'W', 'F', 'T', 'dtype', 'need_grad', 'last_only', 'capturing', 'cells44', 'capture_fallback', 'ring', 'refine_fwd44',
-                 'refine_dgrad44', 'up44', 'cell_dgrad44', 'gates_bwd44', 'cell_dgrad_fused', 'cell_wgrad44f', 'refine1_wgrad44f', 'refine2_wgrad44f', 'up_wgrad44f', 'wgrad_v', 'refine1_wgrad_v', 'recompute', 'paired', 'plans44', 'names')
+                 'refine_dgrad44', 'refine2_fwd44', 'refine2_dgrad44', 'up44', 'cell_dgrad44', 'gates_bwd44', 'cell_dgrad_fused', 'cell_wgrad44f', 'refine1_wgrad44f', 'refine2_wgrad44f', 'up_wgrad44f', 'wgrad_v', 'refine1_wgrad_v', 'recompute', 'paired', 'plans44', 'names')
 
     def uses44(self, plan):
         """Is this plan launched in F(4x4, 3x3) form in this step?"""

@@ -776,8 +776,8 @@ class HipOps:
         return mode == 'all' or (mode != '0' and bool(getattr(plan, 'wino44f', False)))
 
     def wgrad(self, plan: WgradPlan, xsrcs, ysrcs, B, H, W, dw, db=None, accumulate=False, vsrcs=None, vN=None):
-        """dw (+)= the weight gradient of the plan's convolution over B images.  ``vsrcs`` (optional, one entry per x source): (V, first, step) - the
-        (frames, floats) tensor of transformed images (wino44_v / wino44_transform of the source's WHOLE tensor, ``vN`` images per frame), the row of the
+        """dw (+)= the weight gradient of the plan's convolution over B images.  ``vsrcs`` (optional, one entry per x source): (V, first, step[, C, c_first]) - the
+        (frames, floats) tensor of transformed images (wino44_v / wino44_transform of the source's whole tensor - or of its channels [c_first, c_first + C) -, ``vN`` images per frame), the row of the
         frame that holds the launch's first vN images, and the row step per frame (+1 / -1): where the fused F(4x4)-tile kernel takes the call it then copies
         the x operand from those images instead of transforming the raw tensor again (rnh_wino44f_wgrad_v); otherwise they are ignored."""
         m = self._plan_maps(plan)
@@ -848,14 +848,15 @@ class HipOps:
         nfr = B // vN
         vs = (L.Wino44VSrc * len(vsrcs))()
         keep = []
-        for i, ((V, first, step), sx) in enumerate(zip(vsrcs, xsrcs)):
+        for i, (vsrc, sx) in enumerate(zip(vsrcs, xsrcs)):
+            V, first, step = vsrc[:3]
+            Cs, c_first = (vsrc[3], vsrc[4]) if len(vsrc) > 3 else (sx.t.shape[-1], 0)      # the image holds channels [c_first, c_first + Cs) of the tensor
             self._chk(V)
-            Cs = sx.t.shape[-1]
             last = first + step * (nfr - 1)
             if V.dim() != 2 or V.dtype != torch.float32 or Cs % 16 or not (0 <= first < V.shape[0] and 0 <= last < V.shape[0]) or \
                     V.shape[1] != int(self.lib.rnh_wino44_v_floats(vN, H, W, Cs)):
                 raise L.HipKernelError(f'{plan.name}: transformed image {i}: a (frames, rnh_wino44_v_floats(vN, H, W, C)) fp32 tensor holding rows {first}..{last}')
-            vs[i].v, vs[i].frame_stride, vs[i].nchunks = V.data_ptr() + first * V.shape[1] * 4, step * V.shape[1], Cs // 16
+            vs[i].v, vs[i].frame_stride, vs[i].nchunks, vs[i].c_first = V.data_ptr() + first * V.shape[1] * 4, step * V.shape[1], Cs // 16, c_first
             keep.append(a.xs[i].img_off)
             a.xs[i].img_off = 0                               # (the frame pointer carries it)
         ok = bool(self.lib.rnh_wino44f_wgrad_v_supported(C.byref(a), vs, vN))

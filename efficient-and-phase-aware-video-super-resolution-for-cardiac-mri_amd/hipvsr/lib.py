@@ -105,7 +105,7 @@ class ConvArgs(C.Structure):
 
 class Wino44VSrc(C.Structure):
     """rnh_wino44_vsrc_t: the transformed image that stands for one x source of rnh_wino44f_wgrad_v."""
-    _fields_ = [('v', C.c_void_p), ('frame_stride', C.c_int64), ('nchunks', C.c_int32), ('reserved', C.c_int32)]
+    _fields_ = [('v', C.c_void_p), ('frame_stride', C.c_int64), ('nchunks', C.c_int32), ('c_first', C.c_int32)]
 
 
 class WgradArgs(C.Structure):

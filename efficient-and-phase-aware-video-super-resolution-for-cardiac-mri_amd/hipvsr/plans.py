@@ -376,6 +376,12 @@ class NetPlans:
                 self.r2_fwd_h = ConvPlan_('refine2.fwd.h', k2, b2, ws2, [KSeg(2 * Cl, 2 * Cl, 0)], list(range(Cl)), wino=True)
                 self.r2_fwd_x = ConvPlan_('refine2.fwd.x', k2, None, ws2, [KSeg(self.C1p - 2 * Cl, C1 - 2 * Cl, 2 * Cl)], list(range(Cl)))
                 self.r2_dgrad_h = ConvPlan_('refine2.dgrad.h', k2, None, ws2, [KSeg(Cl, Cl, 0)], list(range(2 * Cl)), transposed=True, wino=True)
+                # conv2's hidden-state part and its data gradient in F(4x4, 3x3) form (rnh_wino44_conv; one transform of R1's 2 Cl channels / of dR each; the
+                # transformed R1 then also serves conv2's weight gradient, rnh_wino44f_wgrad_v): an OPT-IN (RNH_WINO44_REFINE2=1) - parity green, but the step is
+                # the same with it, 238.8 / 239.1 against 238.2 / 239.3 ms at BASELINE config 2 (profiles/r06_y_*): the launches are small and run beside others
+                r2_44 = (not bf) and Cl % 64 == 0 and os.environ.get('RNH_WINO44', '1') != '0' and os.environ.get('RNH_WINO44_REFINE2', '0') == '1'
+                self.r2_fwd_h.wino44 = r2_44
+                self.r2_dgrad_h.wino44 = r2_44
                 self.r2_dgrad_x = ConvPlan_('refine2.dgrad.x', k2, None, ws2, [KSeg(Cl, Cl, 0)],
                                            list(range(2 * Cl, C1)) + [-1] * (self.C1p - C1), transposed=True)
                 # ... and its weight gradient (round 4; until then one pixel-contraction GEMM over all C1p rows, 2 % of the fp32 step): the 2*Cl

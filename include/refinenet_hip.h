@@ -206,15 +206,16 @@ int rnh_wino44f_wgrad(const rnh_wgrad_args_t *args /* host */, float *xp, float 
 /* The same launch with its x operand taken from TRANSFORMED images that already exist (ABI 7): the forward's F(4x4) cells and refine conv1 read their
  * inputs as V = B^T d B (rnh_wino44_transform), and where the caller has kept those images the kernel copies them to LDS (LDS-DMA) instead of transforming the
  * raw tensor again - on this chip every vector instruction of a transform is matrix-core time.  vsrcs[i] belongs to args->xs[i]: `v` = the transformed image of
- * the WHOLE tensor (all its C channels: nchunks = C / 16) of the frame that holds the launch's first `images_per_frame` images, frame f (images f *
- * images_per_frame ...) at v + f * frame_stride floats (signed: the backward direction's frames sit in descending slots); xs[i].c0 (a multiple of 16) and
- * nch select the channels, xs[i].img_off must be 0, xs[i].ptr is not read (non-null).  args->B a multiple of images_per_frame; the images were transformed
- * as rnh_wino44_transform(x, C, 0, C, images_per_frame, H, W, ...).  Everything else as rnh_wino44f_wgrad (same workspaces part / bpart, same finish). */
+ * channels [c_first, c_first + 16 nchunks) of the tensor, of the frame that holds the launch's first `images_per_frame` images, frame f (images f *
+ * images_per_frame ...) at v + f * frame_stride floats (signed: the backward direction's frames sit in descending slots); xs[i].c0 (c0 - c_first a multiple
+ * of 16) and nch select channels inside the image, xs[i].img_off must be 0, xs[i].ptr is not read (non-null).  args->B a multiple of images_per_frame; the
+ * images were transformed as rnh_wino44_transform(x, C, c_first, 16 nchunks, images_per_frame, H, W, ...).  Everything else as rnh_wino44f_wgrad (same
+ * workspaces part / bpart, same finish). */
 typedef struct rnh_wino44_vsrc {
     const float *v;
     int64_t frame_stride;
     int32_t nchunks;
-    int32_t reserved;
+    int32_t c_first;
 } rnh_wino44_vsrc_t;
 int rnh_wino44f_wgrad_v_supported(const rnh_wgrad_args_t *args /* host */, const rnh_wino44_vsrc_t *vsrcs /* host, args->nxs entries */, int images_per_frame);
 int rnh_wino44f_wgrad_v(const rnh_wgrad_args_t *args /* host */, const rnh_wino44_vsrc_t *vsrcs /* host */, int images_per_frame, float *part, float *bpart,

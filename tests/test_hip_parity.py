@@ -652,11 +652,14 @@ def _cfg2_step(n, seed=202):
     return cfg, sd, inputs, targets, pos
 
 
-@pytest.fixture(params=['0', 'force'], ids=['cell_f2x2', 'cell_f4x4'])
+@pytest.fixture(params=['0', 'force', 'force+refine2'], ids=['cell_f2x2', 'cell_f4x4', 'cell_f4x4_refine2_f4x4'])
 def cell_form(request, monkeypatch):
     """The two forms of the fp32 ConvLSTM cell forward: Winograd F(2x2, 3x3) (rnh_conv_wino; RNH_WINO44=0) and F(4x4, 3x3) (rnh_wino44_cell; the engine's
-    choice wherever the images are whole 4x4 tiles)."""
-    monkeypatch.setenv('RNH_WINO44', request.param)
+    choice wherever the images are whole 4x4 tiles); the third case adds the opt-in F(4x4) form of refine conv2's forward / data gradient, whose
+    transformed input also feeds conv2's weight gradient (RNH_WINO44_REFINE2=1)."""
+    monkeypatch.setenv('RNH_WINO44', request.param.split('+')[0])
+    if '+' in request.param:
+        monkeypatch.setenv('RNH_WINO44_REFINE2', '1')
     return request.param
 
 
