@@ -788,7 +788,8 @@ def test_fused_f4x4_tile_weight_gradient_vs_float64(which, B, H, W, accumulate, 
 
 
 @pytest.mark.parametrize('which,vN,nfr,H,W,accumulate', [('lstm', 1, 3, 8, 16, False), ('lstm', 2, 3, 16, 32, True), ('lstm', 3, 2, 12, 48, False), ('lstm', 2, 2, 32, 64, False),
-                                                         ('refine1', 2, 2, 16, 32, False), ('refine1', 1, 3, 8, 32, True), ('lstm', 8, 2, 128, 128, False)])
+                                                         ('refine1', 2, 2, 16, 32, False), ('refine1', 1, 3, 8, 32, True), ('refine2', 6, 1, 16, 32, False),
+                                                         ('lstm', 8, 2, 128, 128, False)])
 def test_fused_f4x4_tile_weight_gradient_from_transformed_images_vs_float64(which, vN, nfr, H, W, accumulate, monkeypatch):
     """rnh_wino44f_wgrad_v (round 6, ABI 7): the same weight gradient with its x operand copied (LDS-DMA) from the transformed images the forward's F(4x4)
     cells read (rnh_wino44_transform of vN images per frame) instead of transformed again from the raw tensor - against float64 autograd of conv2d.  The
@@ -828,6 +829,19 @@ def test_fused_f4x4_tile_weight_gradient_from_transformed_images_vs_float64(whic
         Vh = images(h, nfr + 3, [nfr + 1 - f for f in range(nfr)])             # descending from row nfr + 1
         vsrcs = [(Vx, 1, 1), (Vh, nfr + 1, -1)]
         rw, rb = (None, None) if big else ref_wgrad(torch.cat([n64(x.cpu()), n64(h.cpu())], 1), n64(dy), 256, 128)
+        hidx = None
+    elif which == 'refine2':
+        # an image that holds a channel SUB-RANGE of its tensor: R1's 128 hidden-state channels of 132 (one frame of all the launch's images)
+        plan = P.r2_wgrad_h
+        r1, dy = R(B, H, W, 132).to(dev), R(B, H, W, 64)
+        xs, ys, shape = [Src(r1, nch=128)], [Src(dy.to(dev))], (64, 129, 3, 3)
+        V = ops.wino44_v(vN, H, W, 128, frames=2)
+        V.normal_()
+        ops.wino44_transform(Src(r1, nch=128), vN, H, W, V[1])
+        vsrcs = [(V, 1, 1, 128, 0)]
+        g128, rb = ref_wgrad(n64(r1.cpu()[..., :128]), n64(dy), 64, 128)
+        rw = torch.zeros(shape, dtype=torch.float64)
+        rw[:, :128] = g128
         hidx = None
     else:
         plan = P.r1_wgrad_h
