@@ -466,6 +466,9 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
 
         def wino44_gates_bwd_supported(self, H, W, hd):          # (rnh_wino44_gates_bwd_supported)
             return H % 16 == 0 and W % 32 == 0 and hd % 16 == 0
+
+        def _wgrad44f_v(self, *a, **k):                          # (HipOps has the transformed-images form of the fused weight gradient)
+            return False
     cases = {'config 2': (dict(), 8, 7, 128), 'config 4': (dict(upscale_factor=2), 16, 5, 256), 'config 5': (dict(), 8, 11, 96), 'yaml': (dict(), 16, 7, 32)}
     got = {}
     for name, (over, n, t, size) in cases.items():
@@ -483,6 +486,26 @@ def test_default_forms_at_the_benchmark_shapes(monkeypatch):
         fm = got[name]
         assert fm.ring == 0 and fm.refine_fwd44 and fm.up44 == [True] and fm.recompute == 0, name
         assert "slot per frame" in fm.describe()['cell'] and 'F(4x4,3x3)' in fm.describe()['refine1_fwd'] and 'F(4x4,3x3)' in fm.describe()['up1_fwd']
+    # round 6: where every frame's transformed image has a slot and all stages' images take at most 12 % of the card, the weight gradients copy their x operand
+    # from them (rnh_wino44f_wgrad_v) - and memory_plan counts what is kept; a ring shape, a small card or the switch: the raw-operand form
+    for name in ('config 2', 'config 5', 'yaml'):
+        fm = got[name]
+        assert fm.wgrad_v and fm.refine1_wgrad_v and 'rnh_wino44f_wgrad_v' in fm.describe()['cell_wgrad'] and 'rnh_wino44f_wgrad_v' in fm.describe()['refine1_wgrad'], name
+        assert not fm.refine2_fwd44 and not fm.refine2_dgrad44, name                         # (refine conv2 in F(4x4) form is an opt-in)
+    assert not got['config 4'].wgrad_v and 'rnh_wino44f_wgrad_v' not in got['config 4'].describe()['cell_wgrad']
+
+    class SmallCard(HipLike):
+        def total_memory(self):
+            return 150 * 10**9
+    sm = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), SmallCard('cpu')).resolve_forms(8, 128, 128, 19)
+    assert sm.cells44 and not sm.ring and not sm.wgrad_v                                     # (30 GB of kept images > 12 % of 150 GB; the slots of one stage, 8.6 GB, are under its 8 %)
+    monkeypatch.setenv('RNH_WINO44F_V', '0')
+    off = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu'))
+    assert not off.resolve_forms(8, 128, 128, 19).wgrad_v and off.resolve_forms(8, 128, 128, 19).describe()['env_overrides'] == ['RNH_WINO44F_V=0']
+    kept_raw = off.memory_plan(8, 128, 128, 19)['kept']
+    monkeypatch.delenv('RNH_WINO44F_V')
+    kept_v = RefineNetEngine(NetConfig(**orc.exp1_x4_config()), HipLike('cpu')).memory_plan(8, 128, 128, 19)['kept']
+    assert kept_v - kept_raw == 3 * ((19 * 64 + 2 * 19 * 192) + 3 * 7 * 64) * 8 * 128 * 128 * 9          # features + h' of every frame, the PixelShuffle conv's input: 28.6 GB
     fm4 = got['config 4']
     assert fm4.ring == 4 and not fm4.refine_fwd44 and fm4.up44 == [] and fm4.recompute >= 1 and 'ring of 4' in fm4.describe()['cell']
     assert 'F(2x2,3x3)' in fm4.describe()['refine1_fwd'] and 'recomputed in' in fm4.describe()['gates']
