@@ -338,7 +338,7 @@ class RefineNetEngine:
         f.up_wgrad44f = bool(w44f_ok and n_up > 0 and P.C % 64 == 0 and (allw or getattr(P.up[0]['wgrad'], 'wino44f', False)))
         # ... with the x operand COPIED from the transformed images the forward's cells and refine conv1 read (rnh_wino44f_wgrad_v) instead of transformed
         # again - where every frame's image has a slot of its own (no ring) and keeping the images of ALL stages until the backward takes at most
-        # VKEEP_FRACTION of the card (BASELINE config 2: 23.8 GB); the frame in front of the supervised ones must exist (U >= 1)
+        # VKEEP_FRACTION of the card (BASELINE config 2: 30.1 GB by this count, 10.5 %); the frame in front of the supervised ones must exist (U >= 1)
         vkeep = cfg.num_stages * (F * P.C + 2 * F * sum(nf)) * N * H * W * 9
         f.wgrad_v = bool(w44f and cells44 and not f.ring and U >= 1 and hasattr(ops, '_wgrad44f_v') and os.environ.get('RNH_WINO44F_V', '1') != '0' and
                          bool(total) and vkeep <= VKEEP_FRACTION * total and P.C % 32 == 0 and all(h % 32 == 0 for h in nf))
